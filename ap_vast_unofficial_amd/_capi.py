@@ -1,0 +1,328 @@
+"""ctypes binding of libapvast_hip.so (contract: include/apvast_hip.h).
+
+No fallback: if the HIP library is missing or a call fails this module raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+ABI_VERSION = 1
+MAX_RANKS = 8
+MAX_N = 64
+
+F32, F64 = 0, 1
+REG_ABS, REG_REL = 0, 1
+
+OK = 0
+ERR_ARG, ERR_HIP, ERR_NOT_PD, ERR_NO_CONVERGE, ERR_RCCL, ERR_STATE = -1, -2, -3, -4, -5, -6
+
+LIB_NAME = "libapvast_hip.so"
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+
+# every symbol include/apvast_hip.h declares
+EXPORTS = (
+    "apv_create", "apv_destroy", "apv_last_error", "apv_abi_version",
+    "apv_dev_alloc", "apv_dev_free", "apv_memcpy_h2d", "apv_memcpy_d2h", "apv_sync",
+    "apv_timer_start", "apv_timer_stop",
+    "apv_update_dev", "apv_update", "apv_corr_dev", "apv_gevd_vast_dev", "apv_jdiag_batched",
+    "apv_stft_analysis_dev", "apv_istft_ola_dev",
+    "apv_comm_unique_id", "apv_comm_init", "apv_allgather_filters_dev",
+)
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("device", C.c_int32), ("n_bins", C.c_int32), ("n_srcs", C.c_int32),
+        ("n_mics", C.c_int32), ("n_ranks", C.c_int32), ("ranks", C.c_int32 * MAX_RANKS),
+        ("compute_dtype", C.c_int32), ("out_c128", C.c_int32), ("reg_mode", C.c_int32),
+        ("reg_dark", C.c_double), ("reg_bright", C.c_double), ("mu", C.c_double),
+        ("max_sweeps", C.c_int32), ("block_size", C.c_int32), ("hop_size", C.c_int32), ("n_zones", C.c_int32),
+        ("reserved", C.c_int32 * 8),
+    ]
+
+
+class ApvError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libapvast_hip: {msg} (code {code})")
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """dlopen the in-tree HIP library; raises if it was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C ap_vast_unofficial_amd/csrc`). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, sz = C.c_void_p, C.c_int32, C.c_size_t
+    lib.apv_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    lib.apv_destroy.argtypes = [vp]
+    lib.apv_last_error.argtypes = [vp]
+    lib.apv_last_error.restype = C.c_char_p
+    lib.apv_abi_version.argtypes = []
+    lib.apv_dev_alloc.argtypes = [vp, sz, C.POINTER(vp)]
+    lib.apv_dev_free.argtypes = [vp, vp]
+    lib.apv_memcpy_h2d.argtypes = [vp, vp, vp, sz]
+    lib.apv_memcpy_d2h.argtypes = [vp, vp, vp, sz]
+    lib.apv_sync.argtypes = [vp]
+    lib.apv_timer_start.argtypes = [vp]
+    lib.apv_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.apv_update_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    lib.apv_update.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    lib.apv_corr_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    lib.apv_gevd_vast_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    lib.apv_jdiag_batched.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
+    lib.apv_stft_analysis_dev.argtypes = [vp, i32, vp, vp]
+    lib.apv_istft_ola_dev.argtypes = [vp, i32, vp, vp, vp]
+    lib.apv_comm_unique_id.argtypes = [C.c_char_p]
+    lib.apv_comm_init.argtypes = [vp, C.c_char_p, i32, i32]
+    lib.apv_allgather_filters_dev.argtypes = [vp, vp, vp]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if name != "apv_last_error":
+            fn.restype = C.c_int
+    if lib.apv_abi_version() != ABI_VERSION:
+        raise RuntimeError("libapvast_hip.so ABI version mismatch; rebuild it")
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class DeviceBuffer:
+    """A hipMalloc'd block owned through the C ABI."""
+
+    def __init__(self, engine, nbytes):
+        self.engine = engine
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        engine._chk(engine.lib.apv_dev_alloc(engine.h, self.nbytes, C.byref(p)))
+        self.ptr = p
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        e = self.engine
+        e._chk(e.lib.apv_memcpy_h2d(e.h, self.ptr, _ptr(arr), arr.nbytes))
+        e.sync()                                   # arr may be a temporary
+        return self
+
+    def download(self, shape, dtype):
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        e = self.engine
+        e._chk(e.lib.apv_memcpy_d2h(e.h, _ptr(out), self.ptr, out.nbytes))
+        e.sync()
+        return out
+
+    def free(self):
+        if self.ptr is not None and self.engine.h is not None:
+            self.engine.lib.apv_dev_free(self.engine.h, self.ptr)
+        self.ptr = None
+
+
+class Engine:
+    """One handle = one GPU, one stream, one shard of K bins."""
+
+    def __init__(self, n_bins, n_srcs, n_mics, ranks=(1,), mu=1.0, compute_dtype="f64", out_c128=None,
+                 reg_mode=REG_ABS, reg_dark=1e-7, reg_bright=0.0, device=0, max_sweeps=0,
+                 block_size=0, hop_size=0, n_zones=1):
+        self.lib = load()
+        self.h = None
+        ranks = [int(v) for v in ranks]
+        if not 1 <= len(ranks) <= MAX_RANKS:
+            raise ValueError(f"between 1 and {MAX_RANKS} ranks per launch")
+        cfg = Config()
+        cfg.abi_version = ABI_VERSION
+        cfg.device = device
+        cfg.n_bins, cfg.n_srcs, cfg.n_mics = int(n_bins), int(n_srcs), int(n_mics)
+        cfg.n_ranks = len(ranks)
+        for i, v in enumerate(ranks):
+            cfg.ranks[i] = v
+        self.f64 = compute_dtype in ("f64", F64, np.float64)
+        cfg.compute_dtype = F64 if self.f64 else F32
+        self.out_c128 = self.f64 if out_c128 is None else bool(out_c128)
+        cfg.out_c128 = int(self.out_c128)
+        cfg.reg_mode, cfg.reg_dark, cfg.reg_bright, cfg.mu = reg_mode, reg_dark, reg_bright, mu
+        cfg.max_sweeps = max_sweeps
+        cfg.block_size, cfg.hop_size, cfg.n_zones = block_size, hop_size, n_zones
+        self.cfg = cfg
+        self.K, self.L, self.M, self.nV = cfg.n_bins, cfg.n_srcs, cfg.n_mics, cfg.n_ranks
+        h = C.c_void_p()
+        rc = self.lib.apv_create(C.byref(cfg), C.byref(h))
+        if rc != OK:
+            raise ApvError(rc, self.lib.apv_last_error(None).decode())
+        self.h = h
+
+    # -- plumbing -----------------------------------------------------------
+    def _chk(self, rc):
+        if rc == OK:
+            return
+        msg = self.lib.apv_last_error(self.h).decode()
+        if rc == ERR_NOT_PD:
+            raise np.linalg.LinAlgError(msg)          # apvast.py:21,24
+        raise ApvError(rc, msg)
+
+    def close(self):
+        if self.h is not None:
+            self.lib.apv_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        self._chk(self.lib.apv_sync(self.h))
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def to_device(self, arr):
+        arr = np.ascontiguousarray(arr)
+        return DeviceBuffer(self, arr.nbytes).upload(arr)
+
+    @property
+    def w_dtype(self):
+        return np.complex128 if self.out_c128 else np.complex64
+
+    @property
+    def lam_dtype(self):
+        return np.float64 if self.out_c128 else np.float32
+
+    @property
+    def c_dtype(self):
+        return np.complex128 if self.f64 else np.complex64
+
+    def timer_start(self):
+        self._chk(self.lib.apv_timer_start(self.h))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        self._chk(self.lib.apv_timer_stop(self.h, C.byref(ms)))
+        return ms.value
+
+    # -- hot path -----------------------------------------------------------
+    def update(self, XB, XD, d, raise_on_status=True):
+        """One block of subband filter updates from host arrays.
+
+        XB, XD: (K, M, L) complex64; d: (K, M) complex64.
+        Returns w (K, nV, L), lam (K, L), status (K,).
+        """
+        K, M, L = self.K, self.M, self.L
+        XB = np.ascontiguousarray(XB, dtype=np.complex64)
+        XD = np.ascontiguousarray(XD, dtype=np.complex64)
+        d = np.ascontiguousarray(d, dtype=np.complex64)
+        if XB.shape != (K, M, L) or XD.shape != (K, M, L) or d.shape != (K, M):
+            raise ValueError("expected XB, XD of shape (K, M, L) and d of shape (K, M)")
+        w = np.empty((K, self.nV, L), dtype=self.w_dtype)
+        lam = np.empty((K, L), dtype=self.lam_dtype)
+        status = np.empty(K, dtype=np.int32)
+        rc = self.lib.apv_update(self.h, _ptr(XB), _ptr(XD), _ptr(d), _ptr(w), _ptr(lam), _ptr(status))
+        if rc in (ERR_NOT_PD, ERR_NO_CONVERGE) and not raise_on_status:
+            return w, lam, status
+        self._chk(rc)
+        return w, lam, status
+
+    def update_dev(self, dXB, dXD, dd, dw, dlam=None, dstatus=None):
+        self._chk(self.lib.apv_update_dev(self.h, dXB.ptr, dXD.ptr, dd.ptr, dw.ptr,
+                                          dlam.ptr if dlam else None, dstatus.ptr if dstatus else None))
+
+    def corr(self, XB, XD, d):
+        """K5' alone: returns R_B, R_D (K, L, L) and r (K, L) in the compute dtype."""
+        K, L = self.K, self.L
+        bufs = [self.to_device(np.ascontiguousarray(a, dtype=np.complex64)) for a in (XB, XD, d)]
+        cs = np.dtype(self.c_dtype).itemsize
+        dRB, dRD, dr = self.alloc(K * L * L * cs), self.alloc(K * L * L * cs), self.alloc(K * L * cs)
+        self._chk(self.lib.apv_corr_dev(self.h, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, dRB.ptr, dRD.ptr, dr.ptr))
+        out = (dRB.download((K, L, L), self.c_dtype), dRD.download((K, L, L), self.c_dtype),
+               dr.download((K, L), self.c_dtype))
+        for b in bufs + [dRB, dRD, dr]:
+            b.free()
+        return out
+
+    def gevd_vast(self, RB, RD, r, raise_on_status=True):
+        """K6-K10 alone from explicit matrices (compute dtype)."""
+        K, L = self.K, self.L
+        bufs = [self.to_device(np.ascontiguousarray(a, dtype=self.c_dtype)) for a in (RB, RD, r)]
+        dw = self.alloc(K * self.nV * L * np.dtype(self.w_dtype).itemsize)
+        dl = self.alloc(K * L * np.dtype(self.lam_dtype).itemsize)
+        ds = self.alloc(K * 4)
+        self._chk(self.lib.apv_gevd_vast_dev(self.h, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, dw.ptr, dl.ptr, ds.ptr))
+        w = dw.download((K, self.nV, L), self.w_dtype)
+        lam = dl.download((K, L), self.lam_dtype)
+        status = ds.download((K,), np.int32)
+        for b in bufs + [dw, dl, ds]:
+            b.free()
+        if raise_on_status and (status == 1).any():
+            raise np.linalg.LinAlgError("Matrix is not positive definite (bin %d)" % int(np.argmax(status == 1)))
+        return w, lam, status
+
+    def jdiag_batched(self, A, B):
+        """Batched jdiag (apvast.py:20-36) in c128: returns U (batch, n, n), lam (batch, n)."""
+        A = np.ascontiguousarray(A, dtype=np.complex128)
+        B = np.ascontiguousarray(B, dtype=np.complex128)
+        if A.ndim != 3 or A.shape != B.shape or A.shape[1] != A.shape[2]:
+            raise ValueError("A, B must be (batch, n, n)")
+        batch, n, _ = A.shape
+        U = np.empty_like(A)
+        lam = np.empty((batch, n))
+        status = np.empty(batch, dtype=np.int32)
+        self._chk(self.lib.apv_jdiag_batched(self.h, n, batch, _ptr(A), _ptr(B), _ptr(U), _ptr(lam), _ptr(status)))
+        return U, lam
+
+    # -- STFT stages ----------------------------------------------------------
+    def stft_analysis(self, x):
+        """x: (n_ch, N) float32 -> (n_ch, N/2+1) complex64."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        n_ch, N = x.shape
+        K = N // 2 + 1
+        dx = self.to_device(x)
+        ds = self.alloc(n_ch * K * 8)
+        self._chk(self.lib.apv_stft_analysis_dev(self.h, n_ch, dx.ptr, ds.ptr))
+        out = ds.download((n_ch, K), np.complex64)
+        dx.free()
+        ds.free()
+        return out
+
+    def istft_ola(self, spec, overlap):
+        """spec: (n_ch, N/2+1) c64, overlap: (n_ch, N) f32 -> (new overlap, out (n_ch, H))."""
+        spec = np.ascontiguousarray(spec, dtype=np.complex64)
+        overlap = np.ascontiguousarray(overlap, dtype=np.float32)
+        n_ch, N = overlap.shape
+        H = self.cfg.hop_size
+        dsp, dov = self.to_device(spec), self.to_device(overlap)
+        dout = self.alloc(n_ch * H * 4)
+        self._chk(self.lib.apv_istft_ola_dev(self.h, n_ch, dsp.ptr, dov.ptr, dout.ptr))
+        ov = dov.download((n_ch, N), np.float32)
+        out = dout.download((n_ch, H), np.float32)
+        for b in (dsp, dov, dout):
+            b.free()
+        return ov, out
+
+    # -- multi-GPU --------------------------------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        lib = load()
+        buf = C.create_string_buffer(128)
+        rc = lib.apv_comm_unique_id(buf)
+        if rc != OK:
+            raise ApvError(rc, "ncclGetUniqueId failed")
+        return buf.raw
+
+    def comm_init(self, uid, rank, world):
+        self._chk(self.lib.apv_comm_init(self.h, uid, rank, world))
+
+    def allgather_filters_dev(self, dw_shard, dw_all):
+        self._chk(self.lib.apv_allgather_filters_dev(self.h, dw_shard.ptr, dw_all.ptr))

@@ -1,0 +1,418 @@
+// C ABI of libapvast_hip.so (see include/apvast_hip.h for the contract).
+#include "apv_internal.h"
+
+#include <rccl/rccl.h>
+
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <new>
+
+namespace {
+
+thread_local std::string g_create_err;
+
+int fail(apv_handle* h, int code, const std::string& msg) {
+    if (h) h->err = msg; else g_create_err = msg;
+    return code;
+}
+
+int hipfail(apv_handle* h, hipError_t e, const char* what) {
+    return fail(h, APV_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIPCHK(h, call)                                   \
+    do {                                                  \
+        hipError_t _e = (call);                           \
+        if (_e != hipSuccess) return hipfail(h, _e, #call); \
+    } while (0)
+
+size_t csize(const apv_handle* h) { return h->cfg.compute_dtype == APV_F64 ? 16 : 8; }
+size_t wsize(const apv_handle* h) { return h->cfg.out_c128 ? 16 : 8; }
+size_t lsize(const apv_handle* h) { return h->cfg.out_c128 ? 8 : 4; }
+
+GevdParams base_params(const apv_handle* h) {
+    GevdParams p;
+    std::memset(&p, 0, sizeof(p));
+    const apv_config& c = h->cfg;
+    p.n = c.n_srcs;
+    p.M = c.n_mics;
+    p.K = c.n_bins;
+    p.nV = c.n_ranks;
+    for (int i = 0; i < c.n_ranks; ++i) p.ranks[i] = c.ranks[i];
+    p.mu = c.mu;
+    p.reg_dark = c.reg_dark;
+    p.reg_bright = c.reg_bright;
+    p.reg_mode = c.reg_mode;
+    p.max_sweeps = c.max_sweeps;
+    p.out_c128 = c.out_c128;
+    p.Lspill = h->d_Lspill;
+    return p;
+}
+
+int ensure_spill(apv_handle* h, int n, int K) {
+    const size_t need = apv_gevd_spill_bytes(n, K, h->cfg.compute_dtype);
+    if (need > h->lspill_bytes) {
+        if (h->d_Lspill) HIPCHK(h, hipFree(h->d_Lspill));
+        h->d_Lspill = nullptr;
+        h->lspill_bytes = 0;
+        HIPCHK(h, hipMalloc(&h->d_Lspill, need));
+        h->lspill_bytes = need;
+    }
+    return APV_OK;
+}
+
+int ensure_staging(apv_handle* h) {
+    if (h->d_XB) return APV_OK;
+    const apv_config& c = h->cfg;
+    const size_t K = c.n_bins, M = c.n_mics, L = c.n_srcs;
+    HIPCHK(h, hipMalloc(&h->d_XB, K * M * L * 8));
+    HIPCHK(h, hipMalloc(&h->d_XD, K * M * L * 8));
+    HIPCHK(h, hipMalloc(&h->d_d, K * M * 8));
+    HIPCHK(h, hipMalloc(&h->d_w, K * c.n_ranks * L * 16));
+    HIPCHK(h, hipMalloc(&h->d_lam, K * L * 8));
+    HIPCHK(h, hipMalloc((void**)&h->d_status, K * sizeof(int32_t)));
+    return APV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int apv_abi_version(void) { return APV_ABI_VERSION; }
+
+const char* apv_last_error(const apv_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+int apv_create(const apv_config* cfg, apv_handle** out) {
+    if (!cfg || !out) return fail(nullptr, APV_ERR_ARG, "null argument");
+    *out = nullptr;
+    if (cfg->abi_version != APV_ABI_VERSION) return fail(nullptr, APV_ERR_ARG, "ABI version mismatch");
+    if (cfg->n_srcs < 1 || cfg->n_srcs > APV_MAX_N) return fail(nullptr, APV_ERR_ARG, "n_srcs must be in 1..64");
+    if (cfg->n_bins < 0 || cfg->n_mics < 1) return fail(nullptr, APV_ERR_ARG, "n_bins/n_mics out of range");
+    if (cfg->n_ranks < 1 || cfg->n_ranks > APV_MAX_RANKS) return fail(nullptr, APV_ERR_ARG, "n_ranks must be in 1..8");
+    for (int i = 0; i < cfg->n_ranks; ++i) {
+        if (cfg->ranks[i] < 1 || cfg->ranks[i] > cfg->n_srcs) return fail(nullptr, APV_ERR_ARG, "rank V out of 1..L");
+        if (i && cfg->ranks[i] <= cfg->ranks[i - 1]) return fail(nullptr, APV_ERR_ARG, "ranks must be ascending");
+    }
+    if (cfg->compute_dtype != APV_F32 && cfg->compute_dtype != APV_F64)
+        return fail(nullptr, APV_ERR_ARG, "compute_dtype must be APV_F32 or APV_F64");
+    if (cfg->reg_mode != APV_REG_ABS && cfg->reg_mode != APV_REG_REL)
+        return fail(nullptr, APV_ERR_ARG, "reg_mode must be APV_REG_ABS or APV_REG_REL");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) return fail(nullptr, APV_ERR_HIP, "no HIP device visible");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, APV_ERR_ARG, "device ordinal out of range");
+    apv_handle* h = new (std::nothrow) apv_handle();
+    if (!h) return fail(nullptr, APV_ERR_HIP, "out of host memory");
+    h->cfg = *cfg;
+    h->device = cfg->device;
+    h->stream = nullptr;
+    h->ev0 = h->ev1 = nullptr;
+    h->d_XB = h->d_XD = h->d_d = h->d_w = h->d_lam = nullptr;
+    h->d_status = nullptr;
+    h->d_Lspill = nullptr;
+    h->lspill_bytes = 0;
+    h->comm = nullptr;
+    h->comm_rank = 0;
+    h->comm_world = 1;
+#define CR(call)                                                         \
+    do {                                                                 \
+        hipError_t _e = (call);                                          \
+        if (_e != hipSuccess) {                                          \
+            g_create_err = std::string(#call) + ": " + hipGetErrorString(_e); \
+            delete h;                                                    \
+            return APV_ERR_HIP;                                          \
+        }                                                                \
+    } while (0)
+    CR(hipSetDevice(h->device));
+    CR(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    CR(hipEventCreate(&h->ev0));
+    CR(hipEventCreate(&h->ev1));
+#undef CR
+    int rc = ensure_spill(h, cfg->n_srcs, cfg->n_bins);
+    if (rc != APV_OK) {
+        g_create_err = h->err;
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return APV_OK;
+}
+
+int apv_destroy(apv_handle* h) {
+    if (!h) return APV_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->comm) ncclCommDestroy((ncclComm_t)h->comm);
+    void* bufs[] = {h->d_XB, h->d_XD, h->d_d, h->d_w, h->d_lam, h->d_status, h->d_Lspill};
+    for (void* b : bufs)
+        if (b) (void)hipFree(b);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return APV_OK;
+}
+
+int apv_dev_alloc(apv_handle* h, size_t bytes, void** d_ptr) {
+    if (!h || !d_ptr) return APV_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMalloc(d_ptr, bytes ? bytes : 1));
+    return APV_OK;
+}
+
+int apv_dev_free(apv_handle* h, void* d_ptr) {
+    if (!h) return APV_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipFree(d_ptr));
+    return APV_OK;
+}
+
+int apv_memcpy_h2d(apv_handle* h, void* d_dst, const void* h_src, size_t bytes) {
+    if (!h) return APV_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, h->stream));
+    return APV_OK;
+}
+
+int apv_memcpy_d2h(apv_handle* h, void* h_dst, const void* d_src, size_t bytes) {
+    if (!h) return APV_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, h->stream));
+    return APV_OK;
+}
+
+int apv_sync(apv_handle* h) {
+    if (!h) return APV_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return APV_OK;
+}
+
+int apv_timer_start(apv_handle* h) {
+    if (!h) return APV_ERR_ARG;
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    return APV_OK;
+}
+
+int apv_timer_stop(apv_handle* h, float* elapsed_ms) {
+    if (!h || !elapsed_ms) return APV_ERR_ARG;
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    HIPCHK(h, hipEventSynchronize(h->ev1));
+    HIPCHK(h, hipEventElapsedTime(elapsed_ms, h->ev0, h->ev1));
+    return APV_OK;
+}
+
+int apv_update_dev(apv_handle* h, const void* d_XB, const void* d_XD, const void* d_d, void* d_w, void* d_lam,
+                   int32_t* d_status) {
+    if (!h) return APV_ERR_ARG;
+    if (h->cfg.n_bins == 0) return APV_OK;
+    if (!d_XB || !d_XD || !d_d || !d_w) return fail(h, APV_ERR_ARG, "null device pointer");
+    HIPCHK(h, hipSetDevice(h->device));
+    GevdParams p = base_params(h);
+    p.XB = (const float2*)d_XB;
+    p.XD = (const float2*)d_XD;
+    p.d = (const float2*)d_d;
+    p.w = d_w;
+    p.lam = d_lam;
+    p.status = d_status;
+    std::string why;
+    hipError_t e = apv_launch_gevd(p, h->cfg.compute_dtype, true, h->stream, &why);
+    if (e != hipSuccess) return fail(h, e == hipErrorInvalidValue ? APV_ERR_ARG : APV_ERR_HIP,
+                                     why.empty() ? hipGetErrorString(e) : why);
+    return APV_OK;
+}
+
+static int scan_status(apv_handle* h, const int32_t* st, int K) {
+    int rc = APV_OK;
+    for (int k = 0; k < K; ++k) {
+        if (st[k] == 1) {
+            char buf[96];
+            std::snprintf(buf, sizeof(buf), "Matrix is not positive definite (bin %d)", k);
+            return fail(h, APV_ERR_NOT_PD, buf);
+        }
+        if (st[k] == 2 && rc == APV_OK) {
+            char buf[96];
+            std::snprintf(buf, sizeof(buf), "eigen-iteration did not converge (bin %d)", k);
+            h->err = buf;
+            rc = APV_ERR_NO_CONVERGE;
+        }
+    }
+    return rc;
+}
+
+int apv_update(apv_handle* h, const float* h_XB, const float* h_XD, const float* h_d, void* h_w, void* h_lam,
+               int32_t* h_status) {
+    if (!h) return APV_ERR_ARG;
+    if (h->cfg.n_bins == 0) return APV_OK;
+    if (!h_XB || !h_XD || !h_d || !h_w) return fail(h, APV_ERR_ARG, "null host pointer");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = ensure_staging(h);
+    if (rc != APV_OK) return rc;
+    const apv_config& c = h->cfg;
+    const size_t K = c.n_bins, M = c.n_mics, L = c.n_srcs;
+    HIPCHK(h, hipMemcpyAsync(h->d_XB, h_XB, K * M * L * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_XD, h_XD, K * M * L * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_d, h_d, K * M * 8, hipMemcpyHostToDevice, h->stream));
+    rc = apv_update_dev(h, h->d_XB, h->d_XD, h->d_d, h->d_w, h->d_lam, h->d_status);
+    if (rc != APV_OK) return rc;
+    HIPCHK(h, hipMemcpyAsync(h_w, h->d_w, K * c.n_ranks * L * wsize(h), hipMemcpyDeviceToHost, h->stream));
+    if (h_lam) HIPCHK(h, hipMemcpyAsync(h_lam, h->d_lam, K * L * lsize(h), hipMemcpyDeviceToHost, h->stream));
+    std::string keep;
+    int32_t* st = h_status;
+    std::unique_ptr<int32_t[]> tmp;
+    if (!st) {
+        tmp.reset(new int32_t[K ? K : 1]);
+        st = tmp.get();
+    }
+    HIPCHK(h, hipMemcpyAsync(st, h->d_status, K * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return scan_status(h, st, (int)K);
+}
+
+int apv_corr_dev(apv_handle* h, const void* d_XB, const void* d_XD, const void* d_d, void* d_RB, void* d_RD,
+                 void* d_r) {
+    if (!h || !d_XB || !d_XD || !d_d || !d_RB || !d_RD || !d_r) return fail(h, APV_ERR_ARG, "null device pointer");
+    HIPCHK(h, hipSetDevice(h->device));
+    const apv_config& c = h->cfg;
+    hipError_t e = apv_launch_corr(c.compute_dtype, c.n_bins, c.n_mics, c.n_srcs, (const float2*)d_XB,
+                                   (const float2*)d_XD, (const float2*)d_d, d_RB, d_RD, d_r, h->stream);
+    if (e != hipSuccess) return hipfail(h, e, "corr launch");
+    return APV_OK;
+}
+
+int apv_gevd_vast_dev(apv_handle* h, const void* d_RB, const void* d_RD, const void* d_r, void* d_w, void* d_lam,
+                      int32_t* d_status) {
+    if (!h || !d_RB || !d_RD || !d_r || !d_w) return fail(h, APV_ERR_ARG, "null device pointer");
+    HIPCHK(h, hipSetDevice(h->device));
+    GevdParams p = base_params(h);
+    p.RB = d_RB;
+    p.RD = d_RD;
+    p.r = d_r;
+    p.w = d_w;
+    p.lam = d_lam;
+    p.status = d_status;
+    std::string why;
+    hipError_t e = apv_launch_gevd(p, h->cfg.compute_dtype, false, h->stream, &why);
+    if (e != hipSuccess) return fail(h, e == hipErrorInvalidValue ? APV_ERR_ARG : APV_ERR_HIP,
+                                     why.empty() ? hipGetErrorString(e) : why);
+    return APV_OK;
+}
+
+int apv_jdiag_batched(apv_handle* h, int32_t n, int32_t batch, const double* h_A, const double* h_B, double* h_U,
+                      double* h_lam, int32_t* h_status) {
+    if (!h || !h_A || !h_B || !h_U || !h_lam) return fail(h, APV_ERR_ARG, "null host pointer");
+    if (n < 1 || n > APV_MAX_N || batch < 0) return fail(h, APV_ERR_ARG, "jdiag order n must be in 1..64");
+    if (batch == 0) return APV_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    // always runs in f64 / c128, whatever the handle's streaming dtype
+    const size_t mat = (size_t)batch * n * n * 16;
+    void *dA = nullptr, *dB = nullptr, *dU = nullptr, *dw = nullptr, *dl = nullptr;
+    int32_t* ds = nullptr;
+    HIPCHK(h, hipMalloc(&dA, mat));
+    HIPCHK(h, hipMalloc(&dB, mat));
+    HIPCHK(h, hipMalloc(&dU, mat));
+    HIPCHK(h, hipMalloc(&dw, (size_t)batch * n * 16));
+    HIPCHK(h, hipMalloc(&dl, (size_t)batch * n * 8));
+    HIPCHK(h, hipMalloc((void**)&ds, (size_t)batch * sizeof(int32_t)));
+    void* spill = nullptr;
+    const size_t sb = apv_gevd_spill_bytes(n, batch, APV_F64);
+    if (sb) HIPCHK(h, hipMalloc(&spill, sb));
+    HIPCHK(h, hipMemcpyAsync(dA, h_A, mat, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(dB, h_B, mat, hipMemcpyHostToDevice, h->stream));
+    GevdParams p = base_params(h);
+    p.n = n;
+    p.K = batch;
+    p.nV = 1;
+    p.ranks[0] = 1;
+    p.reg_bright = 0.0;
+    p.out_c128 = 1;
+    p.RB = dA;
+    p.RD = dB;
+    p.r = nullptr;
+    p.w = dw;
+    p.lam = dl;
+    p.status = ds;
+    p.U = dU;
+    p.Lspill = spill;
+    std::string why;
+    hipError_t e = apv_launch_gevd(p, APV_F64, false, h->stream, &why);
+    int rc = APV_OK;
+    if (e != hipSuccess) rc = fail(h, APV_ERR_HIP, why.empty() ? hipGetErrorString(e) : why);
+    std::unique_ptr<int32_t[]> tmp;
+    int32_t* st = h_status;
+    if (!st) {
+        tmp.reset(new int32_t[batch]);
+        st = tmp.get();
+    }
+    if (rc == APV_OK) {
+        (void)hipMemcpyAsync(h_U, dU, mat, hipMemcpyDeviceToHost, h->stream);
+        (void)hipMemcpyAsync(h_lam, dl, (size_t)batch * n * 8, hipMemcpyDeviceToHost, h->stream);
+        (void)hipMemcpyAsync(st, ds, (size_t)batch * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream);
+        hipError_t se = hipStreamSynchronize(h->stream);
+        if (se != hipSuccess) rc = hipfail(h, se, "jdiag sync");
+    }
+    void* tofree[] = {dA, dB, dU, dw, dl, ds, spill};
+    for (void* b : tofree)
+        if (b) (void)hipFree(b);
+    if (rc != APV_OK) return rc;
+    return scan_status(h, st, batch);
+}
+
+int apv_stft_analysis_dev(apv_handle* h, int32_t n_ch, const float* d_x, void* d_spec) {
+    if (!h || !d_x || !d_spec) return fail(h, APV_ERR_ARG, "null device pointer");
+    if (h->cfg.block_size <= 0) return fail(h, APV_ERR_ARG, "handle was created without an STFT geometry");
+    HIPCHK(h, hipSetDevice(h->device));
+    std::string why;
+    hipError_t e = apv_launch_stft_analysis(h->cfg.block_size, n_ch, d_x, (float2*)d_spec, h->stream, &why);
+    if (e != hipSuccess) return fail(h, e == hipErrorInvalidValue ? APV_ERR_ARG : APV_ERR_HIP,
+                                     why.empty() ? hipGetErrorString(e) : why);
+    return APV_OK;
+}
+
+int apv_istft_ola_dev(apv_handle* h, int32_t n_ch, const void* d_spec, float* d_overlap, float* d_out) {
+    if (!h || !d_spec || !d_overlap) return fail(h, APV_ERR_ARG, "null device pointer");
+    if (h->cfg.block_size <= 0) return fail(h, APV_ERR_ARG, "handle was created without an STFT geometry");
+    HIPCHK(h, hipSetDevice(h->device));
+    std::string why;
+    hipError_t e = apv_launch_istft_ola(h->cfg.block_size, h->cfg.hop_size, n_ch, (const float2*)d_spec, d_overlap,
+                                        d_out, h->stream, &why);
+    if (e != hipSuccess) return fail(h, e == hipErrorInvalidValue ? APV_ERR_ARG : APV_ERR_HIP,
+                                     why.empty() ? hipGetErrorString(e) : why);
+    return APV_OK;
+}
+
+int apv_comm_unique_id(char id_out[128]) {
+    if (!id_out) return APV_ERR_ARG;
+    ncclUniqueId id;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    if (ncclGetUniqueId(&id) != ncclSuccess) return APV_ERR_RCCL;
+    std::memcpy(id_out, &id, 128);
+    return APV_OK;
+}
+
+int apv_comm_init(apv_handle* h, const char id[128], int32_t rank, int32_t world) {
+    if (!h || !id || world < 1 || rank < 0 || rank >= world) return fail(h, APV_ERR_ARG, "bad communicator arguments");
+    HIPCHK(h, hipSetDevice(h->device));
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, 128);
+    ncclComm_t comm;
+    ncclResult_t r = ncclCommInitRank(&comm, world, uid, rank);
+    if (r != ncclSuccess) return fail(h, APV_ERR_RCCL, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
+    h->comm = comm;
+    h->comm_rank = rank;
+    h->comm_world = world;
+    return APV_OK;
+}
+
+int apv_allgather_filters_dev(apv_handle* h, const void* d_w_shard, void* d_w_all) {
+    if (!h || !d_w_shard || !d_w_all) return fail(h, APV_ERR_ARG, "null device pointer");
+    if (!h->comm) return fail(h, APV_ERR_RCCL, "communicator not initialised (apv_comm_init)");
+    const apv_config& c = h->cfg;
+    const size_t bytes = (size_t)c.n_bins * c.n_ranks * c.n_srcs * wsize(h);
+    ncclResult_t r = ncclAllGather(d_w_shard, d_w_all, bytes, ncclChar, (ncclComm_t)h->comm, h->stream);
+    if (r != ncclSuccess) return fail(h, APV_ERR_RCCL, std::string("ncclAllGather: ") + ncclGetErrorString(r));
+    return APV_OK;
+}
+
+}  // extern "C"

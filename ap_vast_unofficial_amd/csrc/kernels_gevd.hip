@@ -1,0 +1,500 @@
+// Batched joint diagonalisation (GEVD) + variable-span filter, LDS-resident.
+//
+// One workgroup owns one problem (one frequency bin): the bright/dark pair
+// (A, B) of order n <= NMAX lives in LDS from the first load to the last
+// store; nothing but the inputs and the filter touch HBM.
+//
+// Stages (reference Python/apvast.py, spec Matlab/ControlMethods/jdiag.m:103-117):
+//   0  [fused]  R_B = X_B^H X_B, R_D = X_D^H X_D, r = X_B^H d      apvast.py:329-364 per bin
+//   1  Bc = chol(B + reg I)                                        apvast.py:22-27
+//   2  C  = Bc^-1 A Bc^-H   (two forward substitutions)            apvast.py:28-29
+//   3  C  = Q diag(lam) Q^H (cyclic Jacobi, round-robin ordering)  apvast.py:30  (schur of a Hermitian C)
+//   4  sort lam descending                                         apvast.py:32-35
+//   5  X  = Bc^-H Q         (backward substitution)                apvast.py:31
+//   6  w_V = sum_{i<V} (x_i^H r)/(lam_i+mu) x_i                    apvast.py:406-414
+//
+// gfx950 only.  Wavefront = 64.
+#include "apv_internal.h"
+
+namespace {
+
+template <typename T>
+struct Cx {
+    T x, y;
+};
+
+template <typename T> __device__ __forceinline__ Cx<T> mk(T a, T b) { Cx<T> r; r.x = a; r.y = b; return r; }
+template <typename T> __device__ __forceinline__ Cx<T> cadd(Cx<T> a, Cx<T> b) { return mk<T>(a.x + b.x, a.y + b.y); }
+template <typename T> __device__ __forceinline__ Cx<T> csub(Cx<T> a, Cx<T> b) { return mk<T>(a.x - b.x, a.y - b.y); }
+template <typename T> __device__ __forceinline__ Cx<T> cmul(Cx<T> a, Cx<T> b) {
+    return mk<T>(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+// a * conj(b)
+template <typename T> __device__ __forceinline__ Cx<T> cmulc(Cx<T> a, Cx<T> b) {
+    return mk<T>(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+// conj(a) * b
+template <typename T> __device__ __forceinline__ Cx<T> ccmul(Cx<T> a, Cx<T> b) {
+    return mk<T>(a.x * b.x + a.y * b.y, a.x * b.y - a.y * b.x);
+}
+template <typename T> __device__ __forceinline__ Cx<T> cscale(Cx<T> a, T s) { return mk<T>(a.x * s, a.y * s); }
+template <typename T> __device__ __forceinline__ Cx<T> cconj(Cx<T> a) { return mk<T>(a.x, -a.y); }
+template <typename T> __device__ __forceinline__ T cabs2(Cx<T> a) { return a.x * a.x + a.y * a.y; }
+
+template <typename T> struct Tol;
+template <> struct Tol<double> {
+    static constexpr double sweep_tol2 = 1e-17;   // quadratic convergence: next state is ~1e-17 * ||C||
+    static constexpr int max_sweeps = 16;
+};
+template <> struct Tol<float> {
+    static constexpr float sweep_tol2 = 1e-8f;
+    static constexpr int max_sweeps = 12;
+};
+
+// Round-robin (tournament) pairing: ne players (even), round r in [0, ne-1), slot a in [0, ne/2).
+__device__ __forceinline__ void rr_pair(int ne, int r, int a, int& p, int& q) {
+    int m1 = ne - 1;
+    int u, v;
+    if (a == 0) {
+        u = m1;
+        v = r;
+    } else {
+        u = (r + a) % m1;
+        v = (r - a + m1) % m1;
+    }
+    p = u < v ? u : v;
+    q = u < v ? v : u;
+}
+
+template <typename T, int NMAX, int TPB, bool FUSED, bool SPILL>
+__global__ void __launch_bounds__(TPB) gevd_vast_kernel(const GevdParams p) {
+    using C = Cx<T>;
+    constexpr int LD = NMAX + 1;
+    constexpr int NP = NMAX / 2;
+    constexpr int MT = 16;                                  // control-point rows staged per step (fused)
+    constexpr int NACC = (NMAX * NMAX + TPB - 1) / TPB;
+
+    __shared__ C sA[NMAX * LD];
+    __shared__ C sB[NMAX * LD];
+    __shared__ C sVstore[SPILL ? 1 : NMAX * LD];
+    __shared__ float2 sX[FUSED ? MT * NMAX : 1];
+    __shared__ float2 sd[FUSED ? MT : 1];
+    __shared__ C sr[NMAX];
+    __shared__ C scoef[NMAX];
+    __shared__ T sDiag[NMAX];
+    __shared__ T sDinv[NMAX];
+    __shared__ T sLam[NMAX];
+    __shared__ T sRow[NMAX];
+    __shared__ int sOrder[NMAX];
+    __shared__ T rc[NP];
+    __shared__ C rs[NP];
+    __shared__ T roff[NP];
+    __shared__ int rp[NP];
+    __shared__ int rq[NP];
+
+    C* sV = SPILL ? sB : sVstore;
+
+    const int n = p.n;
+    const int tid = threadIdx.x;
+    const int k = blockIdx.x;
+    int status = 0;
+
+    // ---------------- stage 0: load or correlate ----------------
+    if constexpr (FUSED) {
+        const int M = p.M;
+        for (int which = 0; which < 2; ++which) {
+            const float2* X = (which ? p.XD : p.XB) + (size_t)k * M * n;
+            C acc[NACC];
+#pragma unroll
+            for (int a = 0; a < NACC; ++a) acc[a] = mk<T>(0, 0);
+            C racc = mk<T>(0, 0);
+            for (int m0 = 0; m0 < M; m0 += MT) {
+                const int rows = (M - m0) < MT ? (M - m0) : MT;
+                for (int idx = tid; idx < rows * n; idx += TPB) sX[idx] = X[(size_t)m0 * n + idx];
+                if (which == 0)
+                    for (int idx = tid; idx < rows; idx += TPB) sd[idx] = p.d[(size_t)k * M + m0 + idx];
+                __syncthreads();
+#pragma unroll
+                for (int a = 0; a < NACC; ++a) {
+                    const int idx = tid + a * TPB;
+                    if (idx < n * n) {
+                        const int i = idx / n, j = idx - i * n;
+                        C s = acc[a];
+                        for (int m = 0; m < rows; ++m) {
+                            const float2 xi = sX[m * n + i], xj = sX[m * n + j];
+                            // conj(xi) * xj, products exact in T=double
+                            s.x += (T)xi.x * (T)xj.x + (T)xi.y * (T)xj.y;
+                            s.y += (T)xi.x * (T)xj.y - (T)xi.y * (T)xj.x;
+                        }
+                        acc[a] = s;
+                    }
+                }
+                if (which == 0 && tid < n) {
+                    for (int m = 0; m < rows; ++m) {
+                        const float2 xi = sX[m * n + tid], dm = sd[m];
+                        racc.x += (T)xi.x * (T)dm.x + (T)xi.y * (T)dm.y;
+                        racc.y += (T)xi.x * (T)dm.y - (T)xi.y * (T)dm.x;
+                    }
+                }
+                __syncthreads();
+            }
+            C* dst = which ? sB : sA;
+#pragma unroll
+            for (int a = 0; a < NACC; ++a) {
+                const int idx = tid + a * TPB;
+                if (idx < n * n) {
+                    const int i = idx / n, j = idx - i * n;
+                    dst[i * LD + j] = acc[a];
+                }
+            }
+            if (which == 0 && tid < n) sr[tid] = racc;
+        }
+    } else {
+        const C* RB = reinterpret_cast<const C*>(p.RB) + (size_t)k * n * n;
+        const C* RD = reinterpret_cast<const C*>(p.RD) + (size_t)k * n * n;
+        for (int idx = tid; idx < n * n; idx += TPB) {
+            const int i = idx / n, j = idx - i * n;
+            sA[i * LD + j] = RB[idx];
+            sB[i * LD + j] = RD[idx];
+        }
+        if (p.r != nullptr) {
+            if (tid < n) sr[tid] = reinterpret_cast<const C*>(p.r)[(size_t)k * n + tid];
+        } else if (tid < n) {
+            sr[tid] = mk<T>(0, 0);
+        }
+    }
+    __syncthreads();
+
+    // ---------------- stage 1: loading + Cholesky of B ----------------
+    T load = (T)p.reg_dark;
+    T load_bright = 0;
+    if (p.reg_mode == APV_REG_REL || p.reg_bright != 0.0) {
+        // spectral norm by power iteration on the Hermitian PSD matrix (||.||_2 of apvast.py:26,
+        // apVast.m:552-569).  sRow holds |x|^2 partials, scoef the iterate.
+        for (int which = 0; which < 2; ++which) {
+            const bool need = which ? (p.reg_mode == APV_REG_REL) : (p.reg_bright != 0.0);
+            if (!need) continue;
+            const C* Mx = which ? sB : sA;
+            if (tid < n) scoef[tid] = mk<T>((T)1, (T)0);
+            __syncthreads();
+            T nrm = 0;
+            for (int it = 0; it < 48; ++it) {
+                C y = mk<T>(0, 0);
+                if (tid < n)
+                    for (int j = 0; j < n; ++j) y = cadd(y, cmul(Mx[tid * LD + j], scoef[j]));
+                if (tid < n) sRow[tid] = cabs2(y);
+                __syncthreads();
+                T s2 = 0;
+                for (int j = 0; j < n; ++j) s2 += sRow[j];
+                T xs = 0;
+                for (int j = 0; j < n; ++j) xs += cabs2(scoef[j]);
+                nrm = sqrt(s2 / xs);                       // ||Mx x|| / ||x||
+                __syncthreads();
+                if (tid < n) scoef[tid] = cscale(y, (T)1 / sqrt(s2));
+                __syncthreads();
+            }
+            if (which) load = (T)p.reg_dark * nrm; else load_bright = (T)p.reg_bright * nrm;
+        }
+    }
+    if (tid < n) {
+        C b = sB[tid * LD + tid];
+        sB[tid * LD + tid] = mk<T>(b.x + load, 0);
+        C a = sA[tid * LD + tid];
+        sA[tid * LD + tid] = mk<T>(a.x + load_bright, 0);
+    }
+    __syncthreads();
+
+    for (int kk = 0; kk < n; ++kk) {
+        const T dkk = sB[kk * LD + kk].x;
+        if (!(dkk > (T)0) || !(dkk < (T)3.0e38)) {        // uniform: every thread reads the same word
+            status = 1;
+            break;
+        }
+        const T inv = (T)1 / sqrt(dkk);
+        if (tid == 0) {
+            sDiag[kk] = sqrt(dkk);
+            sDinv[kk] = inv;
+        }
+        for (int i = kk + 1 + tid; i < n; i += TPB) sB[i * LD + kk] = cscale(sB[i * LD + kk], inv);
+        __syncthreads();
+        const int rem = n - kk - 1;                        // trailing block is rem x rem (lower part used)
+        for (int idx = tid; idx < rem * rem; idx += TPB) {
+            const int i = kk + 1 + idx / rem, j = kk + 1 + idx % rem;
+            if (j <= i) sB[i * LD + j] = csub(sB[i * LD + j], cmulc(sB[i * LD + kk], sB[j * LD + kk]));
+        }
+        __syncthreads();
+    }
+
+    if (status == 0) {
+        // ---------------- stage 2: C = L^-1 A L^-H ----------------
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int kk = 0; kk < n; ++kk) {
+                const T inv = sDinv[kk];
+                for (int j = tid; j < n; j += TPB) sA[kk * LD + j] = cscale(sA[kk * LD + j], inv);
+                __syncthreads();
+                const int rem = n - kk - 1;
+                for (int idx = tid; idx < rem * n; idx += TPB) {
+                    const int i = kk + 1 + idx / n, j = idx % n;
+                    sA[i * LD + j] = csub(sA[i * LD + j], cmul(sB[i * LD + kk], sA[kk * LD + j]));
+                }
+                __syncthreads();
+            }
+            if (pass == 0) {
+                // in-place conjugate transpose
+                for (int idx = tid; idx < n * n; idx += TPB) {
+                    const int i = idx / n, j = idx - i * n;
+                    if (i < j) {
+                        const C u = sA[i * LD + j], l = sA[j * LD + i];
+                        sA[i * LD + j] = cconj(l);
+                        sA[j * LD + i] = cconj(u);
+                    } else if (i == j) {
+                        sA[i * LD + i] = cconj(sA[i * LD + i]);
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        // symmetrise, real diagonal
+        for (int idx = tid; idx < n * n; idx += TPB) {
+            const int i = idx / n, j = idx - i * n;
+            if (i < j) {
+                const C u = sA[i * LD + j], l = sA[j * LD + i];
+                const C m = mk<T>((T)0.5 * (u.x + l.x), (T)0.5 * (u.y - l.y));
+                sA[i * LD + j] = m;
+                sA[j * LD + i] = cconj(m);
+            } else if (i == j) {
+                sA[i * LD + i].y = 0;
+            }
+        }
+        if constexpr (SPILL) {
+            // park L in HBM scratch: its LDS slot becomes the eigenvector matrix
+            C* Ls = reinterpret_cast<C*>(p.Lspill) + (size_t)k * n * n;
+            for (int idx = tid; idx < n * n; idx += TPB) {
+                const int i = idx / n, j = idx - i * n;
+                Ls[idx] = sB[i * LD + j];
+            }
+        }
+        __syncthreads();
+
+        // ---------------- stage 3: cyclic Jacobi ----------------
+        for (int idx = tid; idx < n * n; idx += TPB) {
+            const int i = idx / n, j = idx - i * n;
+            sV[i * LD + j] = mk<T>(i == j ? (T)1 : (T)0, (T)0);
+        }
+        if (n & 1) {
+            // odd order: index n is the tournament's bye; give it a zero ghost row and column (n < NMAX)
+            for (int j = tid; j <= n; j += TPB) {
+                sA[n * LD + j] = mk<T>(0, 0);
+                sA[j * LD + n] = mk<T>(0, 0);
+                sV[n * LD + j] = mk<T>(0, 0);
+                sV[j * LD + n] = mk<T>(0, 0);
+            }
+        }
+        if (tid < n) {
+            T s = 0;
+            for (int j = 0; j < n; ++j) s += cabs2(sA[tid * LD + j]);
+            sRow[tid] = s;
+        }
+        __syncthreads();
+        T normF2 = 0;
+        for (int j = 0; j < n; ++j) normF2 += sRow[j];
+
+        const int ne = n + (n & 1);
+        const int np = ne / 2;
+        const int rounds = ne - 1;
+        const int max_sweeps = p.max_sweeps > 0 ? p.max_sweeps : Tol<T>::max_sweeps;
+        bool converged = (n == 1);
+        for (int sweep = 0; sweep < max_sweeps && !converged; ++sweep) {
+            T off = 0;
+            for (int r = 0; r < rounds; ++r) {
+                if (tid < np) {
+                    int pp, qq;
+                    rr_pair(ne, r, tid, pp, qq);
+                    T c = 1, o = 0;
+                    C s = mk<T>(0, 0);
+                    if (qq < n) {
+                        const T alpha = sA[pp * LD + pp].x, gamma = sA[qq * LD + qq].x;
+                        const C beta = sA[pp * LD + qq];
+                        const T b2 = cabs2(beta);
+                        o = b2;
+                        if (b2 > (T)0) {
+                            const T ab = sqrt(b2);
+                            const T tau = (gamma - alpha) / ((T)2 * ab);
+                            const T t = copysign((T)1, tau) / (fabs(tau) + sqrt((T)1 + tau * tau));
+                            c = (T)1 / sqrt((T)1 + t * t);
+                            const T sc = t * c / ab;
+                            s = mk<T>(beta.x * sc, beta.y * sc);
+                        }
+                    }
+                    // qq == n (odd n): the bye.  Row/column n of C and V are zero ghosts and the
+                    // rotation is the identity, so the real index pp still sees its partners' rotations.
+                    rp[tid] = pp;
+                    rq[tid] = qq;
+                    rc[tid] = c;
+                    rs[tid] = s;
+                    roff[tid] = o;
+                }
+                __syncthreads();
+                for (int a = 0; a < np; ++a) off += roff[a];
+                // C <- J^H C J on 2x2 blocks
+                for (int idx = tid; idx < np * np; idx += TPB) {
+                    const int a = idx / np, b = idx - a * np;
+                    const int pa = rp[a], qa = rq[a], pb = rp[b], qb = rq[b];
+                    const T ca = rc[a], cb = rc[b];
+                    const C sa = rs[a], sb = rs[b];
+                    C xpp = sA[pa * LD + pb], xpq = sA[pa * LD + qb];
+                    C xqp = sA[qa * LD + pb], xqq = sA[qa * LD + qb];
+                    // columns: [x_p, x_q] J_b
+                    C ypp = csub(cscale(xpp, cb), cmulc(xpq, sb));
+                    C ypq = cadd(cmul(xpp, sb), cscale(xpq, cb));
+                    C yqp = csub(cscale(xqp, cb), cmulc(xqq, sb));
+                    C yqq = cadd(cmul(xqp, sb), cscale(xqq, cb));
+                    // rows: J_a^H [y_p; y_q]
+                    C zpp = csub(cscale(ypp, ca), cmul(sa, yqp));
+                    C zpq = csub(cscale(ypq, ca), cmul(sa, yqq));
+                    C zqp = cadd(ccmul(sa, ypp), cscale(yqp, ca));
+                    C zqq = cadd(ccmul(sa, ypq), cscale(yqq, ca));
+                    if (a == b) {
+                        zpq = mk<T>(0, 0);
+                        zqp = mk<T>(0, 0);
+                        zpp.y = 0;
+                        zqq.y = 0;
+                    }
+                    sA[pa * LD + pb] = zpp;
+                    sA[pa * LD + qb] = zpq;
+                    sA[qa * LD + pb] = zqp;
+                    sA[qa * LD + qb] = zqq;
+                }
+                // V <- V J
+                for (int idx = tid; idx < n * np; idx += TPB) {
+                    const int i = idx / np, b = idx - i * np;
+                    const int pb = rp[b], qb = rq[b];
+                    const T cb = rc[b];
+                    const C sb = rs[b];
+                    const C vp = sV[i * LD + pb], vq = sV[i * LD + qb];
+                    sV[i * LD + pb] = csub(cscale(vp, cb), cmulc(vq, sb));
+                    sV[i * LD + qb] = cadd(cmul(vp, sb), cscale(vq, cb));
+                }
+                __syncthreads();
+            }
+            if (off <= Tol<T>::sweep_tol2 * normF2) converged = true;
+        }
+        if (!converged) status = 2;
+
+        // ---------------- stage 4: eigenvalues, descending order ----------------
+        if (tid < n) sLam[tid] = sA[tid * LD + tid].x;
+        __syncthreads();
+        if (tid < n) {
+            const T li = sLam[tid];
+            int rank = 0;
+            for (int j = 0; j < n; ++j) {
+                const T lj = sLam[j];
+                rank += (lj > li) || (lj == li && j < tid);
+            }
+            sOrder[rank] = tid;
+        }
+        __syncthreads();
+
+        // ---------------- stage 5: X = L^-H Q ----------------
+        C* sL = sB;
+        if constexpr (SPILL) {
+            sL = sA;                                       // C is spent (lam copied out)
+            const C* Ls = reinterpret_cast<const C*>(p.Lspill) + (size_t)k * n * n;
+            for (int idx = tid; idx < n * n; idx += TPB) {
+                const int i = idx / n, j = idx - i * n;
+                sA[i * LD + j] = Ls[idx];
+            }
+            __syncthreads();
+        }
+        for (int kk = n - 1; kk >= 0; --kk) {
+            const T inv = sDinv[kk];
+            for (int j = tid; j < n; j += TPB) sV[kk * LD + j] = cscale(sV[kk * LD + j], inv);
+            __syncthreads();
+            for (int idx = tid; idx < kk * n; idx += TPB) {
+                const int i = idx / n, j = idx - i * n;
+                // X[i][:] -= conj(L[kk][i]) * X[kk][:]
+                sV[i * LD + j] = csub(sV[i * LD + j], ccmul(sL[kk * LD + i], sV[kk * LD + j]));
+            }
+            __syncthreads();
+        }
+
+        // ---------------- stage 6: variable-span filter ----------------
+        if (tid < n) {
+            C s = mk<T>(0, 0);
+            for (int l = 0; l < n; ++l) s = cadd(s, ccmul(sV[l * LD + tid], sr[l]));
+            const T den = (T)1 / (sLam[tid] + (T)p.mu);
+            scoef[tid] = cscale(s, den);
+        }
+        __syncthreads();
+    }
+
+    // ---------------- outputs ----------------
+    if (tid < n) {
+        C acc = mk<T>(0, 0);
+        int done = 0;
+        for (int t = 0; t < p.nV; ++t) {
+            const int V = p.ranks[t];
+            if (status != 1) {
+                for (; done < V; ++done) {
+                    const int c = sOrder[done];
+                    acc = cadd(acc, cmul(scoef[c], sV[tid * LD + c]));
+                }
+            }
+            const size_t o = ((size_t)k * p.nV + t) * n + tid;
+            if (p.out_c128) {
+                reinterpret_cast<double2*>(p.w)[o] = make_double2((double)acc.x, (double)acc.y);
+            } else {
+                reinterpret_cast<float2*>(p.w)[o] = make_float2((float)acc.x, (float)acc.y);
+            }
+        }
+        if (p.lam != nullptr) {
+            const T lv = (status != 1) ? sLam[sOrder[tid]] : (T)0;
+            if (p.out_c128) reinterpret_cast<double*>(p.lam)[(size_t)k * n + tid] = (double)lv;
+            else reinterpret_cast<float*>(p.lam)[(size_t)k * n + tid] = (float)lv;
+        }
+    }
+    if (p.U != nullptr) {
+        C* U = reinterpret_cast<C*>(p.U) + (size_t)k * n * n;
+        for (int idx = tid; idx < n * n; idx += TPB) {
+            const int i = idx / n, j = idx - i * n;
+            U[idx] = (status != 1) ? sV[i * LD + sOrder[j]] : mk<T>(0, 0);
+        }
+    }
+    if (p.status != nullptr && tid == 0) p.status[k] = status;
+}
+
+template <typename T, int NMAX, int TPB, bool SPILL>
+hipError_t launch_t(const GevdParams& p, bool fused, hipStream_t s) {
+    if (p.K <= 0) return hipSuccess;
+    if (fused)
+        hipLaunchKernelGGL((gevd_vast_kernel<T, NMAX, TPB, true, SPILL>), dim3(p.K), dim3(TPB), 0, s, p);
+    else
+        hipLaunchKernelGGL((gevd_vast_kernel<T, NMAX, TPB, false, SPILL>), dim3(p.K), dim3(TPB), 0, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+size_t apv_gevd_spill_bytes(int n, int K, int compute_dtype) {
+    if (compute_dtype == APV_F64 && n > 32) return (size_t)K * n * n * 2 * sizeof(double);
+    return 0;
+}
+
+hipError_t apv_launch_gevd(const GevdParams& p, int compute_dtype, bool fused, hipStream_t s, std::string* why) {
+    const int n = p.n;
+    if (n < 1 || n > APV_MAX_N) {
+        if (why) *why = "GEVD order n out of range (1..64)";
+        return hipErrorInvalidValue;
+    }
+    if (compute_dtype == APV_F64) {
+        if (n <= 8) return launch_t<double, 8, 64, false>(p, fused, s);
+        if (n <= 16) return launch_t<double, 16, 64, false>(p, fused, s);
+        if (n <= 32) return launch_t<double, 32, 256, false>(p, fused, s);
+        return launch_t<double, 64, 256, true>(p, fused, s);
+    } else {
+        if (n <= 8) return launch_t<float, 8, 64, false>(p, fused, s);
+        if (n <= 16) return launch_t<float, 16, 64, false>(p, fused, s);
+        if (n <= 32) return launch_t<float, 32, 256, false>(p, fused, s);
+        return launch_t<float, 64, 256, false>(p, fused, s);
+    }
+}

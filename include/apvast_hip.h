@@ -1,0 +1,153 @@
+/*
+ * apvast_hip.h -- C ABI of the MI355X-native AP-VAST filter engine.
+ *
+ * This is the drop-in boundary for the per-block, per-subband hot path of the
+ * reference (macoustics/ap-vast-unofficial).  The reference has no native code
+ * and therefore no FFI of its own; each entry point below replaces a span of
+ * NumPy/SciPy calls in Python/apvast.py, cited as "replaces:".  The host side
+ * that binds it is ap_vast_unofficial_amd/_capi.py (ctypes); INTEGRATION.md
+ * shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C types only; every function returns an int status: 0 = OK,
+ *     negative = error (apv_last_error() gives the text).
+ *   - complex numbers are interleaved (re, im) pairs: `float[2]` for c64,
+ *     `double[2]` for c128.
+ *   - a handle owns one HIP device, one stream, its workspaces and (optionally)
+ *     one RCCL communicator.  Handles are thread-compatible, not thread-safe.
+ *   - pointer arguments named h_* are HOST pointers, d_* are DEVICE pointers
+ *     obtained from apv_dev_alloc() (or any hipMalloc'd memory on the handle's
+ *     device).  No entry point allocates on the per-block path.
+ *
+ * Data layout (HBM), subband mode -- bin-major so that one bin's control-point
+ * matrix is one contiguous, coalesced slab:
+ *   X_B, X_D : [K][M][L] c64   bright / dark control-point spectra of the K bins
+ *                              owned by this handle; X[k] = spectra[k].T of
+ *                              apvast.py:239-262, rows = control points (mics),
+ *                              columns = loudspeakers (fastest).
+ *   d        : [K][M]    c64   target spectrum at the bright control points
+ *                              (apvast.py:199-209).
+ *   w        : [K][nV][L] c64 (or c128)  VAST filter per bin and per rank V.
+ *   lam      : [K][L]    f32 (or f64)    generalized eigenvalues, descending.
+ *   status   : [K]       i32   0 OK; 1 = loaded R_D not positive definite
+ *                              (numpy.linalg.LinAlgError at apvast.py:24);
+ *                              2 = eigen-iteration did not converge.
+ */
+#ifndef APVAST_HIP_H
+#define APVAST_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define APV_ABI_VERSION 1
+#define APV_MAX_RANKS 8      /* number of simultaneously produced ranks V (nV) */
+#define APV_MAX_N 64         /* largest GEVD order n = L handled on-chip */
+
+/* status codes */
+#define APV_OK 0
+#define APV_ERR_ARG (-1)        /* invalid argument / unsupported size */
+#define APV_ERR_HIP (-2)        /* HIP runtime error */
+#define APV_ERR_NOT_PD (-3)     /* at least one bin: R_D + reg not positive definite */
+#define APV_ERR_NO_CONVERGE (-4)/* at least one bin: eigen-iteration hit the sweep cap */
+#define APV_ERR_RCCL (-5)       /* RCCL error / communicator not initialised */
+#define APV_ERR_STATE (-6)      /* unknown state name / wrong size */
+
+/* arithmetic the GEVD + filter run in (inputs are always c64) */
+#define APV_F32 0
+#define APV_F64 1
+
+/* dark-matrix loading, apvast.py:22-27 */
+#define APV_REG_ABS 0           /* B + reg_dark * I              (EXPERIMENTAL_REGULARIZATION=True) */
+#define APV_REG_REL 1           /* B + reg_dark * ||B||_2 * I    (else-branch; MATLAB diagonalLoading) */
+
+typedef struct apv_handle apv_handle;
+
+typedef struct apv_config {
+    int32_t abi_version;      /* APV_ABI_VERSION */
+    int32_t device;           /* HIP device ordinal */
+    int32_t n_bins;           /* K  : bins owned by this handle (its shard) */
+    int32_t n_srcs;           /* L  : loudspeakers = GEVD order n (<= APV_MAX_N) */
+    int32_t n_mics;           /* M  : control points per zone */
+    int32_t n_ranks;          /* nV : how many ranks V are produced (<= APV_MAX_RANKS) */
+    int32_t ranks[APV_MAX_RANKS]; /* the V list, each 1..L, ascending */
+    int32_t compute_dtype;    /* APV_F32 | APV_F64 */
+    int32_t out_c128;         /* 0: w c64 / lam f32;  1: w c128 / lam f64 */
+    int32_t reg_mode;         /* APV_REG_ABS | APV_REG_REL */
+    double  reg_dark;         /* 1e-7 in the Python dialect (apvast.py:23) */
+    double  reg_bright;       /* relative bright loading (apVast.m:552-569); 0 in the Python dialect */
+    double  mu;               /* trade-off parameter (apvast.py:49, 410) */
+    int32_t max_sweeps;       /* Jacobi sweep cap; 0 = default */
+    int32_t block_size;       /* N : STFT length for the streaming entry points (0 = kernel-level use only) */
+    int32_t hop_size;         /* H */
+    int32_t n_zones;          /* 1 or 2 zone programs in streaming mode (run_A/run_B, apvast.py:53-54) */
+    int32_t reserved[8];
+} apv_config;
+
+/* ---- lifetime ---------------------------------------------------------- */
+int  apv_create(const apv_config* cfg, apv_handle** out);     /* replaces: apvast.__init__ allocation, apvast.py:115-151 */
+int  apv_destroy(apv_handle* h);
+const char* apv_last_error(const apv_handle* h);               /* h may be NULL: last create() error */
+int  apv_abi_version(void);
+
+/* ---- device memory / stream plumbing ----------------------------------- */
+int  apv_dev_alloc(apv_handle* h, size_t bytes, void** d_ptr);
+int  apv_dev_free(apv_handle* h, void* d_ptr);
+int  apv_memcpy_h2d(apv_handle* h, void* d_dst, const void* h_src, size_t bytes);   /* async on the handle's stream */
+int  apv_memcpy_d2h(apv_handle* h, void* h_dst, const void* d_src, size_t bytes);   /* async on the handle's stream */
+int  apv_sync(apv_handle* h);                                  /* hipStreamSynchronize */
+/* HIP-event timer on the handle's stream (bench.py's roofline leg) */
+int  apv_timer_start(apv_handle* h);
+int  apv_timer_stop(apv_handle* h, float* elapsed_ms);         /* synchronises on the stop event */
+
+/* ---- the hot path, device-resident ------------------------------------- */
+/* One block of subband filter updates: for each owned bin k
+ *   R_B = X_B^H X_B, R_D = X_D^H X_D, r = X_B^H d          replaces apvast.py:329-364 (update_statistics)
+ *   U, lam = jdiag(R_B, R_D)                                replaces apvast.py:20-36, 378-387
+ *   w_V = sum_{i<V} (u_i^H r)/(lam_i+mu) u_i                replaces apvast.py:406-414
+ * R, U never touch HBM.  d_lam / d_status may be NULL.
+ */
+int  apv_update_dev(apv_handle* h, const void* d_XB, const void* d_XD, const void* d_d,
+                    void* d_w, void* d_lam, int32_t* d_status);
+
+/* Same from caller-owned host buffers (copies in, runs, copies out, syncs). */
+int  apv_update(apv_handle* h, const float* h_XB, const float* h_XD, const float* h_d,
+                void* h_w, void* h_lam, int32_t* h_status);
+
+/* K5': correlation only -> R_B, R_D [K][L][L], r [K][L] in the compute dtype
+ * (c64 for APV_F32, c128 for APV_F64), device-resident.   replaces apvast.py:329-364 */
+int  apv_corr_dev(apv_handle* h, const void* d_XB, const void* d_XD, const void* d_d,
+                  void* d_RB, void* d_RD, void* d_r);
+
+/* K6-K10: GEVD + filter from explicit R_B, R_D, r (compute dtype).   replaces apvast.py:378-414 */
+int  apv_gevd_vast_dev(apv_handle* h, const void* d_RB, const void* d_RD, const void* d_r,
+                       void* d_w, void* d_lam, int32_t* d_status);
+
+/* Module-level jdiag drop-in (apvast.py:20-36), batched: `batch` pairs of n x n Hermitian
+ * (A, B) in c128 (row-major), B loaded with reg per the handle's reg_mode/reg_dark.
+ * U: [batch][n][n] c128 (columns = eigenvectors, descending), lam: [batch][n] f64.
+ * Host buffers. n <= APV_MAX_N. */
+int  apv_jdiag_batched(apv_handle* h, int32_t n, int32_t batch, const double* h_A, const double* h_B,
+                       double* h_U, double* h_lam, int32_t* h_status);
+
+/* ---- STFT stages (K2-K4) ------------------------------------------------ */
+/* spectra[c][k] = rfft(window * x[c][:])  for `n_ch` channels of length N (f32 in, c64 out,
+ * both channel-major, device).      replaces apvast.py:202-203, 246-255, 430-431 */
+int  apv_stft_analysis_dev(apv_handle* h, int32_t n_ch, const float* d_x, void* d_spec);
+/* overlap[c] = shift(overlap[c], H) + window * irfft(spec[c]); out[c][0:H] = overlap[c][0:H].
+ *                                   replaces apvast.py:212-225, 265-293, 457-504 */
+int  apv_istft_ola_dev(apv_handle* h, int32_t n_ch, const void* d_spec, float* d_overlap, float* d_out);
+
+/* ---- multi-GPU: bins sharded across ranks, one RCCL all-gather ---------- */
+int  apv_comm_unique_id(char id_out[128]);                                /* rank 0 calls, then broadcasts */
+int  apv_comm_init(apv_handle* h, const char id[128], int32_t rank, int32_t world);
+/* gathers every rank's w shard [K][nV][L] into d_w_all [world*K][nV][L] (device) over xGMI */
+int  apv_allgather_filters_dev(apv_handle* h, const void* d_w_shard, void* d_w_all);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* APVAST_HIP_H */
