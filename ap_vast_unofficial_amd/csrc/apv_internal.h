@@ -17,6 +17,7 @@ struct GevdParams {
     double reg_bright;
     int reg_mode;
     int max_sweeps;
+    double sweep_tol2; // Jacobi stop threshold on off^2/||C||_F^2 seen during a sweep; 0 = per-dtype default
     int out_c128;
     // fused input (c64)
     const float2* XB;
@@ -56,6 +57,9 @@ struct apv_handle {
 // kernels_gevd.hip
 hipError_t apv_launch_gevd(const GevdParams& p, int compute_dtype, bool fused, hipStream_t s, std::string* why);
 size_t apv_gevd_spill_bytes(int n, int K, int compute_dtype);
+
+// kernels_gevd16.hip (order-16 fast path; hipErrorNotSupported when the problem does not qualify)
+hipError_t apv_launch_gevd16(const GevdParams& p, int compute_dtype, bool fused, hipStream_t s);
 
 // kernels_corr.hip
 hipError_t apv_launch_corr(int compute_dtype, int K, int M, int L, const float2* XB, const float2* XD,

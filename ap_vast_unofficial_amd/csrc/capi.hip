@@ -326,6 +326,7 @@ int apv_jdiag_batched(apv_handle* h, int32_t n, int32_t batch, const double* h_A
     p.nV = 1;
     p.ranks[0] = 1;
     p.reg_bright = 0.0;
+    p.sweep_tol2 = 1e-17;          // drop-in for jdiag: iterate to working precision
     p.out_c128 = 1;
     p.RB = dA;
     p.RD = dB;

@@ -16,6 +16,8 @@
 // gfx950 only.  Wavefront = 64.
 #include "apv_internal.h"
 
+#include <cstdlib>
+
 namespace {
 
 template <typename T>
@@ -43,12 +45,16 @@ template <typename T> __device__ __forceinline__ T cabs2(Cx<T> a) { return a.x *
 
 template <typename T> struct Tol;
 template <> struct Tol<double> {
-    static constexpr double sweep_tol2 = 1e-17;   // quadratic convergence: next state is ~1e-17 * ||C||
+    static constexpr double sweep_tol2 = 1e-10;   // quadratic convergence: the sweep that meets it leaves ~tol2^2
     static constexpr int max_sweeps = 16;
+    static constexpr double tiny = 1e-290;
+    static constexpr double skip_rel = 1e-60;
 };
 template <> struct Tol<float> {
     static constexpr float sweep_tol2 = 1e-8f;
-    static constexpr int max_sweeps = 12;
+    static constexpr int max_sweeps = 14;
+    static constexpr float tiny = 1e-35f;
+    static constexpr float skip_rel = 1e-24f;
 };
 
 // Round-robin (tournament) pairing: ne players (even), round r in [0, ne-1), slot a in [0, ne/2).
@@ -317,7 +323,7 @@ __global__ void __launch_bounds__(TPB) gevd_vast_kernel(const GevdParams p) {
                         const C beta = sA[pp * LD + qq];
                         const T b2 = cabs2(beta);
                         o = b2;
-                        if (b2 > (T)0) {
+                        if (b2 > Tol<T>::tiny && b2 > Tol<T>::skip_rel * (alpha * alpha + gamma * gamma)) {
                             const T ab = sqrt(b2);
                             const T tau = (gamma - alpha) / ((T)2 * ab);
                             const T t = copysign((T)1, tau) / (fabs(tau) + sqrt((T)1 + tau * tau));
@@ -377,7 +383,7 @@ __global__ void __launch_bounds__(TPB) gevd_vast_kernel(const GevdParams p) {
                 }
                 __syncthreads();
             }
-            if (off <= Tol<T>::sweep_tol2 * normF2) converged = true;
+            if (off <= (p.sweep_tol2 > 0.0 ? (T)p.sweep_tol2 : Tol<T>::sweep_tol2) * normF2) converged = true;
         }
         if (!converged) status = 2;
 
@@ -482,6 +488,11 @@ size_t apv_gevd_spill_bytes(int n, int K, int compute_dtype) {
 
 hipError_t apv_launch_gevd(const GevdParams& p, int compute_dtype, bool fused, hipStream_t s, std::string* why) {
     const int n = p.n;
+    static const bool force_generic = (getenv("APV_FORCE_GENERIC") != nullptr);
+    if (!force_generic) {
+        const hipError_t e16 = apv_launch_gevd16(p, compute_dtype, fused, s);
+        if (e16 != hipErrorNotSupported) return e16;
+    }
     if (n < 1 || n > APV_MAX_N) {
         if (why) *why = "GEVD order n out of range (1..64)";
         return hipErrorInvalidValue;

@@ -1,0 +1,495 @@
+// Order-16 specialisation of the fused subband update: one wavefront = one frequency bin.
+//
+//   stage 0  R_B, R_D = X^H X on the matrix cores (v_mfma_{f64,f32}_16x16x4): the [M][16] c64 slab of a
+//            bin is read once, fully coalesced (lane l reads element 64 s + l), and the SAME register feeds
+//            the A (X^H) and B (X) operands.                             apvast.py:329-364 per bin
+//   stage 1  Cholesky of R_D + reg I, in LDS                             apvast.py:22-27
+//   stage 2  C = L^-1 R_B L^-H                                           apvast.py:28-29
+//   stage 3  cyclic Jacobi, round-robin order: the 64 lanes are the 8x8 grid of 2x2 blocks of C; lane
+//            (a,b) holds rows {p_a,q_a} x columns {p_b,q_b} in registers for the round and the same
+//            column pair of two fixed rows of V.                          apvast.py:30
+//   stage 4-6 sort, X = L^-H Q, w_V = sum_{i<V} (x_i^H r)/(lam_i+mu) x_i  apvast.py:31-35, 406-414
+//
+// Everything between the load of X and the store of w stays in LDS/registers (13 KiB of LDS per wave).
+#include "apv_internal.h"
+
+namespace {
+
+constexpr int N = 16;
+constexpr int LD = 17;        // row stride of the LDS matrices, in complex elements
+
+template <typename T> struct Cx { T x, y; };
+template <typename T> __device__ __forceinline__ Cx<T> mk(T a, T b) { Cx<T> r; r.x = a; r.y = b; return r; }
+
+template <typename T> struct Prec;
+template <> struct Prec<double> {
+    // a sweep that met off^2/||C||^2 <= tol2 leaves ~tol2^2 behind (quadratic convergence): it is the last one
+    static constexpr double sweep_tol2 = 1e-10;
+    static constexpr int max_sweeps = 14;
+    static constexpr double tiny = 1e-290;        // |beta|^2 below this: rotation skipped (rsq would overflow)
+    static constexpr double skip_rel = 1e-60;     // |beta|^2 <= skip_rel (alpha^2+gamma^2): negligible, and tau^2 stays finite
+};
+template <> struct Prec<float> {
+    static constexpr float sweep_tol2 = 1e-8f;
+    static constexpr int max_sweeps = 12;
+    static constexpr float tiny = 1e-35f;
+    static constexpr float skip_rel = 1e-24f;
+};
+
+// 1/sqrt(x), full precision of T, x > 0 finite
+__device__ __forceinline__ double rsq_full(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double t = x * y;
+    const double e = __builtin_fma(-t, y, 1.0);
+    const double pp = __builtin_fma(0.375, e, 0.5);
+    const double ye = y * e;
+    y = __builtin_fma(ye, pp, y);
+    // second correction keeps the result within ~1 ulp when the hardware seed is only ~2^-23 accurate
+    const double t2 = x * y;
+    const double e2 = __builtin_fma(-t2, y, 1.0);
+    return __builtin_fma(y * e2, 0.5, y);
+}
+__device__ __forceinline__ float rsq_full(float x) {
+    float y = __builtin_amdgcn_rsqf(x);
+    const float t = x * y;
+    const float e = __builtin_fmaf(-t, y, 1.0f);
+    return __builtin_fmaf(y * e, 0.5f, y);
+}
+
+// tournament schedule for 16 players: nibble r of SEQ_P[a] / SEQ_Q[a] = smaller / larger index of slot a in round r
+struct Seq { unsigned long long p[8], q[8]; };
+constexpr Seq make_seq() {
+    Seq s{};
+    for (int a = 0; a < 8; ++a) {
+        unsigned long long sp = 0, sq = 0;
+        for (int r = 0; r < 15; ++r) {
+            int u = 0, v = 0;
+            if (a == 0) { u = 15; v = r; } else { u = (r + a) % 15; v = (r - a + 15) % 15; }
+            const int lo = u < v ? u : v, hi = u < v ? v : u;
+            sp |= (unsigned long long)lo << (4 * r);
+            sq |= (unsigned long long)hi << (4 * r);
+        }
+        s.p[a] = sp;
+        s.q[a] = sq;
+    }
+    return s;
+}
+__constant__ Seq c_seq = make_seq();
+
+template <typename T> __device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return __shfl(v, 0, 64);
+}
+
+using d4 = __attribute__((ext_vector_type(4))) double;
+using f4 = __attribute__((ext_vector_type(4))) float;
+
+// R = X^H X for one [M][16] c64 slab, result written to dst (LDS, row stride LD); optional r = X^H d -> sr
+template <typename T>
+__device__ __forceinline__ void correlate16(const float2* __restrict__ X, const float2* __restrict__ dvec, int M,
+                                            Cx<T>* dst, Cx<T>* sr, int lane);
+
+template <>
+__device__ __forceinline__ void correlate16<double>(const float2* __restrict__ X, const float2* __restrict__ dvec,
+                                                    int M, Cx<double>* dst, Cx<double>* sr, int lane) {
+    d4 re = {0, 0, 0, 0}, im = {0, 0, 0, 0};
+    double rx = 0, ry = 0;
+    const int msub = lane >> 4;
+    for (int m0 = 0; m0 < M; m0 += 4) {
+        const bool ok = (m0 + msub) < M;
+        const float2 xv = ok ? X[(size_t)m0 * N + lane] : make_float2(0.f, 0.f);
+        const double xr = xv.x, xi = xv.y;
+        re = __builtin_amdgcn_mfma_f64_16x16x4f64(xr, xr, re, 0, 0, 0);
+        re = __builtin_amdgcn_mfma_f64_16x16x4f64(xi, xi, re, 0, 0, 0);
+        im = __builtin_amdgcn_mfma_f64_16x16x4f64(xr, xi, im, 0, 0, 0);
+        im = __builtin_amdgcn_mfma_f64_16x16x4f64(-xi, xr, im, 0, 0, 0);
+        if (dvec != nullptr) {
+            const float2 dv = ok ? dvec[m0 + msub] : make_float2(0.f, 0.f);
+            rx += xr * (double)dv.x + xi * (double)dv.y;        // conj(x) * d
+            ry += xr * (double)dv.y - xi * (double)dv.x;
+        }
+    }
+    // f64 16x16x4 accumulator: row = (lane>>4) + 4*reg, col = lane&15
+    const int col = lane & 15;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) dst[(msub + 4 * t) * LD + col] = mk<double>(re[t], im[t]);
+    if (dvec != nullptr) {
+        rx += __shfl_xor(rx, 16, 64); ry += __shfl_xor(ry, 16, 64);
+        rx += __shfl_xor(rx, 32, 64); ry += __shfl_xor(ry, 32, 64);
+        if (lane < N) sr[lane] = mk<double>(rx, ry);
+    }
+}
+
+template <>
+__device__ __forceinline__ void correlate16<float>(const float2* __restrict__ X, const float2* __restrict__ dvec,
+                                                   int M, Cx<float>* dst, Cx<float>* sr, int lane) {
+    f4 re = {0, 0, 0, 0}, im = {0, 0, 0, 0};
+    float rx = 0, ry = 0;
+    const int msub = lane >> 4;
+    for (int m0 = 0; m0 < M; m0 += 4) {
+        const bool ok = (m0 + msub) < M;
+        const float2 xv = ok ? X[(size_t)m0 * N + lane] : make_float2(0.f, 0.f);
+        const float xr = xv.x, xi = xv.y;
+        re = __builtin_amdgcn_mfma_f32_16x16x4f32(xr, xr, re, 0, 0, 0);
+        re = __builtin_amdgcn_mfma_f32_16x16x4f32(xi, xi, re, 0, 0, 0);
+        im = __builtin_amdgcn_mfma_f32_16x16x4f32(xr, xi, im, 0, 0, 0);
+        im = __builtin_amdgcn_mfma_f32_16x16x4f32(-xi, xr, im, 0, 0, 0);
+        if (dvec != nullptr) {
+            const float2 dv = ok ? dvec[m0 + msub] : make_float2(0.f, 0.f);
+            rx += xr * dv.x + xi * dv.y;
+            ry += xr * dv.y - xi * dv.x;
+        }
+    }
+    // f32 16x16x4 accumulator: row = 4*(lane>>4) + reg, col = lane&15
+    const int col = lane & 15;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) dst[(4 * msub + t) * LD + col] = mk<float>(re[t], im[t]);
+    if (dvec != nullptr) {
+        rx += __shfl_xor(rx, 16, 64); ry += __shfl_xor(ry, 16, 64);
+        rx += __shfl_xor(rx, 32, 64); ry += __shfl_xor(ry, 32, 64);
+        if (lane < N) sr[lane] = mk<float>(rx, ry);
+    }
+}
+
+// wave-level ordering point between phases that exchange data through LDS (one wave per workgroup)
+__device__ __forceinline__ void wsync() { __syncthreads(); }
+
+template <typename T, bool FUSED>
+__global__ void __launch_bounds__(64) gevd16_kernel(const GevdParams p) {
+    using C = Cx<T>;
+    __shared__ C sA[N * LD];
+    __shared__ C sB[N * LD];
+    __shared__ C sV[N * LD];
+    __shared__ C sr[N];
+    __shared__ C scoef[N];
+    __shared__ T sDinv[N];
+    __shared__ T sLam[N];
+    __shared__ int sOrder[N];
+
+    const int lane = threadIdx.x;
+    const int k = blockIdx.x;
+    int status = 0;
+
+    // ---------------- stage 0 ----------------
+    if constexpr (FUSED) {
+        const size_t slab = (size_t)k * p.M * N;
+        correlate16<T>(p.XB + slab, p.d + (size_t)k * p.M, p.M, sA, sr, lane);
+        correlate16<T>(p.XD + slab, nullptr, p.M, sB, sr, lane);
+    } else {
+        const C* RB = reinterpret_cast<const C*>(p.RB) + (size_t)k * N * N;
+        const C* RD = reinterpret_cast<const C*>(p.RD) + (size_t)k * N * N;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int idx = lane + 64 * t, i = idx >> 4, j = idx & 15;
+            sA[i * LD + j] = RB[idx];
+            sB[i * LD + j] = RD[idx];
+        }
+        if (lane < N) sr[lane] = p.r ? reinterpret_cast<const C*>(p.r)[(size_t)k * N + lane] : mk<T>(0, 0);
+    }
+    wsync();
+
+    // ---------------- stage 1: dark loading + Cholesky (lower, in place) ----------------
+    if (lane < N) {
+        const C b = sB[lane * LD + lane];
+        sB[lane * LD + lane] = mk<T>(b.x + (T)p.reg_dark, 0);
+        sA[lane * LD + lane].y = 0;
+    }
+    wsync();
+    {
+        // lane (i = lane>>2, jq = lane&3) owns B[i][jq + 4t], t = 0..3
+        const int i = lane >> 2, jq = lane & 3;
+        for (int kk = 0; kk < N; ++kk) {
+            const T dkk = sB[kk * LD + kk].x;
+            if (!(dkk > (T)0) || !(dkk < (T)3.0e38)) { status = 1; break; }
+            const T inv = rsq_full(dkk);
+            if (lane == 0) sDinv[kk] = inv;
+            const C lik = sB[i * LD + kk];                    // unscaled column entries
+            C ljk[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) ljk[t] = sB[(jq + 4 * t) * LD + kk];
+            wsync();
+            const T inv2 = inv * inv;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int j = jq + 4 * t;
+                if (j > kk && i >= j) {
+                    // B[i][j] -= (B[i][kk]/d) * conj(B[j][kk]/d) * ... with d = sqrt(dkk): lik*conj(ljk)/dkk
+                    C v = sB[i * LD + j];
+                    v.x -= (lik.x * ljk[t].x + lik.y * ljk[t].y) * inv2;
+                    v.y -= (lik.y * ljk[t].x - lik.x * ljk[t].y) * inv2;
+                    sB[i * LD + j] = v;
+                }
+            }
+            if (jq == 0 && i > kk) sB[i * LD + kk] = mk<T>(lik.x * inv, lik.y * inv);
+            wsync();
+        }
+    }
+
+    if (status == 0) {
+        // ---------------- stage 2: C = L^-1 A L^-H (two forward substitutions) ----------------
+        // lane (i = lane>>2, jq) owns A[i][jq + 4t]
+        const int i = lane >> 2, jq = lane & 3;
+        for (int pass = 0; pass < 2; ++pass) {
+            C a[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) a[t] = sA[i * LD + jq + 4 * t];
+            for (int kk = 0; kk < N; ++kk) {
+                // row kk is final once scaled; rows below subtract L[i][kk] * row kk
+                const T inv = sDinv[kk];
+                if (i == kk) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        a[t] = mk<T>(a[t].x * inv, a[t].y * inv);
+                        sA[kk * LD + jq + 4 * t] = a[t];
+                    }
+                }
+                wsync();
+                if (i > kk) {
+                    const C l = sB[i * LD + kk];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const C y = sA[kk * LD + jq + 4 * t];
+                        a[t].x -= l.x * y.x - l.y * y.y;
+                        a[t].y -= l.x * y.y + l.y * y.x;
+                    }
+                }
+            }
+            wsync();
+            if (pass == 0) {
+                // rows are now final in sA; conjugate-transpose in place through registers
+#pragma unroll
+                for (int t = 0; t < 4; ++t) a[t] = sA[(jq + 4 * t) * LD + i];
+                wsync();
+#pragma unroll
+                for (int t = 0; t < 4; ++t) sA[i * LD + jq + 4 * t] = mk<T>(a[t].x, -a[t].y);
+                wsync();
+            }
+        }
+        // symmetrise: C[i][j] = (C[i][j] + conj(C[j][i])) / 2
+        {
+            C u[4], l[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                u[t] = sA[i * LD + jq + 4 * t];
+                l[t] = sA[(jq + 4 * t) * LD + i];
+            }
+            wsync();
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                sA[i * LD + jq + 4 * t] = mk<T>((T)0.5 * (u[t].x + l[t].x), (jq + 4 * t == i) ? (T)0 : (T)0.5 * (u[t].y - l[t].y));
+        }
+        // V = I
+#pragma unroll
+        for (int t = 0; t < 4; ++t) sV[i * LD + jq + 4 * t] = mk<T>((jq + 4 * t == i) ? (T)1 : (T)0, (T)0);
+        wsync();
+
+        // ---------------- stage 3: cyclic Jacobi ----------------
+        T nrm = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const C v = sA[i * LD + jq + 4 * t];
+            nrm += v.x * v.x + v.y * v.y;
+        }
+        const T normF2 = wave_sum(nrm);
+
+        const int a = lane >> 3, b = lane & 7;
+        const unsigned long long seqPa = c_seq.p[a], seqQa = c_seq.q[a];
+        const unsigned long long seqPb = c_seq.p[b], seqQb = c_seq.q[b];
+        const int max_sweeps = p.max_sweeps > 0 ? p.max_sweeps : Prec<T>::max_sweeps;
+        const T tol2 = p.sweep_tol2 > 0.0 ? (T)p.sweep_tol2 : Prec<T>::sweep_tol2;
+        bool converged = false;
+        const int v0 = (2 * a) * LD, v1 = (2 * a + 1) * LD;
+        for (int sweep = 0; sweep < max_sweeps && !converged; ++sweep) {
+            T off = 0;
+            for (int r = 0; r < 15; ++r) {
+                const int sh = 4 * r;
+                const int pa = (int)(seqPa >> sh) & 15, qa = (int)(seqQa >> sh) & 15;
+                const int pb = (int)(seqPb >> sh) & 15, qb = (int)(seqQb >> sh) & 15;
+                // this lane's 2x2 block of C and 2x2 block of V
+                const C xpp = sA[pa * LD + pb], xpq = sA[pa * LD + qb];
+                const C xqp = sA[qa * LD + pb], xqq = sA[qa * LD + qb];
+                const C v0p = sV[v0 + pb], v0q = sV[v0 + qb];
+                const C v1p = sV[v1 + pb], v1q = sV[v1 + qb];
+                // rotation of pair a from its diagonal block (8 lanes of a row compute the same thing)
+                const T alpha = sA[pa * LD + pa].x, gamma = sA[qa * LD + qa].x;
+                const C beta = sA[pa * LD + qa];
+                const T b2 = beta.x * beta.x + beta.y * beta.y;
+                off += b2;
+                T ca = 1, sax = 0, say = 0;
+                if (b2 > Prec<T>::tiny && b2 > Prec<T>::skip_rel * (alpha * alpha + gamma * gamma)) {
+                    const T iab = rsq_full(b2);                       // 1/|beta|
+                    const T tau = (gamma - alpha) * (T)0.5 * iab;
+                    const T rrho = rsq_full((T)1 + tau * tau);        // 1/sqrt(1+tau^2)
+                    const T c2 = (T)0.5 + (T)0.5 * fabs(tau) * rrho;  // cos^2(theta), in [1/2, 1]
+                    const T r3 = rsq_full(c2);
+                    ca = c2 * r3;
+                    const T sr_ = copysign((T)0.5 * rrho * r3, tau);  // sin(theta), sign of tau
+                    const T sc = sr_ * iab;
+                    sax = beta.x * sc;
+                    say = beta.y * sc;
+                }
+                // rotation of pair b lives in the lanes of row b
+                const int src = 8 * b;
+                const T cb = __shfl(ca, src, 64), sbx = __shfl(sax, src, 64), sby = __shfl(say, src, 64);
+                wsync();        // every lane has read its operands before anyone overwrites them
+
+                // columns: [x_p, x_q] J_b     (J = [[c, s], [-conj(s), c]])
+                C ypp, ypq, yqp, yqq;
+                ypp.x = cb * xpp.x - (sbx * xpq.x + sby * xpq.y);
+                ypp.y = cb * xpp.y - (sbx * xpq.y - sby * xpq.x);
+                ypq.x = cb * xpq.x + (sbx * xpp.x - sby * xpp.y);
+                ypq.y = cb * xpq.y + (sbx * xpp.y + sby * xpp.x);
+                yqp.x = cb * xqp.x - (sbx * xqq.x + sby * xqq.y);
+                yqp.y = cb * xqp.y - (sbx * xqq.y - sby * xqq.x);
+                yqq.x = cb * xqq.x + (sbx * xqp.x - sby * xqp.y);
+                yqq.y = cb * xqq.y + (sbx * xqp.y + sby * xqp.x);
+                // rows: J_a^H [y_p; y_q]      (J^H = [[c, -s], [conj(s), c]])
+                C zpp, zpq, zqp, zqq;
+                zpp.x = ca * ypp.x - (sax * yqp.x - say * yqp.y);
+                zpp.y = ca * ypp.y - (sax * yqp.y + say * yqp.x);
+                zpq.x = ca * ypq.x - (sax * yqq.x - say * yqq.y);
+                zpq.y = ca * ypq.y - (sax * yqq.y + say * yqq.x);
+                zqp.x = ca * yqp.x + (sax * ypp.x + say * ypp.y);
+                zqp.y = ca * yqp.y + (sax * ypp.y - say * ypp.x);
+                zqq.x = ca * yqq.x + (sax * ypq.x + say * ypq.y);
+                zqq.y = ca * yqq.y + (sax * ypq.y - say * ypq.x);
+                if (a == b) {
+                    zpq = mk<T>(0, 0);
+                    zqp = mk<T>(0, 0);
+                    zpp.y = 0;
+                    zqq.y = 0;
+                }
+                sA[pa * LD + pb] = zpp;
+                sA[pa * LD + qb] = zpq;
+                sA[qa * LD + pb] = zqp;
+                sA[qa * LD + qb] = zqq;
+                // V <- V J_b on rows 2a, 2a+1
+                C w0p, w0q, w1p, w1q;
+                w0p.x = cb * v0p.x - (sbx * v0q.x + sby * v0q.y);
+                w0p.y = cb * v0p.y - (sbx * v0q.y - sby * v0q.x);
+                w0q.x = cb * v0q.x + (sbx * v0p.x - sby * v0p.y);
+                w0q.y = cb * v0q.y + (sbx * v0p.y + sby * v0p.x);
+                w1p.x = cb * v1p.x - (sbx * v1q.x + sby * v1q.y);
+                w1p.y = cb * v1p.y - (sbx * v1q.y - sby * v1q.x);
+                w1q.x = cb * v1q.x + (sbx * v1p.x - sby * v1p.y);
+                w1q.y = cb * v1q.y + (sbx * v1p.y + sby * v1p.x);
+                sV[v0 + pb] = w0p;
+                sV[v0 + qb] = w0q;
+                sV[v1 + pb] = w1p;
+                sV[v1 + qb] = w1q;
+                wsync();
+            }
+            // every row of 8 lanes accumulated the same |beta_a|^2: the wave sum counts each pair 8 times
+            const T tot = wave_sum(off) * (T)0.125;
+            if (tot <= tol2 * normF2) converged = true;
+        }
+        if (!converged) status = 2;
+
+        // ---------------- stage 4: eigenvalues, descending order ----------------
+        if (lane < N) sLam[lane] = sA[lane * LD + lane].x;
+        wsync();
+        if (lane < N) {
+            const T li = sLam[lane];
+            int rank = 0;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const T lj = sLam[j];
+                rank += (lj > li) || (lj == li && j < lane);
+            }
+            sOrder[rank] = lane;
+        }
+
+        // ---------------- stage 5: X = L^-H Q (backward substitution, rows in registers) ----------------
+        {
+            C x[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) x[t] = sV[i * LD + jq + 4 * t];
+            for (int kk = N - 1; kk >= 0; --kk) {
+                const T inv = sDinv[kk];
+                if (i == kk) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        x[t] = mk<T>(x[t].x * inv, x[t].y * inv);
+                        sV[kk * LD + jq + 4 * t] = x[t];
+                    }
+                }
+                wsync();
+                if (i < kk) {
+                    const C l = sB[kk * LD + i];                     // conj(L[kk][i])
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const C y = sV[kk * LD + jq + 4 * t];
+                        x[t].x -= l.x * y.x + l.y * y.y;
+                        x[t].y -= l.x * y.y - l.y * y.x;
+                    }
+                }
+            }
+            wsync();
+        }
+
+        // ---------------- stage 6: coefficients (x_i^H r) / (lam_i + mu) ----------------
+        if (lane < N) {
+            T sx = 0, sy = 0;
+#pragma unroll
+            for (int l = 0; l < N; ++l) {
+                const C v = sV[l * LD + lane], rr = sr[l];
+                sx += v.x * rr.x + v.y * rr.y;
+                sy += v.x * rr.y - v.y * rr.x;
+            }
+            const T den = (T)1 / (sLam[lane] + (T)p.mu);
+            scoef[lane] = mk<T>(sx * den, sy * den);
+        }
+        wsync();
+    }
+
+    // ---------------- outputs ----------------
+    if (lane < N) {
+        T ax = 0, ay = 0;
+        int done = 0;
+        for (int t = 0; t < p.nV; ++t) {
+            const int V = p.ranks[t];
+            if (status != 1) {
+                for (; done < V; ++done) {
+                    const int c = sOrder[done];
+                    const C cf = scoef[c], v = sV[lane * LD + c];
+                    ax += cf.x * v.x - cf.y * v.y;
+                    ay += cf.x * v.y + cf.y * v.x;
+                }
+            }
+            const size_t o = ((size_t)k * p.nV + t) * N + lane;
+            if (p.out_c128) reinterpret_cast<double2*>(p.w)[o] = make_double2((double)ax, (double)ay);
+            else reinterpret_cast<float2*>(p.w)[o] = make_float2((float)ax, (float)ay);
+        }
+        if (p.lam != nullptr) {
+            const T lv = (status != 1) ? sLam[sOrder[lane]] : (T)0;
+            if (p.out_c128) reinterpret_cast<double*>(p.lam)[(size_t)k * N + lane] = (double)lv;
+            else reinterpret_cast<float*>(p.lam)[(size_t)k * N + lane] = (float)lv;
+        }
+    }
+    if (p.U != nullptr) {
+        C* U = reinterpret_cast<C*>(p.U) + (size_t)k * N * N;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int idx = lane + 64 * t, i = idx >> 4, j = idx & 15;
+            U[idx] = (status != 1) ? sV[i * LD + sOrder[j]] : mk<T>(0, 0);
+        }
+    }
+    if (p.status != nullptr && lane == 0) p.status[k] = status;
+}
+
+}  // namespace
+
+// n == 16, absolute dark loading, no bright loading: the fast path.  Returns hipErrorNotSupported otherwise.
+hipError_t apv_launch_gevd16(const GevdParams& p, int compute_dtype, bool fused, hipStream_t s) {
+    if (p.n != 16 || p.reg_mode != APV_REG_ABS || p.reg_bright != 0.0) return hipErrorNotSupported;
+    if (p.K <= 0) return hipSuccess;
+    if (compute_dtype == APV_F64) {
+        if (fused) hipLaunchKernelGGL((gevd16_kernel<double, true>), dim3(p.K), dim3(64), 0, s, p);
+        else hipLaunchKernelGGL((gevd16_kernel<double, false>), dim3(p.K), dim3(64), 0, s, p);
+    } else {
+        if (fused) hipLaunchKernelGGL((gevd16_kernel<float, true>), dim3(p.K), dim3(64), 0, s, p);
+        else hipLaunchKernelGGL((gevd16_kernel<float, false>), dim3(p.K), dim3(64), 0, s, p);
+    }
+    return hipGetLastError();
+}
