@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 ABI_VERSION = 1
-MAX_RANKS = 8
+MAX_RANKS = 64
 MAX_N = 64
 
 F32, F64 = 0, 1
@@ -27,6 +27,7 @@ EXPORTS = (
     "apv_timer_start", "apv_timer_stop",
     "apv_update_dev", "apv_update", "apv_corr_dev", "apv_gevd_vast_dev", "apv_jdiag_batched",
     "apv_stft_analysis_dev", "apv_istft_ola_dev",
+    "apv_stream_init", "apv_process_block", "apv_state_bytes", "apv_get_state", "apv_set_state",
     "apv_comm_unique_id", "apv_comm_init", "apv_allgather_filters_dev",
 )
 
@@ -81,6 +82,11 @@ def load():
     lib.apv_jdiag_batched.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
     lib.apv_stft_analysis_dev.argtypes = [vp, i32, vp, vp]
     lib.apv_istft_ola_dev.argtypes = [vp, i32, vp, vp, vp]
+    lib.apv_stream_init.argtypes = [vp, i32, vp, vp, i32, i32, i32]
+    lib.apv_process_block.argtypes = [vp, vp, vp, vp]
+    lib.apv_state_bytes.argtypes = [vp, C.c_char_p, C.POINTER(sz)]
+    lib.apv_get_state.argtypes = [vp, C.c_char_p, vp, sz]
+    lib.apv_set_state.argtypes = [vp, C.c_char_p, vp, sz]
     lib.apv_comm_unique_id.argtypes = [C.c_char_p]
     lib.apv_comm_init.argtypes = [vp, C.c_char_p, i32, i32]
     lib.apv_allgather_filters_dev.argtypes = [vp, vp, vp]
@@ -310,6 +316,29 @@ class Engine:
         for b in (dsp, dov, dout):
             b.free()
         return ov, out
+
+    # -- streaming ------------------------------------------------------------
+    def stream_init(self, rir_A, rir_B, reference_index_A, reference_index_B, modeling_delay):
+        rir_A = np.ascontiguousarray(rir_A, dtype=np.float64)
+        rir_B = np.ascontiguousarray(rir_B, dtype=np.float64)
+        self._chk(self.lib.apv_stream_init(self.h, rir_A.shape[0], _ptr(rir_A), _ptr(rir_B),
+                                           int(reference_index_A), int(reference_index_B), int(modeling_delay)))
+
+    def process_block(self, in_A, in_B, n_out):
+        in_A = np.ascontiguousarray(in_A, dtype=np.float32).ravel()
+        in_B = np.ascontiguousarray(in_B, dtype=np.float32).ravel()
+        out = np.empty((n_out, self.cfg.hop_size), dtype=np.float32)
+        self._chk(self.lib.apv_process_block(self.h, _ptr(in_A), _ptr(in_B), _ptr(out)))
+        return out
+
+    def get_state(self, name, shape, dtype):
+        out = np.empty(shape, dtype=dtype)
+        self._chk(self.lib.apv_get_state(self.h, name.encode(), _ptr(out), out.nbytes))
+        return out
+
+    def set_state(self, name, arr):
+        arr = np.ascontiguousarray(arr)
+        self._chk(self.lib.apv_set_state(self.h, name.encode(), _ptr(arr), arr.nbytes))
 
     # -- multi-GPU --------------------------------------------------------------
     @staticmethod

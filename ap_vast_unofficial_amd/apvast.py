@@ -1,0 +1,228 @@
+"""Drop-in host surface: class ``apvast`` and function ``jdiag`` with the reference's
+signatures (reference Python/apvast.py:20, 39-56, 153), computing on the MI355X through
+libapvast_hip.so.  No CPU fallback: constructing the class without the HIP library or
+without a GPU raises.
+
+What is the same as the reference
+  * positional constructor signature (apvast.py:40-56) and its three RuntimeErrors with the
+    same messages (apvast.py:86-90, 154-155); LinAlgError when a dark matrix is not positive
+    definite (apvast.py:21, 24)
+  * ``process_input_buffers(input_A, input_B) -> (A, B, A_t, B_t)``: four lists of
+    ``number_of_eigenvectors`` arrays of shape (hop_size, number_of_srcs), one per rank 1..V
+    (apvast.py:406-422, 498-506); ``None`` for a zone that does not run (apvast.py:433-443)
+  * ``rirs.mat`` ingest: ``rirA``/``rirB`` of shape (rir_len, L, M) (make_python_test.m:4, 18)
+  * readable attributes: hop_size, window, number_of_srcs, number_of_mics, w_A/w_B,
+    lambda_A/lambda_B, filter_spectra_*, input_spectrum_A/B
+What is different (keyword-only, after ``perceptual``)
+  * ``mode="subband"`` (default, the only mode on the GPU today): one (R_B, R_D) pair, one GEVD
+    and one filter PER FREQUENCY BIN from the current block's control-point spectra.  The
+    reference's time-domain ("broadband") statistics over ``statistics_buffer_length`` samples with
+    ``filter_length``-tap filters (apvast.py:329-364) are restated on the CPU in oracle/ only.
+    ``filter_length`` and ``statistics_buffer_length`` are accepted and stored, not used.
+  * outputs are fresh arrays (the reference returns views into its overlap buffers that the next
+    call overwrites, apvast.py:500-504).
+  * ``perceptual=True`` needs the third-party ``libdetectability`` (apvast.py:4, 77-83), which is
+    not vendored by the reference; it raises NotImplementedError here.
+"""
+import numpy as np
+
+from . import _capi
+
+EXPERIMENTAL_NORMALIZE_GAINS = True     # apvast.py:6 (only used by the perceptual model)
+EXPERIMENTAL_REGULARIZATION = True      # apvast.py:7: True -> B + 1e-7 I, False -> B + 1e-8 ||B||_2 I
+
+
+def load_rirs(path):
+    """scipy.io.loadmat ingest of the reference's rirs.mat (make_python_test.m:4): (rirA, rirB)."""
+    import scipy.io
+    mat = scipy.io.loadmat(path)
+    return np.ascontiguousarray(mat["rirA"], dtype=np.float64), np.ascontiguousarray(mat["rirB"], dtype=np.float64)
+
+
+_jdiag_engine = None
+
+
+def jdiag(A, B, device=0):
+    """Joint diagonalisation on the GPU: (U, D) with U^H (B + reg I) U = I, U^H A U = D, D descending
+    and returned as a diagonal MATRIX, as apvast.py:20-36 does.  Real or complex Hermitian, n <= 64.
+    Raises numpy.linalg.LinAlgError when the loaded B is not positive definite (apvast.py:21)."""
+    global _jdiag_engine
+    A = np.asarray(A)
+    B = np.asarray(B)
+    n = A.shape[0]
+    if A.shape != (n, n) or B.shape != (n, n):
+        raise ValueError("jdiag expects two square matrices of equal size")
+    if n > _capi.MAX_N:
+        raise NotImplementedError(f"GPU jdiag handles n <= {_capi.MAX_N} (broadband orders are a 'next' row, DESIGN.md)")
+    mode = _capi.REG_ABS if EXPERIMENTAL_REGULARIZATION else _capi.REG_REL
+    key = (device, mode)
+    if _jdiag_engine is None or _jdiag_engine[0] != key:
+        eng = _capi.Engine(1, 4, 4, reg_mode=mode, reg_dark=1e-7 if mode == _capi.REG_ABS else 1e-8, device=device)
+        _jdiag_engine = (key, eng)
+    U, lam = _jdiag_engine[1].jdiag_batched(A[None], B[None])
+    U, lam = U[0], lam[0]
+    if not (np.iscomplexobj(A) or np.iscomplexobj(B)):
+        U = np.ascontiguousarray(U.real)
+    return U, np.diag(lam)
+
+
+class apvast:
+    def __init__(self,
+                 block_size: int,
+                 rir_A,
+                 rir_B,
+                 filter_length: int,
+                 modeling_delay: int,
+                 reference_index_A: int,
+                 reference_index_B: int,
+                 number_of_eigenvectors: int,
+                 mu: float,
+                 statistics_buffer_length: int,
+                 hop_size: int = None,
+                 sampling_rate: int = 48000,
+                 run_A: bool = True,
+                 run_B: bool = True,
+                 perceptual: bool = True,
+                 *,
+                 mode: str = "subband",
+                 dialect: str = "python",
+                 device: int = 0,
+                 dtype: str = "f64",
+                 seed=None):
+        self.block_size = block_size
+        self.rir_A = rir_A
+        self.rir_B = rir_B
+        self.filter_length = filter_length
+        self.modeling_delay = modeling_delay
+        self.reference_index_A = reference_index_A
+        self.reference_index_B = reference_index_B
+        self.number_of_eigenvectors = number_of_eigenvectors
+        self.mu = mu
+        self.sampling_rate = sampling_rate
+        self.statistics_buffer_length = statistics_buffer_length
+        self.run_A = run_A
+        self.run_B = run_B
+        self.perceptual = perceptual
+        self.mode, self.dialect, self.dtype = mode, dialect, dtype
+
+        if self.block_size % 2 != 0:
+            raise RuntimeError("block size must be modulo 2")                 # apvast.py:86-87
+        if rir_A.shape != rir_B.shape:
+            raise RuntimeError("rirs of unequal size")                        # apvast.py:89-90
+        if perceptual:
+            raise NotImplementedError(
+                "perceptual=True needs the third-party libdetectability model (apvast.py:4, 77-83), which the "
+                "reference does not vendor; pass perceptual=False (all-ones weights, apvast.py:326-327)")
+        if mode != "subband":
+            raise NotImplementedError(
+                "only mode='subband' runs on the GPU; the reference's time-domain mode is restated in oracle/ "
+                "for parity checks and is a 'next' row of DESIGN.md")
+        if dialect not in ("python", "matlab"):
+            raise ValueError("dialect must be 'python' or 'matlab'")
+        if not (run_A or run_B):
+            raise ValueError("at least one of run_A / run_B must be True")
+
+        self.hop_size = hop_size if hop_size else self.block_size // 2        # apvast.py:93
+        self.window = np.sin(np.pi / self.block_size * np.arange(self.block_size)).reshape(-1, 1)   # apvast.py:94
+        self.rir_length, self.number_of_srcs, self.number_of_mics = rir_A.shape  # apvast.py:97-99
+        L, M, N, H = self.number_of_srcs, self.number_of_mics, self.block_size, self.hop_size
+        V = int(number_of_eigenvectors)
+        if not 1 <= V <= L:
+            raise ValueError("subband mode: number_of_eigenvectors must be in 1..number_of_srcs")
+        self._ranks = list(range(1, V + 1))            # the reference emits every rank 1..V (apvast.py:406-422)
+        self._K = N // 2 + 1
+        if dialect == "python":
+            reg_mode = _capi.REG_ABS if EXPERIMENTAL_REGULARIZATION else _capi.REG_REL
+            reg_dark = 1e-7 if EXPERIMENTAL_REGULARIZATION else 1e-8          # apvast.py:22-27
+            reg_bright = 0.0
+        else:
+            reg_mode, reg_dark, reg_bright = _capi.REG_REL, 5e-3, 1e-8        # apVast.m:552-569
+        zones = (1 if run_A else 0) | (2 if run_B else 0)
+        self._eng = _capi.Engine(self._K, L, M, ranks=self._ranks, mu=mu, compute_dtype=dtype,
+                                 reg_mode=reg_mode, reg_dark=reg_dark, reg_bright=reg_bright, device=device,
+                                 block_size=N, hop_size=H, n_zones=zones)
+        self._eng.stream_init(rir_A, rir_B, reference_index_A, reference_index_B, modeling_delay)
+        self._n_out = (int(run_A) + int(run_B)) * V * L + 2 * L
+        if dialect == "python":
+            # apvast.py:124-129: response buffers start as 1e-3 * randn, drawn from the global NumPy RNG in this
+            # order; pass seed=... for a private, reproducible generator instead
+            rs = np.random if seed is None else np.random.RandomState(seed)
+            resp = [1e-3 * rs.randn(N, L, M) for _ in range(4)]               # A->A, A->B, B->A, B->B
+            tresp = [1e-3 * rs.randn(N, M) for _ in range(2)]
+            self.set_state({"response": np.stack(resp), "target_response": np.stack(tresp)})
+        self.w_A = self.w_B = None
+        self.lambda_A = self.lambda_B = None
+
+    # ---- per-hop call (apvast.py:153-165) -------------------------------------------------
+    def process_input_buffers(self, input_A, input_B):
+        input_A = np.asarray(input_A)
+        input_B = np.asarray(input_B)
+        if input_A.size != self.hop_size or input_B.size != self.hop_size:
+            raise RuntimeError("invalid input size")                          # apvast.py:154-155
+        out = self._eng.process_block(input_A, input_B, self._n_out).astype(np.float64)
+        L, V, H = self.number_of_srcs, len(self._ranks), self.hop_size
+        pos = 0
+        res = []
+        for run in (self.run_A, self.run_B):
+            if run:
+                blk = out[pos:pos + V * L].reshape(V, L, H)
+                res.append([np.ascontiguousarray(blk[i].T) for i in range(V)])
+                pos += V * L
+            else:
+                res.append(None)                                              # apvast.py:433-443
+        for _ in range(2):
+            t = np.ascontiguousarray(out[pos:pos + L].T)
+            res.append([t.copy() for _ in range(V)])                          # same target filter at every rank
+            pos += L
+        self._refresh_attributes()
+        return tuple(res)
+
+    def _refresh_attributes(self):
+        e, K, L, V = self._eng, self._K, self.number_of_srcs, len(self._ranks)
+        spec = e.get_state("input_spectrum", (2, K), np.complex64)
+        self.input_spectrum_A = spec[0].astype(np.complex128).reshape(-1, 1)   # apvast.py:430-431
+        self.input_spectrum_B = spec[1].astype(np.complex128).reshape(-1, 1)
+        for z, run in (("A", self.run_A), ("B", self.run_B)):
+            if not run:
+                continue
+            w = e.get_state("w_" + z, (K, V, L), e.w_dtype).astype(np.complex128)
+            lam = e.get_state("lambda_" + z, (K, L), e.lam_dtype).astype(np.float64)
+            setattr(self, "w_" + z, np.ascontiguousarray(w.transpose(1, 0, 2)))           # (V, K, L)
+            setattr(self, "lambda_" + z, lam)
+            setattr(self, "filter_spectra_" + z, [getattr(self, "w_" + z)[i] for i in range(V)])   # V x (K, L)
+
+    # ---- checkpoint / fixtures -----------------------------------------
+    def get_state(self):
+        e, N, L, M = self._eng, self.block_size, self.number_of_srcs, self.number_of_mics
+        resp = np.stack([e.get_state(f"response{p}", (M, L, N), np.float32) for p in range(4)])
+        tresp = np.stack([e.get_state(f"target_response{z}", (M, N), np.float32) for z in range(2)])
+        return {
+            "response": resp.transpose(0, 3, 2, 1).astype(np.float64),           # (4, N, L, M)
+            "target_response": tresp.transpose(0, 2, 1).astype(np.float64),      # (2, N, M)
+            "input_block": e.get_state("input_block", (2, N), np.float32).astype(np.float64),
+            "input_history": np.stack([e.get_state(f"input_history{g}", (self.rir_length - 1 + self.hop_size,),
+                                                   np.float32) for g in range(2)]).astype(np.float64),
+            "out_overlap": e.get_state("out_overlap", (self._n_out, N), np.float32).astype(np.float64),
+        }
+
+    def set_state(self, state):
+        e = self._eng
+        if "response" in state:
+            r = np.asarray(state["response"], dtype=np.float32)                  # (4, N, L, M) -> [M][L][N]
+            for p in range(4):
+                e.set_state(f"response{p}", np.ascontiguousarray(r[p].transpose(2, 1, 0)))
+        if "target_response" in state:
+            t = np.asarray(state["target_response"], dtype=np.float32)           # (2, N, M) -> [M][N]
+            for z in range(2):
+                e.set_state(f"target_response{z}", np.ascontiguousarray(t[z].T))
+        if "input_block" in state:
+            e.set_state("input_block", np.asarray(state["input_block"], dtype=np.float32))
+        if "input_history" in state:
+            hst = np.asarray(state["input_history"], dtype=np.float32)
+            for g in range(2):
+                e.set_state(f"input_history{g}", hst[g])
+        if "out_overlap" in state:
+            e.set_state("out_overlap", np.asarray(state["out_overlap"], dtype=np.float32))
+
+    def close(self):
+        self._eng.close()

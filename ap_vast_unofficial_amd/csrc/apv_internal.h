@@ -49,10 +49,15 @@ struct apv_handle {
     int32_t* d_status;
     void* d_Lspill;
     size_t lspill_bytes;
+    struct apv_stream* st;   // streaming state (apv_stream_init), owned
     void* comm;       // ncclComm_t
     int comm_rank, comm_world;
     std::string err;
 };
+
+void apv_stream_free(apv_handle* h);      // stream.hip
+int apv_fail(apv_handle* h, int code, const std::string& msg);
+GevdParams apv_base_params(const apv_handle* h);
 
 // kernels_gevd.hip
 hipError_t apv_launch_gevd(const GevdParams& p, int compute_dtype, bool fused, hipStream_t s, std::string* why);
@@ -69,3 +74,21 @@ hipError_t apv_launch_corr(int compute_dtype, int K, int M, int L, const float2*
 hipError_t apv_launch_stft_analysis(int N, int n_ch, const float* x, float2* spec, hipStream_t s, std::string* why);
 hipError_t apv_launch_istft_ola(int N, int H, int n_ch, const float2* spec, float* overlap, float* out,
                                 hipStream_t s, std::string* why);
+hipError_t apv_launch_stft_analysis_strided(int N, int n_ch, const float* x, int ring_off, float2* spec,
+                                            long stride_c, long stride_k, hipStream_t s, std::string* why);
+hipError_t apv_launch_istft_ola_strided(int N, int H, int n_ch, const float2* spec, long stride_c, long stride_k,
+                                        float* overlap, float* out, hipStream_t s, std::string* why);
+
+// kernels_stream.hip
+// y = FIR(rir, x) for one hop, appended to the ring response buffers:
+//   resp[c*N + ((N-H+n + ring_off) & (N-1))] = sum_p rir[p*C + c] * xhist[P-1 + n - p],  n < H, c < C
+hipError_t apv_launch_fir_hop(int C, int P, int H, int N, int ring_off, const float* rir, const float* xhist,
+                              float* resp, hipStream_t s);
+hipError_t apv_launch_hist_update(int P, int H, int pad, const float* old_hist, const float* x, float* new_hist,
+                                  hipStream_t s);
+hipError_t apv_launch_ring_append(int N, int H, int ring_off, const float* x, float* ring, hipStream_t s);
+int apv_fir_pad();
+// out[ch][k] = in_spec[k] * filt(ch, k): ch < n_filt channels taken from the bin-major filter bank
+// w[k][n_filt] (c64 or c128), remaining channels from the channel-major table tgt[ch - n_filt][k]
+hipError_t apv_launch_apply_filters(int K, int n_filt, int n_tgt, const float2* in_spec, const void* w, int w_c128,
+                                    const float2* tgt, float2* out, hipStream_t s);

@@ -31,7 +31,19 @@ size_t csize(const apv_handle* h) { return h->cfg.compute_dtype == APV_F64 ? 16 
 size_t wsize(const apv_handle* h) { return h->cfg.out_c128 ? 16 : 8; }
 size_t lsize(const apv_handle* h) { return h->cfg.out_c128 ? 8 : 4; }
 
-GevdParams base_params(const apv_handle* h) {
+}  // namespace
+
+int apv_fail(apv_handle* h, int code, const std::string& msg) { return fail(h, code, msg); }
+
+GevdParams apv_base_params(const apv_handle* h);
+
+namespace {
+
+GevdParams base_params(const apv_handle* h) { return apv_base_params(h); }
+
+}  // namespace
+
+GevdParams apv_base_params(const apv_handle* h) {
     GevdParams p;
     std::memset(&p, 0, sizeof(p));
     const apv_config& c = h->cfg;
@@ -49,6 +61,8 @@ GevdParams base_params(const apv_handle* h) {
     p.Lspill = h->d_Lspill;
     return p;
 }
+
+namespace {
 
 int ensure_spill(apv_handle* h, int n, int K) {
     const size_t need = apv_gevd_spill_bytes(n, K, h->cfg.compute_dtype);
@@ -89,7 +103,7 @@ int apv_create(const apv_config* cfg, apv_handle** out) {
     if (cfg->abi_version != APV_ABI_VERSION) return fail(nullptr, APV_ERR_ARG, "ABI version mismatch");
     if (cfg->n_srcs < 1 || cfg->n_srcs > APV_MAX_N) return fail(nullptr, APV_ERR_ARG, "n_srcs must be in 1..64");
     if (cfg->n_bins < 0 || cfg->n_mics < 1) return fail(nullptr, APV_ERR_ARG, "n_bins/n_mics out of range");
-    if (cfg->n_ranks < 1 || cfg->n_ranks > APV_MAX_RANKS) return fail(nullptr, APV_ERR_ARG, "n_ranks must be in 1..8");
+    if (cfg->n_ranks < 1 || cfg->n_ranks > APV_MAX_RANKS) return fail(nullptr, APV_ERR_ARG, "n_ranks must be in 1..64");
     for (int i = 0; i < cfg->n_ranks; ++i) {
         if (cfg->ranks[i] < 1 || cfg->ranks[i] > cfg->n_srcs) return fail(nullptr, APV_ERR_ARG, "rank V out of 1..L");
         if (i && cfg->ranks[i] <= cfg->ranks[i - 1]) return fail(nullptr, APV_ERR_ARG, "ranks must be ascending");
@@ -112,6 +126,7 @@ int apv_create(const apv_config* cfg, apv_handle** out) {
     h->d_status = nullptr;
     h->d_Lspill = nullptr;
     h->lspill_bytes = 0;
+    h->st = nullptr;
     h->comm = nullptr;
     h->comm_rank = 0;
     h->comm_world = 1;
@@ -143,6 +158,7 @@ int apv_destroy(apv_handle* h) {
     if (!h) return APV_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    apv_stream_free(h);
     if (h->comm) ncclCommDestroy((ncclComm_t)h->comm);
     void* bufs[] = {h->d_XB, h->d_XD, h->d_d, h->d_w, h->d_lam, h->d_status, h->d_Lspill};
     for (void* b : bufs)

@@ -85,18 +85,22 @@ __device__ __forceinline__ void fft_lds(float2* z, int Nh, int lg, const float2*
 __device__ __forceinline__ int bitrev(int v, int lg) { return (int)(__brev((unsigned)v) >> (32 - lg)); }
 
 // spec element (c, k) is stored at spec[c * stride_c + k * stride_k]
+// x is a ring: logical sample n of channel c lives at x[c*N + ((n + ring_off) & (N-1))]
 __global__ void __launch_bounds__(STFT_TPB) stft_analysis_kernel(int N, int lg, const float* __restrict__ x,
-                                                                 float2* __restrict__ spec, long stride_c,
-                                                                 long stride_k, const float2* __restrict__ tw,
+                                                                 int ring_off, float2* __restrict__ spec,
+                                                                 long stride_c, long stride_k,
+                                                                 const float2* __restrict__ tw,
                                                                  const float* __restrict__ win) {
     extern __shared__ float2 z[];
     const int Nh = N >> 1;
     const int c = blockIdx.x, tid = threadIdx.x;
-    const float2* xin = reinterpret_cast<const float2*>(x + (size_t)c * N);
+    const float* xin = x + (size_t)c * N;
     const float2* w2 = reinterpret_cast<const float2*>(win);
+    const int mask = N - 1;
     for (int n = tid; n < Nh; n += STFT_TPB) {
-        const float2 v = xin[n], w = w2[n];
-        z[bitrev(n, lg)] = make_float2(v.x * w.x, v.y * w.y);
+        const float2 w = w2[n];
+        const float v0 = xin[(2 * n + ring_off) & mask], v1 = xin[(2 * n + 1 + ring_off) & mask];
+        z[bitrev(n, lg)] = make_float2(v0 * w.x, v1 * w.y);
     }
     __syncthreads();
     fft_lds(z, Nh, lg, tw, N);
@@ -178,8 +182,8 @@ static bool stft_size_ok(int N, std::string* why) {
     return true;
 }
 
-hipError_t apv_launch_stft_analysis_strided(int N, int n_ch, const float* x, float2* spec, long stride_c,
-                                            long stride_k, hipStream_t s, std::string* why) {
+hipError_t apv_launch_stft_analysis_strided(int N, int n_ch, const float* x, int ring_off, float2* spec,
+                                            long stride_c, long stride_k, hipStream_t s, std::string* why) {
     if (!stft_size_ok(N, why)) return hipErrorInvalidValue;
     if (n_ch <= 0) return hipSuccess;
     Tables t;
@@ -187,7 +191,7 @@ hipError_t apv_launch_stft_analysis_strided(int N, int n_ch, const float* x, flo
     if (e != hipSuccess) return e;
     const int Nh = N / 2;
     hipLaunchKernelGGL(stft_analysis_kernel, dim3(n_ch), dim3(STFT_TPB), sizeof(float2) * Nh, s, N, ilog2(Nh), x,
-                       spec, stride_c, stride_k, t.tw, t.win);
+                       ring_off & (N - 1), spec, stride_c, stride_k, t.tw, t.win);
     return hipGetLastError();
 }
 
@@ -209,7 +213,7 @@ hipError_t apv_launch_istft_ola_strided(int N, int H, int n_ch, const float2* sp
 }
 
 hipError_t apv_launch_stft_analysis(int N, int n_ch, const float* x, float2* spec, hipStream_t s, std::string* why) {
-    return apv_launch_stft_analysis_strided(N, n_ch, x, spec, N / 2 + 1, 1, s, why);
+    return apv_launch_stft_analysis_strided(N, n_ch, x, 0, spec, N / 2 + 1, 1, s, why);
 }
 
 hipError_t apv_launch_istft_ola(int N, int H, int n_ch, const float2* spec, float* overlap, float* out,

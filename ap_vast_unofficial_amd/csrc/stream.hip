@@ -1,0 +1,314 @@
+// Streaming composition of the subband hot path: one call = one hop of both input signals.
+//
+//   apv_stream_init   : upload RIRs, allocate every buffer once      reference Python/apvast.py:97-151
+//   apv_process_block : per hop                                       apvast.py:153-165
+//       K1  RIR convolution of the hop to all control points          apvast.py:167-194
+//       K2  sine-window analysis STFT of the response / target rings  apvast.py:197-203, 244-255
+//       K5'-K10 per-bin correlate + jdiag + VAST filter, per zone     apvast.py:329-414 (subband form)
+//       K3  output spectra = input spectrum x filter bank             apvast.py:445-452
+//       K4  inverse STFT, window, overlap-add, emit first H samples   apvast.py:457-504
+//
+// Device layouts: control-point channel c = m*L + l (loudspeaker fastest), so a bin's control-point
+// matrix X[k] = [M][L] is one contiguous slab of the bin-major spectra [K][M*L].
+#include "apv_internal.h"
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+struct apv_stream {
+    int N, H, K, L, M, C, P, nV, zones, pad;
+    int ring_off;                 // physical index of logical sample 0 in every ring
+    int cur;                      // which input-history buffer is current
+    int n_out;                    // synthesis channels: zones*nV*L filtered + 2*L target
+    float* rir[2];                // [P][C]  zone A, zone B
+    float* trir[2];               // [P][M]  target RIRs (reference loudspeaker, delayed)
+    float* xhist[2][2];           // [buf][signal][P-1+H+pad]
+    float* xin;                   // [2][H] staging of the hop
+    float* resp[4];               // [C][N] rings: A->A, A->B, B->A, B->B
+    float* tresp[2];              // [M][N] rings: target A, target B
+    float* inblk;                 // [2][N] rings: input blocks
+    float2* X[4];                 // [K][C] bin-major control-point spectra
+    float2* tspec[2];             // [K][M]
+    float2* inspec;               // [2][K]
+    void* w[2];                   // [K][nV][L] per zone
+    void* lam[2];                 // [K][L]
+    int32_t* status[2];           // [K]
+    float2* tgt;                  // [L][K] target filter spectra (shared by A_t and B_t, apvast.py:389-390)
+    float2* outspec;              // [n_out][K]
+    float* outov;                 // [n_out][N]
+    float* out;                   // [n_out][H]
+    std::vector<int32_t> h_status;
+};
+
+namespace {
+
+#define SCHK(h, call)                                                                    \
+    do {                                                                                 \
+        hipError_t _e = (call);                                                          \
+        if (_e != hipSuccess) return apv_fail(h, APV_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+template <typename T>
+int dalloc(apv_handle* h, T** p, size_t count) {
+    SCHK(h, hipMalloc((void**)p, sizeof(T) * (count ? count : 1)));
+    SCHK(h, hipMemsetAsync(*p, 0, sizeof(T) * (count ? count : 1), h->stream));
+    return APV_OK;
+}
+
+size_t wsz(const apv_handle* h) { return h->cfg.out_c128 ? 16 : 8; }
+size_t lsz(const apv_handle* h) { return h->cfg.out_c128 ? 8 : 4; }
+
+// path p: signal sig(p) through the RIRs of zone zone(p): AA, AB, BA, BB
+inline int path_sig(int p) { return p >> 1; }
+inline int path_zone(int p) { return p & 1; }
+
+}  // namespace
+
+void apv_stream_free(apv_handle* h) {
+    apv_stream* s = h->st;
+    if (!s) return;
+    void* bufs[] = {s->rir[0], s->rir[1], s->trir[0], s->trir[1], s->xhist[0][0], s->xhist[0][1], s->xhist[1][0],
+                    s->xhist[1][1], s->xin, s->resp[0], s->resp[1], s->resp[2], s->resp[3], s->tresp[0], s->tresp[1],
+                    s->inblk, s->X[0], s->X[1], s->X[2], s->X[3], s->tspec[0], s->tspec[1], s->inspec, s->w[0],
+                    s->w[1], s->lam[0], s->lam[1], s->status[0], s->status[1], s->tgt, s->outspec, s->outov, s->out};
+    for (void* b : bufs)
+        if (b) (void)hipFree(b);
+    delete s;
+    h->st = nullptr;
+}
+
+extern "C" {
+
+int apv_stream_init(apv_handle* h, int32_t rir_len, const double* h_rir_A, const double* h_rir_B,
+                    int32_t reference_index_A, int32_t reference_index_B, int32_t modeling_delay) {
+    if (!h || !h_rir_A || !h_rir_B) return apv_fail(h, APV_ERR_ARG, "null argument");
+    const apv_config& c = h->cfg;
+    const int N = c.block_size, H = c.hop_size;
+    if (N < 8 || (N & (N - 1)) != 0 || N > 8192) return apv_fail(h, APV_ERR_ARG, "block_size must be a power of two in [8, 8192]");
+    if (H < 1 || H > N) return apv_fail(h, APV_ERR_ARG, "hop_size must be in 1..block_size");
+    if (c.n_bins != N / 2 + 1) return apv_fail(h, APV_ERR_ARG, "streaming handle needs n_bins == block_size/2 + 1");
+    if (rir_len < 1 || modeling_delay < 0 || modeling_delay >= rir_len) return apv_fail(h, APV_ERR_ARG, "rir_len / modeling_delay out of range");
+    if (reference_index_A < 0 || reference_index_A >= c.n_srcs || reference_index_B < 0 || reference_index_B >= c.n_srcs)
+        return apv_fail(h, APV_ERR_ARG, "reference index out of range");
+    if (c.n_zones < 1 || c.n_zones > 3) return apv_fail(h, APV_ERR_ARG, "n_zones is a bit mask: 1 = A, 2 = B, 3 = both");
+    SCHK(h, hipSetDevice(h->device));
+    apv_stream_free(h);
+    apv_stream* s = new apv_stream();
+    std::memset(static_cast<void*>(s), 0, offsetof(apv_stream, h_status));
+    h->st = s;
+    s->N = N; s->H = H; s->K = N / 2 + 1; s->L = c.n_srcs; s->M = c.n_mics; s->C = s->L * s->M;
+    s->P = rir_len; s->nV = c.n_ranks; s->zones = c.n_zones; s->pad = apv_fir_pad();
+    s->ring_off = 0; s->cur = 0;
+    const int nz = ((s->zones & 1) ? 1 : 0) + ((s->zones & 2) ? 1 : 0);
+    s->n_out = nz * s->nV * s->L + 2 * s->L;
+    const int L = s->L, M = s->M, C = s->C, P = s->P, K = s->K;
+    int rc;
+    // RIRs: host (P, L, M) float64 C-order -> device [P][m*L + l] float32
+    std::vector<float> tmp((size_t)P * C), ttmp((size_t)P * M);
+    for (int z = 0; z < 2; ++z) {
+        const double* src = z ? h_rir_B : h_rir_A;
+        const int ref = z ? reference_index_B : reference_index_A;
+        for (int p = 0; p < P; ++p)
+            for (int l = 0; l < L; ++l)
+                for (int m = 0; m < M; ++m) tmp[(size_t)p * C + m * L + l] = (float)src[((size_t)p * L + l) * M + m];
+        // target RIR: reference loudspeaker delayed by modeling_delay (apvast.py:102-112)
+        std::fill(ttmp.begin(), ttmp.end(), 0.f);
+        for (int p = modeling_delay; p < P; ++p)
+            for (int m = 0; m < M; ++m) ttmp[(size_t)p * M + m] = (float)src[((size_t)(p - modeling_delay) * L + ref) * M + m];
+        if ((rc = dalloc(h, &s->rir[z], (size_t)P * C))) return rc;
+        if ((rc = dalloc(h, &s->trir[z], (size_t)P * M))) return rc;
+        SCHK(h, hipMemcpy(s->rir[z], tmp.data(), sizeof(float) * tmp.size(), hipMemcpyHostToDevice));
+        SCHK(h, hipMemcpy(s->trir[z], ttmp.data(), sizeof(float) * ttmp.size(), hipMemcpyHostToDevice));
+    }
+    const size_t hist = (size_t)P - 1 + H + s->pad;
+    for (int b = 0; b < 2; ++b)
+        for (int g = 0; g < 2; ++g)
+            if ((rc = dalloc(h, &s->xhist[b][g], hist))) return rc;
+    if ((rc = dalloc(h, &s->xin, (size_t)2 * H))) return rc;
+    for (int p = 0; p < 4; ++p) {
+        if ((rc = dalloc(h, &s->resp[p], (size_t)C * N))) return rc;
+        if ((rc = dalloc(h, &s->X[p], (size_t)K * C))) return rc;
+    }
+    for (int z = 0; z < 2; ++z) {
+        if ((rc = dalloc(h, &s->tresp[z], (size_t)M * N))) return rc;
+        if ((rc = dalloc(h, &s->tspec[z], (size_t)K * M))) return rc;
+        if ((rc = dalloc(h, (char**)&s->w[z], (size_t)K * s->nV * L * wsz(h)))) return rc;
+        if ((rc = dalloc(h, (char**)&s->lam[z], (size_t)K * L * lsz(h)))) return rc;
+        if ((rc = dalloc(h, &s->status[z], (size_t)K))) return rc;
+    }
+    if ((rc = dalloc(h, &s->inblk, (size_t)2 * N))) return rc;
+    if ((rc = dalloc(h, &s->inspec, (size_t)2 * K))) return rc;
+    if ((rc = dalloc(h, &s->tgt, (size_t)L * K))) return rc;
+    if ((rc = dalloc(h, &s->outspec, (size_t)s->n_out * K))) return rc;
+    if ((rc = dalloc(h, &s->outov, (size_t)s->n_out * N))) return rc;
+    if ((rc = dalloc(h, &s->out, (size_t)s->n_out * H))) return rc;
+    // target filter spectra: rfft of a unit impulse at tap modeling_delay of the A reference loudspeaker
+    // (apvast.py:389-390, 418, 422: the same filter serves A_t and B_t)
+    std::vector<float2> tg((size_t)L * K, make_float2(0.f, 0.f));
+    const double PI = 3.14159265358979323846;
+    for (int k = 0; k < K; ++k) {
+        const double ph = -2.0 * PI * (double)k * (double)modeling_delay / (double)N;
+        tg[(size_t)reference_index_A * K + k] = make_float2((float)std::cos(ph), (float)std::sin(ph));
+    }
+    SCHK(h, hipMemcpy(s->tgt, tg.data(), sizeof(float2) * tg.size(), hipMemcpyHostToDevice));
+    s->h_status.assign((size_t)2 * K, 0);
+    SCHK(h, hipStreamSynchronize(h->stream));
+    return APV_OK;
+}
+
+int apv_process_block(apv_handle* h, const float* h_in_A, const float* h_in_B, float* h_out) {
+    if (!h || !h_in_A || !h_in_B || !h_out) return apv_fail(h, APV_ERR_ARG, "null argument");
+    apv_stream* s = h->st;
+    if (!s) return apv_fail(h, APV_ERR_ARG, "apv_stream_init has not been called");
+    SCHK(h, hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    const int N = s->N, H = s->H, K = s->K, L = s->L, M = s->M, C = s->C, P = s->P;
+    std::string why;
+    // hop -> device, input history and input-block rings
+    SCHK(h, hipMemcpyAsync(s->xin, h_in_A, sizeof(float) * H, hipMemcpyHostToDevice, st));
+    SCHK(h, hipMemcpyAsync(s->xin + H, h_in_B, sizeof(float) * H, hipMemcpyHostToDevice, st));
+    const int nxt = s->cur ^ 1;
+    for (int g = 0; g < 2; ++g) {
+        SCHK(h, apv_launch_hist_update(P, H, s->pad, s->xhist[s->cur][g], s->xin + (size_t)g * H, s->xhist[nxt][g], st));
+    }
+    s->cur = nxt;
+    // all rings advance by one hop: logical sample n now lives H further on
+    s->ring_off = (s->ring_off + H) & (N - 1);
+    for (int g = 0; g < 2; ++g)
+        SCHK(h, apv_launch_ring_append(N, H, s->ring_off, s->xin + (size_t)g * H, s->inblk + (size_t)g * N, st));
+    // K1: RIR convolution into the response rings
+    for (int p = 0; p < 4; ++p)
+        SCHK(h, apv_launch_fir_hop(C, P, H, N, s->ring_off, s->rir[path_zone(p)], s->xhist[s->cur][path_sig(p)], s->resp[p], st));
+    for (int z = 0; z < 2; ++z)
+        SCHK(h, apv_launch_fir_hop(M, P, H, N, s->ring_off, s->trir[z], s->xhist[s->cur][z], s->tresp[z], st));
+    // K2: analysis, bin-major output
+    const bool runA = s->zones & 1, runB = s->zones & 2;
+    for (int p = 0; p < 4; ++p) {
+        const bool need = (p < 2) ? runA : runB;       // A->A, A->B feed zone program A; B->A, B->B feed B
+        if (!need) continue;
+        SCHK(h, apv_launch_stft_analysis_strided(N, C, s->resp[p], s->ring_off, s->X[p], 1, C, st, &why));
+    }
+    for (int z = 0; z < 2; ++z)
+        SCHK(h, apv_launch_stft_analysis_strided(N, M, s->tresp[z], s->ring_off, s->tspec[z], 1, M, st, &why));
+    SCHK(h, apv_launch_stft_analysis_strided(N, 2, s->inblk, s->ring_off, s->inspec, K, 1, st, &why));
+    // per-bin update per zone program: A: bright A->A, dark A->B, target A;  B: bright B->B, dark B->A, target B
+    int oc = 0;     // output channel cursor
+    for (int z = 0; z < 2; ++z) {
+        if (!(z ? runB : runA)) continue;
+        GevdParams p = apv_base_params(h);
+        p.XB = z ? s->X[3] : s->X[0];
+        p.XD = z ? s->X[2] : s->X[1];
+        p.d = s->tspec[z];
+        p.w = s->w[z];
+        p.lam = s->lam[z];
+        p.status = s->status[z];
+        hipError_t e = apv_launch_gevd(p, h->cfg.compute_dtype, true, st, &why);
+        if (e != hipSuccess) return apv_fail(h, APV_ERR_HIP, why.empty() ? hipGetErrorString(e) : why);
+        // K3: filtered output spectra for this zone's nV*L channels
+        SCHK(h, apv_launch_apply_filters(K, s->nV * L, 0, s->inspec + (size_t)z * K, s->w[z], h->cfg.out_c128, nullptr,
+                                         s->outspec + (size_t)oc * K, st));
+        SCHK(h, hipMemcpyAsync(s->h_status.data() + (size_t)z * K, s->status[z], sizeof(int32_t) * K,
+                               hipMemcpyDeviceToHost, st));
+        oc += s->nV * L;
+    }
+    for (int z = 0; z < 2; ++z) {       // target paths A_t, B_t
+        SCHK(h, apv_launch_apply_filters(K, 0, L, s->inspec + (size_t)z * K, nullptr, 0, s->tgt,
+                                         s->outspec + (size_t)oc * K, st));
+        oc += L;
+    }
+    // K4: synthesis + overlap-add + emit
+    SCHK(h, apv_launch_istft_ola_strided(N, H, s->n_out, s->outspec, K, 1, s->outov, s->out, st, &why));
+    SCHK(h, hipMemcpyAsync(h_out, s->out, sizeof(float) * (size_t)s->n_out * H, hipMemcpyDeviceToHost, st));
+    SCHK(h, hipStreamSynchronize(st));
+    for (int z = 0; z < 2; ++z) {
+        if (!(z ? runB : runA)) continue;
+        for (int k = 0; k < K; ++k) {
+            const int v = s->h_status[(size_t)z * K + k];
+            if (v == 1) {
+                char buf[96];
+                std::snprintf(buf, sizeof(buf), "Matrix is not positive definite (zone %c, bin %d)", z ? 'B' : 'A', k);
+                return apv_fail(h, APV_ERR_NOT_PD, buf);
+            }
+        }
+    }
+    return APV_OK;
+}
+
+// Named state arrays (host float32/complex as stored on the device; rings are returned in LOGICAL order):
+//   "response"        [4][C][N] f32    "target_response" [2][M][N] f32    "input_block" [2][N] f32
+//   "input_history"   [2][P-1]  f32    "out_overlap"     [n_out][N] f32
+//   "spectra"         [4][K][C] c64    "target_spectra"  [2][K][M] c64    "input_spectrum" [2][K] c64
+//   "w_A" / "w_B"     [K][nV][L] c64|c128        "lambda_A" / "lambda_B" [K][L] f32|f64
+static int state_lookup(apv_handle* h, const char* name, void** dptr, size_t* bytes, int* ring_rows) {
+    apv_stream* s = h->st;
+    *ring_rows = 0;
+    const std::string n(name);
+    const size_t N = s->N, K = s->K, C = s->C, M = s->M, L = s->L;
+    if (n.rfind("response", 0) == 0 && n.size() == 9 && n[8] >= '0' && n[8] <= '3') {
+        *dptr = s->resp[n[8] - '0']; *bytes = C * N * 4; *ring_rows = (int)C; return APV_OK; }
+    if (n == "target_response0" || n == "target_response1") {
+        *dptr = s->tresp[n.back() - '0']; *bytes = M * N * 4; *ring_rows = (int)M; return APV_OK; }
+    if (n == "input_block") { *dptr = s->inblk; *bytes = 2 * N * 4; *ring_rows = 2; return APV_OK; }
+    if (n == "input_history0" || n == "input_history1") {
+        *dptr = s->xhist[s->cur][n.back() - '0']; *bytes = (size_t)(s->P - 1 + s->H) * 4; return APV_OK; }
+    if (n == "out_overlap") { *dptr = s->outov; *bytes = (size_t)s->n_out * N * 4; return APV_OK; }
+    if (n.rfind("spectra", 0) == 0 && n.size() == 8 && n[7] >= '0' && n[7] <= '3') {
+        *dptr = s->X[n[7] - '0']; *bytes = K * C * 8; return APV_OK; }
+    if (n == "target_spectra0" || n == "target_spectra1") { *dptr = s->tspec[n.back() - '0']; *bytes = K * M * 8; return APV_OK; }
+    if (n == "input_spectrum") { *dptr = s->inspec; *bytes = 2 * K * 8; return APV_OK; }
+    if (n == "w_A" || n == "w_B") { *dptr = s->w[n == "w_B"]; *bytes = K * s->nV * L * wsz(h); return APV_OK; }
+    if (n == "lambda_A" || n == "lambda_B") { *dptr = s->lam[n == "lambda_B"]; *bytes = K * L * lsz(h); return APV_OK; }
+    return apv_fail(h, APV_ERR_STATE, std::string("unknown state name: ") + name);
+}
+
+int apv_state_bytes(apv_handle* h, const char* name, size_t* bytes) {
+    if (!h || !h->st || !name || !bytes) return apv_fail(h, APV_ERR_ARG, "null argument / no stream");
+    void* d; int rr;
+    return state_lookup(h, name, &d, bytes, &rr);
+}
+
+int apv_get_state(apv_handle* h, const char* name, void* h_dst, size_t bytes) {
+    if (!h || !h->st || !name || !h_dst) return apv_fail(h, APV_ERR_ARG, "null argument / no stream");
+    void* d; size_t need; int rr;
+    int rc = state_lookup(h, name, &d, &need, &rr);
+    if (rc != APV_OK) return rc;
+    if (bytes != need) return apv_fail(h, APV_ERR_STATE, "state size mismatch");
+    SCHK(h, hipSetDevice(h->device));
+    SCHK(h, hipStreamSynchronize(h->stream));
+    if (rr == 0) {
+        SCHK(h, hipMemcpy(h_dst, d, need, hipMemcpyDeviceToHost));
+        return APV_OK;
+    }
+    // ring: rotate rows into logical order
+    const int N = h->st->N, off = h->st->ring_off;
+    std::vector<float> tmp((size_t)rr * N);
+    SCHK(h, hipMemcpy(tmp.data(), d, need, hipMemcpyDeviceToHost));
+    float* out = (float*)h_dst;
+    for (int r = 0; r < rr; ++r)
+        for (int n = 0; n < N; ++n) out[(size_t)r * N + n] = tmp[(size_t)r * N + ((n + off) & (N - 1))];
+    return APV_OK;
+}
+
+int apv_set_state(apv_handle* h, const char* name, const void* h_src, size_t bytes) {
+    if (!h || !h->st || !name || !h_src) return apv_fail(h, APV_ERR_ARG, "null argument / no stream");
+    void* d; size_t need; int rr;
+    int rc = state_lookup(h, name, &d, &need, &rr);
+    if (rc != APV_OK) return rc;
+    if (bytes != need) return apv_fail(h, APV_ERR_STATE, "state size mismatch");
+    SCHK(h, hipSetDevice(h->device));
+    SCHK(h, hipStreamSynchronize(h->stream));
+    if (rr == 0) {
+        SCHK(h, hipMemcpy(d, h_src, need, hipMemcpyHostToDevice));
+        return APV_OK;
+    }
+    const int N = h->st->N, off = h->st->ring_off;
+    std::vector<float> tmp((size_t)rr * N);
+    const float* in = (const float*)h_src;
+    for (int r = 0; r < rr; ++r)
+        for (int n = 0; n < N; ++n) tmp[(size_t)r * N + ((n + off) & (N - 1))] = in[(size_t)r * N + n];
+    SCHK(h, hipMemcpy(d, tmp.data(), need, hipMemcpyHostToDevice));
+    return APV_OK;
+}
+
+}  // extern "C"

@@ -44,7 +44,7 @@ extern "C" {
 #endif
 
 #define APV_ABI_VERSION 1
-#define APV_MAX_RANKS 8      /* number of simultaneously produced ranks V (nV) */
+#define APV_MAX_RANKS 64     /* number of simultaneously produced ranks V (nV) */
 #define APV_MAX_N 64         /* largest GEVD order n = L handled on-chip */
 
 /* status codes */
@@ -72,7 +72,7 @@ typedef struct apv_config {
     int32_t n_bins;           /* K  : bins owned by this handle (its shard) */
     int32_t n_srcs;           /* L  : loudspeakers = GEVD order n (<= APV_MAX_N) */
     int32_t n_mics;           /* M  : control points per zone */
-    int32_t n_ranks;          /* nV : how many ranks V are produced (<= APV_MAX_RANKS) */
+    int32_t n_ranks;          /* nV : how many ranks V are produced (<= APV_MAX_RANKS; the reference emits every rank 1..V, apvast.py:406-422) */
     int32_t ranks[APV_MAX_RANKS]; /* the V list, each 1..L, ascending */
     int32_t compute_dtype;    /* APV_F32 | APV_F64 */
     int32_t out_c128;         /* 0: w c64 / lam f32;  1: w c128 / lam f64 */
@@ -83,7 +83,7 @@ typedef struct apv_config {
     int32_t max_sweeps;       /* Jacobi sweep cap; 0 = default */
     int32_t block_size;       /* N : STFT length for the streaming entry points (0 = kernel-level use only) */
     int32_t hop_size;         /* H */
-    int32_t n_zones;          /* 1 or 2 zone programs in streaming mode (run_A/run_B, apvast.py:53-54) */
+    int32_t n_zones;          /* streaming: bit mask of zone programs, 1 = A, 2 = B (run_A/run_B, apvast.py:53-54) */
     int32_t reserved[8];
 } apv_config;
 
@@ -140,6 +140,23 @@ int  apv_stft_analysis_dev(apv_handle* h, int32_t n_ch, const float* d_x, void* 
 /* overlap[c] = shift(overlap[c], H) + window * irfft(spec[c]); out[c][0:H] = overlap[c][0:H].
  *                                   replaces apvast.py:212-225, 265-293, 457-504 */
 int  apv_istft_ola_dev(apv_handle* h, int32_t n_ch, const void* d_spec, float* d_overlap, float* d_out);
+
+/* ---- streaming composition (one call = one hop) -------------------------- */
+/* Upload the room impulse responses and allocate all streaming state.  h_rir_A / h_rir_B: (rir_len, L, M)
+ * float64, C order -- exactly what scipy.io.loadmat('rirs.mat') gives after np.ascontiguousarray
+ * (make_python_test.m:4,18).  The handle must have been created with block_size, hop_size,
+ * n_bins = block_size/2+1 and n_zones = bit mask (1 = zone A, 2 = zone B: run_A/run_B, apvast.py:53-54).
+ *                                                         replaces apvast.__init__, apvast.py:97-151 */
+int  apv_stream_init(apv_handle* h, int32_t rir_len, const double* h_rir_A, const double* h_rir_B,
+                     int32_t reference_index_A, int32_t reference_index_B, int32_t modeling_delay);
+/* One hop of both input signals (H float32 samples each).  h_out: [n_out][H] float32 with channels
+ * [zone A: nV x L][zone B: nV x L] (zones that run) followed by [A_t: L][B_t: L].
+ *                                                         replaces process_input_buffers, apvast.py:153-165 */
+int  apv_process_block(apv_handle* h, const float* h_in_A, const float* h_in_B, float* h_out);
+/* Named state arrays for fixtures / checkpoint-resume (names: see stream.hip).   apvast.py:115-151 */
+int  apv_state_bytes(apv_handle* h, const char* name, size_t* bytes);
+int  apv_get_state(apv_handle* h, const char* name, void* h_dst, size_t bytes);
+int  apv_set_state(apv_handle* h, const char* name, const void* h_src, size_t bytes);
 
 /* ---- multi-GPU: bins sharded across ranks, one RCCL all-gather ---------- */
 int  apv_comm_unique_id(char id_out[128]);                                /* rank 0 calls, then broadcasts */

@@ -1,0 +1,128 @@
+"""GPU parity of the streaming path (class apvast, mode='subband') against the CPU oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle.subband_stream import SubbandStreamOracle  # noqa: E402  (checker only)
+
+
+def synth_rirs(P, L, M, seed):
+    rng = np.random.default_rng(seed)
+    env = np.exp(-np.arange(P) / (P / 6.0))[:, None, None]
+    return (rng.standard_normal((P, L, M)) * env * 1e-3, rng.standard_normal((P, L, M)) * env * 1e-3)
+
+
+def run_pair(block, hop, rirA, rirB, delay, refA, refB, V, mu, hops, run_A=True, run_B=True, seed=0, dtype="f64",
+             dialect="python"):
+    from ap_vast_unofficial_amd.apvast import apvast
+    P, L, M = rirA.shape
+    ap = apvast(block, rirA, rirB, 16, delay, refA, refB, V, mu, 4 * block, hop_size=hop, run_A=run_A, run_B=run_B,
+                perceptual=False, seed=seed, dtype=dtype, dialect=dialect)
+    init_r = init_t = None
+    if dialect == "python":
+        rs = np.random.RandomState(seed)
+        init_r = np.stack([1e-3 * rs.randn(block, L, M) for _ in range(4)]).astype(np.float32)
+        init_t = np.stack([1e-3 * rs.randn(block, M) for _ in range(2)]).astype(np.float32)
+    orc = SubbandStreamOracle(block, rirA.astype(np.float32), rirB.astype(np.float32), delay, refA, refB,
+                              list(range(1, V + 1)), mu, hop_size=hop, run_A=run_A, run_B=run_B,
+                              init_response=init_r, init_target_response=init_t)
+    H = ap.hop_size
+    x = np.random.default_rng(99).standard_normal((2, hops * H)).astype(np.float32)
+    got, exp = [], []
+    for h in range(hops):
+        got.append(ap.process_input_buffers(x[0, h * H:(h + 1) * H], x[1, h * H:(h + 1) * H]))
+        exp.append(orc.process(x[0, h * H:(h + 1) * H], x[1, h * H:(h + 1) * H]))
+    return ap, orc, got, exp
+
+
+def check_outputs(got, exp, tol):
+    for h, (g, e) in enumerate(zip(got, exp)):
+        for q in range(4):
+            if e[q] is None:
+                assert g[q] is None
+                continue
+            ref = e[q] if q < 2 else np.broadcast_to(e[q], (len(g[q]),) + e[q].shape)
+            arr = np.stack(g[q])
+            scale = max(np.abs(ref).max(), 1e-30)
+            assert np.abs(arr - ref).max() <= tol * scale, (h, q, np.abs(arr - ref).max() / scale)
+
+
+def test_stream_two_zones_vs_oracle():
+    rirA, rirB = synth_rirs(200, 8, 16, 1)
+    ap, orc, got, exp = run_pair(256, 128, rirA, rirB, 12, 2, 5, 4, 1.0, hops=6)
+    # control-point spectra (K2) and filters (K5'-K10) of the last hop
+    K, L, M = 129, 8, 16
+    for p in range(4):
+        X = ap._eng.get_state(f"spectra{p}", (K, M, L), np.complex64)
+        ref = orc.spectra[p].transpose(0, 2, 1)
+        assert np.abs(X - ref).max() <= 5e-6 * np.abs(ref).max()
+    for z, name in enumerate("AB"):
+        w, wr = getattr(ap, "w_" + name), orc.w[z].transpose(1, 0, 2)
+        err = np.linalg.norm(w - wr, axis=-1) / np.linalg.norm(wr, axis=-1)
+        assert np.median(err) < 1e-4 and err.max() < 2e-2, (np.median(err), err.max())
+    check_outputs(got, exp, 5e-3)
+    assert len(got[0][0]) == 4 and got[0][0][0].shape == (128, 8)
+    ap.close()
+
+
+def test_stream_target_path_is_wola_delay():
+    """KA-1/KA-2: target outputs = OLA(w * circshift(w * block, d)); exact, independent of the GEVD."""
+    rirA, rirB = synth_rirs(100, 4, 8, 2)
+    ap, orc, got, exp = run_pair(128, 64, rirA, rirB, 0, 1, 1, 2, 1.0, hops=5)
+    H, N = 64, 128
+    x = np.random.default_rng(99).standard_normal((2, 5 * H)).astype(np.float32)
+    At = np.stack([g[2][0] for g in got])            # (hops, H, L)
+    flat = At[:, :, 1].reshape(-1)
+    assert np.abs(flat[N - H:] - x[0, : flat.size - (N - H)]).max() < 1e-5
+    assert np.abs(np.delete(At, 1, axis=2)).max() == 0.0
+    ap.close()
+
+
+def test_stream_single_zone_and_errors(golden):
+    g = golden("rirs_cfg1")
+    rirA, rirB = g["rirA"], g["rirB"]
+    from ap_vast_unofficial_amd.apvast import apvast
+    with pytest.raises(RuntimeError, match="block size must be modulo 2"):
+        apvast(255, rirA, rirB, 32, 16, 0, 0, 8, 1.0, 512, perceptual=False)
+    with pytest.raises(RuntimeError, match="rirs of unequal size"):
+        apvast(256, rirA, rirB[:, :, :7], 32, 16, 0, 0, 8, 1.0, 512, perceptual=False)
+    ap, orc, got, exp = run_pair(256, 128, rirA, rirB, 16, 0, 0, 8, 1.0, hops=4, run_B=False)
+    with pytest.raises(RuntimeError, match="invalid input size"):
+        ap.process_input_buffers(np.zeros(100), np.zeros(100))
+    assert got[0][1] is None                           # apvast.py:433-443
+    # cfg1 is square (8 loudspeakers x 8 control points): R_D is ill-conditioned, so compare the target
+    # path tightly and the filtered path through the eigenvalues
+    check_outputs([(None, None, g_[2], g_[3]) for g_ in got], [(None, None, e[2], e[3]) for e in exp], 5e-5)
+    lam, lam_ref = ap.lambda_A, orc.lam[0]
+    assert np.median(np.abs(lam[:, 0] / lam_ref[:, 0] - 1)) < 1e-2
+    ap.close()
+
+
+def test_state_roundtrip():
+    rirA, rirB = synth_rirs(60, 4, 8, 3)
+    from ap_vast_unofficial_amd.apvast import apvast
+    a = apvast(128, rirA, rirB, 8, 4, 0, 0, 2, 1.0, 256, perceptual=False, seed=5)
+    b = apvast(128, rirA, rirB, 8, 4, 0, 0, 2, 1.0, 256, perceptual=False, seed=6)
+    x = np.random.default_rng(1).standard_normal((2, 64 * 5)).astype(np.float32)
+    for h in range(3):
+        a.process_input_buffers(x[0, h * 64:(h + 1) * 64], x[1, h * 64:(h + 1) * 64])
+    b.set_state(a.get_state())
+    for h in range(3, 5):
+        oa = a.process_input_buffers(x[0, h * 64:(h + 1) * 64], x[1, h * 64:(h + 1) * 64])
+        ob = b.process_input_buffers(x[0, h * 64:(h + 1) * 64], x[1, h * 64:(h + 1) * 64])
+        for q in range(4):
+            assert np.array_equal(np.stack(oa[q]), np.stack(ob[q]))
+    a.close()
+    b.close()
+
+
+def test_module_jdiag_dropin(golden):
+    from ap_vast_unofficial_amd.apvast import jdiag
+    g = golden("g2_jdiag_real")
+    U, D = jdiag(g["A"][0], g["B"][0])
+    assert U.dtype == np.float64 and D.shape == (12, 12)
+    assert np.abs(np.diag(D) / g["lam"][0] - 1).max() < 1e-9
+    assert np.abs(U.T @ (g["B"][0] + 1e-7 * np.eye(12)) @ U - np.eye(12)).max() < 1e-10
+    with pytest.raises(np.linalg.LinAlgError):
+        jdiag(np.eye(4), -np.eye(4))
