@@ -96,7 +96,12 @@ def main():
     import torch                       # plumbing only: process group, barrier, device sync
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # APV_BENCH_FORCE_DIST=1 takes the multi-rank code path (process group, RCCL communicator, all-gather)
+    # even at world size 1, so that it can be rehearsed on a one-GPU box
+    multi = world > 1 or bool(os.environ.get("APV_BENCH_FORCE_DIST"))
+    if multi:
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from ap_vast_unofficial_amd import Engine     # raises if libapvast_hip.so is missing
@@ -112,23 +117,45 @@ def main():
     dstatus = eng.alloc(K * 4)
     collective = None
     dw_all = None
-    if world > 1:
-        uid = [Engine.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        eng.comm_init(uid[0], rank, world)
-        dw_all = eng.alloc(w_bytes * world)
-        collective = "rccl all-gather (C ABI, ncclAllGather over xGMI)"
+    t_w = t_all = None
+    if multi:
+        try:
+            uid = [Engine.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            eng.comm_init(uid[0], rank, world)
+            dw_all = eng.alloc(w_bytes * world)
+            collective = "rccl all-gather (C ABI, ncclAllGather over xGMI)"
+            ok = 1
+        except Exception as ex:  # keep the job alive: same collective through torch's process group
+            print(f"[bench] rank {rank}: C-ABI communicator failed ({ex}); using torch.distributed", file=sys.stderr)
+            ok = 0
+        flag = torch.tensor([ok], device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            import ctypes
+
+            class _Raw:
+                def __init__(self, t):
+                    self.ptr = ctypes.c_void_p(t.data_ptr())
+            t_w = torch.empty(w_bytes, dtype=torch.uint8, device="cuda")
+            t_all = torch.empty(w_bytes * world, dtype=torch.uint8, device="cuda")
+            dw = _Raw(t_w)
+            collective = "rccl all-gather (torch.distributed nccl backend, all_gather_into_tensor)"
     del XB, XD, d
 
     def step():
         eng.update_dev(dXB, dXD, dd, dw, None, dstatus)
-        if world > 1:
-            eng.allgather_filters_dev(dw, dw_all)
+        if multi:
+            if t_all is None:
+                eng.allgather_filters_dev(dw, dw_all)
+            else:
+                eng.sync()                      # the kernel ran on the engine's stream
+                dist.all_gather_into_tensor(t_all, t_w)
 
     def fence():
         eng.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -150,7 +177,7 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -195,7 +222,7 @@ def main():
         print(json.dumps(out), flush=True)
 
     eng.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

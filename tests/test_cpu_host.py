@@ -1,0 +1,140 @@
+"""CPU-only checks: the C-ABI library loads and exports every declared symbol (no compute calls),
+host-side argument validation mirrors the reference, bin sharding + world_size-2 gloo reassembly."""
+import os
+import re
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "apvast_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(apv_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_all_exported():
+    from ap_vast_unofficial_amd import _capi
+    lib = _capi.load()
+    names = declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/apvast_hip.h but not exported"
+    assert sorted(_capi.EXPORTS) == names
+    assert lib.apv_abi_version() == _capi.ABI_VERSION
+
+
+def test_config_struct_matches_header():
+    """ctypes mirror of apv_config: field order/sizes as in the header."""
+    from ap_vast_unofficial_amd import _capi
+    text = open(os.path.join(ROOT, "include", "apvast_hip.h")).read()
+    body = re.search(r"typedef struct apv_config \{(.*?)\} apv_config;", text, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"(int32_t|double)\s+([a-z_0-9]+)(\[[A-Z_0-9a-z]+\])?;", body)
+    assert [f[1] for f in fields] == [f[0] for f in _capi.Config._fields_]
+    assert int(re.search(r"#define APV_MAX_RANKS (\d+)", text).group(1)) == _capi.MAX_RANKS
+    assert int(re.search(r"#define APV_MAX_N (\d+)", text).group(1)) == _capi.MAX_N
+
+
+def test_no_gpu_fails_loudly():
+    """On a box without a GPU the product path raises; it never falls back to a CPU path."""
+    import ctypes
+    from ap_vast_unofficial_amd import _capi
+    lib = _capi.load()
+    n = ctypes.c_int(0)
+    hip = ctypes.CDLL("libamdhip64.so")
+    if hip.hipGetDeviceCount(ctypes.byref(n)) == 0 and n.value > 0:
+        pytest.skip("a GPU is visible here")
+    with pytest.raises(_capi.ApvError):
+        _capi.Engine(4, 16, 32)
+
+
+def test_reference_error_messages_without_gpu(golden):
+    """apvast.py:86-90: both constructor errors fire before any device work."""
+    from ap_vast_unofficial_amd.apvast import apvast
+    g = golden("rirs_cfg1")
+    e = golden("g6_errors")
+    with pytest.raises(RuntimeError, match=str(e["odd_block"])):
+        apvast(255, g["rirA"], g["rirB"], 32, 16, 0, 0, 8, 1.0, 512, perceptual=False)
+    with pytest.raises(RuntimeError, match=str(e["unequal"])):
+        apvast(256, g["rirA"], g["rirB"][:, :, :7], 32, 16, 0, 0, 8, 1.0, 512, perceptual=False)
+    with pytest.raises(NotImplementedError, match="libdetectability"):
+        apvast(256, g["rirA"], g["rirB"], 32, 16, 0, 0, 8, 1.0, 512)          # perceptual defaults to True
+
+
+def test_rirs_mat_ingest(tmp_path, golden):
+    """Same rirs.mat ingest as make_python_test.m:4 (MAT v5, variables rirA / rirB)."""
+    import scipy.io
+    from ap_vast_unofficial_amd.apvast import load_rirs
+    g = golden("rirs_cfg1")
+    p = tmp_path / "rirs.mat"
+    scipy.io.savemat(p, {"rirA": np.asfortranarray(g["rirA"]), "rirB": np.asfortranarray(g["rirB"])})
+    a, b = load_rirs(str(p))
+    assert a.flags.c_contiguous and a.shape == (800, 8, 8)
+    assert np.array_equal(a, g["rirA"]) and np.array_equal(b, g["rirB"])
+
+
+def test_shard_bins_covers_range():
+    from ap_vast_unofficial_amd.sharding import shard_bins, padded_shard
+    for K, W in [(4096, 8), (1025, 8), (129, 2), (5, 8), (0, 3)]:
+        cover = []
+        for r in range(W):
+            lo, hi = shard_bins(K, W, r)
+            assert 0 <= lo <= hi <= K and hi - lo <= padded_shard(K, W)
+            cover += list(range(lo, hi))
+        assert cover == list(range(K))
+    assert shard_bins(4096, 8, 3) == (1536, 2048)
+    with pytest.raises(ValueError):
+        shard_bins(10, 2, 2)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, K, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from ap_vast_unofficial_amd.sharding import allgather_filters_host, shard_bins
+    from oracle import subband                      # stands in for the GPU kernel on a CPU-only box
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(2024)               # same data on every rank; each computes only its shard
+    L, M = 8, 16
+    def cn(*s):
+        return ((rng.standard_normal(s) + 1j * rng.standard_normal(s)) * np.sqrt(0.5)).astype(np.complex64)
+    XB, XD, d = cn(K, M, L), cn(K, M, L), cn(K, M)
+    lo, hi = shard_bins(K, world, rank)
+    w, _, _ = subband.update(XB[lo:hi], XD[lo:hi], d[lo:hi], 1.0, [1, 4])
+    full = allgather_filters_host(w.astype(np.complex64), K)
+    np.save(os.path.join(out_dir, f"w_{rank}.npy"), full)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("K", [64, 37])
+def test_two_rank_gloo_reassembly(tmp_path, K):
+    """N>1 path on CPU: 2 ranks (gloo), bins sharded, filters all-gathered; equals the unsharded result."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, K, str(tmp_path)), nprocs=2, join=True)
+    from oracle import subband
+    rng = np.random.default_rng(2024)
+    L, M = 8, 16
+    def cn(*s):
+        return ((rng.standard_normal(s) + 1j * rng.standard_normal(s)) * np.sqrt(0.5)).astype(np.complex64)
+    XB, XD, d = cn(K, M, L), cn(K, M, L), cn(K, M)
+    w_ref, _, _ = subband.update(XB, XD, d, 1.0, [1, 4])
+    for r in range(2):
+        got = np.load(tmp_path / f"w_{r}.npy")
+        assert got.shape == (K, 2, L)
+        assert np.abs(got - w_ref.astype(np.complex64)).max() == 0.0

@@ -193,3 +193,22 @@ def test_stft_roundtrip_vs_oracle(Engine, N, H):
     ov_ref = subband.synthesis_ola(spec_in.T.astype(np.complex128), win, ov.T.astype(np.float64), H).T
     assert np.abs(ov_new - ov_ref).max() < 3e-6 * np.abs(ov_ref).max()
     assert np.abs(out - ov_ref[:, :H]).max() < 3e-6 * np.abs(ov_ref).max()
+
+
+def test_rccl_allgather_single_rank(Engine):
+    """The C-ABI communicator path (ncclCommInitRank + ncclAllGather) with world = 1."""
+    rng = np.random.default_rng(5)
+    K, L, M = 32, 16, 32
+    XB, XD, d = cn(rng, K, M, L), cn(rng, K, M, L), cn(rng, K, M)
+    eng = Engine(K, L, M, ranks=(8,), out_c128=False)
+    eng.comm_init(Engine.comm_unique_id(), 0, 1)
+    dXB, dXD, dd = eng.to_device(XB), eng.to_device(XD), eng.to_device(d)
+    dw, dall = eng.alloc(K * L * 8), eng.alloc(K * L * 8)
+    eng.update_dev(dXB, dXD, dd, dw)
+    eng.allgather_filters_dev(dw, dall)
+    eng.sync()
+    w, wall = dw.download((K, 1, L), np.complex64), dall.download((K, 1, L), np.complex64)
+    eng.close()
+    assert np.array_equal(w, wall)
+    w_ref, _, _ = subband.update(XB, XD, d, 1.0, [8])
+    assert w_err(w, w_ref) < 3e-7
