@@ -13,6 +13,8 @@
 // Everything between the load of X and the store of w stays in LDS/registers (13 KiB of LDS per wave).
 #include "apv_internal.h"
 
+#include <cstdlib>
+
 namespace {
 
 constexpr int N = 16;
@@ -155,12 +157,92 @@ __device__ __forceinline__ void correlate16<float>(const float2* __restrict__ X,
 // wave-level ordering point between phases that exchange data through LDS (one wave per workgroup)
 __device__ __forceinline__ void wsync() { __syncthreads(); }
 
-template <typename T, bool FUSED>
+// XOR-schedule for the register-resident Jacobi (JAC == 1).  Pairs of round r are {i, i^r}; the 15 values of r
+// are visited grouped by their highest (odd sweeps: lowest) set bit so that between two rounds only the
+// "bottom" member of every pair changes slot, by a slot-XOR of 1, 2 or 4.  Entry = {transition bit or -1, delta}.
+struct XStep { signed char tbit, delta; };
+__constant__ XStep c_xsched[2][15] = {
+    {{-1, 1}, {-1, 2}, {-1, 1}, {-1, 4}, {-1, 1}, {-1, 2}, {-1, 1}, {-1, 4}, {2, 1}, {-1, 2}, {-1, 1}, {-1, 2}, {1, 1}, {-1, 1}, {0, 0}},
+    {{-1, 1}, {-1, 2}, {-1, 1}, {-1, 4}, {-1, 1}, {-1, 2}, {-1, 1}, {-1, 4}, {0, 2}, {-1, 4}, {-1, 2}, {-1, 4}, {1, 4}, {-1, 4}, {2, 0}}};
+
+template <typename T> __device__ __forceinline__ Cx<T> cshfl(Cx<T> v, int src) {
+    return mk<T>(__shfl(v.x, src, 64), __shfl(v.y, src, 64));
+}
+// members of a (top, bottom) pair trade places across lanes `peer`: the lane whose slot bit is set gives its
+// top and keeps its bottom, the other gives its bottom and keeps its top
+template <typename T> __device__ __forceinline__ void xchg(Cx<T>& top, Cx<T>& bot, bool bit, int peer) {
+    const Cx<T> send = bit ? top : bot;
+    const Cx<T> recv = cshfl(send, peer);
+    if (bit) top = recv; else bot = recv;
+}
+
+// ---- cross-lane moves by XOR of the lane id, on the VALU (DPP) where the ISA allows it ----
+template <int D> __device__ __forceinline__ int dpp_xor_lo(int v);       // lane ^ D, D in {1,2,4} (within 8 lanes)
+template <> __device__ __forceinline__ int dpp_xor_lo<1>(int v) { return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false); }  // quad_perm [1,0,3,2]
+template <> __device__ __forceinline__ int dpp_xor_lo<2>(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false); }  // quad_perm [2,3,0,1]
+template <> __device__ __forceinline__ int dpp_xor_lo<4>(int v) {
+    const int t = __builtin_amdgcn_update_dpp(v, v, 0x104, 0xf, 0x5, false);      // row_shl:4 into banks 0,2
+    return __builtin_amdgcn_update_dpp(t, v, 0x114, 0xf, 0xa, false);             // row_shr:4 into banks 1,3
+}
+__device__ __forceinline__ int dpp_xor8(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false); }  // row_ror:8
+
+template <int D> __device__ __forceinline__ float xcol(float v) { return __int_as_float(dpp_xor_lo<D>(__float_as_int(v))); }
+template <int D> __device__ __forceinline__ double xcol(double v) {
+    return __hiloint2double(dpp_xor_lo<D>(__double2hiint(v)), dpp_xor_lo<D>(__double2loint(v)));
+}
+template <int D> __device__ __forceinline__ float xrow(float v, int lane) {
+    if constexpr (D == 1) return __int_as_float(dpp_xor8(__float_as_int(v)));
+    else return __shfl(v, lane ^ (8 * D), 64);
+}
+template <int D> __device__ __forceinline__ double xrow(double v, int lane) {
+    if constexpr (D == 1) return __hiloint2double(dpp_xor8(__double2hiint(v)), dpp_xor8(__double2loint(v)));
+    else return __shfl(v, lane ^ (8 * D), 64);
+}
+template <int D, typename T> __device__ __forceinline__ Cx<T> cxcol(Cx<T> v) { return mk<T>(xcol<D>(v.x), xcol<D>(v.y)); }
+template <int D, typename T> __device__ __forceinline__ Cx<T> cxrow(Cx<T> v, int lane) { return mk<T>(xrow<D>(v.x, lane), xrow<D>(v.y, lane)); }
+
+// bottoms of every pair move by slot-XOR D: columns (lane bits 0-2) and rows (lane bits 3-5)
+template <int D, typename T>
+__device__ __forceinline__ void move_bottoms(Cx<T>& tb, Cx<T>& bt, Cx<T>& bb, Cx<T>& v0b, Cx<T>& v1b, int lane) {
+    tb = cxcol<D>(tb);
+    v0b = cxcol<D>(v0b);
+    v1b = cxcol<D>(v1b);
+    bb = cxcol<D>(bb);
+    bt = cxrow<D>(bt, lane);
+    bb = cxrow<D>(bb, lane);
+}
+
+// Jacobi rotation J = [[c, s], [-conj(s), c]] for the Hermitian 2x2 [[alpha, beta], [conj(beta), gamma]].
+// Any complex t gives an exactly unitary J once c = 1/sqrt(1+|t|^2), s = t c are formed in T, so the
+// angle t = sign(tau) e^{i arg beta} / (|tau| + sqrt(1+tau^2)) is evaluated in float (relative 1e-7: the pair's
+// off-diagonal drops by that factor instead of to zero, which the next sweep finishes).  Inputs are
+// pre-scaled to ||C||_F ~ 1, so float range is not an issue; |beta|^2 < 1e-30 is skipped.
+template <typename T>
+__device__ __forceinline__ void rotation(T alpha, T gamma, T bx, T by, T& c, T& sx, T& sy) {
+    const float fbx = (float)bx, fby = (float)by, fd = (float)(gamma - alpha);
+    const float b2 = fbx * fbx + fby * fby;
+    float tx = 0.f, ty = 0.f;
+    if (b2 > 1e-30f) {
+        const float iab = __builtin_amdgcn_rsqf(b2);
+        const float tau = fd * 0.5f * iab;
+        const float rho = __builtin_amdgcn_sqrtf(__builtin_fmaf(tau, tau, 1.0f));
+        const float t = copysignf(__builtin_amdgcn_rcpf(fabsf(tau) + rho), tau) * iab;
+        tx = fbx * t;
+        ty = fby * t;
+    }
+    const T dx = (T)tx, dy = (T)ty;
+    c = rsq_full((T)1 + dx * dx + dy * dy);
+    sx = dx * c;
+    sy = dy * c;
+}
+
+template <typename T, bool FUSED, int JAC>
 __global__ void __launch_bounds__(64) gevd16_kernel(const GevdParams p) {
     using C = Cx<T>;
     __shared__ C sA[N * LD];
     __shared__ C sB[N * LD];
-    __shared__ C sV[N * LD];
+    __shared__ C sVstore[JAC == 1 ? 1 : N * LD];
+    C* sV = (JAC == 1) ? sA : sVstore;     // register-resident Jacobi: C is dead by the time V is written
     __shared__ C sr[N];
     __shared__ C scoef[N];
     __shared__ T sDinv[N];
@@ -279,9 +361,10 @@ __global__ void __launch_bounds__(64) gevd16_kernel(const GevdParams p) {
             for (int t = 0; t < 4; ++t)
                 sA[i * LD + jq + 4 * t] = mk<T>((T)0.5 * (u[t].x + l[t].x), (jq + 4 * t == i) ? (T)0 : (T)0.5 * (u[t].y - l[t].y));
         }
-        // V = I
+        if constexpr (JAC == 0) {       // V = I
 #pragma unroll
-        for (int t = 0; t < 4; ++t) sV[i * LD + jq + 4 * t] = mk<T>((jq + 4 * t == i) ? (T)1 : (T)0, (T)0);
+            for (int t = 0; t < 4; ++t) sV[i * LD + jq + 4 * t] = mk<T>((jq + 4 * t == i) ? (T)1 : (T)0, (T)0);
+        }
         wsync();
 
         // ---------------- stage 3: cyclic Jacobi ----------------
@@ -294,11 +377,12 @@ __global__ void __launch_bounds__(64) gevd16_kernel(const GevdParams p) {
         const T normF2 = wave_sum(nrm);
 
         const int a = lane >> 3, b = lane & 7;
-        const unsigned long long seqPa = c_seq.p[a], seqQa = c_seq.q[a];
-        const unsigned long long seqPb = c_seq.p[b], seqQb = c_seq.q[b];
         const int max_sweeps = p.max_sweeps > 0 ? p.max_sweeps : Prec<T>::max_sweeps;
         const T tol2 = p.sweep_tol2 > 0.0 ? (T)p.sweep_tol2 : Prec<T>::sweep_tol2;
         bool converged = false;
+        if constexpr (JAC == 0) {
+        const unsigned long long seqPa = c_seq.p[a], seqQa = c_seq.q[a];
+        const unsigned long long seqPb = c_seq.p[b], seqQb = c_seq.q[b];
         const int v0 = (2 * a) * LD, v1 = (2 * a + 1) * LD;
         for (int sweep = 0; sweep < max_sweeps && !converged; ++sweep) {
             T off = 0;
@@ -384,10 +468,105 @@ __global__ void __launch_bounds__(64) gevd16_kernel(const GevdParams p) {
             const T tot = wave_sum(off) * (T)0.125;
             if (tot <= tol2 * normF2) converged = true;
         }
+        if (lane < N) sLam[lane] = sA[lane * LD + lane].x;
+        } else {
+        // ---- register-resident variant: lane (a,b) keeps the 2x2 block {top_a,bot_a} x {top_b,bot_b} of C and the
+        // columns {top_b,bot_b} of rows 2a, 2a+1 of V in registers for the whole iteration; data changes slot
+        // through cross-lane XOR shuffles only.  Start layout: top_s = s, bot_s = 8 + s.
+        // scale to ||C||_F in [1, 2): exact (power of two), undone on the eigenvalues
+        const int sexp = (normF2 > (T)0) ? -(ilogb((double)normF2) / 2) : 0;
+        const T scl = (T)ldexp(1.0, sexp), iscl = (T)ldexp(1.0, -sexp);
+        C tt = sA[a * LD + b], tb = sA[a * LD + 8 + b], bt = sA[(8 + a) * LD + b], bb = sA[(8 + a) * LD + 8 + b];
+        tt = mk<T>(tt.x * scl, tt.y * scl); tb = mk<T>(tb.x * scl, tb.y * scl);
+        bt = mk<T>(bt.x * scl, bt.y * scl); bb = mk<T>(bb.x * scl, bb.y * scl);
+        const T normS2 = normF2 * scl * scl;
+        C v0t = mk<T>((2 * a == b) ? (T)1 : (T)0, 0), v0b = mk<T>((2 * a == 8 + b) ? (T)1 : (T)0, 0);
+        C v1t = mk<T>((2 * a + 1 == b) ? (T)1 : (T)0, 0), v1b = mk<T>((2 * a + 1 == 8 + b) ? (T)1 : (T)0, 0);
+        const bool diag = (a == b);
+        int sweeps_done = 0;
+        for (int sweep = 0; sweep < max_sweeps && !converged; ++sweep) {
+            T off = 0;
+            const XStep* sched = c_xsched[sweep & 1];
+            for (int r = 0; r < 15; ++r) {
+                const int tbit = sched[r].tbit, delta = sched[r].delta;
+                if (tbit >= 0) {
+                    const bool cb_ = (b >> tbit) & 1, ab_ = (a >> tbit) & 1;
+                    const int pc = lane ^ (1 << tbit), pr = lane ^ (8 << tbit);
+                    xchg(tt, tb, cb_, pc);      // columns
+                    xchg(bt, bb, cb_, pc);
+                    xchg(v0t, v0b, cb_, pc);
+                    xchg(v1t, v1b, cb_, pc);
+                    xchg(tt, bt, ab_, pr);      // rows
+                    xchg(tb, bb, ab_, pr);
+                }
+                switch (delta) {
+                    case 1: move_bottoms<1>(tb, bt, bb, v0b, v1b, lane); break;
+                    case 2: move_bottoms<2>(tb, bt, bb, v0b, v1b, lane); break;
+                    case 4: move_bottoms<4>(tb, bt, bb, v0b, v1b, lane); break;
+                    default: break;
+                }
+                // rotation of this slot's pair, meaningful on the diagonal lanes
+                if (diag) off += tb.x * tb.x + tb.y * tb.y;
+                T c, sx, sy;
+                rotation<T>(tt.x, bb.x, tb.x, tb.y, c, sx, sy);
+                const int da = 9 * a, db = 9 * b;
+                const T ca = __shfl(c, da, 64), sax = __shfl(sx, da, 64), say = __shfl(sy, da, 64);
+                const T cb = __shfl(c, db, 64), sbx = __shfl(sx, db, 64), sby = __shfl(sy, db, 64);
+                // columns: [x_t, x_b] J_b
+                C ypp, ypq, yqp, yqq;
+                ypp.x = cb * tt.x - (sbx * tb.x + sby * tb.y);
+                ypp.y = cb * tt.y - (sbx * tb.y - sby * tb.x);
+                ypq.x = cb * tb.x + (sbx * tt.x - sby * tt.y);
+                ypq.y = cb * tb.y + (sbx * tt.y + sby * tt.x);
+                yqp.x = cb * bt.x - (sbx * bb.x + sby * bb.y);
+                yqp.y = cb * bt.y - (sbx * bb.y - sby * bb.x);
+                yqq.x = cb * bb.x + (sbx * bt.x - sby * bt.y);
+                yqq.y = cb * bb.y + (sbx * bt.y + sby * bt.x);
+                // rows: J_a^H [y_t; y_b]
+                tt.x = ca * ypp.x - (sax * yqp.x - say * yqp.y);
+                tt.y = ca * ypp.y - (sax * yqp.y + say * yqp.x);
+                tb.x = ca * ypq.x - (sax * yqq.x - say * yqq.y);
+                tb.y = ca * ypq.y - (sax * yqq.y + say * yqq.x);
+                bt.x = ca * yqp.x + (sax * ypp.x + say * ypp.y);
+                bt.y = ca * yqp.y + (sax * ypp.y - say * ypp.x);
+                bb.x = ca * yqq.x + (sax * ypq.x + say * ypq.y);
+                bb.y = ca * yqq.y + (sax * ypq.y - say * ypq.x);
+                if (diag) {         // the angle is only float-accurate: the residual beta' ~ 1e-7 beta is real data, keep it
+                    tt.y = 0;
+                    bb.y = 0;
+                }
+                // V <- V J_b
+                C w0p, w0q, w1p, w1q;
+                w0p.x = cb * v0t.x - (sbx * v0b.x + sby * v0b.y);
+                w0p.y = cb * v0t.y - (sbx * v0b.y - sby * v0b.x);
+                w0q.x = cb * v0b.x + (sbx * v0t.x - sby * v0t.y);
+                w0q.y = cb * v0b.y + (sbx * v0t.y + sby * v0t.x);
+                w1p.x = cb * v1t.x - (sbx * v1b.x + sby * v1b.y);
+                w1p.y = cb * v1t.y - (sbx * v1b.y - sby * v1b.x);
+                w1q.x = cb * v1b.x + (sbx * v1t.x - sby * v1t.y);
+                w1q.y = cb * v1b.y + (sbx * v1t.y + sby * v1t.x);
+                v0t = w0p; v0b = w0q; v1t = w1p; v1b = w1q;
+            }
+            ++sweeps_done;
+            const T tot = wave_sum(off);
+            if (tot <= tol2 * normS2) converged = true;
+        }
+        // after an odd number of sweeps slot s holds (2s, 2s+1), after an even number (s, 8+s)
+        const bool nat = sweeps_done & 1;
+        const int it_b = nat ? 2 * b : b, ib_b = nat ? 2 * b + 1 : 8 + b;
+        wsync();
+        sV[(2 * a) * LD + it_b] = v0t;
+        sV[(2 * a) * LD + ib_b] = v0b;
+        sV[(2 * a + 1) * LD + it_b] = v1t;
+        sV[(2 * a + 1) * LD + ib_b] = v1b;
+        if (diag) {
+            sLam[it_b] = tt.x * iscl;
+            sLam[ib_b] = bb.x * iscl;
+        }
+        }
         if (!converged) status = 2;
 
         // ---------------- stage 4: eigenvalues, descending order ----------------
-        if (lane < N) sLam[lane] = sA[lane * LD + lane].x;
         wsync();
         if (lane < N) {
             const T li = sLam[lane];
@@ -484,12 +663,18 @@ __global__ void __launch_bounds__(64) gevd16_kernel(const GevdParams p) {
 hipError_t apv_launch_gevd16(const GevdParams& p, int compute_dtype, bool fused, hipStream_t s) {
     if (p.n != 16 || p.reg_mode != APV_REG_ABS || p.reg_bright != 0.0) return hipErrorNotSupported;
     if (p.K <= 0) return hipSuccess;
+    static const int variant = [] {
+        const char* e = getenv("APV_GEVD16_JACOBI");       // "lds" | "reg" (A/B switch for profiling)
+        return (e && e[0] == 'l') ? 0 : 1;
+    }();
+#define APV_L16(T, F, J) hipLaunchKernelGGL((gevd16_kernel<T, F, J>), dim3(p.K), dim3(64), 0, s, p)
     if (compute_dtype == APV_F64) {
-        if (fused) hipLaunchKernelGGL((gevd16_kernel<double, true>), dim3(p.K), dim3(64), 0, s, p);
-        else hipLaunchKernelGGL((gevd16_kernel<double, false>), dim3(p.K), dim3(64), 0, s, p);
+        if (variant == 0) { if (fused) APV_L16(double, true, 0); else APV_L16(double, false, 0); }
+        else              { if (fused) APV_L16(double, true, 1); else APV_L16(double, false, 1); }
     } else {
-        if (fused) hipLaunchKernelGGL((gevd16_kernel<float, true>), dim3(p.K), dim3(64), 0, s, p);
-        else hipLaunchKernelGGL((gevd16_kernel<float, false>), dim3(p.K), dim3(64), 0, s, p);
+        if (variant == 0) { if (fused) APV_L16(float, true, 0); else APV_L16(float, false, 0); }
+        else              { if (fused) APV_L16(float, true, 1); else APV_L16(float, false, 1); }
     }
+#undef APV_L16
     return hipGetLastError();
 }
