@@ -141,7 +141,7 @@ class Engine:
 
     def __init__(self, n_bins, n_srcs, n_mics, ranks=(1,), mu=1.0, compute_dtype="f64", out_c128=None,
                  reg_mode=REG_ABS, reg_dark=1e-7, reg_bright=0.0, device=0, max_sweeps=0,
-                 block_size=0, hop_size=0, n_zones=1):
+                 block_size=0, hop_size=0, n_zones=1, debug_stop=0):
         self.lib = load()
         self.h = None
         ranks = [int(v) for v in ranks]
@@ -161,6 +161,7 @@ class Engine:
         cfg.reg_mode, cfg.reg_dark, cfg.reg_bright, cfg.mu = reg_mode, reg_dark, reg_bright, mu
         cfg.max_sweeps = max_sweeps
         cfg.block_size, cfg.hop_size, cfg.n_zones = block_size, hop_size, n_zones
+        cfg.reserved[0] = debug_stop          # profiling aid (kernels_gevd16.hip), 0 in normal use
         self.cfg = cfg
         self.K, self.L, self.M, self.nV = cfg.n_bins, cfg.n_srcs, cfg.n_mics, cfg.n_ranks
         h = C.c_void_p()

@@ -17,6 +17,7 @@ struct GevdParams {
     double reg_bright;
     int reg_mode;
     int max_sweeps;
+    int debug_stop;    // profiling aid: return after stage N (1 = correlate, 2 = Cholesky, 3 = whitening); 0 = run everything
     double sweep_tol2; // Jacobi stop threshold on off^2/||C||_F^2 seen during a sweep; 0 = per-dtype default
     int out_c128;
     // fused input (c64)
