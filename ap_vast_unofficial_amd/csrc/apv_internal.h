@@ -34,6 +34,14 @@ struct GevdParams {
     int32_t* status;  // [K]                      (may be null)
     void* U;          // [K][n][n]   complex of compute dtype, sorted columns (may be null)
     void* Lspill;     // [K][n][n]   complex of compute dtype (SPILL instances only)
+    // optional second zone program in the same launch (blockIdx.y == 1), fused path only
+    int n_zones;
+    const float2* XB1;
+    const float2* XD1;
+    const float2* d1;
+    void* w1;
+    void* lam1;
+    int32_t* status1;
 };
 
 struct apv_handle {
@@ -85,6 +93,10 @@ hipError_t apv_launch_istft_ola_strided(int N, int H, int n_ch, const float2* sp
 //   resp[c*N + ((N-H+n + ring_off) & (N-1))] = sum_p rir[p*C + c] * xhist[P-1 + n - p],  n < H, c < C
 hipError_t apv_launch_fir_hop(int C, int P, int H, int N, int ring_off, const float* rir, const float* xhist,
                               float* resp, hipStream_t s);
+struct FirJob { const float* rir; const float* xh; float* resp; int C; };
+struct FirJobs { FirJob j[6]; int n; };
+// all FIR jobs of a hop in one launch, on the matrix cores (v_mfma_f32_32x32x2_f32, implicit Toeplitz operand)
+hipError_t apv_launch_fir_jobs(const FirJobs& jobs, int P, int H, int N, int ring_off, hipStream_t s);
 hipError_t apv_launch_hist_update(int P, int H, int pad, const float* old_hist, const float* x, float* new_hist,
                                   hipStream_t s);
 hipError_t apv_launch_ring_append(int N, int H, int ring_off, const float* x, float* ring, hipStream_t s);

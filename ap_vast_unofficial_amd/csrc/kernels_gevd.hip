@@ -73,7 +73,11 @@ __device__ __forceinline__ void rr_pair(int ne, int r, int a, int& p, int& q) {
 }
 
 template <typename T, int NMAX, int TPB, bool FUSED, bool SPILL>
-__global__ void __launch_bounds__(TPB) gevd_vast_kernel(const GevdParams p) {
+__global__ void __launch_bounds__(TPB) gevd_vast_kernel(const GevdParams p_in) {
+    GevdParams p = p_in;
+    if (blockIdx.y == 1) {          // second zone program of a two-zone launch
+        p.XB = p_in.XB1; p.XD = p_in.XD1; p.d = p_in.d1; p.w = p_in.w1; p.lam = p_in.lam1; p.status = p_in.status1;
+    }
     using C = Cx<T>;
     constexpr int LD = NMAX + 1;
     constexpr int NP = NMAX / 2;
@@ -274,7 +278,7 @@ __global__ void __launch_bounds__(TPB) gevd_vast_kernel(const GevdParams p) {
         }
         if constexpr (SPILL) {
             // park L in HBM scratch: its LDS slot becomes the eigenvector matrix
-            C* Ls = reinterpret_cast<C*>(p.Lspill) + (size_t)k * n * n;
+            C* Ls = reinterpret_cast<C*>(p.Lspill) + ((size_t)blockIdx.y * p.K + k) * n * n;
             for (int idx = tid; idx < n * n; idx += TPB) {
                 const int i = idx / n, j = idx - i * n;
                 Ls[idx] = sB[i * LD + j];
@@ -405,7 +409,7 @@ __global__ void __launch_bounds__(TPB) gevd_vast_kernel(const GevdParams p) {
         C* sL = sB;
         if constexpr (SPILL) {
             sL = sA;                                       // C is spent (lam copied out)
-            const C* Ls = reinterpret_cast<const C*>(p.Lspill) + (size_t)k * n * n;
+            const C* Ls = reinterpret_cast<const C*>(p.Lspill) + ((size_t)blockIdx.y * p.K + k) * n * n;
             for (int idx = tid; idx < n * n; idx += TPB) {
                 const int i = idx / n, j = idx - i * n;
                 sA[i * LD + j] = Ls[idx];
@@ -473,16 +477,16 @@ template <typename T, int NMAX, int TPB, bool SPILL>
 hipError_t launch_t(const GevdParams& p, bool fused, hipStream_t s) {
     if (p.K <= 0) return hipSuccess;
     if (fused)
-        hipLaunchKernelGGL((gevd_vast_kernel<T, NMAX, TPB, true, SPILL>), dim3(p.K), dim3(TPB), 0, s, p);
+        hipLaunchKernelGGL((gevd_vast_kernel<T, NMAX, TPB, true, SPILL>), dim3(p.K, p.n_zones > 1 ? 2 : 1), dim3(TPB), 0, s, p);
     else
-        hipLaunchKernelGGL((gevd_vast_kernel<T, NMAX, TPB, false, SPILL>), dim3(p.K), dim3(TPB), 0, s, p);
+        hipLaunchKernelGGL((gevd_vast_kernel<T, NMAX, TPB, false, SPILL>), dim3(p.K, p.n_zones > 1 ? 2 : 1), dim3(TPB), 0, s, p);
     return hipGetLastError();
 }
 
 }  // namespace
 
 size_t apv_gevd_spill_bytes(int n, int K, int compute_dtype) {
-    if (compute_dtype == APV_F64 && n > 32) return (size_t)K * n * n * 2 * sizeof(double);
+    if (compute_dtype == APV_F64 && n > 32) return (size_t)2 * K * n * n * 2 * sizeof(double);   // x2: two-zone launches
     return 0;
 }
 

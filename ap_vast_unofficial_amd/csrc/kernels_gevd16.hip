@@ -234,7 +234,11 @@ __device__ __forceinline__ void rotation(T alpha, T gamma, T bx, T by, T& c, T& 
 }
 
 template <typename T, bool FUSED, int JAC>
-__global__ void __launch_bounds__(64) gevd16_kernel(const GevdParams p) {
+__global__ void __launch_bounds__(64) gevd16_kernel(const GevdParams p_in) {
+    GevdParams p = p_in;
+    if (blockIdx.y == 1) {          // second zone program of a two-zone launch
+        p.XB = p_in.XB1; p.XD = p_in.XD1; p.d = p_in.d1; p.w = p_in.w1; p.lam = p_in.lam1; p.status = p_in.status1;
+    }
     using C = Cx<T>;
     __shared__ C sA[N * LD];
     __shared__ C sB[N * LD];
@@ -667,7 +671,7 @@ hipError_t apv_launch_gevd16(const GevdParams& p, int compute_dtype, bool fused,
         const char* e = getenv("APV_GEVD16_JACOBI");       // "lds" | "reg" (A/B switch for profiling)
         return (e && e[0] == 'l') ? 0 : 1;
     }();
-#define APV_L16(T, F, J) hipLaunchKernelGGL((gevd16_kernel<T, F, J>), dim3(p.K), dim3(64), 0, s, p)
+#define APV_L16(T, F, J) hipLaunchKernelGGL((gevd16_kernel<T, F, J>), dim3(p.K, p.n_zones > 1 ? 2 : 1), dim3(64), 0, s, p)
     if (compute_dtype == APV_F64) {
         if (variant == 0) { if (fused) APV_L16(double, true, 0); else APV_L16(double, false, 0); }
         else              { if (fused) APV_L16(double, true, 1); else APV_L16(double, false, 1); }

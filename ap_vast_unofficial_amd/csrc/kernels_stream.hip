@@ -33,6 +33,93 @@ __global__ void __launch_bounds__(64) fir_hop_kernel(int C, int P, int H, int N,
     }
 }
 
+// ---- K1 on the matrix cores -------------------------------------------------------------------
+// Y[n][c] = sum_p x[n-p] R[p][c] is the GEMM  T (H x P, Toeplitz, T[n][p] = x[n-p])  times  R (P x C).
+// T is never materialised: the A operand of v_mfma_f32_32x32x2_f32 (lane l: A[i=l&31][k=l>>5]) is read
+// straight from the input history in LDS at offset (n0 + i) - (p0 + k).  One wave = 32 samples x 32
+// channels, one workgroup = 128 samples x 32 channels; blockIdx.z walks a small job table so that all
+// paths (A->A, A->B, B->A, B->B, two targets) go out in ONE launch.
+using f16v = __attribute__((ext_vector_type(16))) float;
+
+__global__ void __launch_bounds__(256) fir_mfma_kernel(FirJobs jobs, int P, int H, int N, int ring_off) {
+    extern __shared__ float xs[];                  // [P - 1 + 128] history window, then reused as 4 x [32][33] tiles
+    const FirJob job = jobs.j[blockIdx.z];
+    const int c0 = blockIdx.y * 32;
+    if (c0 >= job.C) return;                       // uniform per workgroup
+    const int C = job.C;
+    const int n0 = blockIdx.x * 128;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int span = P - 1 + 128;
+    for (int i = tid; i < span; i += 256) xs[i] = job.xh[n0 + i];      // xh is padded to P-1+ceil(H/128)*128
+    __syncthreads();
+    const int i = lane & 31, kk = lane >> 5, nb = 32 * wave;
+    f16v acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // channels past C read a valid (clamped) column; their results are never stored
+    const int cc = (c0 + i) < C ? (c0 + i) : (C - 1);
+    const float* bptr = job.rir + (size_t)kk * C + cc;
+    const float* aptr = xs + (P - 1) + nb + i - kk;
+    const int Peven = P & ~1;
+    // software pipeline: the taps of the next group of 8 k-steps are in flight while this group's MFMAs issue
+    constexpr int G = 8;
+    const int ngroups = Peven / (2 * G);
+    float bn[G];
+#pragma unroll
+    for (int u = 0; u < G; ++u) bn[u] = (ngroups > 0) ? bptr[(size_t)(2 * u) * C] : 0.f;
+    for (int g = 0; g < ngroups; ++g) {
+        const int p0 = g * 2 * G;
+        float a[G], b[G];
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            b[u] = bn[u];
+            a[u] = aptr[-(p0 + 2 * u)];
+        }
+        if (g + 1 < ngroups) {
+#pragma unroll
+            for (int u = 0; u < G; ++u) bn[u] = bptr[(size_t)(p0 + 2 * G + 2 * u) * C];
+        }
+#pragma unroll
+        for (int u = 0; u < G; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+    }
+    for (int p0 = ngroups * 2 * G; p0 < Peven; p0 += 2) {
+        const float a = aptr[-p0];
+        const float b = bptr[(size_t)p0 * C];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    if (P & 1) {                                   // last odd tap: only k = 0 carries data
+        const float a = (kk == 0) ? aptr[-Peven] : 0.f;
+        const float b = (kk == 0) ? bptr[(size_t)Peven * C] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    __syncthreads();                               // everyone is done with the history window
+    // accumulator (row = sample, col = channel): row = (r&3) + 8(r>>2) + 4(lane>>5), col = lane&31
+    float* tile = xs + wave * (32 * 33);           // [channel][sample], padded
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
+        tile[i * 33 + row] = acc[r];
+    }
+    __syncthreads();
+    const int mask = N - 1;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int c = (lane >> 3) + 8 * t, q = (lane & 7) * 4;
+        const int n = n0 + nb + q;
+        if (c0 + c < C && n < H) {
+            float* dst = job.resp + (size_t)(c0 + c) * N;
+            const int base = (N - H + n + ring_off) & mask;
+            if (((base & 3) == 0) && (n + 3 < H) && (base + 3 <= mask)) {
+                *reinterpret_cast<float4*>(dst + base) =
+                    make_float4(tile[c * 33 + q], tile[c * 33 + q + 1], tile[c * 33 + q + 2], tile[c * 33 + q + 3]);
+            } else {
+                for (int u = 0; u < 4; ++u)
+                    if (n + u < H) dst[(base + u) & mask] = tile[c * 33 + q + u];
+            }
+        }
+    }
+}
+
 // new_hist = [old_hist[H : H+P-1], x[0:H], zero pad]
 __global__ void __launch_bounds__(256) hist_update_kernel(int P, int H, int pad, const float* __restrict__ old_hist,
                                                           const float* __restrict__ x, float* __restrict__ new_hist) {
@@ -106,7 +193,19 @@ hipError_t apv_launch_ring_append(int N, int H, int ring_off, const float* x, fl
     return hipGetLastError();
 }
 
-int apv_fir_pad() { return FIR_TN; }
+int apv_fir_pad() { return 128; }      // history buffers are padded so that a 128-sample tile never reads past the end
+
+hipError_t apv_launch_fir_jobs(const FirJobs& jobs, int P, int H, int N, int ring_off, hipStream_t s) {
+    if (jobs.n <= 0 || H <= 0) return hipSuccess;
+    int maxC = 0;
+    for (int j = 0; j < jobs.n; ++j) maxC = jobs.j[j].C > maxC ? jobs.j[j].C : maxC;
+    dim3 grid((H + 127) / 128, (maxC + 31) / 32, jobs.n);
+    size_t lds = sizeof(float) * (size_t)(P - 1 + 128);
+    const size_t tiles = sizeof(float) * 4 * 32 * 33;
+    if (lds < tiles) lds = tiles;
+    hipLaunchKernelGGL(fir_mfma_kernel, grid, dim3(256), lds, s, jobs, P, H, N, ring_off & (N - 1));
+    return hipGetLastError();
+}
 
 hipError_t apv_launch_apply_filters(int K, int n_filt, int n_tgt, const float2* in_spec, const void* w,
                                     int w_c128, const float2* tgt, float2* out, hipStream_t s) {

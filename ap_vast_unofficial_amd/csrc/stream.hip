@@ -13,6 +13,7 @@
 #include "apv_internal.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -177,11 +178,22 @@ int apv_process_block(apv_handle* h, const float* h_in_A, const float* h_in_B, f
     s->ring_off = (s->ring_off + H) & (N - 1);
     for (int g = 0; g < 2; ++g)
         SCHK(h, apv_launch_ring_append(N, H, s->ring_off, s->xin + (size_t)g * H, s->inblk + (size_t)g * N, st));
-    // K1: RIR convolution into the response rings
-    for (int p = 0; p < 4; ++p)
-        SCHK(h, apv_launch_fir_hop(C, P, H, N, s->ring_off, s->rir[path_zone(p)], s->xhist[s->cur][path_sig(p)], s->resp[p], st));
-    for (int z = 0; z < 2; ++z)
-        SCHK(h, apv_launch_fir_hop(M, P, H, N, s->ring_off, s->trir[z], s->xhist[s->cur][z], s->tresp[z], st));
+    // K1: RIR convolution into the response rings (one MFMA launch for all six filter banks)
+    {
+        static const bool valu_fir = (getenv("APV_FIR_VALU") != nullptr);     // A/B switch: direct-form VALU kernel
+        if (valu_fir) {
+            for (int p = 0; p < 4; ++p)
+                SCHK(h, apv_launch_fir_hop(C, P, H, N, s->ring_off, s->rir[path_zone(p)], s->xhist[s->cur][path_sig(p)], s->resp[p], st));
+            for (int z = 0; z < 2; ++z)
+                SCHK(h, apv_launch_fir_hop(M, P, H, N, s->ring_off, s->trir[z], s->xhist[s->cur][z], s->tresp[z], st));
+        } else {
+            FirJobs jobs;
+            jobs.n = 6;
+            for (int p = 0; p < 4; ++p) jobs.j[p] = FirJob{s->rir[path_zone(p)], s->xhist[s->cur][path_sig(p)], s->resp[p], C};
+            for (int z = 0; z < 2; ++z) jobs.j[4 + z] = FirJob{s->trir[z], s->xhist[s->cur][z], s->tresp[z], M};
+            SCHK(h, apv_launch_fir_jobs(jobs, P, H, N, s->ring_off, st));
+        }
+    }
     // K2: analysis, bin-major output
     const bool runA = s->zones & 1, runB = s->zones & 2;
     for (int p = 0; p < 4; ++p) {
@@ -194,17 +206,26 @@ int apv_process_block(apv_handle* h, const float* h_in_A, const float* h_in_B, f
     SCHK(h, apv_launch_stft_analysis_strided(N, 2, s->inblk, s->ring_off, s->inspec, K, 1, st, &why));
     // per-bin update per zone program: A: bright A->A, dark A->B, target A;  B: bright B->B, dark B->A, target B
     int oc = 0;     // output channel cursor
-    for (int z = 0; z < 2; ++z) {
-        if (!(z ? runB : runA)) continue;
+    {
+        // both zone programs go out in ONE launch (blockIdx.y = zone): K = N/2+1 bins alone cannot fill the chip
         GevdParams p = apv_base_params(h);
-        p.XB = z ? s->X[3] : s->X[0];
-        p.XD = z ? s->X[2] : s->X[1];
-        p.d = s->tspec[z];
-        p.w = s->w[z];
-        p.lam = s->lam[z];
-        p.status = s->status[z];
+        const int first = runA ? 0 : 1;
+        p.XB = first ? s->X[3] : s->X[0];
+        p.XD = first ? s->X[2] : s->X[1];
+        p.d = s->tspec[first];
+        p.w = s->w[first];
+        p.lam = s->lam[first];
+        p.status = s->status[first];
+        p.n_zones = (runA && runB) ? 2 : 1;
+        if (p.n_zones == 2) {
+            p.XB1 = s->X[3]; p.XD1 = s->X[2]; p.d1 = s->tspec[1];
+            p.w1 = s->w[1]; p.lam1 = s->lam[1]; p.status1 = s->status[1];
+        }
         hipError_t e = apv_launch_gevd(p, h->cfg.compute_dtype, true, st, &why);
         if (e != hipSuccess) return apv_fail(h, APV_ERR_HIP, why.empty() ? hipGetErrorString(e) : why);
+    }
+    for (int z = 0; z < 2; ++z) {
+        if (!(z ? runB : runA)) continue;
         // K3: filtered output spectra for this zone's nV*L channels
         SCHK(h, apv_launch_apply_filters(K, s->nV * L, 0, s->inspec + (size_t)z * K, s->w[z], h->cfg.out_c128, nullptr,
                                          s->outspec + (size_t)oc * K, st));
