@@ -61,6 +61,9 @@ struct apv_handle {
     struct apv_stream* st;   // streaming state (apv_stream_init), owned
     void* comm;       // ncclComm_t
     int comm_rank, comm_world;
+    hipStream_t comm_stream;      // the all-gather runs here so that it overlaps the next block's kernels
+    hipEvent_t ev_ready;          // compute -> comm: the shard is written
+    struct { const void* ptr; hipEvent_t ev; } gather_done[4];   // comm -> compute: shard buffer may be rewritten
     std::string err;
 };
 

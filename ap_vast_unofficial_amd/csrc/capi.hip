@@ -128,6 +128,9 @@ int apv_create(const apv_config* cfg, apv_handle** out) {
     h->d_Lspill = nullptr;
     h->lspill_bytes = 0;
     h->st = nullptr;
+    h->comm_stream = nullptr;
+    h->ev_ready = nullptr;
+    for (auto& g : h->gather_done) { g.ptr = nullptr; g.ev = nullptr; }
     h->comm = nullptr;
     h->comm_rank = 0;
     h->comm_world = 1;
@@ -160,7 +163,12 @@ int apv_destroy(apv_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     apv_stream_free(h);
+    if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
     if (h->comm) ncclCommDestroy((ncclComm_t)h->comm);
+    for (auto& g : h->gather_done)
+        if (g.ev) (void)hipEventDestroy(g.ev);
+    if (h->ev_ready) (void)hipEventDestroy(h->ev_ready);
+    if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
     void* bufs[] = {h->d_XB, h->d_XD, h->d_d, h->d_w, h->d_lam, h->d_status, h->d_Lspill};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -203,6 +211,7 @@ int apv_sync(apv_handle* h) {
     if (!h) return APV_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->comm_stream) HIPCHK(h, hipStreamSynchronize(h->comm_stream));
     return APV_OK;
 }
 
@@ -226,6 +235,11 @@ int apv_update_dev(apv_handle* h, const void* d_XB, const void* d_XD, const void
     if (h->cfg.n_bins == 0) return APV_OK;
     if (!d_XB || !d_XD || !d_d || !d_w) return fail(h, APV_ERR_ARG, "null device pointer");
     HIPCHK(h, hipSetDevice(h->device));
+    for (auto& g : h->gather_done)
+        if (g.ptr == d_w && g.ev) {       // an all-gather may still be reading this shard buffer
+            HIPCHK(h, hipStreamWaitEvent(h->stream, g.ev, 0));
+            g.ptr = nullptr;
+        }
     GevdParams p = base_params(h);
     p.XB = (const float2*)d_XB;
     p.XD = (const float2*)d_XD;
@@ -420,6 +434,11 @@ int apv_comm_init(apv_handle* h, const char id[128], int32_t rank, int32_t world
     h->comm = comm;
     h->comm_rank = rank;
     h->comm_world = world;
+    if (!h->comm_stream) {
+        HIPCHK(h, hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+        HIPCHK(h, hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming));
+        for (auto& g : h->gather_done) HIPCHK(h, hipEventCreateWithFlags(&g.ev, hipEventDisableTiming));
+    }
     return APV_OK;
 }
 
@@ -428,8 +447,18 @@ int apv_allgather_filters_dev(apv_handle* h, const void* d_w_shard, void* d_w_al
     if (!h->comm) return fail(h, APV_ERR_RCCL, "communicator not initialised (apv_comm_init)");
     const apv_config& c = h->cfg;
     const size_t bytes = (size_t)c.n_bins * c.n_ranks * c.n_srcs * wsize(h);
-    ncclResult_t r = ncclAllGather(d_w_shard, d_w_all, bytes, ncclChar, (ncclComm_t)h->comm, h->stream);
+    HIPCHK(h, hipSetDevice(h->device));
+    // the gather starts once the kernels already queued on the compute stream have written the shard, and runs
+    // on its own stream: the next block's update (into another shard buffer) overlaps it
+    HIPCHK(h, hipEventRecord(h->ev_ready, h->stream));
+    HIPCHK(h, hipStreamWaitEvent(h->comm_stream, h->ev_ready, 0));
+    ncclResult_t r = ncclAllGather(d_w_shard, d_w_all, bytes, ncclChar, (ncclComm_t)h->comm, h->comm_stream);
     if (r != ncclSuccess) return fail(h, APV_ERR_RCCL, std::string("ncclAllGather: ") + ncclGetErrorString(r));
+    int slot = 0;
+    for (int i = 0; i < 4; ++i)
+        if (h->gather_done[i].ptr == d_w_shard || h->gather_done[i].ptr == nullptr) { slot = i; break; }
+    h->gather_done[slot].ptr = d_w_shard;
+    HIPCHK(h, hipEventRecord(h->gather_done[slot].ev, h->comm_stream));
     return APV_OK;
 }
 

@@ -118,6 +118,7 @@ def main():
     dXB, dXD, dd = eng.to_device(XB), eng.to_device(XD), eng.to_device(d)
     w_bytes = K * len(ranks) * L * 8
     dw = eng.alloc(w_bytes)
+    dw2 = eng.alloc(w_bytes)        # second shard buffer: the all-gather of step i overlaps the update of step i+1
     dstatus = eng.alloc(K * 4)
     collective = None
     dw_all = None
@@ -147,11 +148,15 @@ def main():
             collective = "rccl all-gather (torch.distributed nccl backend, all_gather_into_tensor)"
     del XB, XD, d
 
+    flip = [0]
+
     def step():
-        eng.update_dev(dXB, dXD, dd, dw, None, dstatus)
+        out = dw if (flip[0] == 0 or t_all is not None) else dw2
+        flip[0] ^= 1
+        eng.update_dev(dXB, dXD, dd, out, None, dstatus)
         if multi:
             if t_all is None:
-                eng.allgather_filters_dev(dw, dw_all)
+                eng.allgather_filters_dev(out, dw_all)
             else:
                 eng.sync()                      # the kernel ran on the engine's stream
                 dist.all_gather_into_tensor(t_all, t_w)

@@ -161,7 +161,10 @@ int  apv_set_state(apv_handle* h, const char* name, const void* h_src, size_t by
 /* ---- multi-GPU: bins sharded across ranks, one RCCL all-gather ---------- */
 int  apv_comm_unique_id(char id_out[128]);                                /* rank 0 calls, then broadcasts */
 int  apv_comm_init(apv_handle* h, const char id[128], int32_t rank, int32_t world);
-/* gathers every rank's w shard [K][nV][L] into d_w_all [world*K][nV][L] (device) over xGMI */
+/* gathers every rank's w shard [K][nV][L] into d_w_all [world*K][nV][L] (device) over xGMI.  Asynchronous:
+ * it waits for the kernels already queued on the handle's stream, then runs on a second stream so that the
+ * next apv_update_dev (into a different shard buffer) overlaps it; an update into the SAME shard buffer waits
+ * for the gather.  apv_sync() waits for both streams. */
 int  apv_allgather_filters_dev(apv_handle* h, const void* d_w_shard, void* d_w_all);
 
 #ifdef __cplusplus
