@@ -77,6 +77,8 @@ size_t apv_gevd_spill_bytes(int n, int K, int compute_dtype);
 
 // kernels_gevd16.hip (order-16 fast path; hipErrorNotSupported when the problem does not qualify)
 hipError_t apv_launch_gevd16(const GevdParams& p, int compute_dtype, bool fused, hipStream_t s);
+// kernels_gevd16m.hip (order-16, MFMA whitening / back-transform + register-resident Jacobi: the default)
+hipError_t apv_launch_gevd16m(const GevdParams& p, int compute_dtype, bool fused, hipStream_t s);
 
 // kernels_corr.hip
 hipError_t apv_launch_corr(int compute_dtype, int K, int M, int L, const float2* XB, const float2* XD,

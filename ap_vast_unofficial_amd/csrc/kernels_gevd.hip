@@ -73,11 +73,15 @@ __device__ __forceinline__ void rr_pair(int ne, int r, int a, int& p, int& q) {
 }
 
 template <typename T, int NMAX, int TPB, bool FUSED, bool SPILL>
-__global__ void __launch_bounds__(TPB) gevd_vast_kernel(const GevdParams p_in) {
-    GevdParams p = p_in;
-    if (blockIdx.y == 1) {          // second zone program of a two-zone launch
-        p.XB = p_in.XB1; p.XD = p_in.XD1; p.d = p_in.d1; p.w = p_in.w1; p.lam = p_in.lam1; p.status = p_in.status1;
-    }
+__global__ void __launch_bounds__(TPB) gevd_vast_kernel(const GevdParams p) {
+    // zone program of a two-zone launch (blockIdx.y); the argument block itself stays in scalar registers
+    const bool z1 = (blockIdx.y == 1);
+    const float2* const pXB = z1 ? p.XB1 : p.XB;
+    const float2* const pXD = z1 ? p.XD1 : p.XD;
+    const float2* const pd = z1 ? p.d1 : p.d;
+    void* const pw = z1 ? p.w1 : p.w;
+    void* const plam = z1 ? p.lam1 : p.lam;
+    int32_t* const pstatus = z1 ? p.status1 : p.status;
     using C = Cx<T>;
     constexpr int LD = NMAX + 1;
     constexpr int NP = NMAX / 2;
@@ -113,7 +117,7 @@ __global__ void __launch_bounds__(TPB) gevd_vast_kernel(const GevdParams p_in) {
     if constexpr (FUSED) {
         const int M = p.M;
         for (int which = 0; which < 2; ++which) {
-            const float2* X = (which ? p.XD : p.XB) + (size_t)k * M * n;
+            const float2* X = (which ? pXD : pXB) + (size_t)k * M * n;
             C acc[NACC];
 #pragma unroll
             for (int a = 0; a < NACC; ++a) acc[a] = mk<T>(0, 0);
@@ -122,7 +126,7 @@ __global__ void __launch_bounds__(TPB) gevd_vast_kernel(const GevdParams p_in) {
                 const int rows = (M - m0) < MT ? (M - m0) : MT;
                 for (int idx = tid; idx < rows * n; idx += TPB) sX[idx] = X[(size_t)m0 * n + idx];
                 if (which == 0)
-                    for (int idx = tid; idx < rows; idx += TPB) sd[idx] = p.d[(size_t)k * M + m0 + idx];
+                    for (int idx = tid; idx < rows; idx += TPB) sd[idx] = pd[(size_t)k * M + m0 + idx];
                 __syncthreads();
 #pragma unroll
                 for (int a = 0; a < NACC; ++a) {
@@ -452,15 +456,15 @@ __global__ void __launch_bounds__(TPB) gevd_vast_kernel(const GevdParams p_in) {
             }
             const size_t o = ((size_t)k * p.nV + t) * n + tid;
             if (p.out_c128) {
-                reinterpret_cast<double2*>(p.w)[o] = make_double2((double)acc.x, (double)acc.y);
+                reinterpret_cast<double2*>(pw)[o] = make_double2((double)acc.x, (double)acc.y);
             } else {
-                reinterpret_cast<float2*>(p.w)[o] = make_float2((float)acc.x, (float)acc.y);
+                reinterpret_cast<float2*>(pw)[o] = make_float2((float)acc.x, (float)acc.y);
             }
         }
-        if (p.lam != nullptr) {
+        if (plam != nullptr) {
             const T lv = (status != 1) ? sLam[sOrder[tid]] : (T)0;
-            if (p.out_c128) reinterpret_cast<double*>(p.lam)[(size_t)k * n + tid] = (double)lv;
-            else reinterpret_cast<float*>(p.lam)[(size_t)k * n + tid] = (float)lv;
+            if (p.out_c128) reinterpret_cast<double*>(plam)[(size_t)k * n + tid] = (double)lv;
+            else reinterpret_cast<float*>(plam)[(size_t)k * n + tid] = (float)lv;
         }
     }
     if (p.U != nullptr) {
@@ -470,7 +474,7 @@ __global__ void __launch_bounds__(TPB) gevd_vast_kernel(const GevdParams p_in) {
             U[idx] = (status != 1) ? sV[i * LD + sOrder[j]] : mk<T>(0, 0);
         }
     }
-    if (p.status != nullptr && tid == 0) p.status[k] = status;
+    if (pstatus != nullptr && tid == 0) pstatus[k] = status;
 }
 
 template <typename T, int NMAX, int TPB, bool SPILL>
@@ -493,8 +497,11 @@ size_t apv_gevd_spill_bytes(int n, int K, int compute_dtype) {
 hipError_t apv_launch_gevd(const GevdParams& p, int compute_dtype, bool fused, hipStream_t s, std::string* why) {
     const int n = p.n;
     static const bool force_generic = (getenv("APV_FORCE_GENERIC") != nullptr);
+    // APV_GEVD16_JACOBI=lds|reg selects the older order-16 kernels (kept for A/B profiling)
+    static const bool old16 = (getenv("APV_GEVD16_JACOBI") != nullptr);
     if (!force_generic) {
-        const hipError_t e16 = apv_launch_gevd16(p, compute_dtype, fused, s);
+        const hipError_t e16 = old16 ? apv_launch_gevd16(p, compute_dtype, fused, s)
+                                     : apv_launch_gevd16m(p, compute_dtype, fused, s);
         if (e16 != hipErrorNotSupported) return e16;
     }
     if (n < 1 || n > APV_MAX_N) {

@@ -15,230 +15,20 @@
 
 #include <cstdlib>
 
+#include "gevd16_common.h"
+
 namespace {
 
-constexpr int N = 16;
-constexpr int LD = 17;        // row stride of the LDS matrices, in complex elements
-
-template <typename T> struct Cx { T x, y; };
-template <typename T> __device__ __forceinline__ Cx<T> mk(T a, T b) { Cx<T> r; r.x = a; r.y = b; return r; }
-
-template <typename T> struct Prec;
-template <> struct Prec<double> {
-    // a sweep that met off^2/||C||^2 <= tol2 leaves ~tol2^2 behind (quadratic convergence): it is the last one
-    static constexpr double sweep_tol2 = 1e-10;
-    static constexpr int max_sweeps = 14;
-    static constexpr double tiny = 1e-290;        // |beta|^2 below this: rotation skipped (rsq would overflow)
-    static constexpr double skip_rel = 1e-60;     // |beta|^2 <= skip_rel (alpha^2+gamma^2): negligible, and tau^2 stays finite
-};
-template <> struct Prec<float> {
-    static constexpr float sweep_tol2 = 1e-8f;
-    static constexpr int max_sweeps = 12;
-    static constexpr float tiny = 1e-35f;
-    static constexpr float skip_rel = 1e-24f;
-};
-
-// 1/sqrt(x), full precision of T, x > 0 finite
-__device__ __forceinline__ double rsq_full(double x) {
-    double y = __builtin_amdgcn_rsq(x);
-    const double t = x * y;
-    const double e = __builtin_fma(-t, y, 1.0);
-    const double pp = __builtin_fma(0.375, e, 0.5);
-    const double ye = y * e;
-    // v_rsq_f64 is good to 5e-8 on gfx950 (measured); one third-order step brings it to 1.4e-16
-    return __builtin_fma(ye, pp, y);
-}
-__device__ __forceinline__ float rsq_full(float x) {
-    float y = __builtin_amdgcn_rsqf(x);
-    const float t = x * y;
-    const float e = __builtin_fmaf(-t, y, 1.0f);
-    return __builtin_fmaf(y * e, 0.5f, y);
-}
-
-// tournament schedule for 16 players: nibble r of SEQ_P[a] / SEQ_Q[a] = smaller / larger index of slot a in round r
-struct Seq { unsigned long long p[8], q[8]; };
-constexpr Seq make_seq() {
-    Seq s{};
-    for (int a = 0; a < 8; ++a) {
-        unsigned long long sp = 0, sq = 0;
-        for (int r = 0; r < 15; ++r) {
-            int u = 0, v = 0;
-            if (a == 0) { u = 15; v = r; } else { u = (r + a) % 15; v = (r - a + 15) % 15; }
-            const int lo = u < v ? u : v, hi = u < v ? v : u;
-            sp |= (unsigned long long)lo << (4 * r);
-            sq |= (unsigned long long)hi << (4 * r);
-        }
-        s.p[a] = sp;
-        s.q[a] = sq;
-    }
-    return s;
-}
-__constant__ Seq c_seq = make_seq();
-
-template <typename T> __device__ __forceinline__ T wave_sum(T v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-    return __shfl(v, 0, 64);
-}
-
-using d4 = __attribute__((ext_vector_type(4))) double;
-using f4 = __attribute__((ext_vector_type(4))) float;
-
-// R = X^H X for one [M][16] c64 slab, result written to dst (LDS, row stride LD); optional r = X^H d -> sr
-template <typename T>
-__device__ __forceinline__ void correlate16(const float2* __restrict__ X, const float2* __restrict__ dvec, int M,
-                                            Cx<T>* dst, Cx<T>* sr, int lane);
-
-template <>
-__device__ __forceinline__ void correlate16<double>(const float2* __restrict__ X, const float2* __restrict__ dvec,
-                                                    int M, Cx<double>* dst, Cx<double>* sr, int lane) {
-    d4 re = {0, 0, 0, 0}, im = {0, 0, 0, 0};
-    double rx = 0, ry = 0;
-    const int msub = lane >> 4;
-    for (int m0 = 0; m0 < M; m0 += 4) {
-        const bool ok = (m0 + msub) < M;
-        const float2 xv = ok ? X[(size_t)m0 * N + lane] : make_float2(0.f, 0.f);
-        const double xr = xv.x, xi = xv.y;
-        re = __builtin_amdgcn_mfma_f64_16x16x4f64(xr, xr, re, 0, 0, 0);
-        re = __builtin_amdgcn_mfma_f64_16x16x4f64(xi, xi, re, 0, 0, 0);
-        im = __builtin_amdgcn_mfma_f64_16x16x4f64(xr, xi, im, 0, 0, 0);
-        im = __builtin_amdgcn_mfma_f64_16x16x4f64(-xi, xr, im, 0, 0, 0);
-        if (dvec != nullptr) {
-            const float2 dv = ok ? dvec[m0 + msub] : make_float2(0.f, 0.f);
-            rx += xr * (double)dv.x + xi * (double)dv.y;        // conj(x) * d
-            ry += xr * (double)dv.y - xi * (double)dv.x;
-        }
-    }
-    // f64 16x16x4 accumulator: row = (lane>>4) + 4*reg, col = lane&15
-    const int col = lane & 15;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) dst[(msub + 4 * t) * LD + col] = mk<double>(re[t], im[t]);
-    if (dvec != nullptr) {
-        rx += __shfl_xor(rx, 16, 64); ry += __shfl_xor(ry, 16, 64);
-        rx += __shfl_xor(rx, 32, 64); ry += __shfl_xor(ry, 32, 64);
-        if (lane < N) sr[lane] = mk<double>(rx, ry);
-    }
-}
-
-template <>
-__device__ __forceinline__ void correlate16<float>(const float2* __restrict__ X, const float2* __restrict__ dvec,
-                                                   int M, Cx<float>* dst, Cx<float>* sr, int lane) {
-    f4 re = {0, 0, 0, 0}, im = {0, 0, 0, 0};
-    float rx = 0, ry = 0;
-    const int msub = lane >> 4;
-    for (int m0 = 0; m0 < M; m0 += 4) {
-        const bool ok = (m0 + msub) < M;
-        const float2 xv = ok ? X[(size_t)m0 * N + lane] : make_float2(0.f, 0.f);
-        const float xr = xv.x, xi = xv.y;
-        re = __builtin_amdgcn_mfma_f32_16x16x4f32(xr, xr, re, 0, 0, 0);
-        re = __builtin_amdgcn_mfma_f32_16x16x4f32(xi, xi, re, 0, 0, 0);
-        im = __builtin_amdgcn_mfma_f32_16x16x4f32(xr, xi, im, 0, 0, 0);
-        im = __builtin_amdgcn_mfma_f32_16x16x4f32(-xi, xr, im, 0, 0, 0);
-        if (dvec != nullptr) {
-            const float2 dv = ok ? dvec[m0 + msub] : make_float2(0.f, 0.f);
-            rx += xr * dv.x + xi * dv.y;
-            ry += xr * dv.y - xi * dv.x;
-        }
-    }
-    // f32 16x16x4 accumulator: row = 4*(lane>>4) + reg, col = lane&15
-    const int col = lane & 15;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) dst[(4 * msub + t) * LD + col] = mk<float>(re[t], im[t]);
-    if (dvec != nullptr) {
-        rx += __shfl_xor(rx, 16, 64); ry += __shfl_xor(ry, 16, 64);
-        rx += __shfl_xor(rx, 32, 64); ry += __shfl_xor(ry, 32, 64);
-        if (lane < N) sr[lane] = mk<float>(rx, ry);
-    }
-}
-
-// wave-level ordering point between phases that exchange data through LDS (one wave per workgroup)
-__device__ __forceinline__ void wsync() { __syncthreads(); }
-
-// XOR-schedule for the register-resident Jacobi (JAC == 1).  Pairs of round r are {i, i^r}; the 15 values of r
-// are visited grouped by their highest (odd sweeps: lowest) set bit so that between two rounds only the
-// "bottom" member of every pair changes slot, by a slot-XOR of 1, 2 or 4.  Entry = {transition bit or -1, delta}.
-struct XStep { signed char tbit, delta; };
-__constant__ XStep c_xsched[2][15] = {
-    {{-1, 1}, {-1, 2}, {-1, 1}, {-1, 4}, {-1, 1}, {-1, 2}, {-1, 1}, {-1, 4}, {2, 1}, {-1, 2}, {-1, 1}, {-1, 2}, {1, 1}, {-1, 1}, {0, 0}},
-    {{-1, 1}, {-1, 2}, {-1, 1}, {-1, 4}, {-1, 1}, {-1, 2}, {-1, 1}, {-1, 4}, {0, 2}, {-1, 4}, {-1, 2}, {-1, 4}, {1, 4}, {-1, 4}, {2, 0}}};
-
-template <typename T> __device__ __forceinline__ Cx<T> cshfl(Cx<T> v, int src) {
-    return mk<T>(__shfl(v.x, src, 64), __shfl(v.y, src, 64));
-}
-// members of a (top, bottom) pair trade places across lanes `peer`: the lane whose slot bit is set gives its
-// top and keeps its bottom, the other gives its bottom and keeps its top
-template <typename T> __device__ __forceinline__ void xchg(Cx<T>& top, Cx<T>& bot, bool bit, int peer) {
-    const Cx<T> send = bit ? top : bot;
-    const Cx<T> recv = cshfl(send, peer);
-    if (bit) top = recv; else bot = recv;
-}
-
-// ---- cross-lane moves by XOR of the lane id, on the VALU (DPP) where the ISA allows it ----
-template <int D> __device__ __forceinline__ int dpp_xor_lo(int v);       // lane ^ D, D in {1,2,4} (within 8 lanes)
-template <> __device__ __forceinline__ int dpp_xor_lo<1>(int v) { return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false); }  // quad_perm [1,0,3,2]
-template <> __device__ __forceinline__ int dpp_xor_lo<2>(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false); }  // quad_perm [2,3,0,1]
-template <> __device__ __forceinline__ int dpp_xor_lo<4>(int v) {
-    const int t = __builtin_amdgcn_update_dpp(v, v, 0x104, 0xf, 0x5, false);      // row_shl:4 into banks 0,2
-    return __builtin_amdgcn_update_dpp(t, v, 0x114, 0xf, 0xa, false);             // row_shr:4 into banks 1,3
-}
-__device__ __forceinline__ int dpp_xor8(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false); }  // row_ror:8
-
-template <int D> __device__ __forceinline__ float xcol(float v) { return __int_as_float(dpp_xor_lo<D>(__float_as_int(v))); }
-template <int D> __device__ __forceinline__ double xcol(double v) {
-    return __hiloint2double(dpp_xor_lo<D>(__double2hiint(v)), dpp_xor_lo<D>(__double2loint(v)));
-}
-template <int D> __device__ __forceinline__ float xrow(float v, int lane) {
-    if constexpr (D == 1) return __int_as_float(dpp_xor8(__float_as_int(v)));
-    else return __shfl(v, lane ^ (8 * D), 64);
-}
-template <int D> __device__ __forceinline__ double xrow(double v, int lane) {
-    if constexpr (D == 1) return __hiloint2double(dpp_xor8(__double2hiint(v)), dpp_xor8(__double2loint(v)));
-    else return __shfl(v, lane ^ (8 * D), 64);
-}
-template <int D, typename T> __device__ __forceinline__ Cx<T> cxcol(Cx<T> v) { return mk<T>(xcol<D>(v.x), xcol<D>(v.y)); }
-template <int D, typename T> __device__ __forceinline__ Cx<T> cxrow(Cx<T> v, int lane) { return mk<T>(xrow<D>(v.x, lane), xrow<D>(v.y, lane)); }
-
-// bottoms of every pair move by slot-XOR D: columns (lane bits 0-2) and rows (lane bits 3-5)
-template <int D, typename T>
-__device__ __forceinline__ void move_bottoms(Cx<T>& tb, Cx<T>& bt, Cx<T>& bb, Cx<T>& v0b, Cx<T>& v1b, int lane) {
-    tb = cxcol<D>(tb);
-    v0b = cxcol<D>(v0b);
-    v1b = cxcol<D>(v1b);
-    bb = cxcol<D>(bb);
-    bt = cxrow<D>(bt, lane);
-    bb = cxrow<D>(bb, lane);
-}
-
-// Jacobi rotation J = [[c, s], [-conj(s), c]] for the Hermitian 2x2 [[alpha, beta], [conj(beta), gamma]].
-// Any complex t gives an exactly unitary J once c = 1/sqrt(1+|t|^2), s = t c are formed in T, so the
-// angle t = sign(tau) e^{i arg beta} / (|tau| + sqrt(1+tau^2)) is evaluated in float (relative 1e-7: the pair's
-// off-diagonal drops by that factor instead of to zero, which the next sweep finishes).  Inputs are
-// pre-scaled to ||C||_F ~ 1, so float range is not an issue; |beta|^2 < 1e-30 is skipped.
-template <typename T>
-__device__ __forceinline__ void rotation(T alpha, T gamma, T bx, T by, T& c, T& sx, T& sy) {
-    const float fbx = (float)bx, fby = (float)by, fd = (float)(gamma - alpha);
-    const float b2 = fbx * fbx + fby * fby;
-    float tx = 0.f, ty = 0.f;
-    if (b2 > 1e-30f) {
-        const float iab = __builtin_amdgcn_rsqf(b2);
-        const float tau = fd * 0.5f * iab;
-        const float rho = __builtin_amdgcn_sqrtf(__builtin_fmaf(tau, tau, 1.0f));
-        const float t = copysignf(__builtin_amdgcn_rcpf(fabsf(tau) + rho), tau) * iab;
-        tx = fbx * t;
-        ty = fby * t;
-    }
-    const T dx = (T)tx, dy = (T)ty;
-    c = rsq_full((T)1 + dx * dx + dy * dy);
-    sx = dx * c;
-    sy = dy * c;
-}
-
 template <typename T, bool FUSED, int JAC>
-__global__ void __launch_bounds__(64) gevd16_kernel(const GevdParams p_in) {
-    GevdParams p = p_in;
-    if (blockIdx.y == 1) {          // second zone program of a two-zone launch
-        p.XB = p_in.XB1; p.XD = p_in.XD1; p.d = p_in.d1; p.w = p_in.w1; p.lam = p_in.lam1; p.status = p_in.status1;
-    }
+__global__ void __launch_bounds__(64) gevd16_kernel(const GevdParams p) {
+    // zone program of a two-zone launch (blockIdx.y); the argument block itself stays in scalar registers
+    const bool z1 = (blockIdx.y == 1);
+    const float2* const pXB = z1 ? p.XB1 : p.XB;
+    const float2* const pXD = z1 ? p.XD1 : p.XD;
+    const float2* const pd = z1 ? p.d1 : p.d;
+    void* const pw = z1 ? p.w1 : p.w;
+    void* const plam = z1 ? p.lam1 : p.lam;
+    int32_t* const pstatus = z1 ? p.status1 : p.status;
     using C = Cx<T>;
     __shared__ C sA[N * LD];
     __shared__ C sB[N * LD];
@@ -257,8 +47,8 @@ __global__ void __launch_bounds__(64) gevd16_kernel(const GevdParams p_in) {
     // ---------------- stage 0 ----------------
     if constexpr (FUSED) {
         const size_t slab = (size_t)k * p.M * N;
-        correlate16<T>(p.XB + slab, p.d + (size_t)k * p.M, p.M, sA, sr, lane);
-        correlate16<T>(p.XD + slab, nullptr, p.M, sB, sr, lane);
+        correlate16<T>(pXB + slab, pd + (size_t)k * p.M, p.M, sA, sr, lane);
+        correlate16<T>(pXD + slab, nullptr, p.M, sB, sr, lane);
     } else {
         const C* RB = reinterpret_cast<const C*>(p.RB) + (size_t)k * N * N;
         const C* RD = reinterpret_cast<const C*>(p.RD) + (size_t)k * N * N;
@@ -641,13 +431,13 @@ __global__ void __launch_bounds__(64) gevd16_kernel(const GevdParams p_in) {
                 }
             }
             const size_t o = ((size_t)k * p.nV + t) * N + lane;
-            if (p.out_c128) reinterpret_cast<double2*>(p.w)[o] = make_double2((double)ax, (double)ay);
-            else reinterpret_cast<float2*>(p.w)[o] = make_float2((float)ax, (float)ay);
+            if (p.out_c128) reinterpret_cast<double2*>(pw)[o] = make_double2((double)ax, (double)ay);
+            else reinterpret_cast<float2*>(pw)[o] = make_float2((float)ax, (float)ay);
         }
-        if (p.lam != nullptr) {
+        if (plam != nullptr) {
             const T lv = (status != 1) ? sLam[sOrder[lane]] : (T)0;
-            if (p.out_c128) reinterpret_cast<double*>(p.lam)[(size_t)k * N + lane] = (double)lv;
-            else reinterpret_cast<float*>(p.lam)[(size_t)k * N + lane] = (float)lv;
+            if (p.out_c128) reinterpret_cast<double*>(plam)[(size_t)k * N + lane] = (double)lv;
+            else reinterpret_cast<float*>(plam)[(size_t)k * N + lane] = (float)lv;
         }
     }
     if (p.U != nullptr) {
@@ -658,7 +448,7 @@ __global__ void __launch_bounds__(64) gevd16_kernel(const GevdParams p_in) {
             U[idx] = (status != 1) ? sV[i * LD + sOrder[j]] : mk<T>(0, 0);
         }
     }
-    if (p.status != nullptr && lane == 0) p.status[k] = status;
+    if (pstatus != nullptr && lane == 0) pstatus[k] = status;
 }
 
 }  // namespace

@@ -1,0 +1,354 @@
+// Order-16 fused subband update, third generation: every dense 16x16x16 contraction is on the matrix cores.
+//
+//   stage 0  R_B, R_D = X^H X, r = X_B^H d        MFMA 16x16x4 (f64 or f32), slab read once, coalesced
+//   stage 1  Cholesky of R_D + reg I TOGETHER WITH W = L^-1 (elimination applied to [B | I]); rows of B and W
+//            live in registers, one column / one row is broadcast through LDS per step      apvast.py:22-27
+//   stage 2  C = W R_B W^H                         two complex MFMA products                 apvast.py:28-29
+//   stage 3  cyclic Jacobi, register resident, XOR pairing schedule (gevd16_common.h)        apvast.py:30
+//   stage 4  sort                                                                            apvast.py:32-35
+//   stage 5  X = W^H Q                             one complex MFMA product                  apvast.py:31
+//   stage 6  w_V = sum_{i<V} (x_i^H r)/(lam_i+mu) x_i                                        apvast.py:406-414
+//
+// Against kernels_gevd16.hip this removes 48 of the 64 sequential substitution steps (the two forward
+// substitutions and the backward one become three MFMA products) and one LDS matrix (8.7 KiB of LDS per wave).
+#include "apv_internal.h"
+
+#include <cstdlib>
+
+#include "gevd16_common.h"
+
+namespace {
+
+// complex 16x16x16 product on the matrix cores.  fa(i, k) / fb(k, j) fetch operand elements; out[t] is the
+// element (mfma_row<T>(lane, t), lane & 15).
+template <typename T> __device__ __forceinline__ int mfma_row(int lane, int t);
+template <> __device__ __forceinline__ int mfma_row<double>(int lane, int t) { return (lane >> 4) + 4 * t; }
+template <> __device__ __forceinline__ int mfma_row<float>(int lane, int t) { return 4 * (lane >> 4) + t; }
+
+template <typename FA, typename FB>
+__device__ __forceinline__ void cmm16(FA fa, FB fb, int lane, Cx<double> out[4]) {
+    d4 re = {0, 0, 0, 0}, im = {0, 0, 0, 0};
+    const int rc = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const Cx<double> a = fa(rc, 4 * s + kq), b = fb(4 * s + kq, rc);
+        re = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.x, re, 0, 0, 0);
+        re = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.y, b.y, re, 0, 0, 0);
+        im = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.y, im, 0, 0, 0);
+        im = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b.x, im, 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) out[t] = mk<double>(re[t], im[t]);
+}
+template <typename FA, typename FB>
+__device__ __forceinline__ void cmm16(FA fa, FB fb, int lane, Cx<float> out[4]) {
+    f4 re = {0, 0, 0, 0}, im = {0, 0, 0, 0};
+    const int rc = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const Cx<float> a = fa(rc, 4 * s + kq), b = fb(4 * s + kq, rc);
+        re = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, re, 0, 0, 0);
+        re = __builtin_amdgcn_mfma_f32_16x16x4f32(-a.y, b.y, re, 0, 0, 0);
+        im = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.y, im, 0, 0, 0);
+        im = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.x, im, 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) out[t] = mk<float>(re[t], im[t]);
+}
+
+template <typename T, bool FUSED>
+__global__ void __launch_bounds__(64) gevd16m_kernel(const GevdParams p) {
+    // zone program of a two-zone launch (blockIdx.y); the argument block itself stays in scalar registers
+    const bool z1 = (blockIdx.y == 1);
+    const float2* const pXB = z1 ? p.XB1 : p.XB;
+    const float2* const pXD = z1 ? p.XD1 : p.XD;
+    const float2* const pd = z1 ? p.d1 : p.d;
+    void* const pw = z1 ? p.w1 : p.w;
+    void* const plam = z1 ? p.lam1 : p.lam;
+    int32_t* const pstatus = z1 ? p.status1 : p.status;
+    using C = Cx<T>;
+    __shared__ C sA[N * LD];       // R_B -> W R_B -> C -> Q (eigenvectors of C) -> X
+    __shared__ C sB[N * LD];       // R_D -> W = L^-1
+    __shared__ C scol[2][N];       // Cholesky: current column of B (double buffered)
+    __shared__ C swr[2][N];        // Cholesky: current row of W
+    __shared__ C sr[N];
+    __shared__ C scoef[N];
+    __shared__ T sLam[N];
+    __shared__ int sOrder[N];
+
+    const int lane = threadIdx.x;
+    const int k = blockIdx.x;
+    int status = 0;
+
+    // ---------------- stage 0 ----------------
+    if constexpr (FUSED) {
+        const size_t slab = (size_t)k * p.M * N;
+        correlate16<T>(pXB + slab, pd + (size_t)k * p.M, p.M, sA, sr, lane);
+        correlate16<T>(pXD + slab, nullptr, p.M, sB, sr, lane);
+    } else {
+        const C* RB = reinterpret_cast<const C*>(p.RB) + (size_t)k * N * N;
+        const C* RD = reinterpret_cast<const C*>(p.RD) + (size_t)k * N * N;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int idx = lane + 64 * t, i = idx >> 4, j = idx & 15;
+            sA[i * LD + j] = RB[idx];
+            sB[i * LD + j] = RD[idx];
+        }
+        if (lane < N) sr[lane] = p.r ? reinterpret_cast<const C*>(p.r)[(size_t)k * N + lane] : mk<T>(0, 0);
+    }
+    wsync();
+    if (p.debug_stop == 1) return;
+
+    // ---------------- stage 1: Cholesky of B + reg I with W = L^-1 ----------------
+    // lane (i = lane>>2, jq = lane&3) owns B[i][jq+4t] and W[i][jq+4t], t = 0..3, in registers
+    const int i = lane >> 2, jq = lane & 3;
+    C brow[4], wrow[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int j = jq + 4 * t;
+        brow[t] = sB[i * LD + j];
+        if (j == i) brow[t] = mk<T>(brow[t].x + (T)p.reg_dark, 0);
+        wrow[t] = mk<T>((j == i) ? (T)1 : (T)0, 0);
+    }
+#pragma unroll
+    for (int kk = 0; kk < N; ++kk) {
+        const int buf = kk & 1;
+        if (jq == (kk & 3)) scol[buf][i] = brow[kk >> 2];                       // column kk of the working B
+        if (i == kk) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) swr[buf][jq + 4 * t] = wrow[t];         // row kk of the working W
+        }
+        wsync();
+        const T dkk = scol[buf][kk].x;
+        if (!(dkk > (T)0) || !(dkk < (T)3.0e38)) { status = 1; break; }         // uniform: same LDS word for all lanes
+        const T inv = rsq_full(dkk), inv2 = inv * inv;
+        const C li = scol[buf][i];
+        if (i > kk) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int j = jq + 4 * t;
+                if (j > kk && j <= i) {                  // B[i][j] -= B[i][kk] conj(B[j][kk]) / d
+                    const C lj = scol[buf][j];
+                    brow[t].x -= (li.x * lj.x + li.y * lj.y) * inv2;
+                    brow[t].y -= (li.y * lj.x - li.x * lj.y) * inv2;
+                }
+                if (j <= kk) {                           // W[i][j] -= (B[i][kk]/sqrt d) (W[kk][j]/sqrt d)
+                    const C wk = swr[buf][j];
+                    wrow[t].x -= (li.x * wk.x - li.y * wk.y) * inv2;
+                    wrow[t].y -= (li.x * wk.y + li.y * wk.x) * inv2;
+                }
+            }
+        } else if (i == kk) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) wrow[t] = mk<T>(wrow[t].x * inv, wrow[t].y * inv);
+        }
+    }
+    wsync();
+    if (p.debug_stop == 2) return;
+
+    if (status == 0) {
+        // W -> sB (R_D is spent)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) sB[i * LD + jq + 4 * t] = wrow[t];
+        wsync();
+        // ---------------- stage 2: C = W A W^H ----------------
+        C acc[4];
+        cmm16([&](int r, int kx) { return sB[r * LD + kx]; }, [&](int kx, int c) { return sA[kx * LD + c]; }, lane, acc);
+        wsync();
+        const int col = lane & 15;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) sA[mfma_row<T>(lane, t) * LD + col] = acc[t];          // T1 = W A
+        wsync();
+        cmm16([&](int r, int kx) { return sA[r * LD + kx]; },
+              [&](int kx, int c) { const C w = sB[c * LD + kx]; return mk<T>(w.x, -w.y); }, lane, acc);
+        wsync();
+        T nrm = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int row = mfma_row<T>(lane, t);
+            if (row == col) acc[t].y = 0;
+            sA[row * LD + col] = acc[t];                                                    // C
+            nrm += acc[t].x * acc[t].x + acc[t].y * acc[t].y;
+        }
+        const T normF2 = wave_sum(nrm);
+        wsync();
+        if (p.debug_stop == 3) return;
+
+        // ---------------- stage 3: register-resident Jacobi, XOR schedule ----------------
+        const int a = lane >> 3, b = lane & 7;
+        const int max_sweeps = p.max_sweeps > 0 ? p.max_sweeps : Prec<T>::max_sweeps;
+        const T tol2 = p.sweep_tol2 > 0.0 ? (T)p.sweep_tol2 : Prec<T>::sweep_tol2;
+        bool converged = false;
+        const int sexp = (normF2 > (T)0) ? -(ilogb((double)normF2) / 2) : 0;
+        const T scl = (T)ldexp(1.0, sexp), iscl = (T)ldexp(1.0, -sexp);
+        C tt = sA[a * LD + b], tb = sA[a * LD + 8 + b], bt = sA[(8 + a) * LD + b], bb = sA[(8 + a) * LD + 8 + b];
+        tt = mk<T>(tt.x * scl, tt.y * scl); tb = mk<T>(tb.x * scl, tb.y * scl);
+        bt = mk<T>(bt.x * scl, bt.y * scl); bb = mk<T>(bb.x * scl, bb.y * scl);
+        const T normS2 = normF2 * scl * scl;
+        C v0t = mk<T>((2 * a == b) ? (T)1 : (T)0, 0), v0b = mk<T>((2 * a == 8 + b) ? (T)1 : (T)0, 0);
+        C v1t = mk<T>((2 * a + 1 == b) ? (T)1 : (T)0, 0), v1b = mk<T>((2 * a + 1 == 8 + b) ? (T)1 : (T)0, 0);
+        const bool diag = (a == b);
+        int sweeps_done = 0;
+        for (int sweep = 0; sweep < max_sweeps && !converged; ++sweep) {
+            T off = 0;
+            const XStep* sched = c_xsched[sweep & 1];
+            for (int r = 0; r < 15; ++r) {
+                const int tbit = sched[r].tbit, delta = sched[r].delta;
+                if (tbit >= 0) {
+                    const bool cb_ = (b >> tbit) & 1, ab_ = (a >> tbit) & 1;
+                    const int pc = lane ^ (1 << tbit), pr = lane ^ (8 << tbit);
+                    xchg(tt, tb, cb_, pc);
+                    xchg(bt, bb, cb_, pc);
+                    xchg(v0t, v0b, cb_, pc);
+                    xchg(v1t, v1b, cb_, pc);
+                    xchg(tt, bt, ab_, pr);
+                    xchg(tb, bb, ab_, pr);
+                }
+                switch (delta) {
+                    case 1: move_bottoms<1>(tb, bt, bb, v0b, v1b, lane); break;
+                    case 2: move_bottoms<2>(tb, bt, bb, v0b, v1b, lane); break;
+                    case 4: move_bottoms<4>(tb, bt, bb, v0b, v1b, lane); break;
+                    default: break;
+                }
+                if (diag) off += tb.x * tb.x + tb.y * tb.y;
+                T c, sx, sy;
+                rotation<T>(tt.x, bb.x, tb.x, tb.y, c, sx, sy);
+                const int da = 9 * a, db = 9 * b;
+                const T ca = __shfl(c, da, 64), sax = __shfl(sx, da, 64), say = __shfl(sy, da, 64);
+                const T cb = __shfl(c, db, 64), sbx = __shfl(sx, db, 64), sby = __shfl(sy, db, 64);
+                C ypp, ypq, yqp, yqq;
+                ypp.x = cb * tt.x - (sbx * tb.x + sby * tb.y);
+                ypp.y = cb * tt.y - (sbx * tb.y - sby * tb.x);
+                ypq.x = cb * tb.x + (sbx * tt.x - sby * tt.y);
+                ypq.y = cb * tb.y + (sbx * tt.y + sby * tt.x);
+                yqp.x = cb * bt.x - (sbx * bb.x + sby * bb.y);
+                yqp.y = cb * bt.y - (sbx * bb.y - sby * bb.x);
+                yqq.x = cb * bb.x + (sbx * bt.x - sby * bt.y);
+                yqq.y = cb * bb.y + (sbx * bt.y + sby * bt.x);
+                tt.x = ca * ypp.x - (sax * yqp.x - say * yqp.y);
+                tt.y = ca * ypp.y - (sax * yqp.y + say * yqp.x);
+                tb.x = ca * ypq.x - (sax * yqq.x - say * yqq.y);
+                tb.y = ca * ypq.y - (sax * yqq.y + say * yqq.x);
+                bt.x = ca * yqp.x + (sax * ypp.x + say * ypp.y);
+                bt.y = ca * yqp.y + (sax * ypp.y - say * ypp.x);
+                bb.x = ca * yqq.x + (sax * ypq.x + say * ypq.y);
+                bb.y = ca * yqq.y + (sax * ypq.y - say * ypq.x);
+                if (diag) {         // the angle is float-accurate: the residual beta' ~ 1e-7 beta is real data, keep it
+                    tt.y = 0;
+                    bb.y = 0;
+                }
+                C w0p, w0q, w1p, w1q;
+                w0p.x = cb * v0t.x - (sbx * v0b.x + sby * v0b.y);
+                w0p.y = cb * v0t.y - (sbx * v0b.y - sby * v0b.x);
+                w0q.x = cb * v0b.x + (sbx * v0t.x - sby * v0t.y);
+                w0q.y = cb * v0b.y + (sbx * v0t.y + sby * v0t.x);
+                w1p.x = cb * v1t.x - (sbx * v1b.x + sby * v1b.y);
+                w1p.y = cb * v1t.y - (sbx * v1b.y - sby * v1b.x);
+                w1q.x = cb * v1b.x + (sbx * v1t.x - sby * v1t.y);
+                w1q.y = cb * v1b.y + (sbx * v1t.y + sby * v1t.x);
+                v0t = w0p; v0b = w0q; v1t = w1p; v1b = w1q;
+            }
+            ++sweeps_done;
+            const T tot = wave_sum(off);
+            if (tot <= tol2 * normS2) converged = true;
+        }
+        if (!converged) status = 2;
+        // after an odd number of sweeps slot s holds (2s, 2s+1), after an even number (s, 8+s)
+        const bool nat = sweeps_done & 1;
+        const int it_b = nat ? 2 * b : b, ib_b = nat ? 2 * b + 1 : 8 + b;
+        wsync();
+        sA[(2 * a) * LD + it_b] = v0t;
+        sA[(2 * a) * LD + ib_b] = v0b;
+        sA[(2 * a + 1) * LD + it_b] = v1t;
+        sA[(2 * a + 1) * LD + ib_b] = v1b;
+        if (diag) {
+            sLam[it_b] = tt.x * iscl;
+            sLam[ib_b] = bb.x * iscl;
+        }
+        wsync();
+
+        // ---------------- stage 4: descending order ----------------
+        if (lane < N) {
+            const T li = sLam[lane];
+            int rank = 0;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const T lj = sLam[j];
+                rank += (lj > li) || (lj == li && j < lane);
+            }
+            sOrder[rank] = lane;
+        }
+
+        // ---------------- stage 5: X = W^H Q ----------------
+        cmm16([&](int r, int kx) { const C w = sB[kx * LD + r]; return mk<T>(w.x, -w.y); },
+              [&](int kx, int c) { return sA[kx * LD + c]; }, lane, acc);
+        wsync();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) sA[mfma_row<T>(lane, t) * LD + col] = acc[t];
+        wsync();
+
+        // ---------------- stage 6: coefficients (x_i^H r) / (lam_i + mu) ----------------
+        if (lane < N) {
+            T sx = 0, sy = 0;
+#pragma unroll
+            for (int l = 0; l < N; ++l) {
+                const C v = sA[l * LD + lane], rr = sr[l];
+                sx += v.x * rr.x + v.y * rr.y;
+                sy += v.x * rr.y - v.y * rr.x;
+            }
+            const T den = (T)1 / (sLam[lane] + (T)p.mu);
+            scoef[lane] = mk<T>(sx * den, sy * den);
+        }
+        wsync();
+    }
+
+    // ---------------- outputs ----------------
+    if (lane < N) {
+        T ax = 0, ay = 0;
+        int done = 0;
+        for (int t = 0; t < p.nV; ++t) {
+            const int V = p.ranks[t];
+            if (status != 1) {
+                for (; done < V; ++done) {
+                    const int c = sOrder[done];
+                    const C cf = scoef[c], v = sA[lane * LD + c];
+                    ax += cf.x * v.x - cf.y * v.y;
+                    ay += cf.x * v.y + cf.y * v.x;
+                }
+            }
+            const size_t o = ((size_t)k * p.nV + t) * N + lane;
+            if (p.out_c128) reinterpret_cast<double2*>(pw)[o] = make_double2((double)ax, (double)ay);
+            else reinterpret_cast<float2*>(pw)[o] = make_float2((float)ax, (float)ay);
+        }
+        if (plam != nullptr) {
+            const T lv = (status != 1) ? sLam[sOrder[lane]] : (T)0;
+            if (p.out_c128) reinterpret_cast<double*>(plam)[(size_t)k * N + lane] = (double)lv;
+            else reinterpret_cast<float*>(plam)[(size_t)k * N + lane] = (float)lv;
+        }
+    }
+    if (p.U != nullptr) {
+        C* U = reinterpret_cast<C*>(p.U) + (size_t)k * N * N;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int idx = lane + 64 * t, ii = idx >> 4, j = idx & 15;
+            U[idx] = (status != 1) ? sA[ii * LD + sOrder[j]] : mk<T>(0, 0);
+        }
+    }
+    if (pstatus != nullptr && lane == 0) pstatus[k] = status;
+}
+
+}  // namespace
+
+hipError_t apv_launch_gevd16m(const GevdParams& p, int compute_dtype, bool fused, hipStream_t s) {
+    if (p.n != 16 || p.reg_mode != APV_REG_ABS || p.reg_bright != 0.0) return hipErrorNotSupported;
+    if (p.K <= 0) return hipSuccess;
+    const dim3 grid(p.K, p.n_zones > 1 ? 2 : 1);
+    if (compute_dtype == APV_F64) {
+        if (fused) hipLaunchKernelGGL((gevd16m_kernel<double, true>), grid, dim3(64), 0, s, p);
+        else hipLaunchKernelGGL((gevd16m_kernel<double, false>), grid, dim3(64), 0, s, p);
+    } else {
+        if (fused) hipLaunchKernelGGL((gevd16m_kernel<float, true>), grid, dim3(64), 0, s, p);
+        else hipLaunchKernelGGL((gevd16m_kernel<float, false>), grid, dim3(64), 0, s, p);
+    }
+    return hipGetLastError();
+}
