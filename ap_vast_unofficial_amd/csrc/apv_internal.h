@@ -93,6 +93,13 @@ hipError_t apv_launch_stft_analysis_strided(int N, int n_ch, const float* x, int
 hipError_t apv_launch_istft_ola_strided(int N, int H, int n_ch, const float2* spec, long stride_c, long stride_k,
                                         float* overlap, float* out, hipStream_t s, std::string* why);
 
+bool apv_stft_size_ok(int N, std::string* why);
+// general forms: f64 = 0/1 selects float/double data; in_len < N zero-pads; use_win = 0 skips the sine window
+hipError_t apv_launch_analysis(int f64, int N, int n_ch, const void* x, long x_stride, int in_len, int ring_off,
+                               int use_win, void* spec, long stride_c, long stride_k, hipStream_t s, std::string* why);
+hipError_t apv_launch_synthesis(int f64, int N, int H, int n_ch, const void* spec, long stride_c, long stride_k,
+                                void* overlap, void* out, hipStream_t s, std::string* why);
+
 // kernels_stream.hip
 // y = FIR(rir, x) for one hop, appended to the ring response buffers:
 //   resp[c*N + ((N-H+n + ring_off) & (N-1))] = sum_p rir[p*C + c] * xhist[P-1 + n - p],  n < H, c < C

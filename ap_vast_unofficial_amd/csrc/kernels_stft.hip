@@ -1,163 +1,233 @@
-// K2-K4: batched sine-window analysis STFT and synthesis + overlap-add.
+// K2-K4: batched sine-window analysis STFT and synthesis + overlap-add, float or double.
 //
 //   analysis : spec[c][k] = rfft(window * x[c][:])[k]                 reference Python/apvast.py:202-203,
-//                                                                     246-255, 430-431
+//                                                                     246-255, 430-431; un-windowed,
+//                                                                     zero-padded form for apvast.py:417-422
 //   synthesis: new = window * irfft(spec[c]); overlap[c] = shift(overlap[c], H) + new;
 //              out[c][0:H] = overlap[c][0:H]                          apvast.py:212-225, 265-293, 457-504
 //
-// One workgroup per channel.  A length-N real transform is done as an N/2-point complex
-// radix-2 FFT in LDS (N <= 8192 -> <= 32 KiB) plus the even/odd split step.  Twiddles and
-// the window come from tables computed once on the host in double precision.
+// One workgroup per channel.  A length-N real transform (N even) is an N/2-point complex Stockham FFT in LDS
+// (mixed radix 4/2/3/5/7, so the reference's own N = 1600 works) plus the even/odd split step.  Twiddles and
+// the window come from tables computed once per (device, N, dtype) on the host in double precision.
 #include "apv_internal.h"
 
 #include <cmath>
 #include <map>
 #include <mutex>
+#include <tuple>
 #include <vector>
 
 namespace {
 
 constexpr int STFT_TPB = 256;
 constexpr int STFT_MAX_N = 8192;
+constexpr int MAX_STAGES = 14;
 
+struct FftPlan {
+    int N;                 // real length
+    int Nh;                // complex length N/2
+    int nstages;
+    int radix[MAX_STAGES];
+};
+
+template <typename T> struct C2 { T x, y; };
+template <typename T> __device__ __forceinline__ C2<T> c2(T a, T b) { C2<T> r; r.x = a; r.y = b; return r; }
+template <typename T> __device__ __forceinline__ C2<T> cadd(C2<T> a, C2<T> b) { return c2<T>(a.x + b.x, a.y + b.y); }
+template <typename T> __device__ __forceinline__ C2<T> csub(C2<T> a, C2<T> b) { return c2<T>(a.x - b.x, a.y - b.y); }
+template <typename T> __device__ __forceinline__ C2<T> cmul(C2<T> a, C2<T> b) {
+    return c2<T>(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+template <typename T>
 struct Tables {
-    float2* tw = nullptr;     // exp(-2 pi i j / N), j < N/2
-    float* win = nullptr;     // sin(pi n / N), n < N     (apvast.py:94)
+    C2<T>* tw = nullptr;   // exp(-2 pi i j / N), j < N (full circle)
+    T* win = nullptr;      // sin(pi n / N), n < N     (apvast.py:94)
 };
 
 std::mutex g_tab_mu;
-std::map<std::pair<int, int>, Tables> g_tabs;   // (device, N) -> tables
+std::map<std::tuple<int, int, int>, std::pair<void*, void*>> g_tabs;   // (device, N, is_f64) -> (tw, win)
 
-hipError_t get_tables(int N, Tables* out) {
+template <typename T>
+hipError_t get_tables(int N, Tables<T>* out) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     std::lock_guard<std::mutex> lk(g_tab_mu);
-    auto it = g_tabs.find({dev, N});
+    const auto key = std::make_tuple(dev, N, (int)(sizeof(T) == 8));
+    auto it = g_tabs.find(key);
     if (it != g_tabs.end()) {
-        *out = it->second;
+        out->tw = (C2<T>*)it->second.first;
+        out->win = (T*)it->second.second;
         return hipSuccess;
     }
-    std::vector<float2> tw(N / 2);
-    std::vector<float> win(N);
+    std::vector<C2<T>> tw(N);
+    std::vector<T> win(N);
     const double PI = 3.14159265358979323846;
-    for (int j = 0; j < N / 2; ++j) {
-        tw[j].x = (float)std::cos(-2.0 * PI * j / N);
-        tw[j].y = (float)std::sin(-2.0 * PI * j / N);
+    for (int j = 0; j < N; ++j) {
+        tw[j].x = (T)std::cos(-2.0 * PI * j / N);
+        tw[j].y = (T)std::sin(-2.0 * PI * j / N);
+        win[j] = (T)std::sin(PI * j / N);
     }
-    for (int n = 0; n < N; ++n) win[n] = (float)std::sin(PI * n / N);
-    Tables t;
-    e = hipMalloc(&t.tw, sizeof(float2) * (N / 2));
+    void *dtw = nullptr, *dwin = nullptr;
+    e = hipMalloc(&dtw, sizeof(C2<T>) * N);
     if (e != hipSuccess) return e;
-    e = hipMalloc(&t.win, sizeof(float) * N);
+    e = hipMalloc(&dwin, sizeof(T) * N);
     if (e != hipSuccess) return e;
-    e = hipMemcpy(t.tw, tw.data(), sizeof(float2) * (N / 2), hipMemcpyHostToDevice);
+    e = hipMemcpy(dtw, tw.data(), sizeof(C2<T>) * N, hipMemcpyHostToDevice);
     if (e != hipSuccess) return e;
-    e = hipMemcpy(t.win, win.data(), sizeof(float) * N, hipMemcpyHostToDevice);
+    e = hipMemcpy(dwin, win.data(), sizeof(T) * N, hipMemcpyHostToDevice);
     if (e != hipSuccess) return e;
-    g_tabs[{dev, N}] = t;
-    *out = t;
+    g_tabs[key] = {dtw, dwin};
+    out->tw = (C2<T>*)dtw;
+    out->win = (T*)dwin;
     return hipSuccess;
 }
 
-__device__ __forceinline__ float2 cmulf(float2 a, float2 b) {
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+// ---- Stockham stages ---------------------------------------------------------------------------
+// One stage of radix R: sub-transforms of length Ns become length Ns*R.  tw is the N-entry root table;
+// the roots of the Nh-point transform are its even entries.
+template <typename T, int R>
+__device__ __forceinline__ void stockham_stage(const C2<T>* __restrict__ src, C2<T>* __restrict__ dst, int Nh, int Ns,
+                                               const C2<T>* __restrict__ tw, int N) {
+    const int m = Nh / R;
+    const int tstep = 2 * (Nh / (Ns * R));            // tw index step for exp(-2 pi i k / (Ns R))
+    for (int j = threadIdx.x; j < m; j += STFT_TPB) {
+        const int k = j % Ns;
+        C2<T> u[R];
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            u[t] = src[j + t * m];
+            if (t > 0) u[t] = cmul(u[t], tw[(t * k * tstep) % N]);
+        }
+        C2<T> v[R];
+        if constexpr (R == 2) {
+            v[0] = cadd(u[0], u[1]);
+            v[1] = csub(u[0], u[1]);
+        } else if constexpr (R == 4) {
+            const C2<T> a = cadd(u[0], u[2]), b = csub(u[0], u[2]), c = cadd(u[1], u[3]), d = csub(u[1], u[3]);
+            v[0] = cadd(a, c);
+            v[2] = csub(a, c);
+            v[1] = c2<T>(b.x + d.y, b.y - d.x);       // b - i d
+            v[3] = c2<T>(b.x - d.y, b.y + d.x);       // b + i d
+        } else {
+            // direct DFT of prime length R with the roots w_R^q = tw[q N / R]
+            const int rstep = N / R;
+#pragma unroll
+            for (int o = 0; o < R; ++o) {
+                C2<T> acc = u[0];
+#pragma unroll
+                for (int t = 1; t < R; ++t) acc = cadd(acc, cmul(u[t], tw[((o * t) % R) * rstep]));
+                v[o] = acc;
+            }
+        }
+        const int base = (j / Ns) * Ns * R + k;
+#pragma unroll
+        for (int t = 0; t < R; ++t) dst[base + t * Ns] = v[t];
+    }
 }
 
-// In-place radix-2 DIT on bit-reversed data in LDS.  Nh = 2^lg points; tw indexed with stride N/Nh = 2.
-__device__ __forceinline__ void fft_lds(float2* z, int Nh, int lg, const float2* __restrict__ tw, int N) {
-    const int tid = threadIdx.x;
-    for (int s = 1; s <= lg; ++s) {
-        const int half = 1 << (s - 1);
-        const int tstride = N >> s;                       // N / (2*half)
-        for (int b = tid; b < Nh / 2; b += STFT_TPB) {
-            const int grp = b >> (s - 1), pos = b & (half - 1);
-            const int i0 = (grp << s) + pos, i1 = i0 + half;
-            const float2 w = tw[pos * tstride];
-            const float2 u = z[i0], v = cmulf(z[i1], w);
-            z[i0] = make_float2(u.x + v.x, u.y + v.y);
-            z[i1] = make_float2(u.x - v.x, u.y - v.y);
+// forward complex FFT of length plan.Nh on natural-order data in `a`; returns the buffer holding the result
+template <typename T>
+__device__ __forceinline__ C2<T>* fft_forward(const FftPlan& plan, C2<T>* a, C2<T>* b, const C2<T>* __restrict__ tw) {
+    int Ns = 1;
+    C2<T>* src = a;
+    C2<T>* dst = b;
+    for (int s = 0; s < plan.nstages; ++s) {
+        const int R = plan.radix[s];
+        switch (R) {
+            case 4: stockham_stage<T, 4>(src, dst, plan.Nh, Ns, tw, plan.N); break;
+            case 2: stockham_stage<T, 2>(src, dst, plan.Nh, Ns, tw, plan.N); break;
+            case 3: stockham_stage<T, 3>(src, dst, plan.Nh, Ns, tw, plan.N); break;
+            case 5: stockham_stage<T, 5>(src, dst, plan.Nh, Ns, tw, plan.N); break;
+            default: stockham_stage<T, 7>(src, dst, plan.Nh, Ns, tw, plan.N); break;
         }
         __syncthreads();
+        Ns *= R;
+        C2<T>* t = src; src = dst; dst = t;
     }
+    return src;
 }
 
-__device__ __forceinline__ int bitrev(int v, int lg) { return (int)(__brev((unsigned)v) >> (32 - lg)); }
-
-// spec element (c, k) is stored at spec[c * stride_c + k * stride_k]
-// x is a ring: logical sample n of channel c lives at x[c*N + ((n + ring_off) & (N-1))]
-__global__ void __launch_bounds__(STFT_TPB) stft_analysis_kernel(int N, int lg, const float* __restrict__ x,
-                                                                 int ring_off, float2* __restrict__ spec,
-                                                                 long stride_c, long stride_k,
-                                                                 const float2* __restrict__ tw,
-                                                                 const float* __restrict__ win) {
-    extern __shared__ float2 z[];
-    const int Nh = N >> 1;
+// x is a ring: logical sample n of channel c lives at x[c*x_stride + (n + ring_off) mod N]; samples
+// n >= in_len read as zero (zero padding, apvast.py:417: rfft(taps, N)); use_win = 0 skips the window
+template <typename T>
+__global__ void __launch_bounds__(STFT_TPB) stft_analysis_kernel(FftPlan plan, const T* __restrict__ x, long x_stride,
+                                                                 int in_len, int ring_off, int use_win,
+                                                                 C2<T>* __restrict__ spec, long stride_c, long stride_k,
+                                                                 const C2<T>* __restrict__ tw,
+                                                                 const T* __restrict__ win) {
+    extern __shared__ unsigned char smem_raw[];
+    C2<T>* za = reinterpret_cast<C2<T>*>(smem_raw);
+    const int N = plan.N, Nh = plan.Nh;
+    C2<T>* zb = za + Nh;
     const int c = blockIdx.x, tid = threadIdx.x;
-    const float* xin = x + (size_t)c * N;
-    const float2* w2 = reinterpret_cast<const float2*>(win);
-    const int mask = N - 1;
+    const T* xin = x + (size_t)c * x_stride;
     for (int n = tid; n < Nh; n += STFT_TPB) {
-        const float2 w = w2[n];
-        const float v0 = xin[(2 * n + ring_off) & mask], v1 = xin[(2 * n + 1 + ring_off) & mask];
-        z[bitrev(n, lg)] = make_float2(v0 * w.x, v1 * w.y);
+        int i0 = 2 * n + ring_off, i1 = i0 + 1;
+        if (i0 >= N) i0 -= N;
+        if (i1 >= N) i1 -= N;
+        T v0 = (2 * n < in_len) ? xin[i0] : (T)0, v1 = (2 * n + 1 < in_len) ? xin[i1] : (T)0;
+        if (use_win) {
+            v0 *= win[2 * n];
+            v1 *= win[2 * n + 1];
+        }
+        za[n] = c2<T>(v0, v1);
     }
     __syncthreads();
-    fft_lds(z, Nh, lg, tw, N);
+    const C2<T>* z = fft_forward<T>(plan, za, zb, tw);
     // even/odd split: X[k] = E[k] + e^{-2 pi i k/N} O[k]
-    float2* out = spec + (size_t)c * stride_c;
+    C2<T>* out = spec + (size_t)c * stride_c;
     for (int k = tid; k <= Nh; k += STFT_TPB) {
-        const float2 a = z[k == Nh ? 0 : k];
-        const float2 bq = z[k == 0 ? 0 : Nh - k];
-        const float2 b = make_float2(bq.x, -bq.y);                       // conj(Z[Nh-k])
-        const float2 e = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y + b.y));
-        const float2 dm = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y - b.y));
-        const float2 o = make_float2(dm.y, -dm.x);                       // -i * dm
-        const float2 wk = (k == Nh) ? make_float2(-1.f, 0.f) : tw[k];
-        const float2 ow = cmulf(o, wk);
-        out[(size_t)k * stride_k] = make_float2(e.x + ow.x, e.y + ow.y);
+        const C2<T> a = z[k == Nh ? 0 : k];
+        const C2<T> bq = z[k == 0 ? 0 : Nh - k];
+        const C2<T> b = c2<T>(bq.x, -bq.y);                              // conj(Z[Nh-k])
+        const C2<T> e = c2<T>((T)0.5 * (a.x + b.x), (T)0.5 * (a.y + b.y));
+        const C2<T> dm = c2<T>((T)0.5 * (a.x - b.x), (T)0.5 * (a.y - b.y));
+        const C2<T> o = c2<T>(dm.y, -dm.x);                              // -i * dm
+        const C2<T> ow = cmul(o, tw[k]);                                 // tw[Nh] = -1
+        out[(size_t)k * stride_k] = c2<T>(e.x + ow.x, e.y + ow.y);
     }
 }
 
-__global__ void __launch_bounds__(STFT_TPB) istft_ola_kernel(int N, int lg, int H, const float2* __restrict__ spec,
-                                                             long stride_c, long stride_k,
-                                                             float* __restrict__ overlap, float* __restrict__ out,
-                                                             const float2* __restrict__ tw,
-                                                             const float* __restrict__ win) {
-    extern __shared__ float2 z[];
-    const int Nh = N >> 1;
+template <typename T>
+__global__ void __launch_bounds__(STFT_TPB) istft_ola_kernel(FftPlan plan, int H, const C2<T>* __restrict__ spec,
+                                                             long stride_c, long stride_k, T* __restrict__ overlap,
+                                                             T* __restrict__ out, const C2<T>* __restrict__ tw,
+                                                             const T* __restrict__ win) {
+    extern __shared__ unsigned char smem_raw[];
+    C2<T>* za = reinterpret_cast<C2<T>*>(smem_raw);
+    const int N = plan.N, Nh = plan.Nh;
+    C2<T>* zb = za + Nh;
     const int c = blockIdx.x, tid = threadIdx.x;
-    const float2* X = spec + (size_t)c * stride_c;
+    const C2<T>* X = spec + (size_t)c * stride_c;
     // Z[k] = E[k] + i O[k];  inverse transform as conj(FFT(conj(Z))) / Nh
     for (int k = tid; k < Nh; k += STFT_TPB) {
-        float2 a = X[(size_t)k * stride_k];
-        float2 bq = X[(size_t)(Nh - k) * stride_k];
+        C2<T> a = X[(size_t)k * stride_k];
+        C2<T> bq = X[(size_t)(Nh - k) * stride_k];
         if (k == 0) {                                                   // irfft drops imag of DC and Nyquist
-            a.y = 0.f;
-            bq.y = 0.f;
+            a.y = 0;
+            bq.y = 0;
         }
-        const float2 b = make_float2(bq.x, -bq.y);
-        const float2 e = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y + b.y));
-        const float2 dm = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y - b.y));
-        const float2 wk = tw[k];
-        const float2 o = cmulf(dm, make_float2(wk.x, -wk.y));            // * e^{+2 pi i k/N}
-        const float2 Z = make_float2(e.x - o.y, e.y + o.x);              // E + i O
-        z[bitrev(k, lg)] = make_float2(Z.x, -Z.y);                       // conj
+        const C2<T> b = c2<T>(bq.x, -bq.y);
+        const C2<T> e = c2<T>((T)0.5 * (a.x + b.x), (T)0.5 * (a.y + b.y));
+        const C2<T> dm = c2<T>((T)0.5 * (a.x - b.x), (T)0.5 * (a.y - b.y));
+        const C2<T> wk = tw[k];
+        const C2<T> o = cmul(dm, c2<T>(wk.x, -wk.y));                    // * e^{+2 pi i k/N}
+        za[k] = c2<T>(e.x - o.y, -(e.y + o.x));                          // conj(E + i O)
     }
     __syncthreads();
-    fft_lds(z, Nh, lg, tw, N);
-    const float scale = 1.0f / (float)Nh;
-    float* ov = overlap + (size_t)c * N;
-    float* zf = reinterpret_cast<float*>(z);
-    const float2* w2 = reinterpret_cast<const float2*>(win);
+    C2<T>* z = fft_forward<T>(plan, za, zb, tw);
+    const T scale = (T)1 / (T)Nh;
+    T* ov = overlap + (size_t)c * N;
+    T* zf = reinterpret_cast<T*>(z);
     // windowed new block, in place: x[2n] = Re z[n], x[2n+1] = -Im(conj-FFT)[n]
     for (int n = tid; n < Nh; n += STFT_TPB) {
-        const float2 v = z[n], w = w2[n];
-        z[n] = make_float2(v.x * scale * w.x, -v.y * scale * w.y);
+        const C2<T> v = z[n];
+        z[n] = c2<T>(v.x * scale * win[2 * n], -v.y * scale * win[2 * n + 1]);
     }
     __syncthreads();
     for (int n = tid; n < N; n += STFT_TPB) {
-        const float old = (n < N - H) ? ov[n + H] : 0.f;
+        const T old = (n < N - H) ? ov[n + H] : (T)0;
         zf[n] += old;
     }
     __syncthreads();
@@ -166,50 +236,92 @@ __global__ void __launch_bounds__(STFT_TPB) istft_ola_kernel(int N, int lg, int 
         for (int n = tid; n < H; n += STFT_TPB) out[(size_t)c * H + n] = zf[n];
 }
 
-int ilog2(int v) {
-    int l = 0;
-    while ((1 << l) < v) ++l;
-    return l;
-}
-
-}  // namespace
-
-static bool stft_size_ok(int N, std::string* why) {
-    if (N < 8 || N > STFT_MAX_N || (N & (N - 1)) != 0) {
-        if (why) *why = "STFT block size must be a power of two in [8, 8192]";
+bool make_plan(int N, FftPlan* plan, std::string* why) {
+    if (N < 4 || N > STFT_MAX_N || (N & 1)) {
+        if (why) *why = "STFT block size must be even and in [4, 8192]";
+        return false;
+    }
+    plan->N = N;
+    plan->Nh = N / 2;
+    plan->nstages = 0;
+    int rem = N / 2;
+    const int radices[] = {4, 2, 3, 5, 7};
+    for (int r : radices)
+        while (rem % r == 0 && rem > 1) {
+            if (plan->nstages >= MAX_STAGES) break;
+            plan->radix[plan->nstages++] = r;
+            rem /= r;
+        }
+    if (rem != 1) {
+        if (why) *why = "STFT block size / 2 must factor into 2, 3, 5 and 7";
         return false;
     }
     return true;
 }
 
-hipError_t apv_launch_stft_analysis_strided(int N, int n_ch, const float* x, int ring_off, float2* spec,
-                                            long stride_c, long stride_k, hipStream_t s, std::string* why) {
-    if (!stft_size_ok(N, why)) return hipErrorInvalidValue;
+template <typename T>
+hipError_t launch_analysis(int N, int n_ch, const void* x, long x_stride, int in_len, int ring_off, int use_win,
+                           void* spec, long stride_c, long stride_k, hipStream_t s, std::string* why) {
+    FftPlan plan;
+    if (!make_plan(N, &plan, why)) return hipErrorInvalidValue;
     if (n_ch <= 0) return hipSuccess;
-    Tables t;
-    hipError_t e = get_tables(N, &t);
+    Tables<T> t;
+    hipError_t e = get_tables<T>(N, &t);
     if (e != hipSuccess) return e;
-    const int Nh = N / 2;
-    hipLaunchKernelGGL(stft_analysis_kernel, dim3(n_ch), dim3(STFT_TPB), sizeof(float2) * Nh, s, N, ilog2(Nh), x,
-                       ring_off & (N - 1), spec, stride_c, stride_k, t.tw, t.win);
+    const size_t lds = sizeof(C2<T>) * 2 * plan.Nh;
+    int off = ring_off % N;
+    if (off < 0) off += N;
+    hipLaunchKernelGGL(stft_analysis_kernel<T>, dim3(n_ch), dim3(STFT_TPB), lds, s, plan, (const T*)x, x_stride, in_len,
+                       off, use_win, (C2<T>*)spec, stride_c, stride_k, t.tw, t.win);
     return hipGetLastError();
 }
 
-hipError_t apv_launch_istft_ola_strided(int N, int H, int n_ch, const float2* spec, long stride_c, long stride_k,
-                                        float* overlap, float* out, hipStream_t s, std::string* why) {
-    if (!stft_size_ok(N, why)) return hipErrorInvalidValue;
+template <typename T>
+hipError_t launch_synthesis(int N, int H, int n_ch, const void* spec, long stride_c, long stride_k, void* overlap,
+                            void* out, hipStream_t s, std::string* why) {
+    FftPlan plan;
+    if (!make_plan(N, &plan, why)) return hipErrorInvalidValue;
     if (H <= 0 || H > N) {
         if (why) *why = "hop size out of range";
         return hipErrorInvalidValue;
     }
     if (n_ch <= 0) return hipSuccess;
-    Tables t;
-    hipError_t e = get_tables(N, &t);
+    Tables<T> t;
+    hipError_t e = get_tables<T>(N, &t);
     if (e != hipSuccess) return e;
-    const int Nh = N / 2;
-    hipLaunchKernelGGL(istft_ola_kernel, dim3(n_ch), dim3(STFT_TPB), sizeof(float2) * Nh, s, N, ilog2(Nh), H, spec,
-                       stride_c, stride_k, overlap, out, t.tw, t.win);
+    const size_t lds = sizeof(C2<T>) * 2 * plan.Nh;
+    hipLaunchKernelGGL(istft_ola_kernel<T>, dim3(n_ch), dim3(STFT_TPB), lds, s, plan, H, (const C2<T>*)spec, stride_c,
+                       stride_k, (T*)overlap, (T*)out, t.tw, t.win);
     return hipGetLastError();
+}
+
+}  // namespace
+
+bool apv_stft_size_ok(int N, std::string* why) {
+    FftPlan plan;
+    return make_plan(N, &plan, why);
+}
+
+hipError_t apv_launch_analysis(int f64, int N, int n_ch, const void* x, long x_stride, int in_len, int ring_off,
+                               int use_win, void* spec, long stride_c, long stride_k, hipStream_t s, std::string* why) {
+    return f64 ? launch_analysis<double>(N, n_ch, x, x_stride, in_len, ring_off, use_win, spec, stride_c, stride_k, s, why)
+               : launch_analysis<float>(N, n_ch, x, x_stride, in_len, ring_off, use_win, spec, stride_c, stride_k, s, why);
+}
+
+hipError_t apv_launch_synthesis(int f64, int N, int H, int n_ch, const void* spec, long stride_c, long stride_k,
+                                void* overlap, void* out, hipStream_t s, std::string* why) {
+    return f64 ? launch_synthesis<double>(N, H, n_ch, spec, stride_c, stride_k, overlap, out, s, why)
+               : launch_synthesis<float>(N, H, n_ch, spec, stride_c, stride_k, overlap, out, s, why);
+}
+
+hipError_t apv_launch_stft_analysis_strided(int N, int n_ch, const float* x, int ring_off, float2* spec,
+                                            long stride_c, long stride_k, hipStream_t s, std::string* why) {
+    return launch_analysis<float>(N, n_ch, x, N, N, ring_off, 1, spec, stride_c, stride_k, s, why);
+}
+
+hipError_t apv_launch_istft_ola_strided(int N, int H, int n_ch, const float2* spec, long stride_c, long stride_k,
+                                        float* overlap, float* out, hipStream_t s, std::string* why) {
+    return launch_synthesis<float>(N, H, n_ch, spec, stride_c, stride_k, overlap, out, s, why);
 }
 
 hipError_t apv_launch_stft_analysis(int N, int n_ch, const float* x, float2* spec, hipStream_t s, std::string* why) {

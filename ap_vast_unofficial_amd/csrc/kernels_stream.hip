@@ -26,10 +26,9 @@ __global__ void __launch_bounds__(64) fir_hop_kernel(int C, int P, int H, int N,
     }
     if (live) {
         float* dst = resp + (size_t)c * N;
-        const int mask = N - 1;
 #pragma unroll
         for (int t = 0; t < FIR_TN; ++t)
-            if (n0 + t < H) dst[(N - H + n0 + t + ring_off) & mask] = acc[t];
+            if (n0 + t < H) dst[(N - H + n0 + t + ring_off) % N] = acc[t];
     }
 }
 
@@ -101,20 +100,19 @@ __global__ void __launch_bounds__(256) fir_mfma_kernel(FirJobs jobs, int P, int 
         tile[i * 33 + row] = acc[r];
     }
     __syncthreads();
-    const int mask = N - 1;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int c = (lane >> 3) + 8 * t, q = (lane & 7) * 4;
         const int n = n0 + nb + q;
         if (c0 + c < C && n < H) {
             float* dst = job.resp + (size_t)(c0 + c) * N;
-            const int base = (N - H + n + ring_off) & mask;
-            if (((base & 3) == 0) && (n + 3 < H) && (base + 3 <= mask)) {
+            const int base = (N - H + n + ring_off) % N;
+            if (((base & 3) == 0) && (n + 3 < H) && (base + 3 < N) && ((N & 3) == 0)) {
                 *reinterpret_cast<float4*>(dst + base) =
                     make_float4(tile[c * 33 + q], tile[c * 33 + q + 1], tile[c * 33 + q + 2], tile[c * 33 + q + 3]);
             } else {
                 for (int u = 0; u < 4; ++u)
-                    if (n + u < H) dst[(base + u) & mask] = tile[c * 33 + q + u];
+                    if (n + u < H) dst[(base + u) % N] = tile[c * 33 + q + u];
             }
         }
     }
@@ -134,7 +132,7 @@ __global__ void __launch_bounds__(256) hist_update_kernel(int P, int H, int pad,
 __global__ void __launch_bounds__(256) ring_append_kernel(int N, int H, int ring_off, const float* __restrict__ x,
                                                           float* __restrict__ ring) {
     const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n < H) ring[(N - H + n + ring_off) & (N - 1)] = x[n];
+    if (n < H) ring[(N - H + n + ring_off) % N] = x[n];
 }
 
 template <typename W>
@@ -177,7 +175,7 @@ hipError_t apv_launch_fir_hop(int C, int P, int H, int N, int ring_off, const fl
                               float* resp, hipStream_t s) {
     if (C <= 0 || H <= 0) return hipSuccess;
     dim3 grid((C + 63) / 64, (H + FIR_TN - 1) / FIR_TN);
-    hipLaunchKernelGGL(fir_hop_kernel, grid, dim3(64), 0, s, C, P, H, N, ring_off & (N - 1), rir, xhist, resp);
+    hipLaunchKernelGGL(fir_hop_kernel, grid, dim3(64), 0, s, C, P, H, N, ring_off % N, rir, xhist, resp);
     return hipGetLastError();
 }
 
@@ -189,7 +187,7 @@ hipError_t apv_launch_hist_update(int P, int H, int pad, const float* old_hist, 
 }
 
 hipError_t apv_launch_ring_append(int N, int H, int ring_off, const float* x, float* ring, hipStream_t s) {
-    hipLaunchKernelGGL(ring_append_kernel, dim3((H + 255) / 256), dim3(256), 0, s, N, H, ring_off & (N - 1), x, ring);
+    hipLaunchKernelGGL(ring_append_kernel, dim3((H + 255) / 256), dim3(256), 0, s, N, H, ring_off % N, x, ring);
     return hipGetLastError();
 }
 
@@ -203,7 +201,7 @@ hipError_t apv_launch_fir_jobs(const FirJobs& jobs, int P, int H, int N, int rin
     size_t lds = sizeof(float) * (size_t)(P - 1 + 128);
     const size_t tiles = sizeof(float) * 4 * 32 * 33;
     if (lds < tiles) lds = tiles;
-    hipLaunchKernelGGL(fir_mfma_kernel, grid, dim3(256), lds, s, jobs, P, H, N, ring_off & (N - 1));
+    hipLaunchKernelGGL(fir_mfma_kernel, grid, dim3(256), lds, s, jobs, P, H, N, ring_off % N);
     return hipGetLastError();
 }
 

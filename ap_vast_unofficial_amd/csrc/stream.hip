@@ -86,7 +86,10 @@ int apv_stream_init(apv_handle* h, int32_t rir_len, const double* h_rir_A, const
     if (!h || !h_rir_A || !h_rir_B) return apv_fail(h, APV_ERR_ARG, "null argument");
     const apv_config& c = h->cfg;
     const int N = c.block_size, H = c.hop_size;
-    if (N < 8 || (N & (N - 1)) != 0 || N > 8192) return apv_fail(h, APV_ERR_ARG, "block_size must be a power of two in [8, 8192]");
+    {
+        std::string why;
+        if (!apv_stft_size_ok(N, &why)) return apv_fail(h, APV_ERR_ARG, why);
+    }
     if (H < 1 || H > N) return apv_fail(h, APV_ERR_ARG, "hop_size must be in 1..block_size");
     if (c.n_bins != N / 2 + 1) return apv_fail(h, APV_ERR_ARG, "streaming handle needs n_bins == block_size/2 + 1");
     if (rir_len < 1 || modeling_delay < 0 || modeling_delay >= rir_len) return apv_fail(h, APV_ERR_ARG, "rir_len / modeling_delay out of range");
@@ -175,7 +178,7 @@ int apv_process_block(apv_handle* h, const float* h_in_A, const float* h_in_B, f
     }
     s->cur = nxt;
     // all rings advance by one hop: logical sample n now lives H further on
-    s->ring_off = (s->ring_off + H) & (N - 1);
+    s->ring_off = (s->ring_off + H) % N;
     for (int g = 0; g < 2; ++g)
         SCHK(h, apv_launch_ring_append(N, H, s->ring_off, s->xin + (size_t)g * H, s->inblk + (size_t)g * N, st));
     // K1: RIR convolution into the response rings (one MFMA launch for all six filter banks)
@@ -307,7 +310,7 @@ int apv_get_state(apv_handle* h, const char* name, void* h_dst, size_t bytes) {
     SCHK(h, hipMemcpy(tmp.data(), d, need, hipMemcpyDeviceToHost));
     float* out = (float*)h_dst;
     for (int r = 0; r < rr; ++r)
-        for (int n = 0; n < N; ++n) out[(size_t)r * N + n] = tmp[(size_t)r * N + ((n + off) & (N - 1))];
+        for (int n = 0; n < N; ++n) out[(size_t)r * N + n] = tmp[(size_t)r * N + ((n + off) % N)];
     return APV_OK;
 }
 
@@ -327,7 +330,7 @@ int apv_set_state(apv_handle* h, const char* name, const void* h_src, size_t byt
     std::vector<float> tmp((size_t)rr * N);
     const float* in = (const float*)h_src;
     for (int r = 0; r < rr; ++r)
-        for (int n = 0; n < N; ++n) tmp[(size_t)r * N + ((n + off) & (N - 1))] = in[(size_t)r * N + n];
+        for (int n = 0; n < N; ++n) tmp[(size_t)r * N + ((n + off) % N)] = in[(size_t)r * N + n];
     SCHK(h, hipMemcpy(d, tmp.data(), need, hipMemcpyHostToDevice));
     return APV_OK;
 }

@@ -175,7 +175,9 @@ def test_relative_loading(Engine):
     assert w_err(w, w_ref) < 1e-5
 
 
-@pytest.mark.parametrize("N,H", [(256, 128), (2048, 1024), (64, 16), (512, 128)])
+@pytest.mark.parametrize("N,H", [(256, 128), (2048, 1024), (64, 16), (512, 128),
+                                 (1600, 800),       # make_python_test.m:6 (blockSize = 2 * rirLength)
+                                 (210, 70), (96, 32), (8192, 4096)])
 def test_stft_roundtrip_vs_oracle(Engine, N, H):
     """Analysis (apvast.py:246-255) and synthesis+OLA (265-293) against numpy.fft in float64."""
     rng = np.random.default_rng(N)

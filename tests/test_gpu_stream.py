@@ -126,3 +126,11 @@ def test_module_jdiag_dropin(golden):
     assert np.abs(U.T @ (g["B"][0] + 1e-7 * np.eye(12)) @ U - np.eye(12)).max() < 1e-10
     with pytest.raises(np.linalg.LinAlgError):
         jdiag(np.eye(4), -np.eye(4))
+
+
+def test_stream_non_power_of_two_block():
+    """The reference's own fixture script uses blockSize = 1600 (make_python_test.m:6); here 240 = 2^4 * 3 * 5."""
+    rirA, rirB = synth_rirs(90, 4, 8, 4)
+    ap, orc, got, exp = run_pair(240, 120, rirA, rirB, 7, 1, 2, 2, 1.0, hops=5)
+    check_outputs(got, exp, 5e-3)
+    ap.close()
