@@ -25,7 +25,7 @@ EXPORTS = (
     "apv_create", "apv_destroy", "apv_last_error", "apv_abi_version",
     "apv_dev_alloc", "apv_dev_free", "apv_memcpy_h2d", "apv_memcpy_d2h", "apv_sync",
     "apv_timer_start", "apv_timer_stop",
-    "apv_update_dev", "apv_update", "apv_corr_dev", "apv_gevd_vast_dev", "apv_jdiag_batched",
+    "apv_update_dev", "apv_update", "apv_corr_dev", "apv_gevd_vast_dev", "apv_jdiag_batched", "apv_jdiag_large",
     "apv_stft_analysis_dev", "apv_istft_ola_dev",
     "apv_stream_init", "apv_process_block", "apv_state_bytes", "apv_get_state", "apv_set_state",
     "apv_comm_unique_id", "apv_comm_init", "apv_allgather_filters_dev",
@@ -80,6 +80,7 @@ def load():
     lib.apv_corr_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     lib.apv_gevd_vast_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     lib.apv_jdiag_batched.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
+    lib.apv_jdiag_large.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
     lib.apv_stft_analysis_dev.argtypes = [vp, i32, vp, vp]
     lib.apv_istft_ola_dev.argtypes = [vp, i32, vp, vp, vp]
     lib.apv_stream_init.argtypes = [vp, i32, vp, vp, i32, i32, i32]
@@ -287,6 +288,19 @@ class Engine:
         lam = np.empty((batch, n))
         status = np.empty(batch, dtype=np.int32)
         self._chk(self.lib.apv_jdiag_batched(self.h, n, batch, _ptr(A), _ptr(B), _ptr(U), _ptr(lam), _ptr(status)))
+        return U, lam
+
+    def jdiag_large(self, A, B):
+        """Real symmetric pairs of broadband order (n <= 2048): U (batch, n, n), lam (batch, n), float64."""
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        B = np.ascontiguousarray(B, dtype=np.float64)
+        if A.ndim != 3 or A.shape != B.shape or A.shape[1] != A.shape[2]:
+            raise ValueError("A, B must be (batch, n, n)")
+        batch, n, _ = A.shape
+        U = np.empty_like(A)
+        lam = np.empty((batch, n))
+        status = np.empty(batch, dtype=np.int32)
+        self._chk(self.lib.apv_jdiag_large(self.h, n, batch, _ptr(A), _ptr(B), _ptr(U), _ptr(lam), _ptr(status)))
         return U, lam
 
     # -- STFT stages ----------------------------------------------------------

@@ -52,16 +52,21 @@ def jdiag(A, B, device=0):
     n = A.shape[0]
     if A.shape != (n, n) or B.shape != (n, n):
         raise ValueError("jdiag expects two square matrices of equal size")
-    if n > _capi.MAX_N:
-        raise NotImplementedError(f"GPU jdiag handles n <= {_capi.MAX_N} (broadband orders are a 'next' row, DESIGN.md)")
+    cplx = np.iscomplexobj(A) or np.iscomplexobj(B)
+    if n > _capi.MAX_N and (cplx or n > 2048 or not EXPERIMENTAL_REGULARIZATION):
+        raise NotImplementedError("GPU jdiag: complex pairs up to n = 64; real symmetric pairs (the reference's "
+                                  "broadband call sites, apvast.py:380-382) up to n = 2048 with absolute loading")
     mode = _capi.REG_ABS if EXPERIMENTAL_REGULARIZATION else _capi.REG_REL
     key = (device, mode)
     if _jdiag_engine is None or _jdiag_engine[0] != key:
         eng = _capi.Engine(1, 4, 4, reg_mode=mode, reg_dark=1e-7 if mode == _capi.REG_ABS else 1e-8, device=device)
         _jdiag_engine = (key, eng)
+    if n > _capi.MAX_N:
+        U, lam = _jdiag_engine[1].jdiag_large(A[None], B[None])
+        return U[0], np.diag(lam[0])
     U, lam = _jdiag_engine[1].jdiag_batched(A[None], B[None])
     U, lam = U[0], lam[0]
-    if not (np.iscomplexobj(A) or np.iscomplexobj(B)):
+    if not cplx:
         U = np.ascontiguousarray(U.real)
     return U, np.diag(lam)
 

@@ -80,6 +80,10 @@ hipError_t apv_launch_gevd16(const GevdParams& p, int compute_dtype, bool fused,
 // kernels_gevd16m.hip (order-16, MFMA whitening / back-transform + register-resident Jacobi: the default)
 hipError_t apv_launch_gevd16m(const GevdParams& p, int compute_dtype, bool fused, hipStream_t s);
 
+// kernels_gevd_large.hip: real symmetric pairs of broadband order, f64, device pointers (see the file header)
+int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const double* d_B, double reg, double* d_U,
+                   double* d_lam, const double* d_r, double mu, int V, double* d_w, int32_t* h_status);
+
 // kernels_corr.hip
 hipError_t apv_launch_corr(int compute_dtype, int K, int M, int L, const float2* XB, const float2* XD,
                            const float2* d, void* RB, void* RD, void* r, hipStream_t s);

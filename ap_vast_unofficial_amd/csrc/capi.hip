@@ -391,6 +391,46 @@ int apv_jdiag_batched(apv_handle* h, int32_t n, int32_t batch, const double* h_A
     return scan_status(h, st, batch);
 }
 
+int apv_jdiag_large(apv_handle* h, int32_t n, int32_t batch, const double* h_A, const double* h_B, double* h_U,
+                    double* h_lam, int32_t* h_status) {
+    if (!h || !h_A || !h_B || !h_U || !h_lam) return fail(h, APV_ERR_ARG, "null host pointer");
+    if (n < 1 || n > 2048 || batch < 0) return fail(h, APV_ERR_ARG, "apv_jdiag_large: n must be in 1..2048");
+    if (batch == 0) return APV_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t mat = (size_t)batch * n * n * sizeof(double);
+    double *dA = nullptr, *dB = nullptr, *dU = nullptr, *dl = nullptr;
+    HIPCHK(h, hipMalloc((void**)&dA, mat));
+    HIPCHK(h, hipMalloc((void**)&dB, mat));
+    HIPCHK(h, hipMalloc((void**)&dU, mat));
+    HIPCHK(h, hipMalloc((void**)&dl, (size_t)batch * n * sizeof(double)));
+    HIPCHK(h, hipMemcpyAsync(dA, h_A, mat, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(dB, h_B, mat, hipMemcpyHostToDevice, h->stream));
+    std::unique_ptr<int32_t[]> tmp;
+    int32_t* st = h_status;
+    if (!st) {
+        tmp.reset(new int32_t[batch]);
+        st = tmp.get();
+    }
+    double reg = h->cfg.reg_dark;
+    if (h->cfg.reg_mode == APV_REG_REL) {
+        void* tofree[] = {dA, dB, dU, dl};
+        for (void* b : tofree) (void)hipFree(b);
+        return fail(h, APV_ERR_ARG, "apv_jdiag_large supports absolute loading only (EXPERIMENTAL_REGULARIZATION=True)");
+    }
+    int rc = apv_gevd_large(h, n, batch, dA, dB, reg, dU, dl, nullptr, 0.0, 0, nullptr, st);
+    if (rc == APV_OK || rc == APV_ERR_NOT_PD) {
+        (void)hipMemcpyAsync(h_U, dU, mat, hipMemcpyDeviceToHost, h->stream);
+        (void)hipMemcpyAsync(h_lam, dl, (size_t)batch * n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+        (void)hipStreamSynchronize(h->stream);
+    }
+    void* tofree[] = {dA, dB, dU, dl};
+    for (void* b : tofree) (void)hipFree(b);
+    if (rc != APV_OK) return rc;
+    for (int z = 0; z < batch; ++z)
+        if (st[z] == 2) return fail(h, APV_ERR_NO_CONVERGE, "eigen-iteration did not converge");
+    return APV_OK;
+}
+
 int apv_stft_analysis_dev(apv_handle* h, int32_t n_ch, const float* d_x, void* d_spec) {
     if (!h || !d_x || !d_spec) return fail(h, APV_ERR_ARG, "null device pointer");
     if (h->cfg.block_size <= 0) return fail(h, APV_ERR_ARG, "handle was created without an STFT geometry");

@@ -133,6 +133,13 @@ int  apv_gevd_vast_dev(apv_handle* h, const void* d_RB, const void* d_RD, const 
 int  apv_jdiag_batched(apv_handle* h, int32_t n, int32_t batch, const double* h_A, const double* h_B,
                        double* h_U, double* h_lam, int32_t* h_status);
 
+/* The same for REAL symmetric pairs of broadband order (n = filter_length x loudspeakers: 256 at cfg1, 800 with
+ * the parameters of make_python_test.m), n <= 2048: A, B, U are [batch][n][n] f64 row-major, lam [batch][n].
+ * Matrices live in HBM; one launch per elimination step and per Jacobi round.   replaces apvast.py:20-36 at
+ * the sizes of its call sites apvast.py:380, 382 */
+int  apv_jdiag_large(apv_handle* h, int32_t n, int32_t batch, const double* h_A, const double* h_B,
+                     double* h_U, double* h_lam, int32_t* h_status);
+
 /* ---- STFT stages (K2-K4) ------------------------------------------------ */
 /* spectra[c][k] = rfft(window * x[c][:])  for `n_ch` channels of length N (f32 in, c64 out,
  * both channel-major, device).      replaces apvast.py:202-203, 246-255, 430-431 */

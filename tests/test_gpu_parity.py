@@ -214,3 +214,59 @@ def test_rccl_allgather_single_rank(Engine):
     assert np.array_equal(w, wall)
     w_ref, _, _ = subband.update(XB, XD, d, 1.0, [8])
     assert w_err(w, w_ref) < 3e-7
+
+
+def _triu_to_full(t, n):
+    R = np.zeros((n, n))
+    R[np.triu_indices(n)] = t
+    return R + np.triu(R, 1).T
+
+
+def test_jdiag_large_broadband_golden(Engine, golden):
+    """G1/G2: the reference's own broadband pair (R_A_to_A, R_A_to_B) of cfg1, n = J L = 256
+    (apvast.py:380): eigenvalues, invariants and the rank-accumulated filter (apvast.py:406-414)."""
+    import time
+    g = golden("g1_broadband_cfg1")
+    n = 256
+    A, B = _triu_to_full(g["R_AA_triu"], n), _triu_to_full(g["R_AB_triu"], n)
+    eng = Engine(1, 4, 4)
+    t0 = time.perf_counter()
+    U, lam = eng.jdiag_large(A[None], B[None])
+    dt = time.perf_counter() - t0
+    eng.close()
+    U, lam = U[0], lam[0]
+    lam_ref = g["lam"][-1, 0]
+    V = 8
+    assert np.abs(lam[:V] / lam_ref[:V] - 1).max() < 1e-9
+    assert np.abs(lam - lam_ref).max() < 1e-9 * lam_ref[0]
+    G = U.T @ (B + 1e-7 * np.eye(n)) @ U
+    assert np.abs(G - np.eye(n)).max() < 1e-9
+    D = U.T @ A @ U
+    assert np.abs(D - np.diag(lam)).max() < 1e-9 * lam[0]
+    r = g["r"][-1, 0]
+    coef = (U.T @ r) / (lam + 1.0)
+    for i in range(V):
+        w = U[:, : i + 1] @ coef[: i + 1]
+        e = g["w"][-1, 0, i]
+        assert np.linalg.norm(w - e) <= 1e-7 * np.linalg.norm(e), i
+    print(f"jdiag_large n=256: {dt * 1e3:.1f} ms")
+
+
+@pytest.mark.parametrize("n,batch", [(65, 1), (100, 2), (257, 1)])
+def test_jdiag_large_vs_oracle(Engine, n, batch):
+    rng = np.random.default_rng(n)
+    Y = rng.standard_normal((batch, 3 * n, n))
+    Z = rng.standard_normal((batch, 3 * n, n))
+    A = np.einsum("kmi,kmj->kij", Y, Y)
+    B = np.einsum("kmi,kmj->kij", Z, Z)
+    eng = Engine(1, 4, 4)
+    U, lam = eng.jdiag_large(A, B)
+    eng.close()
+    for k in range(batch):
+        _, lam_ref = gevd.jdiag(A[k], B[k])
+        assert np.abs(lam[k] / lam_ref - 1).max() < 1e-9
+        G = U[k].T @ (B[k] + 1e-7 * np.eye(n)) @ U[k]
+        assert np.abs(G - np.eye(n)).max() < 1e-10
+    with pytest.raises(np.linalg.LinAlgError):
+        eng2 = Engine(1, 4, 4)
+        eng2.jdiag_large(np.eye(70)[None], -np.eye(70)[None])
