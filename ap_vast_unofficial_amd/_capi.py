@@ -28,6 +28,7 @@ EXPORTS = (
     "apv_update_dev", "apv_update", "apv_corr_dev", "apv_gevd_vast_dev", "apv_jdiag_batched", "apv_jdiag_large",
     "apv_stft_analysis_dev", "apv_istft_ola_dev",
     "apv_stream_init", "apv_process_block", "apv_state_bytes", "apv_get_state", "apv_set_state",
+    "apv_bb_init", "apv_bb_process_block", "apv_bb_get_state", "apv_bb_set_state",
     "apv_comm_unique_id", "apv_comm_init", "apv_allgather_filters_dev",
 )
 
@@ -88,6 +89,10 @@ def load():
     lib.apv_state_bytes.argtypes = [vp, C.c_char_p, C.POINTER(sz)]
     lib.apv_get_state.argtypes = [vp, C.c_char_p, vp, sz]
     lib.apv_set_state.argtypes = [vp, C.c_char_p, vp, sz]
+    lib.apv_bb_init.argtypes = [vp, i32, vp, vp, i32, i32, i32, i32, i32, i32]
+    lib.apv_bb_process_block.argtypes = [vp, vp, vp, vp]
+    lib.apv_bb_get_state.argtypes = [vp, C.c_char_p, vp, sz]
+    lib.apv_bb_set_state.argtypes = [vp, C.c_char_p, vp, sz]
     lib.apv_comm_unique_id.argtypes = [C.c_char_p]
     lib.apv_comm_init.argtypes = [vp, C.c_char_p, i32, i32]
     lib.apv_allgather_filters_dev.argtypes = [vp, vp, vp]
@@ -354,6 +359,31 @@ class Engine:
     def set_state(self, name, arr):
         arr = np.ascontiguousarray(arr)
         self._chk(self.lib.apv_set_state(self.h, name.encode(), _ptr(arr), arr.nbytes))
+
+    # -- broadband streaming ------------------------------------------------------
+    def bb_init(self, rir_A, rir_B, reference_index_A, reference_index_B, modeling_delay, filter_length,
+                statistics_buffer_length, number_of_eigenvectors):
+        rir_A = np.ascontiguousarray(rir_A, dtype=np.float64)
+        rir_B = np.ascontiguousarray(rir_B, dtype=np.float64)
+        self._chk(self.lib.apv_bb_init(self.h, rir_A.shape[0], _ptr(rir_A), _ptr(rir_B), int(reference_index_A),
+                                       int(reference_index_B), int(modeling_delay), int(filter_length),
+                                       int(statistics_buffer_length), int(number_of_eigenvectors)))
+
+    def bb_process_block(self, in_A, in_B, n_out):
+        in_A = np.ascontiguousarray(in_A, dtype=np.float64).ravel()
+        in_B = np.ascontiguousarray(in_B, dtype=np.float64).ravel()
+        out = np.empty((n_out, self.cfg.hop_size), dtype=np.float64)
+        self._chk(self.lib.apv_bb_process_block(self.h, _ptr(in_A), _ptr(in_B), _ptr(out)))
+        return out
+
+    def bb_get_state(self, name, shape):
+        out = np.empty(shape, dtype=np.float64)
+        self._chk(self.lib.apv_bb_get_state(self.h, name.encode(), _ptr(out), out.size))
+        return out
+
+    def bb_set_state(self, name, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float64)
+        self._chk(self.lib.apv_bb_set_state(self.h, name.encode(), _ptr(arr), arr.size))
 
     # -- multi-GPU --------------------------------------------------------------
     @staticmethod

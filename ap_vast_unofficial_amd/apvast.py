@@ -14,11 +14,12 @@ What is the same as the reference
   * readable attributes: hop_size, window, number_of_srcs, number_of_mics, w_A/w_B,
     lambda_A/lambda_B, filter_spectra_*, input_spectrum_A/B
 What is different (keyword-only, after ``perceptual``)
-  * ``mode="subband"`` (default, the only mode on the GPU today): one (R_B, R_D) pair, one GEVD
-    and one filter PER FREQUENCY BIN from the current block's control-point spectra.  The
-    reference's time-domain ("broadband") statistics over ``statistics_buffer_length`` samples with
-    ``filter_length``-tap filters (apvast.py:329-364) are restated on the CPU in oracle/ only.
-    ``filter_length`` and ``statistics_buffer_length`` are accepted and stored, not used.
+  * ``mode="subband"`` (default): one (R_B, R_D) pair, one GEVD and one filter PER FREQUENCY BIN from the
+    current block's control-point spectra -- the fast path (``filter_length`` and
+    ``statistics_buffer_length`` are accepted and stored, not used).
+  * ``mode="broadband"``: the reference's own time-domain algorithm (one (J L) x (J L) pair per zone from
+    ``statistics_buffer_length`` samples, apvast.py:329-422), float64 on the device, checked against the
+    golden outputs of the reference (tests/test_gpu_broadband.py).
   * outputs are fresh arrays (the reference returns views into its overlap buffers that the next
     call overwrites, apvast.py:500-504).
   * ``perceptual=True`` needs the third-party ``libdetectability`` (apvast.py:4, 77-83), which is
@@ -118,10 +119,8 @@ class apvast:
             raise NotImplementedError(
                 "perceptual=True needs the third-party libdetectability model (apvast.py:4, 77-83), which the "
                 "reference does not vendor; pass perceptual=False (all-ones weights, apvast.py:326-327)")
-        if mode != "subband":
-            raise NotImplementedError(
-                "only mode='subband' runs on the GPU; the reference's time-domain mode is restated in oracle/ "
-                "for parity checks and is a 'next' row of DESIGN.md")
+        if mode not in ("subband", "broadband"):
+            raise ValueError("mode must be 'subband' or 'broadband'")
         if dialect not in ("python", "matlab"):
             raise ValueError("dialect must be 'python' or 'matlab'")
         if not (run_A or run_B):
@@ -132,6 +131,9 @@ class apvast:
         self.rir_length, self.number_of_srcs, self.number_of_mics = rir_A.shape  # apvast.py:97-99
         L, M, N, H = self.number_of_srcs, self.number_of_mics, self.block_size, self.hop_size
         V = int(number_of_eigenvectors)
+        if mode == "broadband":
+            self._init_broadband(device, seed)
+            return
         if not 1 <= V <= L:
             raise ValueError("subband mode: number_of_eigenvectors must be in 1..number_of_srcs")
         self._ranks = list(range(1, V + 1))            # the reference emits every rank 1..V (apvast.py:406-422)
@@ -158,13 +160,64 @@ class apvast:
         self.w_A = self.w_B = None
         self.lambda_A = self.lambda_B = None
 
+    # ---- broadband mode: the reference's own time-domain algorithm, float64 on the device ----------
+    def _init_broadband(self, device, seed):
+        if self.dialect != "python":
+            raise NotImplementedError("broadband mode implements the Python dialect (SURVEY.md section 3.4)")
+        if not EXPERIMENTAL_REGULARIZATION:
+            raise NotImplementedError("broadband mode implements the absolute dark loading (apvast.py:22-24)")
+        L, M, N, H = self.number_of_srcs, self.number_of_mics, self.block_size, self.hop_size
+        V, J, S = int(self.number_of_eigenvectors), int(self.filter_length), int(self.statistics_buffer_length)
+        self._ranks = list(range(1, V + 1))
+        self._K = N // 2 + 1
+        zones = (1 if self.run_A else 0) | (2 if self.run_B else 0)
+        self._eng = _capi.Engine(self._K, L, M, ranks=(1,), mu=self.mu, compute_dtype="f64", reg_mode=_capi.REG_ABS,
+                                 reg_dark=1e-7, device=device, block_size=N, hop_size=H, n_zones=zones)
+        self._eng.bb_init(self.rir_A, self.rir_B, self.reference_index_A, self.reference_index_B, self.modeling_delay,
+                          J, S, V)
+        self._n_out = (int(self.run_A) + int(self.run_B)) * V * L + 2 * L
+        rs = np.random if seed is None else np.random.RandomState(seed)      # apvast.py:124-129
+        resp = [1e-3 * rs.randn(N, L, M) for _ in range(4)]
+        tresp = [1e-3 * rs.randn(N, M) for _ in range(2)]
+        self.set_state({"response": np.stack(resp), "target_response": np.stack(tresp)})
+        self.w_A = self.w_B = None
+        self.lambda_A = self.lambda_B = None
+
+    def _refresh_broadband(self):
+        e, V, n = self._eng, len(self._ranks), self.filter_length * self.number_of_srcs
+        lam = e.bb_get_state("lambda", (2, n))
+        w = e.bb_get_state("w", (2, V, n))
+        r = e.bb_get_state("r", (2, n))
+        spec = e.bb_get_state("input_spectrum", (2, self._K, 2))
+        self.input_spectrum_A = (spec[0, :, 0] + 1j * spec[0, :, 1]).reshape(-1, 1)
+        self.input_spectrum_B = (spec[1, :, 0] + 1j * spec[1, :, 1]).reshape(-1, 1)
+        names = {"A": ("R_A_to_A", "R_A_to_B", 0), "B": ("R_B_to_B", "R_B_to_A", 2)}
+        for zi, (z, run) in enumerate((("A", self.run_A), ("B", self.run_B))):
+            if not run:
+                continue
+            setattr(self, "lambda_" + z, lam[zi].copy())                      # apvast.py:385-387
+            setattr(self, "w_" + z, w[zi][:, :, None].copy())                 # (V, n, 1), apvast.py:393, 398
+            setattr(self, "r_" + z, r[zi][:, None].copy())
+            setattr(self, names[z][0], e.bb_get_state(f"R{names[z][2]}", (n, n)))
+            setattr(self, names[z][1], e.bb_get_state(f"R{names[z][2] + 1}", (n, n)))
+
     # ---- per-hop call (apvast.py:153-165) -------------------------------------------------
     def process_input_buffers(self, input_A, input_B):
         input_A = np.asarray(input_A)
         input_B = np.asarray(input_B)
         if input_A.size != self.hop_size or input_B.size != self.hop_size:
             raise RuntimeError("invalid input size")                          # apvast.py:154-155
+        if self.mode == "broadband":
+            out = self._eng.bb_process_block(input_A, input_B, self._n_out)
+            res = self._split_outputs(out)
+            self._refresh_broadband()
+            return res
         out = self._eng.process_block(input_A, input_B, self._n_out).astype(np.float64)
+        res = self._split_outputs(out)
+        self._refresh_attributes()
+        return res
+
+    def _split_outputs(self, out):
         L, V, H = self.number_of_srcs, len(self._ranks), self.hop_size
         pos = 0
         res = []
@@ -179,7 +232,6 @@ class apvast:
             t = np.ascontiguousarray(out[pos:pos + L].T)
             res.append([t.copy() for _ in range(V)])                          # same target filter at every rank
             pos += L
-        self._refresh_attributes()
         return tuple(res)
 
     def _refresh_attributes(self):
@@ -199,6 +251,14 @@ class apvast:
     # ---- checkpoint / fixtures -----------------------------------------
     def get_state(self):
         e, N, L, M = self._eng, self.block_size, self.number_of_srcs, self.number_of_mics
+        if self.mode == "broadband":
+            S = self.statistics_buffer_length
+            return {
+                "response": np.stack([e.bb_get_state(f"response{p}", (M, L, N)) for p in range(4)]).transpose(0, 3, 2, 1),
+                "target_response": np.stack([e.bb_get_state(f"target_response{z}", (M, N)) for z in range(2)]).transpose(0, 2, 1),
+                "stats": np.stack([e.bb_get_state(f"stats{p}", (M, L, S)) for p in range(4)]).transpose(0, 3, 2, 1),
+                "target_stats": np.stack([e.bb_get_state(f"target_stats{z}", (M, S)) for z in range(2)]).transpose(0, 2, 1),
+            }
         resp = np.stack([e.get_state(f"response{p}", (M, L, N), np.float32) for p in range(4)])
         tresp = np.stack([e.get_state(f"target_response{z}", (M, N), np.float32) for z in range(2)])
         return {
@@ -212,6 +272,16 @@ class apvast:
 
     def set_state(self, state):
         e = self._eng
+        if self.mode == "broadband":
+            if "response" in state:
+                r = np.asarray(state["response"], dtype=np.float64)
+                for p in range(4):
+                    e.bb_set_state(f"response{p}", np.ascontiguousarray(r[p].transpose(2, 1, 0)))
+            if "target_response" in state:
+                t = np.asarray(state["target_response"], dtype=np.float64)
+                for z in range(2):
+                    e.bb_set_state(f"target_response{z}", np.ascontiguousarray(t[z].T))
+            return
         if "response" in state:
             r = np.asarray(state["response"], dtype=np.float32)                  # (4, N, L, M) -> [M][L][N]
             for p in range(4):

@@ -128,6 +128,7 @@ int apv_create(const apv_config* cfg, apv_handle** out) {
     h->d_Lspill = nullptr;
     h->lspill_bytes = 0;
     h->st = nullptr;
+    h->bb = nullptr;
     h->comm_stream = nullptr;
     h->ev_ready = nullptr;
     for (auto& g : h->gather_done) { g.ptr = nullptr; g.ev = nullptr; }
@@ -163,6 +164,7 @@ int apv_destroy(apv_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     apv_stream_free(h);
+    apv_bb_free(h);
     if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
     if (h->comm) ncclCommDestroy((ncclComm_t)h->comm);
     for (auto& g : h->gather_done)

@@ -1,0 +1,456 @@
+// Broadband (time-domain) AP-VAST on the device, float64: the reference's own algorithm, stage by stage.
+//
+//   apv_bb_init          allocate state, upload RIRs                       reference Python/apvast.py:97-151
+//   apv_bb_process_block one hop                                            apvast.py:153-165
+//     1 RIR convolution into the response rings                             apvast.py:167-194
+//     2 WOLA of target / response rings (weights = 1), head of the overlap
+//       buffers appended to the statistics rings                            apvast.py:197-311
+//     3 R = sum_m Y_m Y_m^T, r = sum_m Y_m d_m from the statistics rings,
+//       Y the data matrix of apvast.py:334-338 INCLUDING the sample that
+//       scipy.linalg.toeplitz drops                 apvast.py:329-364
+//     4 jdiag + rank-accumulated filters (apv_gevd_large)                   apvast.py:378-414
+//     5 filter spectra = rfft(taps, N)                                      apvast.py:417-422
+//     6 input spectra x filter spectra, inverse STFT, window, overlap-add   apvast.py:428-506
+//
+// Channel order on the device: c = m*L + l (as in stream.hip).  Everything is double: the dark matrix is loaded
+// with an ABSOLUTE 1e-7 (apvast.py:23) against entries of order 1e-3, so float statistics would not survive.
+#include "apv_internal.h"
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+struct apv_bb {
+    int N, H, K, L, M, C, P, J, S, V, n, zones, pad;
+    int ring_off, stat_off, cur;
+    int n_out;
+    double* rir[2];        // [P][C]
+    double* trir[2];       // [P][M]
+    double* xhist[2][2];   // [buf][signal][P-1+H+pad]
+    double* xin;           // [2][H]
+    double* resp[4];       // [C][N] rings
+    double* tresp[2];      // [M][N] rings
+    double* inblk;         // [2][N] rings
+    double* spec;          // scratch spectra [max(C, n_out)][K] c128
+    double* ov[4];         // [C][N] overlap buffers of the weighted responses (linear, shifted by the kernel)
+    double* tov[2];        // [M][N]
+    double* stats[4];      // [C][S] rings
+    double* tstats[2];     // [M][S] rings
+    double* R;             // [4][n][n]: AA, AB, BB, BA  (pairs (0,1) zone A, (2,3) zone B)
+    double* r;             // [2][n]
+    double* U;             // [2][n][n]
+    double* lam;           // [2][n]
+    double* w;             // [2][V][n]
+    double* fspec;         // [n_out][K] c128 filter spectra (zone A ranks, zone B ranks, target A, target B)
+    double* inspec;        // [2][K] c128
+    double* outov;         // [n_out][N]
+    double* out;           // [n_out][H]
+};
+
+namespace {
+
+#define BCHK(h, call)                                                                    \
+    do {                                                                                 \
+        hipError_t _e = (call);                                                          \
+        if (_e != hipSuccess) return apv_fail(h, APV_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+int dalloc(apv_handle* h, double** p, size_t count) {
+    BCHK(h, hipMalloc((void**)p, sizeof(double) * (count ? count : 1)));
+    BCHK(h, hipMemsetAsync(*p, 0, sizeof(double) * (count ? count : 1), h->stream));
+    return APV_OK;
+}
+
+constexpr int TN = 16;
+
+// direct-form FIR, one thread per channel, TN consecutive samples (sizes here are small: n = J L <= 2048)
+__global__ void __launch_bounds__(64) fir_f64_kernel(int C, int P, int H, int N, int ring_off,
+                                                     const double* __restrict__ rir, const double* __restrict__ xhist,
+                                                     double* __restrict__ resp) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    const int n0 = blockIdx.y * TN;
+    double acc[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t) acc[t] = 0.0;
+    const bool live = c < C;
+    const double* xs = xhist + (P - 1) + n0;
+    for (int p = 0; p < P; ++p) {
+        const double rv = live ? rir[(size_t)p * C + c] : 0.0;
+#pragma unroll
+        for (int t = 0; t < TN; ++t) acc[t] = __builtin_fma(rv, xs[t - p], acc[t]);
+    }
+    if (live) {
+        double* dst = resp + (size_t)c * N;
+#pragma unroll
+        for (int t = 0; t < TN; ++t)
+            if (n0 + t < H) dst[(N - H + n0 + t + ring_off) % N] = acc[t];
+    }
+}
+
+__global__ void __launch_bounds__(256) hist_f64_kernel(int P, int H, int pad, const double* __restrict__ old_hist,
+                                                       const double* __restrict__ x, double* __restrict__ new_hist) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int keep = P - 1;
+    if (i < keep) new_hist[i] = old_hist[i + H];
+    else if (i < keep + H) new_hist[i] = x[i - keep];
+    else if (i < keep + H + pad) new_hist[i] = 0.0;
+}
+
+// ring[c][(len - H + n + off) % len] = src[c][n], n < H   (src row stride src_ld)
+__global__ void __launch_bounds__(256) ring_append_f64_kernel(int len, int H, int off, const double* __restrict__ src,
+                                                              long src_ld, double* __restrict__ ring) {
+    const int c = blockIdx.y;
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n < H) ring[(size_t)c * len + (len - H + n + off) % len] = src[(size_t)c * src_ld + n];
+}
+
+// ---- statistics -----------------------------------------------------------------------------------
+// logical sample t of the "toeplitz" sequence g = buf with sample J removed (apvast.py:336-338)
+__device__ __forceinline__ double stat_at(const double* __restrict__ ring, int S, int off, int J, int t) {
+    const int u = (t < J) ? t : t + 1;
+    int ph = u + off;
+    if (ph >= S) ph -= S;
+    return ring[ph];
+}
+
+using d4 = __attribute__((ext_vector_type(4))) double;
+
+// R[rho][sigma] = sum_m sum_ncol Y_m[rho][ncol] Y_m[sigma][ncol], Y_m[(s, i)][ncol] = g_{s,m}[J-1-i+ncol].
+// One wave = one 16x16 tile of R on v_mfma_f64_16x16x4_f64; the operands are gathered straight from the rings.
+__global__ void __launch_bounds__(64) syrk_hankel_kernel(int n, int J, int L, int M, int S, int off,
+                                                         const double* __restrict__ stats, double* __restrict__ R) {
+    const int lane = threadIdx.x;
+    const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16;
+    const int ra = r0 + (lane & 15), cb = c0 + (lane & 15), kq = lane >> 4;
+    const bool ra_ok = ra < n, cb_ok = cb < n;
+    const int sa = ra_ok ? ra / J : 0, ia = ra_ok ? ra % J : 0;
+    const int sb = cb_ok ? cb / J : 0, ib = cb_ok ? cb % J : 0;
+    const int ncols = S - J;
+    d4 acc = {0, 0, 0, 0};
+    for (int m = 0; m < M; ++m) {
+        const double* ga = stats + (size_t)(m * L + sa) * S;
+        const double* gb = stats + (size_t)(m * L + sb) * S;
+        for (int nc = 0; nc < ncols; nc += 4) {
+            const int col = nc + kq;
+            const bool ok = col < ncols;
+            const double a = (ra_ok && ok) ? stat_at(ga, S, off, J, J - 1 - ia + col) : 0.0;
+            const double b = (cb_ok && ok) ? stat_at(gb, S, off, J, J - 1 - ib + col) : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+    }
+    // f64 accumulator: row = (lane>>4) + 4 t, col = lane & 15
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int row = r0 + kq + 4 * t, col = c0 + (lane & 15);
+        if (row < n && col < n) R[(size_t)row * n + col] = acc[t];
+    }
+}
+
+// r[rho] = sum_m sum_ncol Y_m[rho][ncol] d_m[J + ncol]      (apvast.py:340, 356)
+__global__ void __launch_bounds__(256) xcorr_hankel_kernel(int n, int J, int L, int M, int S, int off,
+                                                           const double* __restrict__ stats,
+                                                           const double* __restrict__ tstats, double* __restrict__ r) {
+    const int rho = blockIdx.x;
+    const int s = rho / J, i = rho % J;
+    const int ncols = S - J;
+    double acc = 0.0;
+    for (int idx = threadIdx.x; idx < M * ncols; idx += 256) {
+        const int m = idx / ncols, nc = idx - m * ncols;
+        const double y = stat_at(stats + (size_t)(m * L + s) * S, S, off, J, J - 1 - i + nc);
+        int ph = J + nc + off;
+        if (ph >= S) ph -= S;
+        acc += y * tstats[(size_t)m * S + ph];
+    }
+    __shared__ double red[256];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) r[rho] = red[0];
+}
+
+// out[ch][k] = in[k] * filt[ch][k]   (complex, channel-major)
+__global__ void __launch_bounds__(256) apply_f64_kernel(int K, int n_ch, const double2* __restrict__ in,
+                                                        const double2* __restrict__ filt, double2* __restrict__ out) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int ch = blockIdx.y;
+    if (k >= K || ch >= n_ch) return;
+    const double2 x = in[k], f = filt[(size_t)ch * K + k];
+    out[(size_t)ch * K + k] = make_double2(x.x * f.x - x.y * f.y, x.x * f.y + x.y * f.x);
+}
+
+inline int path_sig(int p) { return p >> 1; }       // AA, AB, BA, BB
+inline int path_zone(int p) { return p & 1; }
+
+}  // namespace
+
+void apv_bb_free(apv_handle* h) {
+    apv_bb* s = h->bb;
+    if (!s) return;
+    double* bufs[] = {s->rir[0], s->rir[1], s->trir[0], s->trir[1], s->xhist[0][0], s->xhist[0][1], s->xhist[1][0],
+                      s->xhist[1][1], s->xin, s->resp[0], s->resp[1], s->resp[2], s->resp[3], s->tresp[0], s->tresp[1],
+                      s->inblk, s->spec, s->ov[0], s->ov[1], s->ov[2], s->ov[3], s->tov[0], s->tov[1], s->stats[0],
+                      s->stats[1], s->stats[2], s->stats[3], s->tstats[0], s->tstats[1], s->R, s->r, s->U, s->lam, s->w,
+                      s->fspec, s->inspec, s->outov, s->out};
+    for (double* b : bufs)
+        if (b) (void)hipFree(b);
+    delete s;
+    h->bb = nullptr;
+}
+
+extern "C" {
+
+int apv_bb_init(apv_handle* h, int32_t rir_len, const double* h_rir_A, const double* h_rir_B,
+                int32_t reference_index_A, int32_t reference_index_B, int32_t modeling_delay,
+                int32_t filter_length, int32_t statistics_buffer_length, int32_t number_of_eigenvectors) {
+    if (!h || !h_rir_A || !h_rir_B) return apv_fail(h, APV_ERR_ARG, "null argument");
+    const apv_config& c = h->cfg;
+    const int N = c.block_size, H = c.hop_size, J = filter_length, S = statistics_buffer_length;
+    const int V = number_of_eigenvectors, L = c.n_srcs, M = c.n_mics;
+    {
+        std::string why;
+        if (!apv_stft_size_ok(N, &why)) return apv_fail(h, APV_ERR_ARG, why);
+    }
+    if (N > 4096) return apv_fail(h, APV_ERR_ARG, "broadband mode: block_size <= 4096 (double-precision FFT in LDS)");
+    if (H < 1 || H > N) return apv_fail(h, APV_ERR_ARG, "hop_size must be in 1..block_size");
+    if (J < 1 || J > N || S <= J + 1 || H > S) return apv_fail(h, APV_ERR_ARG, "need 1 <= filter_length <= block_size and statistics_buffer_length > filter_length + 1, >= hop_size");
+    const int n = J * L;
+    if (n > 2048) return apv_fail(h, APV_ERR_ARG, "broadband mode: filter_length * loudspeakers <= 2048");
+    if (V < 1 || V > n) return apv_fail(h, APV_ERR_ARG, "number_of_eigenvectors must be in 1..filter_length*loudspeakers");
+    if (rir_len < 1 || modeling_delay < 0 || modeling_delay >= rir_len || modeling_delay >= J)
+        return apv_fail(h, APV_ERR_ARG, "modeling_delay must be < rir_len and < filter_length");
+    if (reference_index_A < 0 || reference_index_A >= L || reference_index_B < 0 || reference_index_B >= L)
+        return apv_fail(h, APV_ERR_ARG, "reference index out of range");
+    if (c.n_zones < 1 || c.n_zones > 3) return apv_fail(h, APV_ERR_ARG, "n_zones is a bit mask: 1 = A, 2 = B, 3 = both");
+    if (c.reg_mode != APV_REG_ABS) return apv_fail(h, APV_ERR_ARG, "broadband mode supports the absolute dark loading only");
+    BCHK(h, hipSetDevice(h->device));
+    apv_bb_free(h);
+    apv_bb* s = new apv_bb();
+    std::memset(static_cast<void*>(s), 0, sizeof(apv_bb));
+    h->bb = s;
+    s->N = N; s->H = H; s->K = N / 2 + 1; s->L = L; s->M = M; s->C = L * M; s->P = rir_len; s->J = J; s->S = S; s->V = V;
+    s->n = n; s->zones = c.n_zones; s->pad = TN;
+    const int nz = ((s->zones & 1) ? 1 : 0) + ((s->zones & 2) ? 1 : 0);
+    s->n_out = nz * V * L + 2 * L;
+    const int C = s->C, P = s->P, K = s->K;
+    int rc;
+    std::vector<double> tmp((size_t)P * C), ttmp((size_t)P * M);
+    for (int z = 0; z < 2; ++z) {
+        const double* src = z ? h_rir_B : h_rir_A;
+        const int ref = z ? reference_index_B : reference_index_A;
+        for (int p = 0; p < P; ++p)
+            for (int l = 0; l < L; ++l)
+                for (int m = 0; m < M; ++m) tmp[(size_t)p * C + m * L + l] = src[((size_t)p * L + l) * M + m];
+        std::fill(ttmp.begin(), ttmp.end(), 0.0);
+        for (int p = modeling_delay; p < P; ++p)
+            for (int m = 0; m < M; ++m) ttmp[(size_t)p * M + m] = src[((size_t)(p - modeling_delay) * L + ref) * M + m];
+        if ((rc = dalloc(h, &s->rir[z], (size_t)P * C))) return rc;
+        if ((rc = dalloc(h, &s->trir[z], (size_t)P * M))) return rc;
+        BCHK(h, hipMemcpy(s->rir[z], tmp.data(), sizeof(double) * tmp.size(), hipMemcpyHostToDevice));
+        BCHK(h, hipMemcpy(s->trir[z], ttmp.data(), sizeof(double) * ttmp.size(), hipMemcpyHostToDevice));
+    }
+    const size_t hist = (size_t)P - 1 + H + s->pad;
+    for (int b = 0; b < 2; ++b)
+        for (int g = 0; g < 2; ++g)
+            if ((rc = dalloc(h, &s->xhist[b][g], hist))) return rc;
+    if ((rc = dalloc(h, &s->xin, (size_t)2 * H))) return rc;
+    for (int p = 0; p < 4; ++p) {
+        if ((rc = dalloc(h, &s->resp[p], (size_t)C * N))) return rc;
+        if ((rc = dalloc(h, &s->ov[p], (size_t)C * N))) return rc;
+        if ((rc = dalloc(h, &s->stats[p], (size_t)C * S))) return rc;
+    }
+    for (int z = 0; z < 2; ++z) {
+        if ((rc = dalloc(h, &s->tresp[z], (size_t)M * N))) return rc;
+        if ((rc = dalloc(h, &s->tov[z], (size_t)M * N))) return rc;
+        if ((rc = dalloc(h, &s->tstats[z], (size_t)M * S))) return rc;
+    }
+    const size_t spec_ch = (size_t)(C > s->n_out ? C : s->n_out);
+    if ((rc = dalloc(h, &s->spec, spec_ch * K * 2))) return rc;
+    if ((rc = dalloc(h, &s->inblk, (size_t)2 * N))) return rc;
+    if ((rc = dalloc(h, &s->R, (size_t)4 * n * n))) return rc;
+    if ((rc = dalloc(h, &s->r, (size_t)2 * n))) return rc;
+    if ((rc = dalloc(h, &s->U, (size_t)2 * n * n))) return rc;
+    if ((rc = dalloc(h, &s->lam, (size_t)2 * n))) return rc;
+    if ((rc = dalloc(h, &s->w, (size_t)2 * V * n))) return rc;
+    if ((rc = dalloc(h, &s->fspec, (size_t)s->n_out * K * 2))) return rc;
+    if ((rc = dalloc(h, &s->inspec, (size_t)2 * K * 2))) return rc;
+    if ((rc = dalloc(h, &s->outov, (size_t)s->n_out * N))) return rc;
+    if ((rc = dalloc(h, &s->out, (size_t)s->n_out * H))) return rc;
+    // target filter spectra (apvast.py:389-390, 418, 422): the same delta filter for A_t and B_t
+    std::vector<double> tg((size_t)2 * L * K * 2, 0.0);
+    const double PI = 3.14159265358979323846;
+    for (int z = 0; z < 2; ++z)
+        for (int k = 0; k < K; ++k) {
+            const double ph = -2.0 * PI * (double)k * (double)modeling_delay / (double)N;
+            const size_t o = (((size_t)z * L + reference_index_A) * K + k) * 2;
+            tg[o] = std::cos(ph);
+            tg[o + 1] = std::sin(ph);
+        }
+    BCHK(h, hipMemcpy(s->fspec + (size_t)nz * V * L * K * 2, tg.data(), sizeof(double) * tg.size(), hipMemcpyHostToDevice));
+    BCHK(h, hipStreamSynchronize(h->stream));
+    return APV_OK;
+}
+
+int apv_bb_process_block(apv_handle* h, const double* h_in_A, const double* h_in_B, double* h_out) {
+    if (!h || !h_in_A || !h_in_B || !h_out) return apv_fail(h, APV_ERR_ARG, "null argument");
+    apv_bb* s = h->bb;
+    if (!s) return apv_fail(h, APV_ERR_ARG, "apv_bb_init has not been called");
+    BCHK(h, hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    const int N = s->N, H = s->H, K = s->K, L = s->L, M = s->M, C = s->C, P = s->P, J = s->J, S = s->S, V = s->V, n = s->n;
+    std::string why;
+    BCHK(h, hipMemcpyAsync(s->xin, h_in_A, sizeof(double) * H, hipMemcpyHostToDevice, st));
+    BCHK(h, hipMemcpyAsync(s->xin + H, h_in_B, sizeof(double) * H, hipMemcpyHostToDevice, st));
+    const int nxt = s->cur ^ 1;
+    const int hist_total = P - 1 + H + s->pad;
+    for (int g = 0; g < 2; ++g)
+        hipLaunchKernelGGL(hist_f64_kernel, dim3((hist_total + 255) / 256), dim3(256), 0, st, P, H, s->pad,
+                           s->xhist[s->cur][g], s->xin + (size_t)g * H, s->xhist[nxt][g]);
+    s->cur = nxt;
+    s->ring_off = (s->ring_off + H) % N;
+    s->stat_off = (s->stat_off + H) % S;
+    hipLaunchKernelGGL(ring_append_f64_kernel, dim3((H + 255) / 256, 2), dim3(256), 0, st, N, H, s->ring_off, s->xin,
+                       (long)H, s->inblk);
+    // 1: RIR convolution
+    const dim3 fg((C + 63) / 64, (H + TN - 1) / TN), tgd((M + 63) / 64, (H + TN - 1) / TN);
+    for (int p = 0; p < 4; ++p)
+        hipLaunchKernelGGL(fir_f64_kernel, fg, dim3(64), 0, st, C, P, H, N, s->ring_off, s->rir[path_zone(p)],
+                           s->xhist[s->cur][path_sig(p)], s->resp[p]);
+    for (int z = 0; z < 2; ++z)
+        hipLaunchKernelGGL(fir_f64_kernel, tgd, dim3(64), 0, st, M, P, H, N, s->ring_off, s->trir[z],
+                           s->xhist[s->cur][z], s->tresp[z]);
+    // 2: WOLA (unit weights, apvast.py:326-327) and append the finished hop to the statistics rings
+    const bool runA = s->zones & 1, runB = s->zones & 2;
+    for (int z = 0; z < 2; ++z) {
+        BCHK(h, apv_launch_analysis(1, N, M, s->tresp[z], N, N, s->ring_off, 1, s->spec, K, 1, st, &why));
+        BCHK(h, apv_launch_synthesis(1, N, H, M, s->spec, K, 1, s->tov[z], nullptr, st, &why));
+        hipLaunchKernelGGL(ring_append_f64_kernel, dim3((H + 255) / 256, M), dim3(256), 0, st, S, H, s->stat_off,
+                           s->tov[z], (long)N, s->tstats[z]);
+    }
+    for (int p = 0; p < 4; ++p) {
+        const bool live = (p == 0 || p == 1) ? runA : runB;      // A->A, A->B belong to zone program A
+        if (live) {
+            BCHK(h, apv_launch_analysis(1, N, C, s->resp[p], N, N, s->ring_off, 1, s->spec, K, 1, st, &why));
+        } else {
+            BCHK(h, hipMemsetAsync(s->spec, 0, sizeof(double) * 2 * (size_t)C * K, st));   // apvast.py:239-255: spectra stay 0
+        }
+        BCHK(h, apv_launch_synthesis(1, N, H, C, s->spec, K, 1, s->ov[p], nullptr, st, &why));
+        hipLaunchKernelGGL(ring_append_f64_kernel, dim3((H + 255) / 256, C), dim3(256), 0, st, S, H, s->stat_off,
+                           s->ov[p], (long)N, s->stats[p]);
+    }
+    // 3: statistics.  R order: [0] A->A, [1] A->B (zone A pair), [2] B->B, [3] B->A (zone B pair)
+    const int stat_src[4] = {0, 1, 3, 2};
+    const dim3 sg((n + 15) / 16, (n + 15) / 16);
+    for (int q = 0; q < 4; ++q) {
+        const bool live = (q < 2) ? runA : runB;
+        if (!live) continue;
+        hipLaunchKernelGGL(syrk_hankel_kernel, sg, dim3(64), 0, st, n, J, L, M, S, s->stat_off, s->stats[stat_src[q]],
+                           s->R + (size_t)q * n * n);
+    }
+    if (runA) hipLaunchKernelGGL(xcorr_hankel_kernel, dim3(n), dim3(256), 0, st, n, J, L, M, S, s->stat_off, s->stats[0], s->tstats[0], s->r);
+    if (runB) hipLaunchKernelGGL(xcorr_hankel_kernel, dim3(n), dim3(256), 0, st, n, J, L, M, S, s->stat_off, s->stats[3], s->tstats[1], s->r + n);
+    // 4: jdiag + filters per zone (pairs are adjacent in s->R)
+    int32_t status[2] = {0, 0};
+    for (int z = 0; z < 2; ++z) {
+        if (!(z ? runB : runA)) continue;
+        const double* A = s->R + (size_t)(2 * z) * n * n;
+        const double* B = s->R + (size_t)(2 * z + 1) * n * n;
+        int rc = apv_gevd_large(h, n, 1, A, B, h->cfg.reg_dark, s->U + (size_t)z * n * n, s->lam + (size_t)z * n,
+                                s->r + (size_t)z * n, h->cfg.mu, V, s->w + (size_t)z * V * n, &status[z]);
+        if (rc != APV_OK) return rc;
+    }
+    // 5: filter spectra: channel (v, l) = taps w[v][l*J : (l+1)*J] zero-padded to N, no window
+    int oc = 0;
+    for (int z = 0; z < 2; ++z) {
+        if (!(z ? runB : runA)) continue;
+        BCHK(h, apv_launch_analysis(1, N, V * L, s->w + (size_t)z * V * n, J, J, 0, 0, s->fspec + (size_t)oc * K * 2, K, 1, st, &why));
+        oc += V * L;
+    }
+    // 6: outputs
+    BCHK(h, apv_launch_analysis(1, N, 2, s->inblk, N, N, s->ring_off, 1, s->inspec, K, 1, st, &why));
+    oc = 0;
+    for (int z = 0; z < 2; ++z) {
+        if (!(z ? runB : runA)) continue;
+        hipLaunchKernelGGL(apply_f64_kernel, dim3((K + 255) / 256, V * L), dim3(256), 0, st, K, V * L,
+                           (const double2*)s->inspec + (size_t)z * K, (const double2*)s->fspec + (size_t)oc * K,
+                           (double2*)s->spec + (size_t)oc * K);
+        oc += V * L;
+    }
+    for (int z = 0; z < 2; ++z) {
+        hipLaunchKernelGGL(apply_f64_kernel, dim3((K + 255) / 256, L), dim3(256), 0, st, K, L,
+                           (const double2*)s->inspec + (size_t)z * K, (const double2*)s->fspec + (size_t)oc * K,
+                           (double2*)s->spec + (size_t)oc * K);
+        oc += L;
+    }
+    BCHK(h, apv_launch_synthesis(1, N, H, s->n_out, s->spec, K, 1, s->outov, s->out, st, &why));
+    BCHK(h, hipMemcpyAsync(h_out, s->out, sizeof(double) * (size_t)s->n_out * H, hipMemcpyDeviceToHost, st));
+    BCHK(h, hipStreamSynchronize(st));
+    BCHK(h, hipGetLastError());
+    return APV_OK;
+}
+
+// state: "response<p>" [C][N], "target_response<z>" [M][N] (rings, logical order); "R<q>" [n][n] (AA, AB, BB, BA),
+// "r" [2][n], "lambda" [2][n], "w" [2][V][n], "stats<p>" [C][S], "target_stats<z>" [M][S] (rings, logical order)
+static int bb_lookup(apv_handle* h, const char* name, double** d, size_t* count, int* rows, int* len, int* off) {
+    apv_bb* s = h->bb;
+    const std::string nm(name);
+    *rows = 0;
+    auto idx = [&](const char* pre, int maxv) -> int {
+        const size_t pl = std::strlen(pre);
+        if (nm.size() == pl + 1 && nm.compare(0, pl, pre) == 0 && nm[pl] >= '0' && nm[pl] < '0' + maxv) return nm[pl] - '0';
+        return -1;
+    };
+    int q;
+    if ((q = idx("response", 4)) >= 0) { *d = s->resp[q]; *count = (size_t)s->C * s->N; *rows = s->C; *len = s->N; *off = s->ring_off; return APV_OK; }
+    if ((q = idx("target_response", 2)) >= 0) { *d = s->tresp[q]; *count = (size_t)s->M * s->N; *rows = s->M; *len = s->N; *off = s->ring_off; return APV_OK; }
+    if ((q = idx("stats", 4)) >= 0) { *d = s->stats[q]; *count = (size_t)s->C * s->S; *rows = s->C; *len = s->S; *off = s->stat_off; return APV_OK; }
+    if ((q = idx("target_stats", 2)) >= 0) { *d = s->tstats[q]; *count = (size_t)s->M * s->S; *rows = s->M; *len = s->S; *off = s->stat_off; return APV_OK; }
+    if ((q = idx("R", 4)) >= 0) { *d = s->R + (size_t)q * s->n * s->n; *count = (size_t)s->n * s->n; return APV_OK; }
+    if (nm == "r") { *d = s->r; *count = (size_t)2 * s->n; return APV_OK; }
+    if (nm == "lambda") { *d = s->lam; *count = (size_t)2 * s->n; return APV_OK; }
+    if (nm == "w") { *d = s->w; *count = (size_t)2 * s->V * s->n; return APV_OK; }
+    if (nm == "input_spectrum") { *d = s->inspec; *count = (size_t)2 * s->K * 2; return APV_OK; }
+    return apv_fail(h, APV_ERR_STATE, std::string("unknown broadband state name: ") + name);
+}
+
+int apv_bb_get_state(apv_handle* h, const char* name, double* h_dst, size_t count) {
+    if (!h || !h->bb || !name || !h_dst) return apv_fail(h, APV_ERR_ARG, "null argument / broadband stream not initialised");
+    double* d; size_t need; int rows, len, off;
+    int rc = bb_lookup(h, name, &d, &need, &rows, &len, &off);
+    if (rc != APV_OK) return rc;
+    if (count != need) return apv_fail(h, APV_ERR_STATE, "state size mismatch");
+    BCHK(h, hipSetDevice(h->device));
+    BCHK(h, hipStreamSynchronize(h->stream));
+    if (rows == 0) {
+        BCHK(h, hipMemcpy(h_dst, d, sizeof(double) * need, hipMemcpyDeviceToHost));
+        return APV_OK;
+    }
+    std::vector<double> tmp(need);
+    BCHK(h, hipMemcpy(tmp.data(), d, sizeof(double) * need, hipMemcpyDeviceToHost));
+    for (int r = 0; r < rows; ++r)
+        for (int t = 0; t < len; ++t) h_dst[(size_t)r * len + t] = tmp[(size_t)r * len + (t + off) % len];
+    return APV_OK;
+}
+
+int apv_bb_set_state(apv_handle* h, const char* name, const double* h_src, size_t count) {
+    if (!h || !h->bb || !name || !h_src) return apv_fail(h, APV_ERR_ARG, "null argument / broadband stream not initialised");
+    double* d; size_t need; int rows, len, off;
+    int rc = bb_lookup(h, name, &d, &need, &rows, &len, &off);
+    if (rc != APV_OK) return rc;
+    if (count != need) return apv_fail(h, APV_ERR_STATE, "state size mismatch");
+    BCHK(h, hipSetDevice(h->device));
+    BCHK(h, hipStreamSynchronize(h->stream));
+    if (rows == 0) {
+        BCHK(h, hipMemcpy(d, h_src, sizeof(double) * need, hipMemcpyHostToDevice));
+        return APV_OK;
+    }
+    std::vector<double> tmp(need);
+    for (int r = 0; r < rows; ++r)
+        for (int t = 0; t < len; ++t) tmp[(size_t)r * len + (t + off) % len] = h_src[(size_t)r * len + t];
+    BCHK(h, hipMemcpy(d, tmp.data(), sizeof(double) * need, hipMemcpyHostToDevice));
+    return APV_OK;
+}
+
+}  // extern "C"

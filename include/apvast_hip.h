@@ -165,6 +165,21 @@ int  apv_state_bytes(apv_handle* h, const char* name, size_t* bytes);
 int  apv_get_state(apv_handle* h, const char* name, void* h_dst, size_t bytes);
 int  apv_set_state(apv_handle* h, const char* name, const void* h_src, size_t bytes);
 
+/* ---- broadband (time-domain) mode: the reference's own algorithm, float64 ---------------------------- */
+/* One real (J L) x (J L) pair per zone per hop from `statistics_buffer_length` samples, J-tap filters, every rank
+ * 1..V (apvast.py:329-422).  The handle needs block_size, hop_size, n_srcs, n_mics, n_zones, mu, reg_dark and
+ * reg_mode = APV_REG_ABS; n_bins / ranks are not used.  J L <= 2048, block_size <= 4096.
+ *                                                         replaces apvast.__init__, apvast.py:40-151 */
+int  apv_bb_init(apv_handle* h, int32_t rir_len, const double* h_rir_A, const double* h_rir_B,
+                 int32_t reference_index_A, int32_t reference_index_B, int32_t modeling_delay,
+                 int32_t filter_length, int32_t statistics_buffer_length, int32_t number_of_eigenvectors);
+/* One hop (H float64 samples per signal).  h_out: [n_out][H] float64, channels as for apv_process_block with
+ * nV = V.                                                 replaces process_input_buffers, apvast.py:153-165 */
+int  apv_bb_process_block(apv_handle* h, const double* h_in_A, const double* h_in_B, double* h_out);
+/* float64 state arrays by name (stream_bb.hip); `count` = number of doubles */
+int  apv_bb_get_state(apv_handle* h, const char* name, double* h_dst, size_t count);
+int  apv_bb_set_state(apv_handle* h, const char* name, const double* h_src, size_t count);
+
 /* ---- multi-GPU: bins sharded across ranks, one RCCL all-gather ---------- */
 int  apv_comm_unique_id(char id_out[128]);                                /* rank 0 calls, then broadcasts */
 int  apv_comm_init(apv_handle* h, const char id[128], int32_t rank, int32_t world);

@@ -1,0 +1,78 @@
+"""Broadband mode on the GPU against the golden vectors captured from the reference (fixture G1):
+same rirs.mat, same initial buffers, same input hops -> same outputs, filters, eigenvalues, statistics."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CFG1 = dict(block_size=256, filter_length=32, modeling_delay=16, reference_index_A=0, reference_index_B=0,
+            number_of_eigenvectors=8, mu=1.0, statistics_buffer_length=512, hop_size=128)
+
+
+def make(g, rirs, **over):
+    from ap_vast_unofficial_amd.apvast import apvast
+    p = dict(CFG1)
+    p.update(over)
+    ap = apvast(p["block_size"], rirs["rirA"], rirs["rirB"], p["filter_length"], p["modeling_delay"],
+                p["reference_index_A"], p["reference_index_B"], p["number_of_eigenvectors"], p["mu"],
+                p["statistics_buffer_length"], hop_size=p["hop_size"], run_A=p.get("run_A", True),
+                run_B=p.get("run_B", True), perceptual=False, mode="broadband", seed=0)
+    ap.set_state({"response": g["init_response"], "target_response": g["init_target_response"]})
+    return ap
+
+
+def test_g1_broadband_end_to_end_on_gpu(golden):
+    """apvast.py:153-165 over 8 hops at cfg1 (bundled rirs.mat): outputs of ranks 1, 4, 8, lambda, w, r per hop;
+    statistics matrices and every buffer after the last hop."""
+    g = golden("g1_broadband_cfg1")
+    rirs = golden("rirs_cfg1")
+    ap = make(g, rirs)
+    x = g["x"]
+    H = 128
+    ranks = g["ranks"]
+    worst = dict(out=0.0, lam=0.0, w=0.0, r=0.0)
+    for h in range(x.shape[1] // H):
+        out = ap.process_input_buffers(x[0, h * H:(h + 1) * H], x[1, h * H:(h + 1) * H])
+        for q in range(4):
+            got = np.stack(out[q])[ranks]
+            exp = g["outputs"][h, q]
+            e = np.abs(got - exp).max() / max(np.abs(exp).max(), 1e-30)
+            worst["out"] = max(worst["out"], e)
+        for z, (lam, w, r) in enumerate(((ap.lambda_A, ap.w_A, ap.r_A), (ap.lambda_B, ap.w_B, ap.r_B))):
+            worst["lam"] = max(worst["lam"], np.abs(lam[:8] / g["lam"][h, z, :8] - 1).max())
+            worst["r"] = max(worst["r"], np.abs(r[:, 0] - g["r"][h, z]).max() / np.abs(g["r"][h, z]).max())
+            for i in range(8):
+                e = g["w"][h, z, i]
+                worst["w"] = max(worst["w"], np.linalg.norm(w[i, :, 0] - e) / np.linalg.norm(e))
+    print("worst relative errors vs the reference:", worst)
+    # tolerances of SURVEY.md section 8(c) for a float64 restatement
+    assert worst["r"] < 1e-12
+    assert worst["lam"] < 1e-9
+    assert worst["w"] < 1e-8
+    assert worst["out"] < 1e-9
+    iu = np.triu_indices(256)
+    assert np.abs(ap.R_A_to_A[iu] - g["R_AA_triu"]).max() < 1e-11 * np.abs(g["R_AA_triu"]).max()
+    assert np.abs(ap.R_A_to_B[iu] - g["R_AB_triu"]).max() < 1e-11 * np.abs(g["R_AB_triu"]).max()
+    assert abs(np.trace(ap.R_B_to_B) / g["R_BB_trace"] - 1) < 1e-11
+    assert abs(np.trace(ap.R_B_to_A) / g["R_BA_trace"] - 1) < 1e-11
+    st = ap.get_state()
+    for name in ("response", "target_response", "stats", "target_stats"):
+        ref = g["final_" + name]
+        assert np.abs(st[name] - ref).max() < 1e-11 * np.abs(ref).max(), name
+    assert np.abs(ap.input_spectrum_A[:, 0] - g["input_spectrum"][-1, 0]).max() < 1e-11 * np.abs(g["input_spectrum"][-1]).max()
+    ap.close()
+
+
+def test_g1b_single_zone_on_gpu(golden):
+    g = golden("g1b_single_zone")
+    rirs = golden("rirs_cfg1")
+    ap = make(g, rirs, run_B=False, number_of_eigenvectors=4)
+    x = g["x"]
+    H = 128
+    for h in range(x.shape[1] // H):
+        out = ap.process_input_buffers(x[0, h * H:(h + 1) * H], x[1, h * H:(h + 1) * H])
+        assert out[1] is None
+        assert np.abs(np.stack(out[0]) - g["out_A"][h]).max() <= 1e-9 * np.abs(g["out_A"][h]).max()
+        assert np.abs(np.stack(out[3]) - g["out_Bt"][h]).max() <= 1e-9 * np.abs(g["out_Bt"][h]).max()
+    assert np.abs(ap.lambda_A[:4] / g["lam"][:4] - 1).max() < 1e-8
+    ap.close()
