@@ -191,7 +191,7 @@ class apvast:
         spec = e.bb_get_state("input_spectrum", (2, self._K, 2))
         self.input_spectrum_A = (spec[0, :, 0] + 1j * spec[0, :, 1]).reshape(-1, 1)
         self.input_spectrum_B = (spec[1, :, 0] + 1j * spec[1, :, 1]).reshape(-1, 1)
-        names = {"A": ("R_A_to_A", "R_A_to_B", 0), "B": ("R_B_to_B", "R_B_to_A", 2)}
+        names = {"A": ("R_A_to_A", "R_A_to_B", 0, 2), "B": ("R_B_to_B", "R_B_to_A", 1, 3)}
         for zi, (z, run) in enumerate((("A", self.run_A), ("B", self.run_B))):
             if not run:
                 continue
@@ -199,7 +199,7 @@ class apvast:
             setattr(self, "w_" + z, w[zi][:, :, None].copy())                 # (V, n, 1), apvast.py:393, 398
             setattr(self, "r_" + z, r[zi][:, None].copy())
             setattr(self, names[z][0], e.bb_get_state(f"R{names[z][2]}", (n, n)))
-            setattr(self, names[z][1], e.bb_get_state(f"R{names[z][2] + 1}", (n, n)))
+            setattr(self, names[z][1], e.bb_get_state(f"R{names[z][3]}", (n, n)))
 
     # ---- per-hop call (apvast.py:153-165) -------------------------------------------------
     def process_input_buffers(self, input_A, input_B):

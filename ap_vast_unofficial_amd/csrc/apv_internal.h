@@ -60,6 +60,7 @@ struct apv_handle {
     size_t lspill_bytes;
     struct apv_stream* st;   // streaming state (apv_stream_init), owned
     struct apv_bb* bb;       // broadband streaming state (apv_bb_init), owned
+    void* gl_ws;             // workspace + captured sweep graph of apv_gevd_large, owned
     void* comm;       // ncclComm_t
     int comm_rank, comm_world;
     hipStream_t comm_stream;      // the all-gather runs here so that it overlaps the next block's kernels
@@ -70,6 +71,7 @@ struct apv_handle {
 
 void apv_stream_free(apv_handle* h);      // stream.hip
 void apv_bb_free(apv_handle* h);          // stream_bb.hip
+void apv_gevd_large_free(apv_handle* h);  // kernels_gevd_large.hip
 int apv_fail(apv_handle* h, int code, const std::string& msg);
 GevdParams apv_base_params(const apv_handle* h);
 

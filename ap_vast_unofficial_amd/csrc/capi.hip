@@ -129,6 +129,7 @@ int apv_create(const apv_config* cfg, apv_handle** out) {
     h->lspill_bytes = 0;
     h->st = nullptr;
     h->bb = nullptr;
+    h->gl_ws = nullptr;
     h->comm_stream = nullptr;
     h->ev_ready = nullptr;
     for (auto& g : h->gather_done) { g.ptr = nullptr; g.ev = nullptr; }
@@ -165,6 +166,7 @@ int apv_destroy(apv_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     apv_stream_free(h);
     apv_bb_free(h);
+    apv_gevd_large_free(h);
     if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
     if (h->comm) ncclCommDestroy((ncclComm_t)h->comm);
     for (auto& g : h->gather_done)

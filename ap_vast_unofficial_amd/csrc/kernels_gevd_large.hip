@@ -256,6 +256,32 @@ __global__ void __launch_bounds__(TPB) vast_prefix_kernel(int n, int V, const do
 
 }  // namespace
 
+// Workspace + captured two-sweep graph, cached on the handle (sizes rarely change between hops).
+struct GevdLargeWs {
+    int n = 0, batch = 0;
+    double *Bw = nullptr, *W = nullptr, *T1 = nullptr, *C0 = nullptr, *C1 = nullptr, *V0 = nullptr, *V1 = nullptr;
+    double *dinv = nullptr, *acc = nullptr, *coef = nullptr;
+    int *flag = nullptr, *order = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    void release() {
+        if (exec) (void)hipGraphExecDestroy(exec);
+        if (graph) (void)hipGraphDestroy(graph);
+        void* bufs[] = {Bw, W, T1, C0, C1, V0, V1, dinv, acc, coef, flag, order};
+        for (void* b : bufs)
+            if (b) (void)hipFree(b);
+        *this = GevdLargeWs();
+    }
+};
+
+void apv_gevd_large_free(apv_handle* h) {
+    if (h->gl_ws) {
+        static_cast<GevdLargeWs*>(h->gl_ws)->release();
+        delete static_cast<GevdLargeWs*>(h->gl_ws);
+        h->gl_ws = nullptr;
+    }
+}
+
 // Everything above, for `batch` independent pairs.  d_A, d_B: [batch][n][n] f64 (row-major, device, B is loaded
 // with +reg on its diagonal here); outputs d_U [batch][n][n] (sorted columns), d_lam [batch][n]; optional
 // d_r [batch][n] -> d_w [batch][V][n].  h_status[batch]: 0 ok, 1 not positive definite, 2 sweep cap.
@@ -264,96 +290,108 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
     hipStream_t st = h->stream;
     const int ne = n + (n & 1), ld = ne;
     const size_t ms = (size_t)ne * ne, vs = (size_t)ne;
-    double *Bw = nullptr, *W = nullptr, *T1 = nullptr, *C0 = nullptr, *C1 = nullptr, *V0 = nullptr, *V1 = nullptr;
-    double *dinv = nullptr, *acc = nullptr, *coef = nullptr;
-    int *flag = nullptr, *order = nullptr;
-    std::vector<void*> owned;
-    auto alloc = [&](void** p, size_t bytes) {
-        hipError_t e = hipMalloc(p, bytes);
-        if (e == hipSuccess) { owned.push_back(*p); e = hipMemsetAsync(*p, 0, bytes, st); }
-        return e;
-    };
-    auto cleanup = [&]() { for (void* p : owned) (void)hipFree(p); };
 #define LCHK(call)                                                                                   \
     do {                                                                                             \
         hipError_t _e = (call);                                                                      \
-        if (_e != hipSuccess) { cleanup(); return apv_fail(h, APV_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_e)); } \
+        if (_e != hipSuccess) return apv_fail(h, APV_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_e)); \
     } while (0)
+    if (!h->gl_ws) h->gl_ws = new GevdLargeWs();
+    GevdLargeWs& ws = *static_cast<GevdLargeWs*>(h->gl_ws);
     const size_t mb = sizeof(double) * ms * batch;
-    LCHK(alloc((void**)&Bw, mb)); LCHK(alloc((void**)&W, mb)); LCHK(alloc((void**)&T1, mb));
-    LCHK(alloc((void**)&C0, mb)); LCHK(alloc((void**)&C1, mb)); LCHK(alloc((void**)&V0, mb)); LCHK(alloc((void**)&V1, mb));
-    LCHK(alloc((void**)&dinv, sizeof(double) * vs * batch)); LCHK(alloc((void**)&acc, sizeof(double) * 2 * batch));
-    LCHK(alloc((void**)&coef, sizeof(double) * vs * batch));
-    LCHK(alloc((void**)&flag, sizeof(int) * batch)); LCHK(alloc((void**)&order, sizeof(int) * vs * batch));
+    const int gx = (ne + TPB - 1) / TPB;
+    const int np = ne / 2, rounds = ne - 1;
+    const int jb = (np * np + TPB - 1) / TPB;
+    if (ws.n != n || ws.batch != batch) {
+        ws.release();
+        ws.n = n;
+        ws.batch = batch;
+        LCHK(hipMalloc((void**)&ws.Bw, mb)); LCHK(hipMalloc((void**)&ws.W, mb)); LCHK(hipMalloc((void**)&ws.T1, mb));
+        LCHK(hipMalloc((void**)&ws.C0, mb)); LCHK(hipMalloc((void**)&ws.C1, mb));
+        LCHK(hipMalloc((void**)&ws.V0, mb)); LCHK(hipMalloc((void**)&ws.V1, mb));
+        LCHK(hipMalloc((void**)&ws.dinv, sizeof(double) * vs * batch));
+        LCHK(hipMalloc((void**)&ws.acc, sizeof(double) * 3 * batch));         // [sweep a | sweep b | ||C||_F^2]
+        LCHK(hipMalloc((void**)&ws.coef, sizeof(double) * vs * batch));
+        LCHK(hipMalloc((void**)&ws.flag, sizeof(int) * batch));
+        LCHK(hipMalloc((void**)&ws.order, sizeof(int) * vs * batch));
+        // two sweeps as one graph: 2 (ne - 1) rounds bring the ping-pong buffers back to where they started
+        if (n > 1) {
+            LCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            LCHK(hipMemsetAsync(ws.acc, 0, sizeof(double) * 2 * batch, st));
+            double *Cc = ws.C0, *Cn = ws.C1, *Vc = ws.V0, *Vn = ws.V1;
+            for (int sw = 0; sw < 2; ++sw)
+                for (int r = 0; r < rounds; ++r) {
+                    hipLaunchKernelGGL(jacobi_round_kernel, dim3(jb, 1, batch), dim3(TPB), 0, st, n, ne, ld, r, Cc, Cn, Vc, Vn,
+                                       ws.acc + (size_t)sw * batch, ms);
+                    double* t = Cc; Cc = Cn; Cn = t;
+                    t = Vc; Vc = Vn; Vn = t;
+                }
+            LCHK(hipStreamEndCapture(st, &ws.graph));
+            LCHK(hipGraphInstantiate(&ws.exec, ws.graph, nullptr, nullptr, 0));
+        }
+    }
+    LCHK(hipMemsetAsync(ws.Bw, 0, mb, st));
+    LCHK(hipMemsetAsync(ws.C0, 0, mb, st));
+    LCHK(hipMemsetAsync(ws.C1, 0, mb, st));
+    LCHK(hipMemsetAsync(ws.V1, 0, mb, st));
+    LCHK(hipMemsetAsync(ws.flag, 0, sizeof(int) * batch, st));
+    LCHK(hipMemsetAsync(ws.acc, 0, sizeof(double) * 3 * batch, st));
     // working copies with leading dimension ld (ghost row/column of an odd order stay zero)
     for (int z = 0; z < batch; ++z) {
-        LCHK(hipMemcpy2DAsync(Bw + z * ms, sizeof(double) * ld, d_B + (size_t)z * n * n, sizeof(double) * n,
+        LCHK(hipMemcpy2DAsync(ws.Bw + z * ms, sizeof(double) * ld, d_B + (size_t)z * n * n, sizeof(double) * n,
                               sizeof(double) * n, n, hipMemcpyDeviceToDevice, st));
-        LCHK(hipMemcpy2DAsync(C0 + z * ms, sizeof(double) * ld, d_A + (size_t)z * n * n, sizeof(double) * n,
+        LCHK(hipMemcpy2DAsync(ws.C0 + z * ms, sizeof(double) * ld, d_A + (size_t)z * n * n, sizeof(double) * n,
                               sizeof(double) * n, n, hipMemcpyDeviceToDevice, st));      // C0 holds A for now
     }
-    const int gx = (ne + TPB - 1) / TPB;
-    hipLaunchKernelGGL(set_identity_kernel, dim3(gx, ne, batch), dim3(TPB), 0, st, ne, ld, W, ms);
-    hipLaunchKernelGGL(add_diag_kernel, dim3(gx, 1, batch), dim3(TPB), 0, st, n, ld, Bw, reg, ms);      // apvast.py:24
+    hipLaunchKernelGGL(set_identity_kernel, dim3(gx, ne, batch), dim3(TPB), 0, st, ne, ld, ws.W, ms);
+    hipLaunchKernelGGL(add_diag_kernel, dim3(gx, 1, batch), dim3(TPB), 0, st, n, ld, ws.Bw, reg, ms);      // apvast.py:24
     for (int kk = 0; kk < n; ++kk) {
         const int rows = n - kk - 1;
-        hipLaunchKernelGGL(chol_inv_step_kernel, dim3(gx, rows > 0 ? rows : 1, batch), dim3(TPB), 0, st, n, ld, kk, Bw, W,
-                           dinv, flag, ms, vs);
+        hipLaunchKernelGGL(chol_inv_step_kernel, dim3(gx, rows > 0 ? rows : 1, batch), dim3(TPB), 0, st, n, ld, kk, ws.Bw,
+                           ws.W, ws.dinv, ws.flag, ms, vs);
     }
-    hipLaunchKernelGGL(scale_rows_kernel, dim3(gx, n, batch), dim3(TPB), 0, st, n, ld, W, dinv, ms, vs);
+    hipLaunchKernelGGL(scale_rows_kernel, dim3(gx, n, batch), dim3(TPB), 0, st, n, ld, ws.W, ws.dinv, ms, vs);
     const dim3 gg((n + 15) / 16, (n + 15) / 16, batch);
-    hipLaunchKernelGGL((gemm_kernel<false, false>), gg, dim3(256), 0, st, n, ld, W, C0, T1, ms);     // T1 = W A
-    hipLaunchKernelGGL((gemm_kernel<false, true>), gg, dim3(256), 0, st, n, ld, T1, W, C0, ms);      // C = T1 W^T
-    hipLaunchKernelGGL(symmetrise_kernel, dim3(gx, n, batch), dim3(TPB), 0, st, n, ld, C0, ms);
-    hipLaunchKernelGGL(set_identity_kernel, dim3(gx, ne, batch), dim3(TPB), 0, st, ne, ld, V0, ms);
-    LCHK(hipMemsetAsync(C1, 0, mb, st));
-    LCHK(hipMemsetAsync(V1, 0, mb, st));
-    hipLaunchKernelGGL(frob2_kernel, dim3(64, 1, batch), dim3(TPB), 0, st, n, ld, C0, acc + batch, ms);
+    hipLaunchKernelGGL((gemm_kernel<false, false>), gg, dim3(256), 0, st, n, ld, ws.W, ws.C0, ws.T1, ms);     // T1 = W A
+    hipLaunchKernelGGL((gemm_kernel<false, true>), gg, dim3(256), 0, st, n, ld, ws.T1, ws.W, ws.C0, ms);      // C = T1 W^T
+    hipLaunchKernelGGL(symmetrise_kernel, dim3(gx, n, batch), dim3(TPB), 0, st, n, ld, ws.C0, ms);
+    hipLaunchKernelGGL(set_identity_kernel, dim3(gx, ne, batch), dim3(TPB), 0, st, ne, ld, ws.V0, ms);
+    hipLaunchKernelGGL(frob2_kernel, dim3(64, 1, batch), dim3(TPB), 0, st, n, ld, ws.C0, ws.acc + 2 * batch, ms);
     std::vector<int> hflag(batch, 0);
-    std::vector<double> hacc(2 * batch, 0.0);
-    LCHK(hipMemcpyAsync(hflag.data(), flag, sizeof(int) * batch, hipMemcpyDeviceToHost, st));
-    LCHK(hipMemcpyAsync(hacc.data(), acc, sizeof(double) * 2 * batch, hipMemcpyDeviceToHost, st));
+    std::vector<double> hacc(3 * batch, 0.0);
+    LCHK(hipMemcpyAsync(hflag.data(), ws.flag, sizeof(int) * batch, hipMemcpyDeviceToHost, st));
+    LCHK(hipMemcpyAsync(hacc.data(), ws.acc, sizeof(double) * 3 * batch, hipMemcpyDeviceToHost, st));
     LCHK(hipStreamSynchronize(st));
     bool any_bad = false;
     for (int z = 0; z < batch; ++z) {
         h_status[z] = hflag[z] ? 1 : 0;
         any_bad = any_bad || hflag[z];
     }
-    double *Cc = C0, *Cn = C1, *Vc = V0, *Vn = V1;
-    const int np = ne / 2, rounds = ne - 1;
-    const int jb = (np * np + TPB - 1) / TPB;
-    const int max_sweeps = h->cfg.max_sweeps > 0 ? h->cfg.max_sweeps : 30;
+    std::vector<double> norm2(hacc.begin() + 2 * batch, hacc.end());
+    const int max_pairs = (h->cfg.max_sweeps > 0 ? h->cfg.max_sweeps : 30) / 2 + 1;
     bool converged = (n == 1);
-    for (int sweep = 0; sweep < max_sweeps && !converged; ++sweep) {
-        LCHK(hipMemsetAsync(acc, 0, sizeof(double) * batch, st));
-        for (int r = 0; r < rounds; ++r) {
-            hipLaunchKernelGGL(jacobi_round_kernel, dim3(jb, 1, batch), dim3(TPB), 0, st, n, ne, ld, r, Cc, Cn, Vc, Vn, acc, ms);
-            double* t = Cc; Cc = Cn; Cn = t;
-            t = Vc; Vc = Vn; Vn = t;
-        }
-        LCHK(hipMemcpyAsync(hacc.data(), acc, sizeof(double) * batch, hipMemcpyDeviceToHost, st));
+    for (int it = 0; it < max_pairs && !converged; ++it) {
+        LCHK(hipGraphLaunch(ws.exec, st));
+        LCHK(hipMemcpyAsync(hacc.data(), ws.acc, sizeof(double) * 2 * batch, hipMemcpyDeviceToHost, st));
         LCHK(hipStreamSynchronize(st));
-        converged = true;
+        converged = true;                     // judged on the second sweep of the pair
         for (int z = 0; z < batch; ++z)
-            if (!hflag[z] && !(hacc[z] <= 1e-20 * hacc[batch + z])) converged = false;
+            if (!hflag[z] && !(hacc[batch + z] <= 1e-20 * norm2[z])) converged = false;
     }
     if (!converged)
         for (int z = 0; z < batch; ++z)
             if (!hflag[z]) h_status[z] = 2;
-    // eigenvalues + order, X = W^T Q into T1, gather sorted columns
-    hipLaunchKernelGGL(rank_kernel, dim3(gx, 1, batch), dim3(TPB), 0, st, n, ld, Cc, d_lam, order, ms, vs);
-    hipLaunchKernelGGL((gemm_kernel<true, false>), gg, dim3(256), 0, st, n, ld, W, Vc, T1, ms);
-    hipLaunchKernelGGL(gather_cols_kernel, dim3(gx, n, batch), dim3(TPB), 0, st, n, ld, T1, order, d_U, ms, vs,
+    // after an even number of sweeps the current matrices are back in C0 / V0
+    hipLaunchKernelGGL(rank_kernel, dim3(gx, 1, batch), dim3(TPB), 0, st, n, ld, ws.C0, d_lam, ws.order, ms, vs);
+    hipLaunchKernelGGL((gemm_kernel<true, false>), gg, dim3(256), 0, st, n, ld, ws.W, ws.V0, ws.T1, ms);       // X = W^T Q
+    hipLaunchKernelGGL(gather_cols_kernel, dim3(gx, n, batch), dim3(TPB), 0, st, n, ld, ws.T1, ws.order, d_U, ms, vs,
                        (size_t)n * n);
     if (d_r != nullptr && d_w != nullptr && V > 0) {
-        hipLaunchKernelGGL(coef_kernel, dim3(gx, 1, batch), dim3(TPB), 0, st, n, d_U, d_lam, d_r, mu, coef, (size_t)n * n, vs);
-        hipLaunchKernelGGL(vast_prefix_kernel, dim3(gx, 1, batch), dim3(TPB), 0, st, n, V, d_U, coef, d_w, (size_t)n * n, vs,
+        hipLaunchKernelGGL(coef_kernel, dim3(gx, 1, batch), dim3(TPB), 0, st, n, d_U, d_lam, d_r, mu, ws.coef, (size_t)n * n, vs);
+        hipLaunchKernelGGL(vast_prefix_kernel, dim3(gx, 1, batch), dim3(TPB), 0, st, n, V, d_U, ws.coef, d_w, (size_t)n * n, vs,
                            (size_t)V * n);
     }
     LCHK(hipStreamSynchronize(st));
-    hipError_t le = hipGetLastError();
-    cleanup();
-    if (le != hipSuccess) return apv_fail(h, APV_ERR_HIP, hipGetErrorString(le));
+    LCHK(hipGetLastError());
     if (any_bad) return apv_fail(h, APV_ERR_NOT_PD, "Matrix is not positive definite");
 #undef LCHK
     return APV_OK;

@@ -36,7 +36,7 @@ struct apv_bb {
     double* tov[2];        // [M][N]
     double* stats[4];      // [C][S] rings
     double* tstats[2];     // [M][S] rings
-    double* R;             // [4][n][n]: AA, AB, BB, BA  (pairs (0,1) zone A, (2,3) zone B)
+    double* R;             // [4][n][n]: bright AA, BB, then dark AB, BA (zone A = (0, 2), zone B = (1, 3))
     double* r;             // [2][n]
     double* U;             // [2][n][n]
     double* lam;           // [2][n]
@@ -340,25 +340,25 @@ int apv_bb_process_block(apv_handle* h, const double* h_in_A, const double* h_in
         hipLaunchKernelGGL(ring_append_f64_kernel, dim3((H + 255) / 256, C), dim3(256), 0, st, S, H, s->stat_off,
                            s->ov[p], (long)N, s->stats[p]);
     }
-    // 3: statistics.  R order: [0] A->A, [1] A->B (zone A pair), [2] B->B, [3] B->A (zone B pair)
-    const int stat_src[4] = {0, 1, 3, 2};
+    // 3: statistics.  R order: bright [0] A->A, [1] B->B; dark [2] A->B, [3] B->A
+    const int stat_src[4] = {0, 3, 1, 2};
     const dim3 sg((n + 15) / 16, (n + 15) / 16);
     for (int q = 0; q < 4; ++q) {
-        const bool live = (q < 2) ? runA : runB;
+        const bool live = (q == 0 || q == 2) ? runA : runB;
         if (!live) continue;
         hipLaunchKernelGGL(syrk_hankel_kernel, sg, dim3(64), 0, st, n, J, L, M, S, s->stat_off, s->stats[stat_src[q]],
                            s->R + (size_t)q * n * n);
     }
     if (runA) hipLaunchKernelGGL(xcorr_hankel_kernel, dim3(n), dim3(256), 0, st, n, J, L, M, S, s->stat_off, s->stats[0], s->tstats[0], s->r);
     if (runB) hipLaunchKernelGGL(xcorr_hankel_kernel, dim3(n), dim3(256), 0, st, n, J, L, M, S, s->stat_off, s->stats[3], s->tstats[1], s->r + n);
-    // 4: jdiag + filters per zone (pairs are adjacent in s->R)
-    int32_t status[2] = {0, 0};
-    for (int z = 0; z < 2; ++z) {
-        if (!(z ? runB : runA)) continue;
-        const double* A = s->R + (size_t)(2 * z) * n * n;
-        const double* B = s->R + (size_t)(2 * z + 1) * n * n;
-        int rc = apv_gevd_large(h, n, 1, A, B, h->cfg.reg_dark, s->U + (size_t)z * n * n, s->lam + (size_t)z * n,
-                                s->r + (size_t)z * n, h->cfg.mu, V, s->w + (size_t)z * V * n, &status[z]);
+    // 4: jdiag + filters; both zone programs in one batch when both run
+    {
+        int32_t status[2] = {0, 0};
+        const int first = runA ? 0 : 1, batch = (runA && runB) ? 2 : 1;
+        const size_t nn = (size_t)n * n;
+        int rc = apv_gevd_large(h, n, batch, s->R + first * nn, s->R + (2 + first) * nn, h->cfg.reg_dark, s->U + first * nn,
+                                s->lam + (size_t)first * n, s->r + (size_t)first * n, h->cfg.mu, V,
+                                s->w + (size_t)first * V * n, status);
         if (rc != APV_OK) return rc;
     }
     // 5: filter spectra: channel (v, l) = taps w[v][l*J : (l+1)*J] zero-padded to N, no window
@@ -391,7 +391,7 @@ int apv_bb_process_block(apv_handle* h, const double* h_in_A, const double* h_in
     return APV_OK;
 }
 
-// state: "response<p>" [C][N], "target_response<z>" [M][N] (rings, logical order); "R<q>" [n][n] (AA, AB, BB, BA),
+// state: "response<p>" [C][N], "target_response<z>" [M][N] (rings, logical order); "R<q>" [n][n] (AA, BB, AB, BA),
 // "r" [2][n], "lambda" [2][n], "w" [2][V][n], "stats<p>" [C][S], "target_stats<z>" [M][S] (rings, logical order)
 static int bb_lookup(apv_handle* h, const char* name, double** d, size_t* count, int* rows, int* len, int* off) {
     apv_bb* s = h->bb;

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""cfg1 of BASELINE.json in the reference's own (broadband) formulation: bundled rirs.mat (8 x 8), N=256, J=32,
+S=512, V=8: ms per hop on the GPU next to the CPU oracle (a float64 NumPy restatement of apvast.py)."""
+import json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+def main():
+    hops = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    g = np.load(os.path.join(ROOT, "tests", "golden", "rirs_cfg1.npz"))
+    rirA, rirB = g["rirA"], g["rirB"]
+    from ap_vast_unofficial_amd.apvast import apvast
+    ap = apvast(256, rirA, rirB, 32, 16, 0, 0, 8, 1.0, 512, hop_size=128, perceptual=False, mode="broadband", seed=0)
+    x = np.random.default_rng(7).standard_normal((2, (hops + 2) * 128))
+    for h in range(2):
+        ap.process_input_buffers(x[0, h * 128:(h + 1) * 128], x[1, h * 128:(h + 1) * 128])
+    t0 = time.perf_counter()
+    for h in range(2, hops + 2):
+        ap.process_input_buffers(x[0, h * 128:(h + 1) * 128], x[1, h * 128:(h + 1) * 128])
+    gpu = (time.perf_counter() - t0) / hops
+    from oracle.broadband import BroadbandOracle
+    np.random.seed(0)
+    orc = BroadbandOracle(256, rirA, rirB, 32, 16, 0, 0, 8, 1.0, 512, hop_size=128)
+    for h in range(2):
+        orc.process_input_buffers(x[0, h * 128:(h + 1) * 128], x[1, h * 128:(h + 1) * 128])
+    t0 = time.perf_counter()
+    nc = min(hops, 6)
+    for h in range(2, nc + 2):
+        orc.process_input_buffers(x[0, h * 128:(h + 1) * 128], x[1, h * 128:(h + 1) * 128])
+    cpu = (time.perf_counter() - t0) / nc
+    print(json.dumps({"workload": "cfg1 broadband 8x8, N=256, J=32 (n=256), S=512, V=8, both zones", "gpu_ms_per_hop": gpu * 1e3,
+                      "cpu_oracle_ms_per_hop": cpu * 1e3, "cpu_count": os.cpu_count(), "speedup": cpu / gpu}))
+main()
