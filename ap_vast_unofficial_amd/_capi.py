@@ -29,6 +29,7 @@ EXPORTS = (
     "apv_stft_analysis_dev", "apv_istft_ola_dev",
     "apv_stream_init", "apv_process_block", "apv_state_bytes", "apv_get_state", "apv_set_state",
     "apv_bb_init", "apv_bb_process_block", "apv_bb_get_state", "apv_bb_set_state",
+    "apv_predict_pressure", "apv_vast_static",
     "apv_comm_unique_id", "apv_comm_init", "apv_allgather_filters_dev",
 )
 
@@ -93,6 +94,8 @@ def load():
     lib.apv_bb_process_block.argtypes = [vp, vp, vp, vp]
     lib.apv_bb_get_state.argtypes = [vp, C.c_char_p, vp, sz]
     lib.apv_bb_set_state.argtypes = [vp, C.c_char_p, vp, sz]
+    lib.apv_predict_pressure.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp]
+    lib.apv_vast_static.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, i32, C.c_double, vp, vp, vp]
     lib.apv_comm_unique_id.argtypes = [C.c_char_p]
     lib.apv_comm_init.argtypes = [vp, C.c_char_p, i32, i32]
     lib.apv_allgather_filters_dev.argtypes = [vp, vp, vp]
@@ -384,6 +387,31 @@ class Engine:
     def bb_set_state(self, name, arr):
         arr = np.ascontiguousarray(arr, dtype=np.float64)
         self._chk(self.lib.apv_bb_set_state(self.h, name.encode(), _ptr(arr), arr.size))
+
+    # -- evaluation / static solver ------------------------------------------------
+    def predict_pressure(self, x, rirs):
+        """predictPressure.m: x (T, L), rirs (P, L, M) -> (T, M), float64."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        rirs = np.ascontiguousarray(rirs, dtype=np.float64)
+        T, L = x.shape
+        P, L2, M = rirs.shape
+        if L2 != L:
+            raise ValueError("x and rirs disagree on the number of loudspeakers")
+        out = np.empty((T, M))
+        self._chk(self.lib.apv_predict_pressure(self.h, T, L, M, P, _ptr(x), _ptr(rirs), _ptr(out)))
+        return out
+
+    def vast_static(self, gB, gD, filter_length, modeling_delay, reference_index, number_of_eigenvectors, mu):
+        """vast.m: gB (Nb, P, L), gD (Nd, P, L) -> w (J*L,), float64; reference_index is 0-based here."""
+        gB = np.ascontiguousarray(gB, dtype=np.float64)
+        gD = np.ascontiguousarray(gD, dtype=np.float64)
+        Nb, P, L = gB.shape
+        Nd = gD.shape[0]
+        w = np.empty(filter_length * L)
+        self._chk(self.lib.apv_vast_static(self.h, Nb, Nd, P, L, int(filter_length), int(modeling_delay),
+                                           int(reference_index), int(number_of_eigenvectors), float(mu),
+                                           _ptr(gB), _ptr(gD), _ptr(w)))
+        return w
 
     # -- multi-GPU --------------------------------------------------------------
     @staticmethod

@@ -106,8 +106,9 @@ __global__ void __launch_bounds__(256) ring_append_f64_kernel(int len, int H, in
 
 // ---- statistics -----------------------------------------------------------------------------------
 // logical sample t of the "toeplitz" sequence g = buf with sample J removed (apvast.py:336-338)
-__device__ __forceinline__ double stat_at(const double* __restrict__ ring, int S, int off, int J, int t) {
-    const int u = (t < J) ? t : t + 1;
+// (skip = 0: plain Hankel data matrix, used by the static solver)
+__device__ __forceinline__ double stat_at(const double* __restrict__ ring, int S, int off, int J, int t, int skip = 1) {
+    const int u = (t < J || !skip) ? t : t + 1;
     int ph = u + off;
     if (ph >= S) ph -= S;
     return ring[ph];
@@ -117,7 +118,7 @@ using d4 = __attribute__((ext_vector_type(4))) double;
 
 // R[rho][sigma] = sum_m sum_ncol Y_m[rho][ncol] Y_m[sigma][ncol], Y_m[(s, i)][ncol] = g_{s,m}[J-1-i+ncol].
 // One wave = one 16x16 tile of R on v_mfma_f64_16x16x4_f64; the operands are gathered straight from the rings.
-__global__ void __launch_bounds__(64) syrk_hankel_kernel(int n, int J, int L, int M, int S, int off,
+__global__ void __launch_bounds__(64) syrk_hankel_kernel(int n, int J, int L, int M, int S, int off, int skip,
                                                          const double* __restrict__ stats, double* __restrict__ R) {
     const int lane = threadIdx.x;
     const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16;
@@ -133,8 +134,8 @@ __global__ void __launch_bounds__(64) syrk_hankel_kernel(int n, int J, int L, in
         for (int nc = 0; nc < ncols; nc += 4) {
             const int col = nc + kq;
             const bool ok = col < ncols;
-            const double a = (ra_ok && ok) ? stat_at(ga, S, off, J, J - 1 - ia + col) : 0.0;
-            const double b = (cb_ok && ok) ? stat_at(gb, S, off, J, J - 1 - ib + col) : 0.0;
+            const double a = (ra_ok && ok) ? stat_at(ga, S, off, J, J - 1 - ia + col, skip) : 0.0;
+            const double b = (cb_ok && ok) ? stat_at(gb, S, off, J, J - 1 - ib + col, skip) : 0.0;
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
         }
     }
@@ -147,7 +148,7 @@ __global__ void __launch_bounds__(64) syrk_hankel_kernel(int n, int J, int L, in
 }
 
 // r[rho] = sum_m sum_ncol Y_m[rho][ncol] d_m[J + ncol]      (apvast.py:340, 356)
-__global__ void __launch_bounds__(256) xcorr_hankel_kernel(int n, int J, int L, int M, int S, int off,
+__global__ void __launch_bounds__(256) xcorr_hankel_kernel(int n, int J, int L, int M, int S, int off, int skip,
                                                            const double* __restrict__ stats,
                                                            const double* __restrict__ tstats, double* __restrict__ r) {
     const int rho = blockIdx.x;
@@ -156,7 +157,7 @@ __global__ void __launch_bounds__(256) xcorr_hankel_kernel(int n, int J, int L, 
     double acc = 0.0;
     for (int idx = threadIdx.x; idx < M * ncols; idx += 256) {
         const int m = idx / ncols, nc = idx - m * ncols;
-        const double y = stat_at(stats + (size_t)(m * L + s) * S, S, off, J, J - 1 - i + nc);
+        const double y = stat_at(stats + (size_t)(m * L + s) * S, S, off, J, J - 1 - i + nc, skip);
         int ph = J + nc + off;
         if (ph >= S) ph -= S;
         acc += y * tstats[(size_t)m * S + ph];
@@ -179,6 +180,28 @@ __global__ void __launch_bounds__(256) apply_f64_kernel(int K, int n_ch, const d
     if (k >= K || ch >= n_ch) return;
     const double2 x = in[k], f = filt[(size_t)ch * K + k];
     out[(size_t)ch * K + k] = make_double2(x.x * f.x - x.y * f.y, x.x * f.y + x.y * f.x);
+}
+
+// p[t][m] = sum_s sum_q rir[q][s][m] x[t-q][s]          (Matlab/ControlMethods/predictPressure.m:12-16)
+__global__ void __launch_bounds__(256) predict_pressure_kernel(int T, int L, int M, int P, const double* __restrict__ x,
+                                                               const double* __restrict__ rir, double* __restrict__ out) {
+    const int m = threadIdx.x % M, tl = threadIdx.x / M;
+    const int tpb = 256 / M;
+    const int t = blockIdx.x * tpb + tl;
+    if (tl >= tpb || t >= T) return;
+    double acc = 0.0;
+    const int qmax = (t + 1 < P) ? t + 1 : P;
+    for (int q = 0; q < qmax; ++q) {
+        const double* xr = x + (size_t)(t - q) * L;
+        const double* rr = rir + (size_t)q * L * M + m;
+        for (int s = 0; s < L; ++s) acc = __builtin_fma(rr[(size_t)s * M], xr[s], acc);
+    }
+    out[(size_t)t * M + m] = acc;
+}
+
+__global__ void __launch_bounds__(256) scale_kernel(size_t count, double* __restrict__ v, double f) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < count) v[i] *= f;
 }
 
 inline int path_sig(int p) { return p >> 1; }       // AA, AB, BA, BB
@@ -346,11 +369,11 @@ int apv_bb_process_block(apv_handle* h, const double* h_in_A, const double* h_in
     for (int q = 0; q < 4; ++q) {
         const bool live = (q == 0 || q == 2) ? runA : runB;
         if (!live) continue;
-        hipLaunchKernelGGL(syrk_hankel_kernel, sg, dim3(64), 0, st, n, J, L, M, S, s->stat_off, s->stats[stat_src[q]],
+        hipLaunchKernelGGL(syrk_hankel_kernel, sg, dim3(64), 0, st, n, J, L, M, S, s->stat_off, 1, s->stats[stat_src[q]],
                            s->R + (size_t)q * n * n);
     }
-    if (runA) hipLaunchKernelGGL(xcorr_hankel_kernel, dim3(n), dim3(256), 0, st, n, J, L, M, S, s->stat_off, s->stats[0], s->tstats[0], s->r);
-    if (runB) hipLaunchKernelGGL(xcorr_hankel_kernel, dim3(n), dim3(256), 0, st, n, J, L, M, S, s->stat_off, s->stats[3], s->tstats[1], s->r + n);
+    if (runA) hipLaunchKernelGGL(xcorr_hankel_kernel, dim3(n), dim3(256), 0, st, n, J, L, M, S, s->stat_off, 1, s->stats[0], s->tstats[0], s->r);
+    if (runB) hipLaunchKernelGGL(xcorr_hankel_kernel, dim3(n), dim3(256), 0, st, n, J, L, M, S, s->stat_off, 1, s->stats[3], s->tstats[1], s->r + n);
     // 4: jdiag + filters; both zone programs in one batch when both run
     {
         int32_t status[2] = {0, 0};
@@ -389,6 +412,86 @@ int apv_bb_process_block(apv_handle* h, const double* h_in_A, const double* h_in
     BCHK(h, hipStreamSynchronize(st));
     BCHK(h, hipGetLastError());
     return APV_OK;
+}
+
+// Evaluation: pressure at the microphones for given loudspeaker signals.  h_x [T][L], h_rir [P][L][M] (the
+// (rir_len, L, M) layout of rirs.mat), h_out [T][M], all float64.      replaces predictPressure.m:1-17
+int apv_predict_pressure(apv_handle* h, int32_t T, int32_t L, int32_t M, int32_t P, const double* h_x,
+                         const double* h_rir, double* h_out) {
+    if (!h || !h_x || !h_rir || !h_out) return apv_fail(h, APV_ERR_ARG, "null argument");
+    if (T < 0 || L < 1 || M < 1 || M > 256 || P < 1) return apv_fail(h, APV_ERR_ARG, "predict_pressure: bad sizes (M <= 256)");
+    if (T == 0) return APV_OK;
+    BCHK(h, hipSetDevice(h->device));
+    double *dx = nullptr, *dr = nullptr, *dout = nullptr;
+    BCHK(h, hipMalloc((void**)&dx, sizeof(double) * (size_t)T * L));
+    BCHK(h, hipMalloc((void**)&dr, sizeof(double) * (size_t)P * L * M));
+    BCHK(h, hipMalloc((void**)&dout, sizeof(double) * (size_t)T * M));
+    BCHK(h, hipMemcpyAsync(dx, h_x, sizeof(double) * (size_t)T * L, hipMemcpyHostToDevice, h->stream));
+    BCHK(h, hipMemcpyAsync(dr, h_rir, sizeof(double) * (size_t)P * L * M, hipMemcpyHostToDevice, h->stream));
+    const int tpb = 256 / M;
+    hipLaunchKernelGGL(predict_pressure_kernel, dim3((T + tpb - 1) / tpb), dim3(256), 0, h->stream, T, L, M, P, dx, dr, dout);
+    BCHK(h, hipMemcpyAsync(h_out, dout, sizeof(double) * (size_t)T * M, hipMemcpyDeviceToHost, h->stream));
+    BCHK(h, hipStreamSynchronize(h->stream));
+    (void)hipFree(dx); (void)hipFree(dr); (void)hipFree(dout);
+    return APV_OK;
+}
+
+// Static (signal-independent) VAST from the impulse responses alone.  h_gB [Nb][P][L], h_gD [Nd][P][L] (the
+// (mics, rirLength, sources) layout of vast.m), h_w [J L].               replaces Matlab/ControlMethods/vast.m:46-91
+int apv_vast_static(apv_handle* h, int32_t Nb, int32_t Nd, int32_t P, int32_t L, int32_t J, int32_t modeling_delay,
+                    int32_t reference_index, int32_t V, double mu, const double* h_gB, const double* h_gD, double* h_w) {
+    if (!h || !h_gB || !h_gD || !h_w) return apv_fail(h, APV_ERR_ARG, "null argument");
+    const int n = J * L;
+    if (Nb < 1 || Nd < 1 || P < 1 || L < 1 || J < 1 || n > 2048 || V < 1 || V > n || modeling_delay < 0 || modeling_delay >= P ||
+        reference_index < 0 || reference_index >= L || P <= J)
+        return apv_fail(h, APV_ERR_ARG, "vast_static: bad sizes (J L <= 2048, rir_len > J)");
+    BCHK(h, hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    // vast.m drives the filters with a unit impulse for N = 1000 steps (vast.m:50-53): 999 of them are non-trivial
+    const int ncols = 999, S = ncols + J;
+    auto pack = [&](const double* g, int Nm, std::vector<double>& out) {          // [m*L + s][S], g'[u] = g[u-(J-1)]
+        out.assign((size_t)Nm * L * S, 0.0);
+        for (int m = 0; m < Nm; ++m)
+            for (int sI = 0; sI < L; ++sI)
+                for (int q = 0; q < P && q + J - 1 < S; ++q)
+                    out[((size_t)m * L + sI) * S + q + J - 1] = g[((size_t)m * P + q) * L + sI];
+    };
+    std::vector<double> sb, sd, td((size_t)Nb * S, 0.0);
+    pack(h_gB, Nb, sb);
+    pack(h_gD, Nd, sd);
+    for (int m = 0; m < Nb; ++m)                                                   // target: delayed reference RIR (vast.m:59)
+        for (int q = modeling_delay; q < P && J + q < S; ++q)
+            td[(size_t)m * S + J + q] = h_gB[((size_t)m * P + (q - modeling_delay)) * L + reference_index];
+    double *dsb = nullptr, *dsd = nullptr, *dtd = nullptr, *dR = nullptr, *dr = nullptr, *dU = nullptr, *dl = nullptr, *dw = nullptr;
+    BCHK(h, hipMalloc((void**)&dsb, sizeof(double) * sb.size()));
+    BCHK(h, hipMalloc((void**)&dsd, sizeof(double) * sd.size()));
+    BCHK(h, hipMalloc((void**)&dtd, sizeof(double) * td.size()));
+    BCHK(h, hipMalloc((void**)&dR, sizeof(double) * 2 * (size_t)n * n));
+    BCHK(h, hipMalloc((void**)&dr, sizeof(double) * n));
+    BCHK(h, hipMalloc((void**)&dU, sizeof(double) * (size_t)n * n));
+    BCHK(h, hipMalloc((void**)&dl, sizeof(double) * n));
+    BCHK(h, hipMalloc((void**)&dw, sizeof(double) * (size_t)V * n));
+    BCHK(h, hipMemcpyAsync(dsb, sb.data(), sizeof(double) * sb.size(), hipMemcpyHostToDevice, st));
+    BCHK(h, hipMemcpyAsync(dsd, sd.data(), sizeof(double) * sd.size(), hipMemcpyHostToDevice, st));
+    BCHK(h, hipMemcpyAsync(dtd, td.data(), sizeof(double) * td.size(), hipMemcpyHostToDevice, st));
+    const dim3 sg((n + 15) / 16, (n + 15) / 16);
+    hipLaunchKernelGGL(syrk_hankel_kernel, sg, dim3(64), 0, st, n, J, L, Nb, S, 0, 0, dsb, dR);
+    hipLaunchKernelGGL(syrk_hankel_kernel, sg, dim3(64), 0, st, n, J, L, Nd, S, 0, 0, dsd, dR + (size_t)n * n);
+    hipLaunchKernelGGL(xcorr_hankel_kernel, dim3(n), dim3(256), 0, st, n, J, L, Nb, S, 0, 0, dsb, dtd, dr);
+    // vast.m:71-73 normalises all three by numberOfMics (of the BRIGHT zone) * (rirLength - filterLength)
+    const double f = 1.0 / ((double)Nb * (double)(P - J));
+    const size_t nn = (size_t)n * n;
+    hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((2 * nn + 255) / 256)), dim3(256), 0, st, 2 * nn, dR, f);
+    hipLaunchKernelGGL(scale_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (size_t)n, dr, f);
+    int32_t status = 0;
+    int rc = apv_gevd_large(h, n, 1, dR, dR + nn, 0.0, dU, dl, dr, mu, V, dw, &status);     // jdiag(RB, RD, 'vector', true): no loading
+    if (rc == APV_OK) {
+        (void)hipMemcpyAsync(h_w, dw + (size_t)(V - 1) * n, sizeof(double) * n, hipMemcpyDeviceToHost, st);
+        (void)hipStreamSynchronize(st);
+    }
+    double* tofree[] = {dsb, dsd, dtd, dR, dr, dU, dl, dw};
+    for (double* b : tofree) (void)hipFree(b);
+    return rc;
 }
 
 // state: "response<p>" [C][N], "target_response<z>" [M][N] (rings, logical order); "R<q>" [n][n] (AA, BB, AB, BA),

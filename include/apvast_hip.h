@@ -180,6 +180,17 @@ int  apv_bb_process_block(apv_handle* h, const double* h_in_A, const double* h_i
 int  apv_bb_get_state(apv_handle* h, const char* name, double* h_dst, size_t count);
 int  apv_bb_set_state(apv_handle* h, const char* name, const double* h_src, size_t count);
 
+/* ---- evaluation and the static solver, float64 ------------------------- */
+/* p[t][m] = sum_s filter(rir[:, s, m], 1, x[:, s])[t].  h_x [T][L], h_rir [P][L][M], h_out [T][M].
+ *                                                         replaces Matlab/ControlMethods/predictPressure.m:1-17 */
+int  apv_predict_pressure(apv_handle* h, int32_t T, int32_t L, int32_t M, int32_t P, const double* h_x,
+                          const double* h_rir, double* h_out);
+/* Static (signal-independent) VAST filters from the impulse responses: h_gB [Nb][P][L], h_gD [Nd][P][L]
+ * (vast.m's (mics, rirLength, sources) layout), h_w [J*L] (speaker-major taps).
+ *                                                         replaces Matlab/ControlMethods/vast.m:1-97 */
+int  apv_vast_static(apv_handle* h, int32_t Nb, int32_t Nd, int32_t P, int32_t L, int32_t J, int32_t modeling_delay,
+                     int32_t reference_index, int32_t V, double mu, const double* h_gB, const double* h_gD, double* h_w);
+
 /* ---- multi-GPU: bins sharded across ranks, one RCCL all-gather ---------- */
 int  apv_comm_unique_id(char id_out[128]);                                /* rank 0 calls, then broadcasts */
 int  apv_comm_init(apv_handle* h, const char id[128], int32_t rank, int32_t world);
