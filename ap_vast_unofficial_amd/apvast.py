@@ -22,8 +22,10 @@ What is different (keyword-only, after ``perceptual``)
     golden outputs of the reference (tests/test_gpu_broadband.py).
   * outputs are fresh arrays (the reference returns views into its overlap buffers that the next
     call overwrites, apvast.py:500-504).
-  * ``perceptual=True`` needs the third-party ``libdetectability`` (apvast.py:4, 77-83), which is
-    not vendored by the reference; it raises NotImplementedError here.
+  * ``perceptual=True`` (subband mode): the reference's Python class calls the third-party
+    ``libdetectability`` (apvast.py:4, 77-83), which it does not vendor; here the weighting is the van de Par
+    masking model carried by the reference's MATLAB twin (perceptualModel.m), evaluated per block on the
+    device.  Parity for it is unpinned (no MATLAB here).
 """
 import numpy as np
 
@@ -94,7 +96,8 @@ class apvast:
                  dialect: str = "python",
                  device: int = 0,
                  dtype: str = "f64",
-                 seed=None):
+                 seed=None,
+                 fullscale_db_spl: float = 94.0):
         self.block_size = block_size
         self.rir_A = rir_A
         self.rir_B = rir_B
@@ -115,10 +118,10 @@ class apvast:
             raise RuntimeError("block size must be modulo 2")                 # apvast.py:86-87
         if rir_A.shape != rir_B.shape:
             raise RuntimeError("rirs of unequal size")                        # apvast.py:89-90
-        if perceptual:
+        if perceptual and mode == "broadband":
             raise NotImplementedError(
-                "perceptual=True needs the third-party libdetectability model (apvast.py:4, 77-83), which the "
-                "reference does not vendor; pass perceptual=False (all-ones weights, apvast.py:326-327)")
+                "perceptual=True is implemented for mode='subband' (the masking model of the reference's MATLAB twin); "
+                "the Python reference delegates it to the un-vendored libdetectability (apvast.py:4, 77-83)")
         if mode not in ("subband", "broadband"):
             raise ValueError("mode must be 'subband' or 'broadband'")
         if dialect not in ("python", "matlab"):
@@ -149,6 +152,13 @@ class apvast:
                                  reg_mode=reg_mode, reg_dark=reg_dark, reg_bright=reg_bright, device=device,
                                  block_size=N, hop_size=H, n_zones=zones)
         self._eng.stream_init(rir_A, rir_B, reference_index_A, reference_index_B, modeling_delay)
+        if perceptual:
+            # the masking model carried by the MATLAB twin (perceptualModel.m); per-block curves are formed on the
+            # device from the target spectra, normalised as the dialect prescribes (apvast.py:322-324 /
+            # perceptualModel.m:177-190)
+            from .perceptual import PerceptualTables
+            self.model = PerceptualTables(N, sampling_rate, fullscale_db_spl)
+            self._eng.stream_set_perceptual(self.model, dialect)
         self._n_out = (int(run_A) + int(run_B)) * V * L + 2 * L
         if dialect == "python":
             # apvast.py:124-129: response buffers start as 1e-3 * randn, drawn from the global NumPy RNG in this

@@ -135,6 +135,71 @@ __global__ void __launch_bounds__(256) ring_append_kernel(int N, int H, int ring
     if (n < H) ring[(N - H + n + ring_off) % N] = x[n];
 }
 
+// ---- perceptual weighting (van de Par 2005, Matlab/ControlMethods/perceptualModel.m:118-139, 177-190) --------
+// One workgroup = one control point m of one zone.  spec: target spectra, bin-major [K][M] c64 (unscaled rfft);
+// G2 [K][nch] and G2T [nch][K]: squared outer/middle-ear x gammatone responses.  Out: W [K][M] real weights.
+//   masker_i = sum_k G2[k][i] |sqrt(2)/N S[k]|^2;  w^2[k] = Cs Leff sum_i G2[k][i] / (masker_i + Ca)
+//   W = w / ||w||  over the K bins (norm_mode 0, apvast.py:322-324) or over the full symmetric curve (1)
+__global__ void __launch_bounds__(256) perceptual_weights_kernel(int K, int M, int nch, const float2* __restrict__ spec,
+                                                                 const double* __restrict__ G2,
+                                                                 const double* __restrict__ G2T, double Cs, double Ca,
+                                                                 double Leff, double fscale2, int norm_mode,
+                                                                 float* __restrict__ W) {
+    extern __shared__ double sm[];
+    double* P2 = sm;               // [K]
+    double* inv = sm + K;          // [nch]
+    double* red = inv + nch;       // [256]
+    const int m = blockIdx.x, tid = threadIdx.x;
+    for (int k = tid; k < K; k += 256) {
+        const float2 v = spec[(size_t)k * M + m];
+        P2[k] = fscale2 * ((double)v.x * v.x + (double)v.y * v.y);
+    }
+    __syncthreads();
+    for (int i = 0; i < nch; ++i) {
+        double a = 0.0;
+        const double* g = G2T + (size_t)i * K;
+        for (int k = tid; k < K; k += 256) a += g[k] * P2[k];
+        red[tid] = a;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) {
+            if (tid < w) red[tid] += red[tid + w];
+            __syncthreads();
+        }
+        if (tid == 0) inv[i] = 1.0 / (red[0] + Ca);
+        __syncthreads();
+    }
+    double part = 0.0;
+    for (int k = tid; k < K; k += 256) {
+        double a = 0.0;
+        const double* g = G2 + (size_t)k * nch;
+        for (int i = 0; i < nch; ++i) a += g[i] * inv[i];
+        a *= Cs * Leff;
+        P2[k] = a;                                                  // w^2[k]
+        part += (norm_mode == 1 && k > 0 && k < K - 1) ? 2.0 * a : a;
+    }
+    red[tid] = part;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (tid < w) red[tid] += red[tid + w];
+        __syncthreads();
+    }
+    const double inorm = 1.0 / red[0];
+    for (int k = tid; k < K; k += 256) W[(size_t)k * M + m] = (float)sqrt(P2[k] * inorm);
+}
+
+// spec[k][c] *= W[k][c / L]   (bin-major c64; L = 1 scales the target spectra themselves)
+__global__ void __launch_bounds__(256) scale_spectra_kernel(int K, int C, int L, float2* __restrict__ spec,
+                                                            const float* __restrict__ W) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)K * C) return;
+    const int k = (int)(idx / C), c = (int)(idx - (size_t)k * C);
+    const float w = W[(size_t)k * (C / L) + c / L];
+    float2 v = spec[idx];
+    v.x *= w;
+    v.y *= w;
+    spec[idx] = v;
+}
+
 template <typename W>
 __global__ void __launch_bounds__(256) apply_filters_kernel(int K, int n_filt, int n_tgt,
                                                             const float2* __restrict__ in_spec,
@@ -176,6 +241,20 @@ hipError_t apv_launch_fir_hop(int C, int P, int H, int N, int ring_off, const fl
     if (C <= 0 || H <= 0) return hipSuccess;
     dim3 grid((C + 63) / 64, (H + FIR_TN - 1) / FIR_TN);
     hipLaunchKernelGGL(fir_hop_kernel, grid, dim3(64), 0, s, C, P, H, N, ring_off % N, rir, xhist, resp);
+    return hipGetLastError();
+}
+
+hipError_t apv_launch_perceptual_weights(int K, int M, int nch, const float2* spec, const double* G2, const double* G2T,
+                                         double Cs, double Ca, double Leff, int N, int norm_mode, float* W, hipStream_t s) {
+    const size_t lds = sizeof(double) * ((size_t)K + nch + 256);
+    hipLaunchKernelGGL(perceptual_weights_kernel, dim3(M), dim3(256), lds, s, K, M, nch, spec, G2, G2T, Cs, Ca, Leff,
+                       2.0 / ((double)N * (double)N), norm_mode, W);
+    return hipGetLastError();
+}
+
+hipError_t apv_launch_scale_spectra(int K, int C, int L, float2* spec, const float* W, hipStream_t s) {
+    const size_t total = (size_t)K * C;
+    hipLaunchKernelGGL(scale_spectra_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, K, C, L, spec, W);
     return hipGetLastError();
 }
 

@@ -39,6 +39,12 @@ struct apv_stream {
     float2* outspec;              // [n_out][K]
     float* outov;                 // [n_out][N]
     float* out;                   // [n_out][H]
+    // perceptual weighting (off when nch == 0)
+    int nch, norm_mode;
+    double Cs, Ca, Leff;
+    double* G2;                   // [K][nch]
+    double* G2T;                  // [nch][K]
+    float* Wgt[2];                // [K][M] per zone
     std::vector<int32_t> h_status;
 };
 
@@ -72,7 +78,8 @@ void apv_stream_free(apv_handle* h) {
     void* bufs[] = {s->rir[0], s->rir[1], s->trir[0], s->trir[1], s->xhist[0][0], s->xhist[0][1], s->xhist[1][0],
                     s->xhist[1][1], s->xin, s->resp[0], s->resp[1], s->resp[2], s->resp[3], s->tresp[0], s->tresp[1],
                     s->inblk, s->X[0], s->X[1], s->X[2], s->X[3], s->tspec[0], s->tspec[1], s->inspec, s->w[0],
-                    s->w[1], s->lam[0], s->lam[1], s->status[0], s->status[1], s->tgt, s->outspec, s->outov, s->out};
+                    s->w[1], s->lam[0], s->lam[1], s->status[0], s->status[1], s->tgt, s->outspec, s->outov, s->out,
+                    s->G2, s->G2T, s->Wgt[0], s->Wgt[1]};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     delete s;
@@ -207,6 +214,18 @@ int apv_process_block(apv_handle* h, const float* h_in_A, const float* h_in_B, f
     for (int z = 0; z < 2; ++z)
         SCHK(h, apv_launch_stft_analysis_strided(N, M, s->tresp[z], s->ring_off, s->tspec[z], 1, M, st, &why));
     SCHK(h, apv_launch_stft_analysis_strided(N, 2, s->inblk, s->ring_off, s->inspec, K, 1, st, &why));
+    if (s->nch > 0) {
+        // weights from the UNWEIGHTED target spectra (apvast.py:205), then spectra x weights (apvast.py:208-209,
+        // 258-262): A->A and B->A take zone A's curve, A->B and B->B zone B's
+        for (int z = 0; z < 2; ++z)
+            SCHK(h, apv_launch_perceptual_weights(K, M, s->nch, s->tspec[z], s->G2, s->G2T, s->Cs, s->Ca, s->Leff, N,
+                                                  s->norm_mode, s->Wgt[z], st));
+        for (int p = 0; p < 4; ++p) {
+            const bool need = (p < 2) ? runA : runB;
+            if (need) SCHK(h, apv_launch_scale_spectra(K, C, L, s->X[p], s->Wgt[path_zone(p)], st));
+        }
+        for (int z = 0; z < 2; ++z) SCHK(h, apv_launch_scale_spectra(K, M, 1, s->tspec[z], s->Wgt[z], st));
+    }
     // per-bin update per zone program: A: bright A->A, dark A->B, target A;  B: bright B->B, dark B->A, target B
     int oc = 0;     // output channel cursor
     {
@@ -259,6 +278,39 @@ int apv_process_block(apv_handle* h, const float* h_in_A, const float* h_in_B, f
     return APV_OK;
 }
 
+// Enable (n_channels > 0) or disable (0) the perceptual weighting.  h_G2 [K][n_channels]: squared
+// outer/middle-ear x gammatone responses (perceptualModel.m:52-54); Cs, Ca, Leff: perceptualModel.m:57, 114-115;
+// normalisation 0: unit vector over the K bins (apvast.py:322-324), 1: over the full symmetric curve
+// (perceptualModel.m:177-190).                                        replaces apvast.py:313-324 / apVast.m:386-408
+int apv_stream_set_perceptual(apv_handle* h, int32_t n_channels, const double* h_G2, double Cs, double Ca, double Leff,
+                              int32_t normalisation) {
+    if (!h || !h->st) return apv_fail(h, APV_ERR_ARG, "apv_stream_init has not been called");
+    apv_stream* s = h->st;
+    SCHK(h, hipSetDevice(h->device));
+    SCHK(h, hipStreamSynchronize(h->stream));
+    if (n_channels <= 0) {
+        s->nch = 0;
+        return APV_OK;
+    }
+    if (!h_G2 || n_channels > 512 || (normalisation != 0 && normalisation != 1)) return apv_fail(h, APV_ERR_ARG, "bad perceptual tables");
+    const int K = s->K;
+    void* old[] = {s->G2, s->G2T, s->Wgt[0], s->Wgt[1]};
+    for (void* b : old)
+        if (b) (void)hipFree(b);
+    s->G2 = s->G2T = nullptr;
+    s->Wgt[0] = s->Wgt[1] = nullptr;
+    std::vector<double> gt((size_t)n_channels * K);
+    for (int k = 0; k < K; ++k)
+        for (int i = 0; i < n_channels; ++i) gt[(size_t)i * K + k] = h_G2[(size_t)k * n_channels + i];
+    SCHK(h, hipMalloc((void**)&s->G2, sizeof(double) * (size_t)K * n_channels));
+    SCHK(h, hipMalloc((void**)&s->G2T, sizeof(double) * (size_t)K * n_channels));
+    for (int z = 0; z < 2; ++z) SCHK(h, hipMalloc((void**)&s->Wgt[z], sizeof(float) * (size_t)K * s->M));
+    SCHK(h, hipMemcpy(s->G2, h_G2, sizeof(double) * (size_t)K * n_channels, hipMemcpyHostToDevice));
+    SCHK(h, hipMemcpy(s->G2T, gt.data(), sizeof(double) * gt.size(), hipMemcpyHostToDevice));
+    s->nch = n_channels; s->Cs = Cs; s->Ca = Ca; s->Leff = Leff; s->norm_mode = normalisation;
+    return APV_OK;
+}
+
 // Named state arrays (host float32/complex as stored on the device; rings are returned in LOGICAL order):
 //   "response"        [4][C][N] f32    "target_response" [2][M][N] f32    "input_block" [2][N] f32
 //   "input_history"   [2][P-1]  f32    "out_overlap"     [n_out][N] f32
@@ -281,6 +333,7 @@ static int state_lookup(apv_handle* h, const char* name, void** dptr, size_t* by
         *dptr = s->X[n[7] - '0']; *bytes = K * C * 8; return APV_OK; }
     if (n == "target_spectra0" || n == "target_spectra1") { *dptr = s->tspec[n.back() - '0']; *bytes = K * M * 8; return APV_OK; }
     if (n == "input_spectrum") { *dptr = s->inspec; *bytes = 2 * K * 8; return APV_OK; }
+    if ((n == "weights0" || n == "weights1") && s->nch > 0) { *dptr = s->Wgt[n.back() - '0']; *bytes = K * M * 4; return APV_OK; }
     if (n == "w_A" || n == "w_B") { *dptr = s->w[n == "w_B"]; *bytes = K * s->nV * L * wsz(h); return APV_OK; }
     if (n == "lambda_A" || n == "lambda_B") { *dptr = s->lam[n == "lambda_B"]; *bytes = K * L * lsz(h); return APV_OK; }
     return apv_fail(h, APV_ERR_STATE, std::string("unknown state name: ") + name);

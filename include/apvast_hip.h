@@ -160,6 +160,12 @@ int  apv_stream_init(apv_handle* h, int32_t rir_len, const double* h_rir_A, cons
  * [zone A: nV x L][zone B: nV x L] (zones that run) followed by [A_t: L][B_t: L].
  *                                                         replaces process_input_buffers, apvast.py:153-165 */
 int  apv_process_block(apv_handle* h, const float* h_in_A, const float* h_in_B, float* h_out);
+/* Perceptual ("AP") weighting of the control-point and target spectra, evaluated per block on the device from the
+ * target spectra (van de Par 2005 model as carried by the reference's MATLAB twin).  h_G2 [K][n_channels] float64
+ * = squared outer/middle-ear x gammatone responses; n_channels = 0 switches it off (all-ones, apvast.py:326-327).
+ *                         replaces update_perceptual_weighting, apvast.py:313-324 / apVast.m:386-408 */
+int  apv_stream_set_perceptual(apv_handle* h, int32_t n_channels, const double* h_G2, double Cs, double Ca,
+                               double Leff, int32_t normalisation);
 /* Named state arrays for fixtures / checkpoint-resume (names: see stream.hip).   apvast.py:115-151 */
 int  apv_state_bytes(apv_handle* h, const char* name, size_t* bytes);
 int  apv_get_state(apv_handle* h, const char* name, void* h_dst, size_t bytes);

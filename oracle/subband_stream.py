@@ -19,7 +19,8 @@ from .broadband import fir_with_state
 class SubbandStreamOracle:
     def __init__(self, block_size, rir_A, rir_B, modeling_delay, reference_index_A, reference_index_B,
                  ranks, mu, hop_size=None, run_A=True, run_B=True, reg=1e-7, init_response=None,
-                 init_target_response=None):
+                 init_target_response=None, perceptual=None, normalisation="python"):
+        self.perceptual, self.normalisation = perceptual, normalisation     # oracle.perceptual.Model or None
         self.N = block_size
         self.H = hop_size if hop_size else block_size // 2
         self.K = block_size // 2 + 1
@@ -64,6 +65,15 @@ class SubbandStreamOracle:
         self.spectra = [subband.analysis(self.response[p], self.window) for p in range(4)]     # (K, L, M)
         self.target_spectra = [subband.analysis(self.target_response[z], self.window) for z in range(2)]
         self.input_spectrum = np.fft.rfft(self.window * self.input_block, axis=1)              # (2, K)
+        if self.perceptual is not None:
+            # apvast.py:205-209, 258-262: curves from the unweighted target spectra; A->A, B->A x zone A's curve,
+            # A->B, B->B x zone B's
+            self.weights = [np.stack([self.perceptual.weights(self.target_spectra[z][:, m], self.normalisation)
+                                      for m in range(M)], axis=1) for z in range(2)]           # (K, M)
+            for p in range(4):
+                self.spectra[p] = self.spectra[p] * self.weights[zone[p]][:, None, :]
+            for z in range(2):
+                self.target_spectra[z] = self.target_spectra[z] * self.weights[z]
         self.w = [None, None]
         self.lam = [None, None]
         outs = [None, None, None, None]

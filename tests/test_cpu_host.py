@@ -63,7 +63,24 @@ def test_reference_error_messages_without_gpu(golden):
     with pytest.raises(RuntimeError, match=str(e["unequal"])):
         apvast(256, g["rirA"], g["rirB"][:, :, :7], 32, 16, 0, 0, 8, 1.0, 512, perceptual=False)
     with pytest.raises(NotImplementedError, match="libdetectability"):
-        apvast(256, g["rirA"], g["rirB"], 32, 16, 0, 0, 8, 1.0, 512)          # perceptual defaults to True
+        apvast(256, g["rirA"], g["rirB"], 32, 16, 0, 0, 8, 1.0, 512, mode="broadband")   # perceptual defaults to True
+
+
+def test_perceptual_tables_calibration():
+    """perceptualModel.m:59-115: with the 70 dB SPL masker in place the 52 dB SPL probe has detectability 1; product
+    tables agree with the independent restatement in oracle/."""
+    from ap_vast_unofficial_amd.perceptual import PerceptualTables, threshold_of_hearing_db
+    from oracle.perceptual import Model
+    for N, Fs in ((2048, 48000), (1600, 48000), (256, 8000)):
+        t, m = PerceptualTables(N, Fs), Model(N, Fs)
+        assert np.abs(t.G2 - m.cr ** 2).max() < 1e-12 * np.abs(m.cr ** 2).max()
+        assert abs(t.Cs / m.Cs - 1) < 1e-6 and abs(t.Ca / m.Ca - 1) < 1e-6 and t.Leff == m.Leff
+        spec = np.zeros(N // 2 + 1)
+        spec[m.cal_bin] = m.S70
+        masker = (t.G2 * spec[:, None] ** 2).sum(axis=0)
+        wsq = t.Cs * t.Leff * (t.G2 / (masker[None] + t.Ca)).sum(axis=1)
+        assert abs(wsq[m.cal_bin] * m.S52 ** 2 - 1) < 1e-4
+    assert abs(threshold_of_hearing_db([1000.0])[0] - 2.4) < 1e-12            # a node of the ISO 226 table
 
 
 def test_rirs_mat_ingest(tmp_path, golden):

@@ -134,3 +134,38 @@ def test_stream_non_power_of_two_block():
     ap, orc, got, exp = run_pair(240, 120, rirA, rirB, 7, 1, 2, 2, 1.0, hops=5)
     check_outputs(got, exp, 5e-3)
     ap.close()
+
+
+@pytest.mark.parametrize("dialect", ["python", "matlab"])
+def test_stream_perceptual_weighting(dialect):
+    """perceptual=True: device weighting curves (perceptualModel.m:118-139, 177-190) against the independent NumPy
+    restatement, then the weighted streaming path against the oracle."""
+    from ap_vast_unofficial_amd.apvast import apvast
+    from oracle.perceptual import Model
+    rirA, rirB = synth_rirs(150, 4, 8, 6)
+    N, H, L, M, V = 512, 256, 4, 8, 2
+    ap = apvast(N, rirA, rirB, 16, 9, 1, 2, V, 1.0, 4 * N, hop_size=H, sampling_rate=16000, perceptual=True,
+                dialect=dialect, seed=0, fullscale_db_spl=100.0)
+    rs = np.random.RandomState(0)
+    init_r = np.stack([1e-3 * rs.randn(N, L, M) for _ in range(4)]).astype(np.float32)
+    init_t = np.stack([1e-3 * rs.randn(N, M) for _ in range(2)]).astype(np.float32)
+    if dialect == "matlab":
+        init_r[:] = 0
+        init_t[:] = 0
+    model = Model(N, 16000, 100.0)
+    # the MATLAB dialect also loads both matrices relatively (apVast.m:552-569); the oracle run below only
+    # checks the weighting curves for it
+    orc = SubbandStreamOracle(N, rirA.astype(np.float32), rirB.astype(np.float32), 9, 1, 2, [1, 2], 1.0, hop_size=H,
+                              init_response=init_r, init_target_response=init_t, perceptual=model,
+                              normalisation=dialect)
+    x = np.random.default_rng(5).standard_normal((2, 4 * H)).astype(np.float32)
+    for h in range(4):
+        got = ap.process_input_buffers(x[0, h * H:(h + 1) * H], x[1, h * H:(h + 1) * H])
+        exp = orc.process(x[0, h * H:(h + 1) * H], x[1, h * H:(h + 1) * H])
+        for z in range(2):
+            W = ap._eng.get_state(f"weights{z}", (N // 2 + 1, M), np.float32)
+            assert np.abs(W - orc.weights[z]).max() < 2e-4 * np.abs(orc.weights[z]).max(), (h, z)
+        if dialect == "python":
+            check_outputs([got], [exp], 2e-2)
+    assert abs(np.linalg.norm(W[:, 0]) - (1.0 if dialect == "python" else np.linalg.norm(W[:, 0]))) < 1e-5
+    ap.close()
