@@ -351,7 +351,7 @@ int apv_jdiag_batched(apv_handle* h, int32_t n, int32_t batch, const double* h_A
     HIPCHK(h, hipMalloc(&dl, (size_t)batch * n * 8));
     HIPCHK(h, hipMalloc((void**)&ds, (size_t)batch * sizeof(int32_t)));
     void* spill = nullptr;
-    const size_t sb = apv_gevd_spill_bytes(n, batch, APV_F64);
+    const size_t sb = apv_gevd_spill_bytes(n, batch, APV_F64);   // jdiag always runs in f64
     if (sb) HIPCHK(h, hipMalloc(&spill, sb));
     HIPCHK(h, hipMemcpyAsync(dA, h_A, mat, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(dB, h_B, mat, hipMemcpyHostToDevice, h->stream));
