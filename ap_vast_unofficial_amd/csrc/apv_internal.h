@@ -79,9 +79,8 @@ GevdParams apv_base_params(const apv_handle* h);
 hipError_t apv_launch_gevd(const GevdParams& p, int compute_dtype, bool fused, hipStream_t s, std::string* why);
 size_t apv_gevd_spill_bytes(int n, int K, int compute_dtype);
 
-// kernels_gevd16.hip (order-16 fast path; hipErrorNotSupported when the problem does not qualify)
-hipError_t apv_launch_gevd16(const GevdParams& p, int compute_dtype, bool fused, hipStream_t s);
-// kernels_gevd16m.hip (order-16, MFMA whitening / back-transform + register-resident Jacobi: the default)
+// kernels_gevd16m.hip: order-16 fast path (MFMA correlation / whitening / back-transform + register-resident
+// Jacobi); hipErrorNotSupported when the problem does not qualify
 hipError_t apv_launch_gevd16m(const GevdParams& p, int compute_dtype, bool fused, hipStream_t s);
 
 // kernels_gevd_large.hip: real symmetric pairs of broadband order, f64, device pointers (see the file header)

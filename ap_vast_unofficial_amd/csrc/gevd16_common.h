@@ -1,4 +1,4 @@
-// Shared device helpers of the order-16 kernels (kernels_gevd16.hip, kernels_gevd16m.hip).
+// Device helpers of the order-16 kernel (kernels_gevd16m.hip).
 #pragma once
 #include "apv_internal.h"
 
@@ -15,14 +15,10 @@ template <> struct Prec<double> {
     // a sweep that met off^2/||C||^2 <= tol2 leaves ~tol2^2 behind (quadratic convergence): it is the last one
     static constexpr double sweep_tol2 = 1e-10;
     static constexpr int max_sweeps = 14;
-    static constexpr double tiny = 1e-290;        // |beta|^2 below this: rotation skipped (rsq would overflow)
-    static constexpr double skip_rel = 1e-60;     // |beta|^2 <= skip_rel (alpha^2+gamma^2): negligible, and tau^2 stays finite
 };
 template <> struct Prec<float> {
     static constexpr float sweep_tol2 = 1e-8f;
     static constexpr int max_sweeps = 12;
-    static constexpr float tiny = 1e-35f;
-    static constexpr float skip_rel = 1e-24f;
 };
 
 // 1/sqrt(x), full precision of T, x > 0 finite
@@ -41,26 +37,6 @@ __device__ __forceinline__ float rsq_full(float x) {
     const float e = __builtin_fmaf(-t, y, 1.0f);
     return __builtin_fmaf(y * e, 0.5f, y);
 }
-
-// tournament schedule for 16 players: nibble r of SEQ_P[a] / SEQ_Q[a] = smaller / larger index of slot a in round r
-struct Seq { unsigned long long p[8], q[8]; };
-constexpr Seq make_seq() {
-    Seq s{};
-    for (int a = 0; a < 8; ++a) {
-        unsigned long long sp = 0, sq = 0;
-        for (int r = 0; r < 15; ++r) {
-            int u = 0, v = 0;
-            if (a == 0) { u = 15; v = r; } else { u = (r + a) % 15; v = (r - a + 15) % 15; }
-            const int lo = u < v ? u : v, hi = u < v ? v : u;
-            sp |= (unsigned long long)lo << (4 * r);
-            sq |= (unsigned long long)hi << (4 * r);
-        }
-        s.p[a] = sp;
-        s.q[a] = sq;
-    }
-    return s;
-}
-__constant__ Seq c_seq = make_seq();
 
 template <typename T> __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll
@@ -145,9 +121,18 @@ __device__ __forceinline__ void wsync() { __syncthreads(); }
 // are visited grouped by their highest (odd sweeps: lowest) set bit so that between two rounds only the
 // "bottom" member of every pair changes slot, by a slot-XOR of 1, 2 or 4.  Entry = {transition bit or -1, delta}.
 struct XStep { signed char tbit, delta; };
-__constant__ XStep c_xsched[2][15] = {
+constexpr XStep XSCHED[2][15] = {
     {{-1, 1}, {-1, 2}, {-1, 1}, {-1, 4}, {-1, 1}, {-1, 2}, {-1, 1}, {-1, 4}, {2, 1}, {-1, 2}, {-1, 1}, {-1, 2}, {1, 1}, {-1, 1}, {0, 0}},
     {{-1, 1}, {-1, 2}, {-1, 1}, {-1, 4}, {-1, 1}, {-1, 2}, {-1, 1}, {-1, 4}, {0, 2}, {-1, 4}, {-1, 2}, {-1, 4}, {1, 4}, {-1, 4}, {2, 0}}};
+// the same schedule as nibble strings: nibble r = delta of round r / (transition bit + 1) of round r
+constexpr unsigned long long xs_pack(int sweep, bool tb) {
+    unsigned long long v = 0;
+    for (int r = 0; r < 15; ++r)
+        v |= (unsigned long long)(tb ? (XSCHED[sweep][r].tbit + 1) : XSCHED[sweep][r].delta) << (4 * r);
+    return v;
+}
+constexpr unsigned long long XS_DELTA0 = xs_pack(0, false), XS_DELTA1 = xs_pack(1, false);
+constexpr unsigned long long XS_TBIT0 = xs_pack(0, true), XS_TBIT1 = xs_pack(1, true);
 
 template <typename T> __device__ __forceinline__ Cx<T> cshfl(Cx<T> v, int src) {
     return mk<T>(__shfl(v.x, src, 64), __shfl(v.y, src, 64));

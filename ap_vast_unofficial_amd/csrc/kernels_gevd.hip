@@ -504,11 +504,8 @@ size_t apv_gevd_spill_bytes(int n, int K, int compute_dtype) {
 hipError_t apv_launch_gevd(const GevdParams& p, int compute_dtype, bool fused, hipStream_t s, std::string* why) {
     const int n = p.n;
     static const bool force_generic = (getenv("APV_FORCE_GENERIC") != nullptr);
-    // APV_GEVD16_JACOBI=lds|reg selects the older order-16 kernels (kept for A/B profiling)
-    static const bool old16 = (getenv("APV_GEVD16_JACOBI") != nullptr);
     if (!force_generic) {
-        const hipError_t e16 = old16 ? apv_launch_gevd16(p, compute_dtype, fused, s)
-                                     : apv_launch_gevd16m(p, compute_dtype, fused, s);
+        const hipError_t e16 = apv_launch_gevd16m(p, compute_dtype, fused, s);
         if (e16 != hipErrorNotSupported) return e16;
     }
     if (n < 1 || n > APV_MAX_N) {

@@ -1,4 +1,5 @@
-// Order-16 fused subband update, third generation: every dense 16x16x16 contraction is on the matrix cores.
+// Order-16 fused subband update, one wavefront per frequency bin; every dense 16x16x16 contraction is on the
+// matrix cores.
 //
 //   stage 0  R_B, R_D = X^H X, r = X_B^H d        MFMA 16x16x4 (f64 or f32), slab read once, coalesced
 //   stage 1  Cholesky of R_D + reg I TOGETHER WITH W = L^-1 (elimination applied to [B | I]); rows of B and W
@@ -9,8 +10,8 @@
 //   stage 5  X = W^H Q                             one complex MFMA product                  apvast.py:31
 //   stage 6  w_V = sum_{i<V} (x_i^H r)/(lam_i+mu) x_i                                        apvast.py:406-414
 //
-// Against kernels_gevd16.hip this removes 48 of the 64 sequential substitution steps (the two forward
-// substitutions and the backward one become three MFMA products) and one LDS matrix (8.7 KiB of LDS per wave).
+// Against a textbook arrangement this removes 48 of the 64 sequential substitution steps (the two forward
+// substitutions and the backward one become three MFMA products) and needs two LDS matrices (10 KiB per wave).
 #include "apv_internal.h"
 
 #include <cstdlib>
@@ -191,9 +192,11 @@ __global__ void __launch_bounds__(64) gevd16m_kernel(const GevdParams p) {
         int sweeps_done = 0;
         for (int sweep = 0; sweep < max_sweeps && !converged; ++sweep) {
             T off = 0;
-            const XStep* sched = c_xsched[sweep & 1];
+            // the schedule as two nibble strings in scalar registers (a table in memory costs a load per round)
+            const unsigned long long dseq = (sweep & 1) ? XS_DELTA1 : XS_DELTA0;
+            const unsigned long long tseq = (sweep & 1) ? XS_TBIT1 : XS_TBIT0;
             for (int r = 0; r < 15; ++r) {
-                const int tbit = sched[r].tbit, delta = sched[r].delta;
+                const int delta = (int)((dseq >> (4 * r)) & 15), tbit = (int)((tseq >> (4 * r)) & 15) - 1;
                 if (tbit >= 0) {
                     const bool cb_ = (b >> tbit) & 1, ab_ = (a >> tbit) & 1;
                     const int pc = lane ^ (1 << tbit), pr = lane ^ (8 << tbit);
