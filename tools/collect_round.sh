@@ -12,7 +12,7 @@ python tools/bench_broadband.py 20 > $OUT/broadband_cfg1.json 2>/dev/null; cat $
 python tools/bench_cfg5.py > $OUT/cfg5.json 2>/dev/null; cat $OUT/cfg5.json
 export TMPDIR=/tmp; cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stream -- python3 $REPO/tools/bench_stream.py --hops 100 > /dev/null 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bb -- python3 $REPO/tools/bench_broadband.py 10 > /dev/null 2>&1
+# (rocprofv3 segfaults on the broadband path: captured hipGraphs; wall-clock numbers only)
 cp $OUT/prof_stream/*/*kernel_stats.csv $OUT/stream_kernel_stats.csv
-cp $OUT/prof_bb/*/*kernel_stats.csv $OUT/broadband_kernel_stats.csv
-rm -rf $OUT/prof_stream $OUT/prof_bb
+
+rm -rf $OUT/prof_stream

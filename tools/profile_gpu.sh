@@ -19,4 +19,4 @@ echo "[profile] pmc SQ"
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES --output-format csv -d "$OUT/pmc_sq" -- python3 "$REPO/bench.py" $ARGS > "$OUT/pmc_sq.log" 2>&1 || echo "SQ pass failed"
 find "$OUT" -name "*.csv" | head -30
 python3 "$REPO/tools/summarise_profile.py" "$OUT" "$TAG" $ARGS
-mkdir -p "$REPO/gpurun_out/profiles_out" && cp "$REPO"/profiles/* "$REPO/gpurun_out/profiles_out/"
+mkdir -p "$REPO/gpurun_out/profiles_out" && cp "$REPO"/profiles/*.md "$REPO"/profiles/*.json "$REPO/gpurun_out/profiles_out/"
