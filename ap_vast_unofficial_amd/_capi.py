@@ -25,7 +25,7 @@ EXPORTS = (
     "apv_create", "apv_destroy", "apv_last_error", "apv_abi_version",
     "apv_dev_alloc", "apv_dev_free", "apv_memcpy_h2d", "apv_memcpy_d2h", "apv_sync",
     "apv_timer_start", "apv_timer_stop",
-    "apv_update_dev", "apv_update", "apv_corr_dev", "apv_gevd_vast_dev", "apv_jdiag_batched", "apv_jdiag_large",
+    "apv_update_dev", "apv_update", "apv_corr_dev", "apv_corr_bf16_dev", "apv_to_bf16_dev", "apv_gevd_vast_dev", "apv_jdiag_batched", "apv_jdiag_large",
     "apv_stft_analysis_dev", "apv_istft_ola_dev",
     "apv_stream_init", "apv_stream_set_perceptual", "apv_process_block", "apv_state_bytes", "apv_get_state", "apv_set_state",
     "apv_bb_init", "apv_bb_process_block", "apv_bb_get_state", "apv_bb_set_state",
@@ -80,6 +80,8 @@ def load():
     lib.apv_update_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     lib.apv_update.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     lib.apv_corr_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    lib.apv_corr_bf16_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    lib.apv_to_bf16_dev.argtypes = [vp, sz, vp, vp]
     lib.apv_gevd_vast_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     lib.apv_jdiag_batched.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
     lib.apv_jdiag_large.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
@@ -266,6 +268,22 @@ class Engine:
         out = (dRB.download((K, L, L), self.c_dtype), dRD.download((K, L, L), self.c_dtype),
                dr.download((K, L), self.c_dtype))
         for b in bufs + [dRB, dRD, dr]:
+            b.free()
+        return out
+
+    def corr_bf16(self, XB, XD, d):
+        """K5' from bf16-rounded inputs (converted on the device), f32 accumulation: R_B, R_D, r as complex64."""
+        K, L, M = self.K, self.L, self.M
+        src = [self.to_device(np.ascontiguousarray(a, dtype=np.complex64)) for a in (XB, XD, d)]
+        counts = (K * M * L, K * M * L, K * M)
+        bf = [self.alloc(c * 4) for c in counts]
+        for s_, b_, c_ in zip(src, bf, counts):
+            self._chk(self.lib.apv_to_bf16_dev(self.h, c_, s_.ptr, b_.ptr))
+        dRB, dRD, dr = self.alloc(K * L * L * 8), self.alloc(K * L * L * 8), self.alloc(K * L * 8)
+        self._chk(self.lib.apv_corr_bf16_dev(self.h, bf[0].ptr, bf[1].ptr, bf[2].ptr, dRB.ptr, dRD.ptr, dr.ptr))
+        out = (dRB.download((K, L, L), np.complex64), dRD.download((K, L, L), np.complex64),
+               dr.download((K, L), np.complex64))
+        for b in src + bf + [dRB, dRD, dr]:
             b.free()
         return out
 

@@ -91,6 +91,11 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
 hipError_t apv_launch_corr(int compute_dtype, int K, int M, int L, const float2* XB, const float2* XD,
                            const float2* d, void* RB, void* RD, void* r, hipStream_t s);
 
+// bf16 inputs ((re, im) bf16 pairs, 4 B per element), f32 accumulation on v_mfma_f32_32x32x16_bf16; L in {32, 64}
+hipError_t apv_launch_corr_bf16(int K, int M, int L, const uint32_t* XB, const uint32_t* XD, const uint32_t* d,
+                                float2* RB, float2* RD, float2* r, hipStream_t s);
+hipError_t apv_launch_to_bf16(size_t count, const float2* in, uint32_t* out, hipStream_t s);
+
 // kernels_stft.hip
 hipError_t apv_launch_stft_analysis(int N, int n_ch, const float* x, float2* spec, hipStream_t s, std::string* why);
 hipError_t apv_launch_istft_ola(int N, int H, int n_ch, const float2* spec, float* overlap, float* out,

@@ -316,6 +316,27 @@ int apv_corr_dev(apv_handle* h, const void* d_XB, const void* d_XD, const void* 
     return APV_OK;
 }
 
+int apv_to_bf16_dev(apv_handle* h, size_t count, const void* d_c64, void* d_bf16) {
+    if (!h || !d_c64 || !d_bf16) return fail(h, APV_ERR_ARG, "null device pointer");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipError_t e = apv_launch_to_bf16(count, (const float2*)d_c64, (uint32_t*)d_bf16, h->stream);
+    if (e != hipSuccess) return hipfail(h, e, "to_bf16 launch");
+    return APV_OK;
+}
+
+int apv_corr_bf16_dev(apv_handle* h, const void* d_XB, const void* d_XD, const void* d_d, void* d_RB, void* d_RD,
+                      void* d_r) {
+    if (!h || !d_XB || !d_XD || !d_d || !d_RB || !d_RD || !d_r) return fail(h, APV_ERR_ARG, "null device pointer");
+    HIPCHK(h, hipSetDevice(h->device));
+    const apv_config& c = h->cfg;
+    if ((c.n_srcs != 32 && c.n_srcs != 64) || (c.n_mics % 16) != 0)
+        return fail(h, APV_ERR_ARG, "bf16 correlation: n_srcs must be 32 or 64 and n_mics a multiple of 16");
+    hipError_t e = apv_launch_corr_bf16(c.n_bins, c.n_mics, c.n_srcs, (const uint32_t*)d_XB, (const uint32_t*)d_XD,
+                                        (const uint32_t*)d_d, (float2*)d_RB, (float2*)d_RD, (float2*)d_r, h->stream);
+    if (e != hipSuccess) return hipfail(h, e, "corr_bf16 launch");
+    return APV_OK;
+}
+
 int apv_gevd_vast_dev(apv_handle* h, const void* d_RB, const void* d_RD, const void* d_r, void* d_w, void* d_lam,
                       int32_t* d_status) {
     if (!h || !d_RB || !d_RD || !d_r || !d_w) return fail(h, APV_ERR_ARG, "null device pointer");

@@ -1,8 +1,16 @@
-// K5': batched Hermitian rank-M correlation, stand-alone form.
+// K5': batched Hermitian rank-M correlation, stand-alone form (R goes to HBM).
 //   R_B[k] = X_B[k]^H X_B[k], R_D[k] = X_D[k]^H X_D[k], r[k] = X_B[k]^H d[k]
 // (complex twin of `R += Y @ Y.T`, `r += Y @ d`, reference Python/apvast.py:339-340, 347).
-// The fused update kernels never write R to HBM; this entry point exists for the
-// apv_corr_dev / apv_gevd_vast_dev split of the C ABI and for stage-level parity tests.
+// The fused update kernels never write R to HBM; these entry points serve the apv_corr_dev / apv_gevd_vast_dev
+// split of the C ABI, the stage-level parity tests, and the fp32-vs-bf16 accumulation study of BASELINE config 5.
+//
+//   corr_kernel<T>            any L <= 64, any M: LDS-staged VALU (f32 or f64 accumulation)
+//   corr_mfma_f32_kernel      L in {32, 64}: v_mfma_f32_32x32x2_f32, exact f32 products, one wave per (bin, matrix)
+//   corr_mfma_bf16_kernel     L in {32, 64}: v_mfma_f32_32x32x16_bf16 on bf16 inputs, f32 accumulation
+//
+// In both MFMA kernels the slab is read ONCE from HBM straight into the operand registers: the two complex values a
+// lane loads per row pair (columns l&31 and 32 + (l&31)) are the A (X^H) and the B (X) operands of all four 32x32
+// tiles of R, so there is no LDS staging and the kernel is bound by HBM, not by the matrix cores.
 #include "apv_internal.h"
 
 namespace {
@@ -66,17 +74,206 @@ __global__ void __launch_bounds__(256) corr_kernel(int M, int L, const float2* _
     }
 }
 
+using f16v = __attribute__((ext_vector_type(16))) float;
+using bf8v = __attribute__((ext_vector_type(8))) short;
+
+// accumulator element r of a 32x32 tile: row = (r&3) + 8 (r>>2) + 4 (lane>>5), col = lane & 31
+__device__ __forceinline__ void store_tile(float2* __restrict__ R, int L, int ti, int tj, const f16v& re, const f16v& im,
+                                           int lane) {
+    const int col = tj * 32 + (lane & 31), h = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        R[(size_t)row * L + col] = make_float2(re[r], im[r]);
+    }
+}
+
+// One workgroup per (bin, matrix), one wave per 32x32 tile of R (NT = L / 32 tiles per side): wave w owns tile
+// (a, b) = (w / NT, w % NT) and needs only the column halves a and b of every row.
+template <int NT>
+__global__ void __launch_bounds__(64 * NT * NT) corr_mfma_f32_kernel(int M, const float2* __restrict__ XB,
+                                                                     const float2* __restrict__ XD,
+                                                                     const float2* __restrict__ d,
+                                                                     float2* __restrict__ RB, float2* __restrict__ RD,
+                                                                     float2* __restrict__ r) {
+    constexpr int L = 32 * NT;
+    constexpr int G = 4;                                   // k-steps in flight
+    const int k = blockIdx.x, which = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ta = wave / NT, tb = wave % NT;
+    const float2* X = (which ? XD : XB) + (size_t)k * M * L;
+    const int c = lane & 31, h = lane >> 5;
+    f16v re, im;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { re[q] = 0.f; im[q] = 0.f; }
+    float rx = 0.f, ry = 0.f;
+    const bool want_r = (which == 0) && (tb == 0);          // the waves of tile column 0 cover every loudspeaker once
+    // lane (c, h): A[i = c][k = h] = conj(X[m0 + h][32 ta + c]), B[k = h][j = c] = X[m0 + h][32 tb + c]
+    const float2* pa = X + (size_t)h * L + ta * 32 + c;
+    const float2* pb = X + (size_t)h * L + tb * 32 + c;
+    const float2* pd = d + (size_t)k * M + h;
+    const int steps = M / 2, groups = steps / G;             // M even is required (checked by the launcher)
+    float2 na[G], nb[G], nd[G];
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+        na[u] = pa[(size_t)(2 * u) * L];                     // M >= 2 G (launcher)
+        nb[u] = pb[(size_t)(2 * u) * L];
+        nd[u] = pd[2 * u];
+    }
+    for (int g = 0; g < groups; ++g) {
+        float2 xa[G], xb[G], dv[G];
+#pragma unroll
+        for (int u = 0; u < G; ++u) { xa[u] = na[u]; xb[u] = nb[u]; dv[u] = nd[u]; }
+        if (g + 1 < groups) {
+            const size_t m0 = (size_t)(g + 1) * 2 * G;
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                na[u] = pa[(m0 + 2 * u) * L];
+                nb[u] = pb[(m0 + 2 * u) * L];
+                if (want_r) nd[u] = pd[m0 + 2 * u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            if (want_r) {
+                rx += xa[u].x * dv[u].x + xa[u].y * dv[u].y;
+                ry += xa[u].x * dv[u].y - xa[u].y * dv[u].x;
+            }
+            re = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[u].x, xb[u].x, re, 0, 0, 0);
+            re = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[u].y, xb[u].y, re, 0, 0, 0);
+            im = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[u].x, xb[u].y, im, 0, 0, 0);
+            im = __builtin_amdgcn_mfma_f32_32x32x2f32(-xa[u].y, xb[u].x, im, 0, 0, 0);
+        }
+    }
+    for (int st = groups * G; st < steps; ++st) {
+        const float2 xa = pa[(size_t)(2 * st) * L], xb = pb[(size_t)(2 * st) * L];
+        if (want_r) {
+            const float2 dv = pd[2 * st];
+            rx += xa.x * dv.x + xa.y * dv.y;
+            ry += xa.x * dv.y - xa.y * dv.x;
+        }
+        re = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.x, xb.x, re, 0, 0, 0);
+        re = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.y, xb.y, re, 0, 0, 0);
+        im = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.x, xb.y, im, 0, 0, 0);
+        im = __builtin_amdgcn_mfma_f32_32x32x2f32(-xa.y, xb.x, im, 0, 0, 0);
+    }
+    store_tile((which ? RD : RB) + (size_t)k * L * L, L, ta, tb, re, im, lane);
+    if (want_r) {
+        const float sx = rx + __shfl_xor(rx, 32, 64), sy = ry + __shfl_xor(ry, 32, 64);
+        if (h == 0) r[(size_t)k * L + ta * 32 + c] = make_float2(sx, sy);
+    }
+}
+
+// bf16 inputs: X as (re, im) bf16 pairs, 4 bytes per complex element, same [K][M][L] layout.
+// v_mfma_f32_32x32x16_bf16: lane (c = l&31, h = l>>5) holds A[i = c][k = 8h + j], B[k = 8h + j][j' = c], j = 0..7.
+template <int NT>
+__global__ void __launch_bounds__(64 * NT * NT) corr_mfma_bf16_kernel(int M, const uint32_t* __restrict__ XB,
+                                                                      const uint32_t* __restrict__ XD,
+                                                                      const uint32_t* __restrict__ d,
+                                                                      float2* __restrict__ RB, float2* __restrict__ RD,
+                                                                      float2* __restrict__ r) {
+    constexpr int L = 32 * NT;
+    const int k = blockIdx.x, which = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ta = wave / NT, tb = wave % NT;
+    const uint32_t* X = (which ? XD : XB) + (size_t)k * M * L;
+    const int c = lane & 31, h = lane >> 5;
+    f16v re, im;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { re[q] = 0.f; im[q] = 0.f; }
+    float rx = 0.f, ry = 0.f;
+    const bool want_r = (which == 0) && (tb == 0);
+    const uint32_t* pa = X + (size_t)(8 * h) * L + ta * 32 + c;
+    const uint32_t* pb = X + (size_t)(8 * h) * L + tb * 32 + c;
+    const int steps = M / 16;                                // M % 16 == 0 is required (checked by the launcher)
+    uint32_t na[8], nb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        na[j] = pa[(size_t)j * L];                           // M >= 16 (launcher)
+        nb[j] = pb[(size_t)j * L];
+    }
+    for (int st = 0; st < steps; ++st) {
+        uint32_t va[8], vb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { va[j] = na[j]; vb[j] = nb[j]; }
+        if (st + 1 < steps) {
+            const size_t m0 = (size_t)(st + 1) * 16;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                na[j] = pa[(m0 + j) * L];
+                nb[j] = pb[(m0 + j) * L];
+            }
+        }
+        bf8v ar, ai, nai, br, bi;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {                        // lo half = re, hi half = im
+            ar[j] = (short)(va[j] & 0xffffu);
+            ai[j] = (short)(va[j] >> 16);
+            nai[j] = (short)((va[j] >> 16) ^ 0x8000u);
+            br[j] = (short)(vb[j] & 0xffffu);
+            bi[j] = (short)(vb[j] >> 16);
+        }
+        {   // r = X_B^H d: every wave accumulates (no divergent region in the loop), only tile column 0 stores
+            const uint32_t* dp = d + (size_t)k * M + st * 16 + 8 * h;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t dv = dp[j];
+                const float dr = __uint_as_float(dv << 16), di = __uint_as_float(dv & 0xffff0000u);
+                const float fr = __uint_as_float(va[j] << 16), fi = __uint_as_float(va[j] & 0xffff0000u);
+                rx += fr * dr + fi * di;
+                ry += fr * di - fi * dr;
+            }
+        }
+        re = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar, br, re, 0, 0, 0);
+        re = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ai, bi, re, 0, 0, 0);
+        im = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar, bi, im, 0, 0, 0);
+        im = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nai, br, im, 0, 0, 0);
+    }
+    store_tile((which ? RD : RB) + (size_t)k * L * L, L, ta, tb, re, im, lane);
+    const float sx = rx + __shfl_xor(rx, 32, 64), sy = ry + __shfl_xor(ry, 32, 64);
+    if (want_r && h == 0) r[(size_t)k * L + ta * 32 + c] = make_float2(sx, sy);
+}
+
+// c64 -> (bf16, bf16), round to nearest even (plain cast: v_cvt_pk_bf16_f32 keeps NaNs NaN)
+__global__ void __launch_bounds__(256) to_bf16_kernel(size_t count, const float2* __restrict__ in, uint32_t* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const float2 v = in[i];
+    const __bf16 a = (__bf16)v.x, b = (__bf16)v.y;
+    const uint16_t ua = *reinterpret_cast<const uint16_t*>(&a), ub = *reinterpret_cast<const uint16_t*>(&b);
+    out[i] = (uint32_t)ua | ((uint32_t)ub << 16);
+}
+
 }  // namespace
 
 hipError_t apv_launch_corr(int compute_dtype, int K, int M, int L, const float2* XB, const float2* XD,
                            const float2* d, void* RB, void* RD, void* r, hipStream_t s) {
     if (K <= 0) return hipSuccess;
     if (L < 1 || L > APV_MAX_N || M < 1) return hipErrorInvalidValue;
-    if (compute_dtype == APV_F64)
+    if (compute_dtype == APV_F64) {
         hipLaunchKernelGGL(corr_kernel<double>, dim3(K), dim3(256), 0, s, M, L, XB, XD, d, (double*)RB,
                            (double*)RD, (double*)r);
-    else
+    } else if (L == 64 && (M % 2) == 0 && M >= 8) {
+        hipLaunchKernelGGL(corr_mfma_f32_kernel<2>, dim3(K, 2), dim3(256), 0, s, M, XB, XD, d, (float2*)RB, (float2*)RD, (float2*)r);
+    } else if (L == 32 && (M % 2) == 0 && M >= 8) {
+        hipLaunchKernelGGL(corr_mfma_f32_kernel<1>, dim3(K, 2), dim3(64), 0, s, M, XB, XD, d, (float2*)RB, (float2*)RD, (float2*)r);
+    } else {
         hipLaunchKernelGGL(corr_kernel<float>, dim3(K), dim3(256), 0, s, M, L, XB, XD, d, (float*)RB,
                            (float*)RD, (float*)r);
+    }
+    return hipGetLastError();
+}
+
+hipError_t apv_launch_corr_bf16(int K, int M, int L, const uint32_t* XB, const uint32_t* XD, const uint32_t* d,
+                                float2* RB, float2* RD, float2* r, hipStream_t s) {
+    if (K <= 0) return hipSuccess;
+    if ((M % 16) != 0 || M < 16) return hipErrorInvalidValue;
+    if (L == 64) hipLaunchKernelGGL(corr_mfma_bf16_kernel<2>, dim3(K, 2), dim3(256), 0, s, M, XB, XD, d, RB, RD, r);
+    else if (L == 32) hipLaunchKernelGGL(corr_mfma_bf16_kernel<1>, dim3(K, 2), dim3(64), 0, s, M, XB, XD, d, RB, RD, r);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t apv_launch_to_bf16(size_t count, const float2* in, uint32_t* out, hipStream_t s) {
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(to_bf16_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, count, in, out);
     return hipGetLastError();
 }

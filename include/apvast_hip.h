@@ -122,6 +122,13 @@ int  apv_update(apv_handle* h, const float* h_XB, const float* h_XD, const float
 int  apv_corr_dev(apv_handle* h, const void* d_XB, const void* d_XD, const void* d_d,
                   void* d_RB, void* d_RD, void* d_r);
 
+/* The same contraction from bf16 inputs ((re, im) bf16 pairs, 4 bytes per element, same [K][M][L] layout), f32
+ * accumulation on the bf16 matrix cores; R_B, R_D [K][L][L] and r [K][L] come out as c64.  n_srcs in {32, 64}.
+ * (BASELINE config 5: fp32 vs bf16 correlation accumulation.)  apv_to_bf16_dev converts `count` c64 elements. */
+int  apv_corr_bf16_dev(apv_handle* h, const void* d_XB, const void* d_XD, const void* d_d,
+                       void* d_RB, void* d_RD, void* d_r);
+int  apv_to_bf16_dev(apv_handle* h, size_t count, const void* d_c64, void* d_bf16);
+
 /* K6-K10: GEVD + filter from explicit R_B, R_D, r (compute dtype).   replaces apvast.py:378-414 */
 int  apv_gevd_vast_dev(apv_handle* h, const void* d_RB, const void* d_RD, const void* d_r,
                        void* d_w, void* d_lam, int32_t* d_status);

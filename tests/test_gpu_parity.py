@@ -270,3 +270,52 @@ def test_jdiag_large_vs_oracle(Engine, n, batch):
     with pytest.raises(np.linalg.LinAlgError):
         eng2 = Engine(1, 4, 4)
         eng2.jdiag_large(np.eye(70)[None], -np.eye(70)[None])
+
+
+@pytest.mark.parametrize("L,M", [(64, 128), (32, 48)])
+def test_corr_mfma_f32_and_bf16(Engine, L, M):
+    """BASELINE config 5: correlation accumulated in fp32 (exact-product f32 MFMA) and from bf16 inputs (bf16 MFMA,
+    f32 accumulation) against the float64 oracle."""
+    rng = np.random.default_rng(L + M)
+    K = 7
+    XB, XD, d = cn(rng, K, M, L), cn(rng, K, M, L), cn(rng, K, M)
+    RB0, RD0, r0 = subband.correlate(XB, XD, d)
+    eng = Engine(K, L, M, compute_dtype="f32")
+    RB, RD, r = eng.corr(XB, XD, d)
+    RBh, RDh, rh = eng.corr_bf16(XB, XD, d)
+    eng.close()
+    for a, b in ((RB, RB0), (RD, RD0), (r, r0)):
+        assert np.abs(a - b).max() <= 3e-6 * np.abs(b).max()
+    # bf16 keeps 8 significant bits per input: gate of SURVEY.md section 8(c), R rel-Frobenius <= 1e-2
+    for a, b in ((RBh, RB0), (RDh, RD0), (rh, r0)):
+        rel = np.linalg.norm((a - b).reshape(K, -1), axis=1) / np.linalg.norm(b.reshape(K, -1), axis=1)
+        assert rel.max() < 1e-2, rel.max()
+    # Hermitian by construction of the four products
+    assert np.abs(RBh - RBh.conj().transpose(0, 2, 1)).max() <= 1e-5 * np.abs(RBh).max()
+
+
+def test_corr_bf16_exact_on_rounded_inputs(Engine):
+    """The bf16 path is exact up to f32 accumulation once the inputs are rounded to bf16: many bins, two runs
+    (a scheduling-dependent fault in an earlier build showed up in a few bins per launch only)."""
+    rng = np.random.default_rng(77)
+    K, L, M = 300, 64, 128
+    XB, XD, d = cn(rng, K, M, L), cn(rng, K, M, L), cn(rng, K, M)
+
+    def rnd(a):
+        def r32(x):
+            u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+            u = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+            return u.astype(np.uint32).view(np.float32)
+        return r32(a.real) + 1j * r32(a.imag)
+    RB0, RD0, r0 = subband.correlate(rnd(XB), rnd(XD), rnd(d))
+    eng = Engine(K, L, M, compute_dtype="f32")
+    first = None
+    for _ in range(2):
+        RB, RD, r = eng.corr_bf16(XB, XD, d)
+        for a, b in ((RB, RB0), (RD, RD0), (r, r0)):
+            rel = np.linalg.norm((a - b).reshape(K, -1), axis=1) / np.linalg.norm(b.reshape(K, -1), axis=1)
+            assert rel.max() < 2e-6, rel.max()
+        if first is not None:
+            assert np.array_equal(first, r)
+        first = r
+    eng.close()
