@@ -58,6 +58,8 @@ struct apv_handle {
     int32_t* d_status;
     void* d_Lspill;
     size_t lspill_bytes;
+    void* d_Rscratch;  // [2][K][L][L] + [K][L] c64: MFMA correlation output of the split n in {32, 64} f32 update
+    size_t rscratch_bytes;
     struct apv_stream* st;   // streaming state (apv_stream_init), owned
     struct apv_bb* bb;       // broadband streaming state (apv_bb_init), owned
     void* gl_ws;             // workspace + captured sweep graph of apv_gevd_large, owned

@@ -127,6 +127,8 @@ int apv_create(const apv_config* cfg, apv_handle** out) {
     h->d_status = nullptr;
     h->d_Lspill = nullptr;
     h->lspill_bytes = 0;
+    h->d_Rscratch = nullptr;
+    h->rscratch_bytes = 0;
     h->st = nullptr;
     h->bb = nullptr;
     h->gl_ws = nullptr;
@@ -173,7 +175,7 @@ int apv_destroy(apv_handle* h) {
         if (g.ev) (void)hipEventDestroy(g.ev);
     if (h->ev_ready) (void)hipEventDestroy(h->ev_ready);
     if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
-    void* bufs[] = {h->d_XB, h->d_XD, h->d_d, h->d_w, h->d_lam, h->d_status, h->d_Lspill};
+    void* bufs[] = {h->d_XB, h->d_XD, h->d_d, h->d_w, h->d_lam, h->d_status, h->d_Lspill, h->d_Rscratch};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -245,14 +247,40 @@ int apv_update_dev(apv_handle* h, const void* d_XB, const void* d_XD, const void
             g.ptr = nullptr;
         }
     GevdParams p = base_params(h);
-    p.XB = (const float2*)d_XB;
-    p.XD = (const float2*)d_XD;
-    p.d = (const float2*)d_d;
     p.w = d_w;
     p.lam = d_lam;
     p.status = d_status;
     std::string why;
-    hipError_t e = apv_launch_gevd(p, h->cfg.compute_dtype, true, h->stream, &why);
+    const apv_config& c = h->cfg;
+    hipError_t e;
+    if (c.compute_dtype == APV_F32 && (c.n_srcs == 32 || c.n_srcs == 64) && (c.n_mics % 2) == 0 && c.n_mics >= 8) {
+        // large orders in f32: correlation on the f32 matrix cores into a scratch R (HBM round trip of
+        // 2 L^2 c64 per bin, small against the eigen-iteration), then the LDS-resident GEVD from explicit R
+        const size_t K = c.n_bins, L = c.n_srcs;
+        const size_t need = (2 * K * L * L + K * L) * 8;
+        if (need > h->rscratch_bytes) {
+            if (h->d_Rscratch) HIPCHK(h, hipFree(h->d_Rscratch));
+            h->d_Rscratch = nullptr;
+            h->rscratch_bytes = 0;
+            HIPCHK(h, hipMalloc(&h->d_Rscratch, need));
+            h->rscratch_bytes = need;
+        }
+        float2* RB = (float2*)h->d_Rscratch;
+        float2* RD = RB + K * L * L;
+        float2* rr = RD + K * L * L;
+        e = apv_launch_corr(APV_F32, c.n_bins, c.n_mics, c.n_srcs, (const float2*)d_XB, (const float2*)d_XD,
+                            (const float2*)d_d, RB, RD, rr, h->stream);
+        if (e != hipSuccess) return hipfail(h, e, "corr launch");
+        p.RB = RB;
+        p.RD = RD;
+        p.r = rr;
+        e = apv_launch_gevd(p, APV_F32, false, h->stream, &why);
+    } else {
+        p.XB = (const float2*)d_XB;
+        p.XD = (const float2*)d_XD;
+        p.d = (const float2*)d_d;
+        e = apv_launch_gevd(p, h->cfg.compute_dtype, true, h->stream, &why);
+    }
     if (e != hipSuccess) return fail(h, e == hipErrorInvalidValue ? APV_ERR_ARG : APV_ERR_HIP,
                                      why.empty() ? hipGetErrorString(e) : why);
     return APV_OK;
