@@ -108,6 +108,7 @@ hipError_t apv_launch_istft_ola_strided(int N, int H, int n_ch, const float2* sp
                                         float* overlap, float* out, hipStream_t s, std::string* why);
 
 bool apv_stft_size_ok(int N, std::string* why);
+hipError_t apv_stft_prepare(int N, int f64);
 // general forms: f64 = 0/1 selects float/double data; in_len < N zero-pads; use_win = 0 skips the sine window
 hipError_t apv_launch_analysis(int f64, int N, int n_ch, const void* x, long x_stride, int in_len, int ring_off,
                                int use_win, void* spec, long stride_c, long stride_k, hipStream_t s, std::string* why);

@@ -297,6 +297,13 @@ hipError_t launch_synthesis(int N, int H, int n_ch, const void* spec, long strid
 
 }  // namespace
 
+// build (or find) the twiddle / window tables now, so that no allocation happens on the per-hop path
+hipError_t apv_stft_prepare(int N, int f64) {
+    if (f64) { Tables<double> t; return get_tables<double>(N, &t); }
+    Tables<float> t;
+    return get_tables<float>(N, &t);
+}
+
 bool apv_stft_size_ok(int N, std::string* why) {
     FftPlan plan;
     return make_plan(N, &plan, why);

@@ -45,6 +45,13 @@ struct apv_stream {
     double* G2;                   // [K][nch]
     double* G2T;                  // [nch][K]
     float* Wgt[2];                // [K][M] per zone
+    // pinned staging + one captured hipGraph per phase of the (ring offset, history buffer) cycle
+    float* pin_in;                // [2][H]
+    float* pin_out;               // [n_out][H]
+    int32_t* pin_status;          // [2][K]
+    int period;                   // hops after which (ring_off, cur) repeat; 0 = graphs off
+    long hop;                     // hops processed
+    std::vector<hipGraphExec_t> execs;
     std::vector<int32_t> h_status;
 };
 
@@ -82,6 +89,11 @@ void apv_stream_free(apv_handle* h) {
                     s->G2, s->G2T, s->Wgt[0], s->Wgt[1]};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
+    for (hipGraphExec_t e : s->execs)
+        if (e) (void)hipGraphExecDestroy(e);
+    if (s->pin_in) (void)hipHostFree(s->pin_in);
+    if (s->pin_out) (void)hipHostFree(s->pin_out);
+    if (s->pin_status) (void)hipHostFree(s->pin_status);
     delete s;
     h->st = nullptr;
 }
@@ -106,7 +118,7 @@ int apv_stream_init(apv_handle* h, int32_t rir_len, const double* h_rir_A, const
     SCHK(h, hipSetDevice(h->device));
     apv_stream_free(h);
     apv_stream* s = new apv_stream();
-    std::memset(static_cast<void*>(s), 0, offsetof(apv_stream, h_status));
+    std::memset(static_cast<void*>(s), 0, offsetof(apv_stream, execs));
     h->st = s;
     s->N = N; s->H = H; s->K = N / 2 + 1; s->L = c.n_srcs; s->M = c.n_mics; s->C = s->L * s->M;
     s->P = rir_len; s->nV = c.n_ranks; s->zones = c.n_zones; s->pad = apv_fir_pad();
@@ -164,16 +176,33 @@ int apv_stream_init(apv_handle* h, int32_t rir_len, const double* h_rir_A, const
     }
     SCHK(h, hipMemcpy(s->tgt, tg.data(), sizeof(float2) * tg.size(), hipMemcpyHostToDevice));
     s->h_status.assign((size_t)2 * K, 0);
+    SCHK(h, hipHostMalloc((void**)&s->pin_in, sizeof(float) * 2 * H, hipHostMallocDefault));
+    SCHK(h, hipHostMalloc((void**)&s->pin_out, sizeof(float) * (size_t)s->n_out * H, hipHostMallocDefault));
+    SCHK(h, hipHostMalloc((void**)&s->pin_status, sizeof(int32_t) * 2 * K, hipHostMallocDefault));
+    std::memset(s->pin_status, 0, sizeof(int32_t) * 2 * K);
+    // the launch sequence of a hop depends on (ring_off, cur) only: ring_off has period N / gcd(N, H), cur period 2
+    {
+        int a = N, b = H;
+        while (b) { const int t = a % b; a = b; b = t; }
+        int per = N / a;
+        if (per % 2) per *= 2;
+        s->period = (per <= 16 && getenv("APV_NO_GRAPH") == nullptr) ? per : 0;
+        s->execs.assign(s->period > 0 ? s->period : 0, nullptr);
+    }
+    s->hop = 0;
+    SCHK(h, apv_stft_prepare(N, 0));
     SCHK(h, hipStreamSynchronize(h->stream));
     return APV_OK;
 }
 
-int apv_process_block(apv_handle* h, const float* h_in_A, const float* h_in_B, float* h_out) {
-    if (!h || !h_in_A || !h_in_B || !h_out) return apv_fail(h, APV_ERR_ARG, "null argument");
+// everything one hop puts on the stream, from the pinned input staging to the pinned output staging; advances
+// (ring_off, cur) on the host.  Pure enqueue: also used under stream capture.
+static int enqueue_hop(apv_handle* h) {
     apv_stream* s = h->st;
-    if (!s) return apv_fail(h, APV_ERR_ARG, "apv_stream_init has not been called");
-    SCHK(h, hipSetDevice(h->device));
     hipStream_t st = h->stream;
+    const float* h_in_A = s->pin_in;
+    const float* h_in_B = s->pin_in + s->H;
+    float* h_out = s->pin_out;
     const int N = s->N, H = s->H, K = s->K, L = s->L, M = s->M, C = s->C, P = s->P;
     std::string why;
     // hop -> device, input history and input-block rings
@@ -251,7 +280,7 @@ int apv_process_block(apv_handle* h, const float* h_in_A, const float* h_in_B, f
         // K3: filtered output spectra for this zone's nV*L channels
         SCHK(h, apv_launch_apply_filters(K, s->nV * L, 0, s->inspec + (size_t)z * K, s->w[z], h->cfg.out_c128, nullptr,
                                          s->outspec + (size_t)oc * K, st));
-        SCHK(h, hipMemcpyAsync(s->h_status.data() + (size_t)z * K, s->status[z], sizeof(int32_t) * K,
+        SCHK(h, hipMemcpyAsync(s->pin_status + (size_t)z * K, s->status[z], sizeof(int32_t) * K,
                                hipMemcpyDeviceToHost, st));
         oc += s->nV * L;
     }
@@ -263,11 +292,57 @@ int apv_process_block(apv_handle* h, const float* h_in_A, const float* h_in_B, f
     // K4: synthesis + overlap-add + emit
     SCHK(h, apv_launch_istft_ola_strided(N, H, s->n_out, s->outspec, K, 1, s->outov, s->out, st, &why));
     SCHK(h, hipMemcpyAsync(h_out, s->out, sizeof(float) * (size_t)s->n_out * H, hipMemcpyDeviceToHost, st));
+    return APV_OK;
+}
+
+int apv_process_block(apv_handle* h, const float* h_in_A, const float* h_in_B, float* h_out) {
+    if (!h || !h_in_A || !h_in_B || !h_out) return apv_fail(h, APV_ERR_ARG, "null argument");
+    apv_stream* s = h->st;
+    if (!s) return apv_fail(h, APV_ERR_ARG, "apv_stream_init has not been called");
+    SCHK(h, hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    const int H = s->H, K = s->K;
+    const bool runA = s->zones & 1, runB = s->zones & 2;
+    std::memcpy(s->pin_in, h_in_A, sizeof(float) * H);
+    std::memcpy(s->pin_in + H, h_in_B, sizeof(float) * H);
+    if (s->period > 0) {
+        // replay the captured launch sequence of this phase; capture it the first time the phase comes up
+        const int phase = (int)(s->hop % s->period);
+        const int ring_before = s->ring_off, cur_before = s->cur;
+        if (!s->execs[phase]) {
+            hipGraph_t graph = nullptr;
+            SCHK(h, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            int rc = enqueue_hop(h);
+            hipError_t ce = hipStreamEndCapture(st, &graph);
+            if (rc != APV_OK || ce != hipSuccess) {
+                if (graph) (void)hipGraphDestroy(graph);
+                s->ring_off = ring_before;
+                s->cur = cur_before;
+                s->period = 0;                       // fall back to eager launches for good
+                rc = enqueue_hop(h);
+                if (rc != APV_OK) return rc;
+            } else {
+                SCHK(h, hipGraphInstantiate(&s->execs[phase], graph, nullptr, nullptr, 0));
+                (void)hipGraphDestroy(graph);
+                SCHK(h, hipGraphLaunch(s->execs[phase], st));
+            }
+        } else {
+            SCHK(h, hipGraphLaunch(s->execs[phase], st));
+            // the host-side cursor moves exactly as enqueue_hop moves it
+            s->cur ^= 1;
+            s->ring_off = (s->ring_off + H) % s->N;
+        }
+    } else {
+        int rc = enqueue_hop(h);
+        if (rc != APV_OK) return rc;
+    }
+    s->hop++;
     SCHK(h, hipStreamSynchronize(st));
+    std::memcpy(h_out, s->pin_out, sizeof(float) * (size_t)s->n_out * H);
     for (int z = 0; z < 2; ++z) {
         if (!(z ? runB : runA)) continue;
         for (int k = 0; k < K; ++k) {
-            const int v = s->h_status[(size_t)z * K + k];
+            const int v = s->pin_status[(size_t)z * K + k];
             if (v == 1) {
                 char buf[96];
                 std::snprintf(buf, sizeof(buf), "Matrix is not positive definite (zone %c, bin %d)", z ? 'B' : 'A', k);
@@ -288,6 +363,11 @@ int apv_stream_set_perceptual(apv_handle* h, int32_t n_channels, const double* h
     apv_stream* s = h->st;
     SCHK(h, hipSetDevice(h->device));
     SCHK(h, hipStreamSynchronize(h->stream));
+    // the captured launch sequences depend on whether the weighting is on
+    for (hipGraphExec_t& e : s->execs) {
+        if (e) (void)hipGraphExecDestroy(e);
+        e = nullptr;
+    }
     if (n_channels <= 0) {
         s->nch = 0;
         return APV_OK;

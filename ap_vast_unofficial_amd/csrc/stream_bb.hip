@@ -312,6 +312,7 @@ int apv_bb_init(apv_handle* h, int32_t rir_len, const double* h_rir_A, const dou
             tg[o + 1] = std::sin(ph);
         }
     BCHK(h, hipMemcpy(s->fspec + (size_t)nz * V * L * K * 2, tg.data(), sizeof(double) * tg.size(), hipMemcpyHostToDevice));
+    BCHK(h, apv_stft_prepare(N, 1));
     BCHK(h, hipStreamSynchronize(h->stream));
     return APV_OK;
 }
