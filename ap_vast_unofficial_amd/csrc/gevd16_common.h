@@ -147,13 +147,14 @@ template <typename T> __device__ __forceinline__ void xchg(Cx<T>& top, Cx<T>& bo
 
 // ---- cross-lane moves by XOR of the lane id, on the VALU (DPP) where the ISA allows it ----
 template <int D> __device__ __forceinline__ int dpp_xor_lo(int v);       // lane ^ D, D in {1,2,4} (within 8 lanes)
-template <> __device__ __forceinline__ int dpp_xor_lo<1>(int v) { return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false); }  // quad_perm [1,0,3,2]
-template <> __device__ __forceinline__ int dpp_xor_lo<2>(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false); }  // quad_perm [2,3,0,1]
+// full permutations: no `old` operand, so no copy in front of the DPP move
+template <> __device__ __forceinline__ int dpp_xor_lo<1>(int v) { return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, false); }  // quad_perm [1,0,3,2]
+template <> __device__ __forceinline__ int dpp_xor_lo<2>(int v) { return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, false); }  // quad_perm [2,3,0,1]
 template <> __device__ __forceinline__ int dpp_xor_lo<4>(int v) {
     const int t = __builtin_amdgcn_update_dpp(v, v, 0x104, 0xf, 0x5, false);      // row_shl:4 into banks 0,2
     return __builtin_amdgcn_update_dpp(t, v, 0x114, 0xf, 0xa, false);             // row_shr:4 into banks 1,3
 }
-__device__ __forceinline__ int dpp_xor8(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false); }  // row_ror:8
+__device__ __forceinline__ int dpp_xor8(int v) { return __builtin_amdgcn_mov_dpp(v, 0x128, 0xf, 0xf, false); }  // row_ror:8
 
 template <int D> __device__ __forceinline__ float xcol(float v) { return __int_as_float(dpp_xor_lo<D>(__float_as_int(v))); }
 template <int D> __device__ __forceinline__ double xcol(double v) {
@@ -161,11 +162,15 @@ template <int D> __device__ __forceinline__ double xcol(double v) {
 }
 template <int D> __device__ __forceinline__ float xrow(float v, int lane) {
     if constexpr (D == 1) return __int_as_float(dpp_xor8(__float_as_int(v)));
-    else return __shfl(v, lane ^ (8 * D), 64);
+    else return __int_as_float(__builtin_amdgcn_ds_bpermute((lane ^ (8 * D)) << 2, __float_as_int(v)));
 }
 template <int D> __device__ __forceinline__ double xrow(double v, int lane) {
     if constexpr (D == 1) return __hiloint2double(dpp_xor8(__double2hiint(v)), dpp_xor8(__double2loint(v)));
-    else return __shfl(v, lane ^ (8 * D), 64);
+    else {
+        const int addr = (lane ^ (8 * D)) << 2;
+        return __hiloint2double(__builtin_amdgcn_ds_bpermute(addr, __double2hiint(v)),
+                                __builtin_amdgcn_ds_bpermute(addr, __double2loint(v)));
+    }
 }
 template <int D, typename T> __device__ __forceinline__ Cx<T> cxcol(Cx<T> v) { return mk<T>(xcol<D>(v.x), xcol<D>(v.y)); }
 template <int D, typename T> __device__ __forceinline__ Cx<T> cxrow(Cx<T> v, int lane) { return mk<T>(xrow<D>(v.x, lane), xrow<D>(v.y, lane)); }
