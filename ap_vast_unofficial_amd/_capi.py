@@ -28,7 +28,7 @@ EXPORTS = (
     "apv_update_dev", "apv_update", "apv_corr_dev", "apv_corr_bf16_dev", "apv_to_bf16_dev", "apv_gevd_vast_dev", "apv_jdiag_batched", "apv_jdiag_large",
     "apv_stft_analysis_dev", "apv_istft_ola_dev",
     "apv_stream_init", "apv_stream_set_perceptual", "apv_process_block", "apv_state_bytes", "apv_get_state", "apv_set_state",
-    "apv_bb_init", "apv_bb_process_block", "apv_bb_get_state", "apv_bb_set_state",
+    "apv_bb_init", "apv_bb_set_perceptual", "apv_bb_process_block", "apv_bb_get_state", "apv_bb_set_state",
     "apv_predict_pressure", "apv_vast_static",
     "apv_comm_unique_id", "apv_comm_init", "apv_allgather_filters_dev",
 )
@@ -94,6 +94,7 @@ def load():
     lib.apv_get_state.argtypes = [vp, C.c_char_p, vp, sz]
     lib.apv_set_state.argtypes = [vp, C.c_char_p, vp, sz]
     lib.apv_bb_init.argtypes = [vp, i32, vp, vp, i32, i32, i32, i32, i32, i32]
+    lib.apv_bb_set_perceptual.argtypes = [vp, i32, vp, C.c_double, C.c_double, C.c_double, i32]
     lib.apv_bb_process_block.argtypes = [vp, vp, vp, vp]
     lib.apv_bb_get_state.argtypes = [vp, C.c_char_p, vp, sz]
     lib.apv_bb_set_state.argtypes = [vp, C.c_char_p, vp, sz]
@@ -399,6 +400,11 @@ class Engine:
         self._chk(self.lib.apv_bb_init(self.h, rir_A.shape[0], _ptr(rir_A), _ptr(rir_B), int(reference_index_A),
                                        int(reference_index_B), int(modeling_delay), int(filter_length),
                                        int(statistics_buffer_length), int(number_of_eigenvectors)))
+
+    def bb_set_perceptual(self, tables, normalisation):
+        G2 = np.ascontiguousarray(tables.G2, dtype=np.float64)
+        self._chk(self.lib.apv_bb_set_perceptual(self.h, G2.shape[1], _ptr(G2), float(tables.Cs), float(tables.Ca),
+                                                 float(tables.Leff), 1 if normalisation == "matlab" else 0))
 
     def bb_process_block(self, in_A, in_B, n_out):
         in_A = np.ascontiguousarray(in_A, dtype=np.float64).ravel()

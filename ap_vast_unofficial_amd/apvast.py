@@ -22,7 +22,7 @@ What is different (keyword-only, after ``perceptual``)
     golden outputs of the reference (tests/test_gpu_broadband.py).
   * outputs are fresh arrays (the reference returns views into its overlap buffers that the next
     call overwrites, apvast.py:500-504).
-  * ``perceptual=True`` (subband mode): the reference's Python class calls the third-party
+  * ``perceptual=True``: the reference's Python class calls the third-party
     ``libdetectability`` (apvast.py:4, 77-83), which it does not vendor; here the weighting is the van de Par
     masking model carried by the reference's MATLAB twin (perceptualModel.m), evaluated per block on the
     device.  Parity for it is unpinned (no MATLAB here).
@@ -118,10 +118,7 @@ class apvast:
             raise RuntimeError("block size must be modulo 2")                 # apvast.py:86-87
         if rir_A.shape != rir_B.shape:
             raise RuntimeError("rirs of unequal size")                        # apvast.py:89-90
-        if perceptual and mode == "broadband":
-            raise NotImplementedError(
-                "perceptual=True is implemented for mode='subband' (the masking model of the reference's MATLAB twin); "
-                "the Python reference delegates it to the un-vendored libdetectability (apvast.py:4, 77-83)")
+        self._fullscale_db_spl = fullscale_db_spl
         if mode not in ("subband", "broadband"):
             raise ValueError("mode must be 'subband' or 'broadband'")
         if dialect not in ("python", "matlab"):
@@ -186,6 +183,10 @@ class apvast:
         self._eng.bb_init(self.rir_A, self.rir_B, self.reference_index_A, self.reference_index_B, self.modeling_delay,
                           J, S, V)
         self._n_out = (int(self.run_A) + int(self.run_B)) * V * L + 2 * L
+        if self.perceptual:
+            from .perceptual import PerceptualTables
+            self.model = PerceptualTables(N, self.sampling_rate, self._fullscale_db_spl)
+            self._eng.bb_set_perceptual(self.model, "python")                 # apvast.py:322-324 normalisation
         rs = np.random if seed is None else np.random.RandomState(seed)      # apvast.py:124-129
         resp = [1e-3 * rs.randn(N, L, M) for _ in range(4)]
         tresp = [1e-3 * rs.randn(N, M) for _ in range(2)]

@@ -127,6 +127,10 @@ hipError_t apv_launch_fir_jobs(const FirJobs& jobs, int P, int H, int N, int rin
 hipError_t apv_launch_perceptual_weights(int K, int M, int nch, const float2* spec, const double* G2, const double* G2T,
                                          double Cs, double Ca, double Leff, int N, int norm_mode, float* W, hipStream_t s);
 hipError_t apv_launch_scale_spectra(int K, int C, int L, float2* spec, const float* W, hipStream_t s);
+hipError_t apv_launch_perceptual_weights_f64(int K, int M, int nch, const double2* spec, const double* G2,
+                                             const double* G2T, double Cs, double Ca, double Leff, int N, int norm_mode,
+                                             double* W, hipStream_t s);
+hipError_t apv_launch_scale_spectra_cm_f64(int K, int C, int L, double2* spec, const double* W, hipStream_t s);
 hipError_t apv_launch_hist_update(int P, int H, int pad, const float* old_hist, const float* x, float* new_hist,
                                   hipStream_t s);
 hipError_t apv_launch_ring_append(int N, int H, int ring_off, const float* x, float* ring, hipStream_t s);

@@ -140,18 +140,20 @@ __global__ void __launch_bounds__(256) ring_append_kernel(int N, int H, int ring
 // G2 [K][nch] and G2T [nch][K]: squared outer/middle-ear x gammatone responses.  Out: W [K][M] real weights.
 //   masker_i = sum_k G2[k][i] |sqrt(2)/N S[k]|^2;  w^2[k] = Cs Leff sum_i G2[k][i] / (masker_i + Ca)
 //   W = w / ||w||  over the K bins (norm_mode 0, apvast.py:322-324) or over the full symmetric curve (1)
-__global__ void __launch_bounds__(256) perceptual_weights_kernel(int K, int M, int nch, const float2* __restrict__ spec,
-                                                                 const double* __restrict__ G2,
+// spec element (k, m) at spec[k * s_k + m * s_m]; W element (k, m) at W[k * w_k + m * w_m]
+template <typename S2, typename WT>
+__global__ void __launch_bounds__(256) perceptual_weights_kernel(int K, int M, int nch, const S2* __restrict__ spec,
+                                                                 long s_k, long s_m, const double* __restrict__ G2,
                                                                  const double* __restrict__ G2T, double Cs, double Ca,
                                                                  double Leff, double fscale2, int norm_mode,
-                                                                 float* __restrict__ W) {
+                                                                 WT* __restrict__ W, long w_k, long w_m) {
     extern __shared__ double sm[];
     double* P2 = sm;               // [K]
     double* inv = sm + K;          // [nch]
     double* red = inv + nch;       // [256]
     const int m = blockIdx.x, tid = threadIdx.x;
     for (int k = tid; k < K; k += 256) {
-        const float2 v = spec[(size_t)k * M + m];
+        const S2 v = spec[(size_t)k * s_k + (size_t)m * s_m];
         P2[k] = fscale2 * ((double)v.x * v.x + (double)v.y * v.y);
     }
     __syncthreads();
@@ -184,7 +186,7 @@ __global__ void __launch_bounds__(256) perceptual_weights_kernel(int K, int M, i
         __syncthreads();
     }
     const double inorm = 1.0 / red[0];
-    for (int k = tid; k < K; k += 256) W[(size_t)k * M + m] = (float)sqrt(P2[k] * inorm);
+    for (int k = tid; k < K; k += 256) W[(size_t)k * w_k + (size_t)m * w_m] = (WT)sqrt(P2[k] * inorm);
 }
 
 // spec[k][c] *= W[k][c / L]   (bin-major c64; L = 1 scales the target spectra themselves)
@@ -195,6 +197,19 @@ __global__ void __launch_bounds__(256) scale_spectra_kernel(int K, int C, int L,
     const int k = (int)(idx / C), c = (int)(idx - (size_t)k * C);
     const float w = W[(size_t)k * (C / L) + c / L];
     float2 v = spec[idx];
+    v.x *= w;
+    v.y *= w;
+    spec[idx] = v;
+}
+
+// channel-major float64 form (broadband mode): spec[c][k] *= W[c / L][k]
+__global__ void __launch_bounds__(256) scale_spectra_cm_f64_kernel(int K, int C, int L, double2* __restrict__ spec,
+                                                                   const double* __restrict__ W) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)K * C) return;
+    const int c = (int)(idx / K), k = (int)(idx - (size_t)c * K);
+    const double w = W[(size_t)(c / L) * K + k];
+    double2 v = spec[idx];
     v.x *= w;
     v.y *= w;
     spec[idx] = v;
@@ -247,8 +262,24 @@ hipError_t apv_launch_fir_hop(int C, int P, int H, int N, int ring_off, const fl
 hipError_t apv_launch_perceptual_weights(int K, int M, int nch, const float2* spec, const double* G2, const double* G2T,
                                          double Cs, double Ca, double Leff, int N, int norm_mode, float* W, hipStream_t s) {
     const size_t lds = sizeof(double) * ((size_t)K + nch + 256);
-    hipLaunchKernelGGL(perceptual_weights_kernel, dim3(M), dim3(256), lds, s, K, M, nch, spec, G2, G2T, Cs, Ca, Leff,
-                       2.0 / ((double)N * (double)N), norm_mode, W);
+    hipLaunchKernelGGL((perceptual_weights_kernel<float2, float>), dim3(M), dim3(256), lds, s, K, M, nch, spec, (long)M, 1L,
+                       G2, G2T, Cs, Ca, Leff, 2.0 / ((double)N * (double)N), norm_mode, W, (long)M, 1L);
+    return hipGetLastError();
+}
+
+// float64, channel-major spectra [M][K] -> weights [M][K] (broadband mode)
+hipError_t apv_launch_perceptual_weights_f64(int K, int M, int nch, const double2* spec, const double* G2,
+                                             const double* G2T, double Cs, double Ca, double Leff, int N, int norm_mode,
+                                             double* W, hipStream_t s) {
+    const size_t lds = sizeof(double) * ((size_t)K + nch + 256);
+    hipLaunchKernelGGL((perceptual_weights_kernel<double2, double>), dim3(M), dim3(256), lds, s, K, M, nch, spec, 1L, (long)K,
+                       G2, G2T, Cs, Ca, Leff, 2.0 / ((double)N * (double)N), norm_mode, W, 1L, (long)K);
+    return hipGetLastError();
+}
+
+hipError_t apv_launch_scale_spectra_cm_f64(int K, int C, int L, double2* spec, const double* W, hipStream_t s) {
+    const size_t total = (size_t)K * C;
+    hipLaunchKernelGGL(scale_spectra_cm_f64_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, K, C, L, spec, W);
     return hipGetLastError();
 }
 

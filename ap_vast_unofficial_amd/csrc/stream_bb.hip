@@ -45,6 +45,13 @@ struct apv_bb {
     double* inspec;        // [2][K] c128
     double* outov;         // [n_out][N]
     double* out;           // [n_out][H]
+    // perceptual weighting (off when nch == 0)
+    int nch, norm_mode;
+    double Cs, Ca, Leff;
+    double* G2;            // [K][nch]
+    double* G2T;           // [nch][K]
+    double* tspec[2];      // [M][K] c128 target spectra (kept: the curves come from both zones before any scaling)
+    double* Wgt[2];        // [M][K]
 };
 
 namespace {
@@ -216,7 +223,7 @@ void apv_bb_free(apv_handle* h) {
                       s->xhist[1][1], s->xin, s->resp[0], s->resp[1], s->resp[2], s->resp[3], s->tresp[0], s->tresp[1],
                       s->inblk, s->spec, s->ov[0], s->ov[1], s->ov[2], s->ov[3], s->tov[0], s->tov[1], s->stats[0],
                       s->stats[1], s->stats[2], s->stats[3], s->tstats[0], s->tstats[1], s->R, s->r, s->U, s->lam, s->w,
-                      s->fspec, s->inspec, s->outov, s->out};
+                      s->fspec, s->inspec, s->outov, s->out, s->G2, s->G2T, s->tspec[0], s->tspec[1], s->Wgt[0], s->Wgt[1]};
     for (double* b : bufs)
         if (b) (void)hipFree(b);
     delete s;
@@ -291,6 +298,8 @@ int apv_bb_init(apv_handle* h, int32_t rir_len, const double* h_rir_A, const dou
     }
     const size_t spec_ch = (size_t)(C > s->n_out ? C : s->n_out);
     if ((rc = dalloc(h, &s->spec, spec_ch * K * 2))) return rc;
+    for (int z = 0; z < 2; ++z)
+        if ((rc = dalloc(h, &s->tspec[z], (size_t)M * K * 2))) return rc;
     if ((rc = dalloc(h, &s->inblk, (size_t)2 * N))) return rc;
     if ((rc = dalloc(h, &s->R, (size_t)4 * n * n))) return rc;
     if ((rc = dalloc(h, &s->r, (size_t)2 * n))) return rc;
@@ -345,11 +354,20 @@ int apv_bb_process_block(apv_handle* h, const double* h_in_A, const double* h_in
     for (int z = 0; z < 2; ++z)
         hipLaunchKernelGGL(fir_f64_kernel, tgd, dim3(64), 0, st, M, P, H, N, s->ring_off, s->trir[z],
                            s->xhist[s->cur][z], s->tresp[z]);
-    // 2: WOLA (unit weights, apvast.py:326-327) and append the finished hop to the statistics rings
+    // 2: WOLA (unit weights, apvast.py:326-327, or the perceptual curves) and append the finished hop to the statistics rings
     const bool runA = s->zones & 1, runB = s->zones & 2;
+    for (int z = 0; z < 2; ++z)
+        BCHK(h, apv_launch_analysis(1, N, M, s->tresp[z], N, N, s->ring_off, 1, s->tspec[z], K, 1, st, &why));
+    if (s->nch > 0) {
+        // curves from the unweighted target spectra of both zones (apvast.py:205), then the scaling (208-209)
+        for (int z = 0; z < 2; ++z)
+            BCHK(h, apv_launch_perceptual_weights_f64(K, M, s->nch, (const double2*)s->tspec[z], s->G2, s->G2T, s->Cs, s->Ca,
+                                                      s->Leff, N, s->norm_mode, s->Wgt[z], st));
+        for (int z = 0; z < 2; ++z)
+            BCHK(h, apv_launch_scale_spectra_cm_f64(K, M, 1, (double2*)s->tspec[z], s->Wgt[z], st));
+    }
     for (int z = 0; z < 2; ++z) {
-        BCHK(h, apv_launch_analysis(1, N, M, s->tresp[z], N, N, s->ring_off, 1, s->spec, K, 1, st, &why));
-        BCHK(h, apv_launch_synthesis(1, N, H, M, s->spec, K, 1, s->tov[z], nullptr, st, &why));
+        BCHK(h, apv_launch_synthesis(1, N, H, M, s->tspec[z], K, 1, s->tov[z], nullptr, st, &why));
         hipLaunchKernelGGL(ring_append_f64_kernel, dim3((H + 255) / 256, M), dim3(256), 0, st, S, H, s->stat_off,
                            s->tov[z], (long)N, s->tstats[z]);
     }
@@ -357,6 +375,8 @@ int apv_bb_process_block(apv_handle* h, const double* h_in_A, const double* h_in
         const bool live = (p == 0 || p == 1) ? runA : runB;      // A->A, A->B belong to zone program A
         if (live) {
             BCHK(h, apv_launch_analysis(1, N, C, s->resp[p], N, N, s->ring_off, 1, s->spec, K, 1, st, &why));
+            // A->A, B->A x zone A's curve; A->B, B->B x zone B's (apvast.py:258-262)
+            if (s->nch > 0) BCHK(h, apv_launch_scale_spectra_cm_f64(K, C, L, (double2*)s->spec, s->Wgt[path_zone(p)], st));
         } else {
             BCHK(h, hipMemsetAsync(s->spec, 0, sizeof(double) * 2 * (size_t)C * K, st));   // apvast.py:239-255: spectra stay 0
         }
@@ -412,6 +432,38 @@ int apv_bb_process_block(apv_handle* h, const double* h_in_A, const double* h_in
     BCHK(h, hipMemcpyAsync(h_out, s->out, sizeof(double) * (size_t)s->n_out * H, hipMemcpyDeviceToHost, st));
     BCHK(h, hipStreamSynchronize(st));
     BCHK(h, hipGetLastError());
+    return APV_OK;
+}
+
+// Perceptual weighting for the broadband stream (see apv_stream_set_perceptual).      replaces apvast.py:313-324
+int apv_bb_set_perceptual(apv_handle* h, int32_t n_channels, const double* h_G2, double Cs, double Ca, double Leff,
+                          int32_t normalisation) {
+    if (!h || !h->bb) return apv_fail(h, APV_ERR_ARG, "apv_bb_init has not been called");
+    apv_bb* s = h->bb;
+    BCHK(h, hipSetDevice(h->device));
+    BCHK(h, hipStreamSynchronize(h->stream));
+    if (n_channels <= 0) {
+        s->nch = 0;
+        return APV_OK;
+    }
+    if (!h_G2 || n_channels > 512 || (normalisation != 0 && normalisation != 1)) return apv_fail(h, APV_ERR_ARG, "bad perceptual tables");
+    const int K = s->K;
+    double* old[] = {s->G2, s->G2T, s->Wgt[0], s->Wgt[1]};
+    for (double* b : old)
+        if (b) (void)hipFree(b);
+    s->G2 = s->G2T = nullptr;
+    s->Wgt[0] = s->Wgt[1] = nullptr;
+    std::vector<double> gt((size_t)n_channels * K);
+    for (int k = 0; k < K; ++k)
+        for (int i = 0; i < n_channels; ++i) gt[(size_t)i * K + k] = h_G2[(size_t)k * n_channels + i];
+    int rc;
+    if ((rc = dalloc(h, &s->G2, (size_t)K * n_channels))) return rc;
+    if ((rc = dalloc(h, &s->G2T, (size_t)K * n_channels))) return rc;
+    for (int z = 0; z < 2; ++z)
+        if ((rc = dalloc(h, &s->Wgt[z], (size_t)K * s->M))) return rc;
+    BCHK(h, hipMemcpy(s->G2, h_G2, sizeof(double) * (size_t)K * n_channels, hipMemcpyHostToDevice));
+    BCHK(h, hipMemcpy(s->G2T, gt.data(), sizeof(double) * gt.size(), hipMemcpyHostToDevice));
+    s->nch = n_channels; s->Cs = Cs; s->Ca = Ca; s->Leff = Leff; s->norm_mode = normalisation;
     return APV_OK;
 }
 
@@ -516,6 +568,7 @@ static int bb_lookup(apv_handle* h, const char* name, double** d, size_t* count,
     if (nm == "lambda") { *d = s->lam; *count = (size_t)2 * s->n; return APV_OK; }
     if (nm == "w") { *d = s->w; *count = (size_t)2 * s->V * s->n; return APV_OK; }
     if (nm == "input_spectrum") { *d = s->inspec; *count = (size_t)2 * s->K * 2; return APV_OK; }
+    if ((q = idx("weights", 2)) >= 0 && s->nch > 0) { *d = s->Wgt[q]; *count = (size_t)s->M * s->K; return APV_OK; }
     return apv_fail(h, APV_ERR_STATE, std::string("unknown broadband state name: ") + name);
 }
 

@@ -189,6 +189,9 @@ int  apv_bb_init(apv_handle* h, int32_t rir_len, const double* h_rir_A, const do
 /* One hop (H float64 samples per signal).  h_out: [n_out][H] float64, channels as for apv_process_block with
  * nV = V.                                                 replaces process_input_buffers, apvast.py:153-165 */
 int  apv_bb_process_block(apv_handle* h, const double* h_in_A, const double* h_in_B, double* h_out);
+/* perceptual weighting for the broadband stream; arguments as for apv_stream_set_perceptual */
+int  apv_bb_set_perceptual(apv_handle* h, int32_t n_channels, const double* h_G2, double Cs, double Ca, double Leff,
+                           int32_t normalisation);
 /* float64 state arrays by name (stream_bb.hip); `count` = number of doubles */
 int  apv_bb_get_state(apv_handle* h, const char* name, double* h_dst, size_t count);
 int  apv_bb_set_state(apv_handle* h, const char* name, const double* h_src, size_t count);

@@ -57,9 +57,12 @@ class BroadbandOracle:
     def __init__(self, block_size, rir_A, rir_B, filter_length, modeling_delay,
                  reference_index_A, reference_index_B, number_of_eigenvectors, mu,
                  statistics_buffer_length, hop_size=None, sampling_rate=48000,
-                 run_A=True, run_B=True, perceptual=False):
-        if perceptual:
-            raise NotImplementedError("perceptual=True needs libdetectability (unpinned, absent)")
+                 run_A=True, run_B=True, perceptual=False, model=None):
+        # perceptual=True: `model` is an oracle.perceptual.Model (the MATLAB twin's masking model; the reference's
+        # Python class would call the absent libdetectability here -- unpinned)
+        if perceptual and model is None:
+            raise NotImplementedError("perceptual=True needs a model (libdetectability is unpinned and absent)")
+        self.model = model if perceptual else None
         if block_size % 2 != 0:
             raise RuntimeError("block size must be modulo 2")          # apvast.py:86-87
         if rir_A.shape != rir_B.shape:
@@ -116,10 +119,12 @@ class BroadbandOracle:
             self.target_response[z] = np.concatenate([self.target_response[z, H:], y])
 
     # ---- stages 2+3: apvast.py:197-311 (weights are all ones, 326-327) ----
-    def _wola(self, buf, overlap, stats):
+    def _wola(self, buf, overlap, stats, weights=None):
         N, H = self.N, self.H
         w = self.window.reshape((-1,) + (1,) * (buf.ndim - 1))
         spec = np.fft.rfft(w * buf, axis=0)
+        if weights is not None:                      # (K, M): last axis of buf is the microphone
+            spec = spec * (weights if buf.ndim == 2 else weights[:, None, :])
         new = w * np.fft.irfft(spec, N, axis=0)
         overlap[: N - H] = overlap[H:]
         overlap[N - H:] = 0.0
@@ -128,12 +133,19 @@ class BroadbandOracle:
         stats[self.S - H:] = overlap[:H]
 
     def _update_weighted(self):
+        wts = [None, None]
+        if self.model is not None:                   # apvast.py:313-324 with the MATLAB twin's model
+            for z in range(2):
+                tspec = np.fft.rfft(self.window[:, None] * self.target_response[z], axis=0)
+                wts[z] = np.stack([self.model.weights(tspec[:, m], "python") for m in range(self.M)], axis=1)
+            self.weights = wts
         for z in range(2):
-            self._wola(self.target_response[z], self.target_overlap[z], self.target_stats[z])
+            self._wola(self.target_response[z], self.target_overlap[z], self.target_stats[z], wts[z])
         active = ([AA, AB] if self.run_A else []) + ([BB, BA] if self.run_B else [])
+        zone_of = {AA: 0, AB: 1, BA: 0, BB: 1}       # apvast.py:259-262
         for p in range(4):
             if p in active:
-                self._wola(self.response[p], self.overlap[p], self.stats[p])
+                self._wola(self.response[p], self.overlap[p], self.stats[p], wts[zone_of[p]])
             else:
                 # apvast.py:244-311 still runs synthesis/append on zero spectra
                 self._wola(np.zeros_like(self.response[p]), self.overlap[p], self.stats[p])

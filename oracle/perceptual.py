@@ -41,12 +41,16 @@ class Model:
         k52, k70 = self.cr[i] ** 2 * S52 ** 2, self.cr[i] ** 2 * S70 ** 2
         g = lambda x: self.Leff * (k52 / (k70 + x * K)).sum() - 1 / x            # noqa: E731
         lo, hi = 0.1, 200.0 if g(200.0) >= 0 else 1000.0
-        for _ in range(200):
+        for _ in range(1000):                       # perceptualModel.m:91-107: stops at half-width 1e-6, not at convergence
             mid = 0.5 * (lo + hi)
-            if np.sign(g(mid)) == np.sign(g(lo)):
+            gm = g(mid)
+            stop = gm == 0 or (hi - lo) / 2 < 1e-6
+            if np.sign(gm) == np.sign(g(lo)):
                 lo = mid
             else:
                 hi = mid
+            if stop:
+                break
         self.Cs, self.Ca = mid, mid * K
         self.S52, self.S70, self.cal_bin = S52, S70, i
 

@@ -76,3 +76,30 @@ def test_g1b_single_zone_on_gpu(golden):
         assert np.abs(np.stack(out[3]) - g["out_Bt"][h]).max() <= 1e-9 * np.abs(g["out_Bt"][h]).max()
     assert np.abs(ap.lambda_A[:4] / g["lam"][:4] - 1).max() < 1e-8
     ap.close()
+
+
+def test_broadband_perceptual_vs_oracle(golden):
+    """perceptual=True in broadband mode: curves and the whole weighted chain against the oracle (unpinned model)."""
+    from ap_vast_unofficial_amd.apvast import apvast
+    from oracle.broadband import BroadbandOracle
+    from oracle.perceptual import Model
+    rirs = golden("rirs_cfg1")
+    rA, rB = rirs["rirA"][:, :4, :6], rirs["rirB"][:, :4, :6]
+    N, H, J, S, V = 256, 128, 16, 384, 3
+    ap = apvast(N, rA, rB, J, 8, 1, 2, V, 1.0, S, hop_size=H, sampling_rate=16000, perceptual=True, mode="broadband",
+                seed=4, fullscale_db_spl=100.0)
+    np.random.seed(4)
+    orc = BroadbandOracle(N, rA, rB, J, 8, 1, 2, V, 1.0, S, hop_size=H, sampling_rate=16000, perceptual=True,
+                          model=Model(N, 16000, 100.0))
+    x = np.random.default_rng(8).standard_normal((2, 5 * H))
+    for h in range(5):
+        got = ap.process_input_buffers(x[0, h * H:(h + 1) * H], x[1, h * H:(h + 1) * H])
+        exp = orc.process_input_buffers(x[0, h * H:(h + 1) * H], x[1, h * H:(h + 1) * H])
+        for z in range(2):
+            W = ap._eng.bb_get_state(f"weights{z}", (6, N // 2 + 1)).T
+            assert np.abs(W - orc.weights[z]).max() < 1e-9 * np.abs(orc.weights[z]).max()
+        for q in range(4):
+            e = exp[q]
+            assert np.abs(np.stack(got[q]) - e).max() <= 1e-7 * max(np.abs(e).max(), 1e-30), (h, q)
+    assert np.abs(ap.lambda_A[:V] / orc.lambda_A[:V] - 1).max() < 1e-8
+    ap.close()
