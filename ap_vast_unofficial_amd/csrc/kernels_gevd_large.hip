@@ -3,16 +3,22 @@
 //
 //   jdiag(A, B)   reference Python/apvast.py:20-36, called at apvast.py:380, 382 with n = J L
 //
-//   1  elimination on [B + reg I | I]: after n steps the left block holds the (unscaled) columns of the Cholesky
-//      factor and the right block W' with W = diag(1/sqrt d) W' = L^-1                         apvast.py:22-27
+//   1  B + reg I = L L^T               left-looking Cholesky in 32-wide column panels, one launch per panel; the
+//                                      32 x 32 diagonal block is eliminated on [D | I] in LDS, which also yields
+//                                      its inverse                                            apvast.py:22-27
+//      W = L^-1                        forward substitution on 32 x 32 tiles, one launch
 //   2  C = W A W^T                     two tiled GEMMs                                         apvast.py:28-29
-//   3  C = Q diag(lam) Q^T             cyclic Jacobi, round-robin order, one launch per round,
-//                                      matrices ping-pong between two buffers                  apvast.py:30
-//   4  rank of every eigenvalue (descending), X = W^T Q, columns gathered in that order         apvast.py:31-35
+//   3  C = Q diag(lam) Q^T             block cyclic Jacobi: the order is cut into 16-wide blocks, paired round-robin;
+//                                      one launch per block round.  A workgroup owns one 32 x 32 tile (P, Q) of the
+//                                      pair grid, re-derives the rotations of BOTH diagonal tiles it depends on with
+//                                      an in-LDS Jacobi sweep (redundant across the row/column of workgroups, but it
+//                                      removes every dependency inside the launch), and applies V_P^T . V_Q.
+//                                      X = W^T Q is accumulated in place by the same workgroups.    apvast.py:30-35
+//   4  rank of every eigenvalue (descending), columns of X gathered in that order               apvast.py:31-35
 //   5  (optional) w_v = sum_{i<v} (x_i^T r)/(lam_i + mu) x_i for v = 1..V                       apvast.py:406-414
 //
-// Launch-bound by construction (n + ~8(n-1) small launches); what it buys is the reference's own
-// broadband GEVD on the device, checked against fixture G1.
+// The sequential depth is what bounds a single n = 256 problem, not flops or bytes: ~8 sweeps x (n/16 - 1)
+// launches, each dominated by 16 (31 in the first round of a sweep) LDS-synchronised inner rounds.
 #include "apv_internal.h"
 
 #include <vector>
@@ -21,49 +27,166 @@ namespace {
 
 constexpr int TPB = 256;
 
-// ---- step 1 ---------------------------------------------------------------------------------------
-// one elimination step kk on the ne x ne working matrices (row-major, leading dimension ld)
-__global__ void __launch_bounds__(TPB) chol_inv_step_kernel(int n, int ld, int kk, double* __restrict__ B,
-                                                            double* __restrict__ W, double* __restrict__ dinv,
-                                                            int* __restrict__ flag, size_t mat_stride,
-                                                            size_t vec_stride) {
-    const int z = blockIdx.z;
-    B += z * mat_stride;
-    W += z * mat_stride;
-    dinv += z * vec_stride;
-    if (flag[z]) return;
-    const double d = B[(size_t)kk * ld + kk];
-    if (!(d > 0.0) || !(d < 1e300)) {
-        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) flag[z] = 1;
-        return;
-    }
-    const double inv2 = 1.0 / d;
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) dinv[kk] = 1.0 / sqrt(d);
-    // rows i > kk, all columns j: j in (kk, i] updates B, j <= kk updates W'
-    const int i = kk + 1 + blockIdx.y;
-    if (i >= n) return;
-    const double lik = B[(size_t)i * ld + kk];
-    for (int j = blockIdx.x * TPB + threadIdx.x; j <= i; j += gridDim.x * TPB) {
-        if (j > kk) B[(size_t)i * ld + j] -= lik * B[(size_t)j * ld + kk] * inv2;
-        else W[(size_t)i * ld + j] -= lik * W[(size_t)kk * ld + j] * inv2;
+constexpr int BT = 32;   // tile edge: two 16-wide Jacobi blocks, one Cholesky panel
+constexpr int BH = 16;
+constexpr int LS = 33;   // LDS row stride in doubles (bank-conflict padding)
+
+// 32 x 32 x 32 product from LDS tiles, 2 x 2 outputs per thread: o = {(ty,tx), (ty,tx+16), (ty+16,tx), (ty+16,tx+16)}
+// of sum_k A(t,k) B(k,u) with A(t,k) = TA ? A[k][t] : A[t][k], B(k,u) = TB ? B[u][k] : B[k][u]
+template <bool TA, bool TB>
+__device__ __forceinline__ void mm32(const double* A, const double* B, int ty, int tx, double (&o)[4]) {
+    o[0] = o[1] = o[2] = o[3] = 0.0;
+#pragma unroll 8
+    for (int k = 0; k < BT; ++k) {
+        const double a0 = TA ? A[k * LS + ty] : A[ty * LS + k];
+        const double a1 = TA ? A[k * LS + ty + 16] : A[(ty + 16) * LS + k];
+        const double b0 = TB ? B[tx * LS + k] : B[k * LS + tx];
+        const double b1 = TB ? B[(tx + 16) * LS + k] : B[k * LS + tx + 16];
+        o[0] += a0 * b0;
+        o[1] += a0 * b1;
+        o[2] += a1 * b0;
+        o[3] += a1 * b1;
     }
 }
 
-__global__ void __launch_bounds__(TPB) add_diag_kernel(int n, int ld, double* __restrict__ B, double reg, size_t mat_stride) {
+// ---- step 1 ---------------------------------------------------------------------------------------
+// Left-looking Cholesky, column panel k (32 wide); workgroup x handles the row tile I = k + x.  Every workgroup
+// forms the updated diagonal block D = B[K,K] - sum_J L[K,J] L[K,J]^T itself and eliminates [D | I] in LDS (unscaled
+// columns of L_D on the left, rows of L_D^-1 up to 1/sqrt(d) on the right), then writes L[I,K] = T L_D^-T.
+// B holds A's lower tiles being replaced by L; LiBuf[k] receives L_D^-1.
+__global__ void __launch_bounds__(256) chol_panel_kernel(int ld, int k, int nbk, double* __restrict__ B,
+                                                         double* __restrict__ LiBuf, int* __restrict__ flag,
+                                                         size_t mat_stride) {
+    __shared__ double La[BT * LS], Lb[BT * LS], Dm[BT * LS], Wp[BT * LS], rs[BT];
+    const int z = blockIdx.z;
+    if (flag[z]) return;
+    B += z * mat_stride;
+    LiBuf += (size_t)z * nbk * BT * BT;
+    const int I = k + blockIdx.x;
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    double accT[4] = {0.0, 0.0, 0.0, 0.0}, accD[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int J = 0; J < k; ++J) {
+        for (int e = tid; e < BT * BT; e += 256) {
+            const int t = e >> 5, u = e & 31;
+            La[t * LS + u] = B[(size_t)(I * BT + t) * ld + J * BT + u];
+            Lb[t * LS + u] = B[(size_t)(k * BT + t) * ld + J * BT + u];
+        }
+        __syncthreads();
+        double o[4];
+        mm32<false, true>(Lb, Lb, ty, tx, o);
+        for (int i = 0; i < 4; ++i) accD[i] -= o[i];
+        if (I != k) {
+            mm32<false, true>(La, Lb, ty, tx, o);
+            for (int i = 0; i < 4; ++i) accT[i] -= o[i];
+        }
+        __syncthreads();
+    }
+    for (int i = 0; i < 4; ++i) {
+        const int r = ty + ((i >> 1) << 4), c = tx + ((i & 1) << 4);
+        Dm[r * LS + c] = B[(size_t)(k * BT + r) * ld + k * BT + c] + accD[i];
+        if (I != k) La[r * LS + c] = B[(size_t)(I * BT + r) * ld + k * BT + c] + accT[i];
+        Wp[r * LS + c] = (r == c) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    for (int j = 0; j < BT; ++j) {
+        const double d = Dm[j * LS + j];
+        if (!(d > 0.0) || !(d < 1e300)) {          // the same value in every workgroup of the panel: all leave
+            if (tid == 0 && blockIdx.x == 0) flag[z] = 1;
+            return;
+        }
+        const double inv = 1.0 / d;
+        for (int i = 0; i < 4; ++i) {
+            const int r = ty + ((i >> 1) << 4), c = tx + ((i & 1) << 4);
+            if (r > j) {
+                const double lik = Dm[r * LS + j] * inv;
+                if (c > j) {
+                    if (c <= r) Dm[r * LS + c] -= lik * Dm[c * LS + j];
+                } else {
+                    Wp[r * LS + c] -= lik * Wp[j * LS + c];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (tid < BT) rs[tid] = 1.0 / sqrt(Dm[tid * LS + tid]);
+    __syncthreads();
+    for (int i = 0; i < 4; ++i) {
+        const int r = ty + ((i >> 1) << 4), c = tx + ((i & 1) << 4);
+        Wp[r * LS + c] *= rs[r];                                   // L_D^-1 (lower)
+    }
+    if (I == k) {
+        for (int i = 0; i < 4; ++i) {
+            const int r = ty + ((i >> 1) << 4), c = tx + ((i & 1) << 4);
+            B[(size_t)(k * BT + r) * ld + k * BT + c] = (c <= r) ? Dm[r * LS + c] * rs[c] : 0.0;
+            LiBuf[(size_t)k * BT * BT + r * BT + c] = Wp[r * LS + c];
+        }
+        return;
+    }
+    __syncthreads();
+    double o[4];
+    mm32<false, true>(La, Wp, ty, tx, o);                          // T L_D^-T
+    for (int i = 0; i < 4; ++i) {
+        const int r = ty + ((i >> 1) << 4), c = tx + ((i & 1) << 4);
+        B[(size_t)(I * BT + r) * ld + k * BT + c] = o[i];
+    }
+}
+
+// W = L^-1 by forward substitution on tiles: workgroup (K, cq) owns 8 columns of block column K and walks down
+// the block rows; the tiles it wrote are re-read through global memory after a workgroup barrier.
+__global__ void __launch_bounds__(256) tri_inverse_kernel(int ld, int nbk, const double* __restrict__ Lm,
+                                                          const double* __restrict__ LiBuf, double* W,
+                                                          const int* __restrict__ flag, size_t mat_stride) {
+    __shared__ double Lt[BT * LS], Li[BT * LS], Wt[BT * 8], Acc[BT * 8];
+    const int z = blockIdx.z;
+    if (flag[z]) return;
+    Lm += z * mat_stride;
+    W += z * mat_stride;
+    LiBuf += (size_t)z * nbk * BT * BT;
+    const int K = blockIdx.x, cq = blockIdx.y;
+    const int tid = threadIdx.x, t = tid >> 3, u = tid & 7, c = cq * 8 + u;
+    for (int I = K; I < nbk; ++I) {
+        for (int e = tid; e < BT * BT; e += 256) Li[(e >> 5) * LS + (e & 31)] = LiBuf[(size_t)I * BT * BT + e];
+        double acc = 0.0;
+        for (int J = K; J < I; ++J) {
+            __syncthreads();
+            for (int e = tid; e < BT * BT; e += 256) Lt[(e >> 5) * LS + (e & 31)] = Lm[(size_t)(I * BT + (e >> 5)) * ld + J * BT + (e & 31)];
+            Wt[t * 8 + u] = W[(size_t)(J * BT + t) * ld + K * BT + c];
+            __syncthreads();
+#pragma unroll 8
+            for (int m = 0; m < BT; ++m) acc += Lt[t * LS + m] * Wt[m * 8 + u];
+        }
+        double val;
+        if (I == K) {
+            __syncthreads();
+            val = Li[t * LS + c];
+        } else {
+            Acc[t * 8 + u] = acc;
+            __syncthreads();
+            val = 0.0;
+#pragma unroll 8
+            for (int m = 0; m < BT; ++m) val -= Li[t * LS + m] * Acc[m * 8 + u];
+        }
+        W[(size_t)(I * BT + t) * ld + K * BT + c] = val;
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+// B += reg on the diagonal; the ghost rows of the padding get a unit diagonal so that the factorisation runs through
+__global__ void __launch_bounds__(TPB) add_diag_kernel(int n, int ne, int ld, double* __restrict__ B, double reg, size_t mat_stride) {
     B += blockIdx.z * mat_stride;
     const int i = blockIdx.x * TPB + threadIdx.x;
     if (i < n) B[(size_t)i * ld + i] += reg;
+    else if (i < ne) B[(size_t)i * ld + i] = 1.0;
 }
 
-__global__ void __launch_bounds__(TPB) scale_rows_kernel(int n, int ld, double* __restrict__ W,
-                                                         const double* __restrict__ dinv, size_t mat_stride,
-                                                         size_t vec_stride) {
-    const int z = blockIdx.z;
-    W += z * mat_stride;
-    dinv += z * vec_stride;
+// X = W^T
+__global__ void __launch_bounds__(TPB) transpose_kernel(int n, int ld, const double* __restrict__ W, double* __restrict__ X,
+                                                        size_t mat_stride) {
+    W += blockIdx.z * mat_stride;
+    X += blockIdx.z * mat_stride;
     const int i = blockIdx.y;
-    const double s = dinv[i];
-    for (int j = blockIdx.x * TPB + threadIdx.x; j < n; j += gridDim.x * TPB) W[(size_t)i * ld + j] *= s;
+    for (int j = blockIdx.x * TPB + threadIdx.x; j < n; j += gridDim.x * TPB) X[(size_t)i * ld + j] = W[(size_t)j * ld + i];
 }
 
 // ---- step 2: C = op(A) op(B), 16x16 tiles ---------------------------------------------------------
@@ -101,12 +224,6 @@ __global__ void __launch_bounds__(TPB) symmetrise_kernel(int n, int ld, double* 
     }
 }
 
-__global__ void __launch_bounds__(TPB) set_identity_kernel(int ne, int ld, double* __restrict__ V, size_t mat_stride) {
-    V += blockIdx.z * mat_stride;
-    const int i = blockIdx.y;
-    for (int j = blockIdx.x * TPB + threadIdx.x; j < ne; j += gridDim.x * TPB) V[(size_t)i * ld + j] = (i == j) ? 1.0 : 0.0;
-}
-
 // ---- step 3 ---------------------------------------------------------------------------------------
 __device__ __forceinline__ void rr_pair(int ne, int r, int a, int& p, int& q) {
     const int m1 = ne - 1;
@@ -128,51 +245,145 @@ __device__ __forceinline__ void sym_rotation(double alpha, double gamma, double 
     }
 }
 
-// one round: thread (a, b) owns rows {p_a, q_a} x columns {p_b, q_b} of C and rows {2a, 2a+1} x the same
-// columns of V; everything is read from `cur` and written to `nxt`, so no ordering is needed inside the launch
-__global__ void __launch_bounds__(TPB) jacobi_round_kernel(int n, int ne, int ld, int round,
-                                                           const double* __restrict__ Ccur, double* __restrict__ Cnxt,
-                                                           const double* __restrict__ Vcur, double* __restrict__ Vnxt,
-                                                           double* __restrict__ off, size_t mat_stride) {
+__device__ __forceinline__ int tile_index(int I, int J, int t) { return t < BH ? I * BH + t : J * BH + t - BH; }
+
+// One block round.  Tile (P, Q), P <= Q, of the pair grid: rows = the two 16-blocks of pair P, columns = those of
+// pair Q.  The workgroup runs the inner sweep on the diagonal tiles (P, P) and (Q, Q) side by side -- thread (a, b)
+// owns the 2 x 2 block rows {p_a, q_a} x columns {p_b, q_b} of each and rows {2a, 2a+1} of the accumulated rotation
+// V -- then writes V_P^T C[P,Q] V_Q (and its transpose) to the other buffer and rotates its two tiles of X in place.
+// `full`: the inner sweep visits all 496 pairs of the 32 indices (first round of a sweep: that is where the pairs
+// inside one 16-block are annihilated); otherwise only the 256 pairs across the two blocks, in 16 rounds.
+__global__ void __launch_bounds__(256) block_jacobi_round_kernel(int ld, int nb, int round, int full,
+                                                                 const double* __restrict__ Cin, double* __restrict__ Cout,
+                                                                 double* __restrict__ X, double* __restrict__ off,
+                                                                 size_t mat_stride) {
+    __shared__ double sm[6 * BT * LS];
+    __shared__ double2 rot[2][BH];
+    double *SP = sm, *SQ = sm + BT * LS, *VP = sm + 2 * BT * LS, *VQ = sm + 3 * BT * LS, *T = sm + 4 * BT * LS,
+           *U = sm + 5 * BT * LS;
     const int z = blockIdx.z;
-    Ccur += z * mat_stride; Cnxt += z * mat_stride; Vcur += z * mat_stride; Vnxt += z * mat_stride;
-    const int np = ne / 2;
-    const int idx = blockIdx.x * TPB + threadIdx.x;
-    if (idx >= np * np) return;
-    const int a = idx / np, b = idx - a * np;
-    int pa, qa, pb, qb;
-    rr_pair(ne, round, a, pa, qa);
-    rr_pair(ne, round, b, pb, qb);
-    double ca, sa, cb, sb;
-    // an index >= n is the bye of an odd order: identity rotation, zero ghost row/column
-    if (qa < n) sym_rotation(Ccur[(size_t)pa * ld + pa], Ccur[(size_t)qa * ld + qa], Ccur[(size_t)pa * ld + qa], ca, sa);
-    else { ca = 1.0; sa = 0.0; }
-    if (qb < n) sym_rotation(Ccur[(size_t)pb * ld + pb], Ccur[(size_t)qb * ld + qb], Ccur[(size_t)pb * ld + qb], cb, sb);
-    else { cb = 1.0; sb = 0.0; }
-    const double xpp = Ccur[(size_t)pa * ld + pb], xpq = Ccur[(size_t)pa * ld + qb];
-    const double xqp = Ccur[(size_t)qa * ld + pb], xqq = Ccur[(size_t)qa * ld + qb];
-    // columns: [x_p, x_q] J_b, J = [[c, s], [-s, c]]
-    const double ypp = cb * xpp - sb * xpq, ypq = sb * xpp + cb * xpq;
-    const double yqp = cb * xqp - sb * xqq, yqq = sb * xqp + cb * xqq;
-    // rows: J_a^T [y_p; y_q]
-    double zpp = ca * ypp - sa * yqp, zpq = ca * ypq - sa * yqq;
-    double zqp = sa * ypp + ca * yqp, zqq = sa * ypq + ca * yqq;
-    if (a == b) {
-        if (qa < n) atomicAdd(off + z, xpq * xpq);
-        zpq = 0.0;
-        zqp = 0.0;
+    Cin += z * mat_stride;
+    Cout += z * mat_stride;
+    X += z * mat_stride;
+    const int np = nb / 2;
+    int P = 0, rem = blockIdx.x;
+    while (rem >= np - P) {
+        rem -= np - P;
+        ++P;
     }
-    Cnxt[(size_t)pa * ld + pb] = zpp;
-    Cnxt[(size_t)pa * ld + qb] = zpq;
-    Cnxt[(size_t)qa * ld + pb] = zqp;
-    Cnxt[(size_t)qa * ld + qb] = zqq;
-    const int r0 = 2 * a, r1 = 2 * a + 1;
-    const double v0p = Vcur[(size_t)r0 * ld + pb], v0q = Vcur[(size_t)r0 * ld + qb];
-    const double v1p = Vcur[(size_t)r1 * ld + pb], v1q = Vcur[(size_t)r1 * ld + qb];
-    Vnxt[(size_t)r0 * ld + pb] = cb * v0p - sb * v0q;
-    Vnxt[(size_t)r0 * ld + qb] = sb * v0p + cb * v0q;
-    Vnxt[(size_t)r1 * ld + pb] = cb * v1p - sb * v1q;
-    Vnxt[(size_t)r1 * ld + qb] = sb * v1p + cb * v1q;
+    const int Q = P + rem;
+    const bool diag = P == Q;
+    int IP, JP, IQ, JQ;
+    rr_pair(nb, round, P, IP, JP);
+    rr_pair(nb, round, Q, IQ, JQ);
+    const int tid = threadIdx.x, a = tid >> 4, b = tid & 15;
+    for (int e = tid; e < BT * BT; e += 256) {
+        const int t = e >> 5, u = e & 31;
+        const size_t gr = (size_t)tile_index(IP, JP, t) * ld;
+        SP[t * LS + u] = Cin[gr + tile_index(IP, JP, u)];
+        VP[t * LS + u] = (t == u) ? 1.0 : 0.0;
+        if (!diag) {
+            SQ[t * LS + u] = Cin[(size_t)tile_index(IQ, JQ, t) * ld + tile_index(IQ, JQ, u)];
+            T[t * LS + u] = Cin[gr + tile_index(IQ, JQ, u)];
+            VQ[t * LS + u] = (t == u) ? 1.0 : 0.0;
+        }
+    }
+    __syncthreads();
+    // ---- inner sweep -------------------------------------------------------------------------------
+    const int nm = diag ? 1 : 2;
+    const int inner_rounds = full ? BT - 1 : BH;
+    const int mrot = (b == a) ? 0 : ((b == (a ^ 1)) ? 1 : 2);      // which matrix's rotation of pair a this thread derives
+    double offacc = 0.0;
+    for (int t = 0; t < inner_rounds; ++t) {
+        int pa, qa, pb, qb;
+        if (full) {
+            rr_pair(BT, t, a, pa, qa);
+            rr_pair(BT, t, b, pb, qb);
+        } else {
+            pa = a;
+            qa = BH + ((a + t) & 15);
+            pb = b;
+            qb = BH + ((b + t) & 15);
+        }
+        if (mrot < nm) {
+            const double* S = mrot ? SQ : SP;
+            const double beta = S[pa * LS + qa];
+            double c, s;
+            sym_rotation(S[pa * LS + pa], S[qa * LS + qa], beta, c, s);
+            rot[mrot][a] = make_double2(c, s);
+            if (mrot == 0) offacc += beta * beta;
+        }
+        __syncthreads();
+        for (int m = 0; m < nm; ++m) {
+            double* S = m ? SQ : SP;
+            double* V = m ? VQ : VP;
+            const double2 ra = rot[m][a], rb = rot[m][b];
+            const double ca = ra.x, sa = ra.y, cb = rb.x, sb = rb.y;
+            const double xpp = S[pa * LS + pb], xpq = S[pa * LS + qb], xqp = S[qa * LS + pb], xqq = S[qa * LS + qb];
+            // columns: [x_p, x_q] J_b, J = [[c, s], [-s, c]]; rows: J_a^T [y_p; y_q]
+            const double ypp = cb * xpp - sb * xpq, ypq = sb * xpp + cb * xpq;
+            const double yqp = cb * xqp - sb * xqq, yqq = sb * xqp + cb * xqq;
+            double zpq = ca * ypq - sa * yqq, zqp = sa * ypp + ca * yqp;
+            if (a == b) zpq = zqp = 0.0;
+            S[pa * LS + pb] = ca * ypp - sa * yqp;
+            S[pa * LS + qb] = zpq;
+            S[qa * LS + pb] = zqp;
+            S[qa * LS + qb] = sa * ypq + ca * yqq;
+            const int r0 = 2 * a, r1 = 2 * a + 1;
+            const double v0p = V[r0 * LS + pb], v0q = V[r0 * LS + qb], v1p = V[r1 * LS + pb], v1q = V[r1 * LS + qb];
+            V[r0 * LS + pb] = cb * v0p - sb * v0q;
+            V[r0 * LS + qb] = sb * v0p + cb * v0q;
+            V[r1 * LS + pb] = cb * v1p - sb * v1q;
+            V[r1 * LS + qb] = sb * v1p + cb * v1q;
+        }
+        __syncthreads();
+    }
+    // ---- outer update --------------------------------------------------------------------------------
+    const int ty = a, tx = b;
+    double o[4];
+    if (diag) {
+        if (offacc != 0.0) atomicAdd(off + z, offacc);
+        for (int e = tid; e < BT * BT; e += 256) {
+            const int t = e >> 5, u = e & 31;
+            Cout[(size_t)tile_index(IP, JP, t) * ld + tile_index(IP, JP, u)] = SP[t * LS + u];
+            T[t * LS + u] = X[(size_t)(P * BT + t) * ld + tile_index(IP, JP, u)];
+        }
+        __syncthreads();
+        mm32<false, false>(T, VP, ty, tx, o);
+        for (int i = 0; i < 4; ++i) {
+            const int r = ty + ((i >> 1) << 4), c = tx + ((i & 1) << 4);
+            X[(size_t)(P * BT + r) * ld + tile_index(IP, JP, c)] = o[i];
+        }
+        return;
+    }
+    mm32<false, false>(T, VQ, ty, tx, o);                          // U = C[P,Q] V_Q
+    for (int i = 0; i < 4; ++i) U[(ty + ((i >> 1) << 4)) * LS + tx + ((i & 1) << 4)] = o[i];
+    // the rotated diagonal tiles are not needed here any more: their buffers take the X tiles
+    for (int e = tid; e < BT * BT; e += 256) {
+        const int t = e >> 5, u = e & 31;
+        SP[t * LS + u] = X[(size_t)(Q * BT + t) * ld + tile_index(IP, JP, u)];
+        SQ[t * LS + u] = X[(size_t)(P * BT + t) * ld + tile_index(IQ, JQ, u)];
+    }
+    __syncthreads();
+    mm32<true, false>(VP, U, ty, tx, o);                           // V_P^T U
+    for (int i = 0; i < 4; ++i) {
+        const int r = ty + ((i >> 1) << 4), c = tx + ((i & 1) << 4);
+        Cout[(size_t)tile_index(IP, JP, r) * ld + tile_index(IQ, JQ, c)] = o[i];
+        T[r * LS + c] = o[i];                                       // every thread is past its reads of T
+    }
+    double x1[4], x2[4];
+    mm32<false, false>(SP, VP, ty, tx, x1);
+    mm32<false, false>(SQ, VQ, ty, tx, x2);
+    for (int i = 0; i < 4; ++i) {
+        const int r = ty + ((i >> 1) << 4), c = tx + ((i & 1) << 4);
+        X[(size_t)(Q * BT + r) * ld + tile_index(IP, JP, c)] = x1[i];
+        X[(size_t)(P * BT + r) * ld + tile_index(IQ, JQ, c)] = x2[i];
+    }
+    __syncthreads();
+    for (int e = tid; e < BT * BT; e += 256) {                     // the mirrored tile, coalesced
+        const int t = e >> 5, u = e & 31;
+        Cout[(size_t)tile_index(IQ, JQ, t) * ld + tile_index(IP, JP, u)] = T[u * LS + t];
+    }
 }
 
 __global__ void __launch_bounds__(TPB) frob2_kernel(int n, int ld, const double* __restrict__ C, double* __restrict__ out,
@@ -259,15 +470,15 @@ __global__ void __launch_bounds__(TPB) vast_prefix_kernel(int n, int V, const do
 // Workspace + captured two-sweep graph, cached on the handle (sizes rarely change between hops).
 struct GevdLargeWs {
     int n = 0, batch = 0;
-    double *Bw = nullptr, *W = nullptr, *T1 = nullptr, *C0 = nullptr, *C1 = nullptr, *V0 = nullptr, *V1 = nullptr;
-    double *dinv = nullptr, *acc = nullptr, *coef = nullptr;
+    double *Bw = nullptr, *W = nullptr, *T1 = nullptr, *C0 = nullptr, *C1 = nullptr, *X = nullptr, *Li = nullptr;
+    double *acc = nullptr, *coef = nullptr;
     int *flag = nullptr, *order = nullptr;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     void release() {
         if (exec) (void)hipGraphExecDestroy(exec);
         if (graph) (void)hipGraphDestroy(graph);
-        void* bufs[] = {Bw, W, T1, C0, C1, V0, V1, dinv, acc, coef, flag, order};
+        void* bufs[] = {Bw, W, T1, C0, C1, X, Li, acc, coef, flag, order};
         for (void* b : bufs)
             if (b) (void)hipFree(b);
         *this = GevdLargeWs();
@@ -288,7 +499,8 @@ void apv_gevd_large_free(apv_handle* h) {
 int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const double* d_B, double reg, double* d_U,
                    double* d_lam, const double* d_r, double mu, int V, double* d_w, int32_t* h_status) {
     hipStream_t st = h->stream;
-    const int ne = n + (n & 1), ld = ne;
+    const int ne = (n + BT - 1) / BT * BT, ld = ne;          // padded with ghost rows/columns: zero in A and C, unit in B
+    const int nbk = ne / BT, nb = ne / BH, np = nb / 2, rounds = nb - 1;
     const size_t ms = (size_t)ne * ne, vs = (size_t)ne;
 #define LCHK(call)                                                                                   \
     do {                                                                                             \
@@ -299,62 +511,53 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
     GevdLargeWs& ws = *static_cast<GevdLargeWs*>(h->gl_ws);
     const size_t mb = sizeof(double) * ms * batch;
     const int gx = (ne + TPB - 1) / TPB;
-    const int np = ne / 2, rounds = ne - 1;
-    const int jb = (np * np + TPB - 1) / TPB;
+    const int tiles = np * (np + 1) / 2;
     if (ws.n != n || ws.batch != batch) {
         ws.release();
         ws.n = n;
         ws.batch = batch;
         LCHK(hipMalloc((void**)&ws.Bw, mb)); LCHK(hipMalloc((void**)&ws.W, mb)); LCHK(hipMalloc((void**)&ws.T1, mb));
-        LCHK(hipMalloc((void**)&ws.C0, mb)); LCHK(hipMalloc((void**)&ws.C1, mb));
-        LCHK(hipMalloc((void**)&ws.V0, mb)); LCHK(hipMalloc((void**)&ws.V1, mb));
-        LCHK(hipMalloc((void**)&ws.dinv, sizeof(double) * vs * batch));
+        LCHK(hipMalloc((void**)&ws.C0, mb)); LCHK(hipMalloc((void**)&ws.C1, mb)); LCHK(hipMalloc((void**)&ws.X, mb));
+        LCHK(hipMalloc((void**)&ws.Li, sizeof(double) * BT * BT * nbk * batch));
         LCHK(hipMalloc((void**)&ws.acc, sizeof(double) * 3 * batch));         // [sweep a | sweep b | ||C||_F^2]
         LCHK(hipMalloc((void**)&ws.coef, sizeof(double) * vs * batch));
         LCHK(hipMalloc((void**)&ws.flag, sizeof(int) * batch));
         LCHK(hipMalloc((void**)&ws.order, sizeof(int) * vs * batch));
-        // two sweeps as one graph: 2 (ne - 1) rounds bring the ping-pong buffers back to where they started
-        if (n > 1) {
-            LCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-            LCHK(hipMemsetAsync(ws.acc, 0, sizeof(double) * 2 * batch, st));
-            double *Cc = ws.C0, *Cn = ws.C1, *Vc = ws.V0, *Vn = ws.V1;
-            for (int sw = 0; sw < 2; ++sw)
-                for (int r = 0; r < rounds; ++r) {
-                    hipLaunchKernelGGL(jacobi_round_kernel, dim3(jb, 1, batch), dim3(TPB), 0, st, n, ne, ld, r, Cc, Cn, Vc, Vn,
-                                       ws.acc + (size_t)sw * batch, ms);
-                    double* t = Cc; Cc = Cn; Cn = t;
-                    t = Vc; Vc = Vn; Vn = t;
-                }
-            LCHK(hipStreamEndCapture(st, &ws.graph));
-            LCHK(hipGraphInstantiate(&ws.exec, ws.graph, nullptr, nullptr, 0));
-        }
+        // two sweeps as one graph: 2 (nb - 1) block rounds bring the ping-pong buffers back to where they started
+        LCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        LCHK(hipMemsetAsync(ws.acc, 0, sizeof(double) * 2 * batch, st));
+        double *Cc = ws.C0, *Cn = ws.C1;
+        for (int sw = 0; sw < 2; ++sw)
+            for (int r = 0; r < rounds; ++r) {
+                hipLaunchKernelGGL(block_jacobi_round_kernel, dim3(tiles, 1, batch), dim3(256), 0, st, ld, nb, r, r == 0 ? 1 : 0,
+                                   Cc, Cn, ws.X, ws.acc + (size_t)sw * batch, ms);
+                double* t = Cc; Cc = Cn; Cn = t;
+            }
+        LCHK(hipStreamEndCapture(st, &ws.graph));
+        LCHK(hipGraphInstantiate(&ws.exec, ws.graph, nullptr, nullptr, 0));
     }
     LCHK(hipMemsetAsync(ws.Bw, 0, mb, st));
+    LCHK(hipMemsetAsync(ws.W, 0, mb, st));
     LCHK(hipMemsetAsync(ws.C0, 0, mb, st));
     LCHK(hipMemsetAsync(ws.C1, 0, mb, st));
-    LCHK(hipMemsetAsync(ws.V1, 0, mb, st));
+    LCHK(hipMemsetAsync(ws.X, 0, mb, st));
     LCHK(hipMemsetAsync(ws.flag, 0, sizeof(int) * batch, st));
     LCHK(hipMemsetAsync(ws.acc, 0, sizeof(double) * 3 * batch, st));
-    // working copies with leading dimension ld (ghost row/column of an odd order stay zero)
     for (int z = 0; z < batch; ++z) {
         LCHK(hipMemcpy2DAsync(ws.Bw + z * ms, sizeof(double) * ld, d_B + (size_t)z * n * n, sizeof(double) * n,
                               sizeof(double) * n, n, hipMemcpyDeviceToDevice, st));
         LCHK(hipMemcpy2DAsync(ws.C0 + z * ms, sizeof(double) * ld, d_A + (size_t)z * n * n, sizeof(double) * n,
                               sizeof(double) * n, n, hipMemcpyDeviceToDevice, st));      // C0 holds A for now
     }
-    hipLaunchKernelGGL(set_identity_kernel, dim3(gx, ne, batch), dim3(TPB), 0, st, ne, ld, ws.W, ms);
-    hipLaunchKernelGGL(add_diag_kernel, dim3(gx, 1, batch), dim3(TPB), 0, st, n, ld, ws.Bw, reg, ms);      // apvast.py:24
-    for (int kk = 0; kk < n; ++kk) {
-        const int rows = n - kk - 1;
-        hipLaunchKernelGGL(chol_inv_step_kernel, dim3(gx, rows > 0 ? rows : 1, batch), dim3(TPB), 0, st, n, ld, kk, ws.Bw,
-                           ws.W, ws.dinv, ws.flag, ms, vs);
-    }
-    hipLaunchKernelGGL(scale_rows_kernel, dim3(gx, n, batch), dim3(TPB), 0, st, n, ld, ws.W, ws.dinv, ms, vs);
+    hipLaunchKernelGGL(add_diag_kernel, dim3(gx, 1, batch), dim3(TPB), 0, st, n, ne, ld, ws.Bw, reg, ms);      // apvast.py:24
+    for (int k = 0; k < nbk; ++k)
+        hipLaunchKernelGGL(chol_panel_kernel, dim3(nbk - k, 1, batch), dim3(256), 0, st, ld, k, nbk, ws.Bw, ws.Li, ws.flag, ms);
+    hipLaunchKernelGGL(tri_inverse_kernel, dim3(nbk, BT / 8, batch), dim3(256), 0, st, ld, nbk, ws.Bw, ws.Li, ws.W, ws.flag, ms);
     const dim3 gg((n + 15) / 16, (n + 15) / 16, batch);
     hipLaunchKernelGGL((gemm_kernel<false, false>), gg, dim3(256), 0, st, n, ld, ws.W, ws.C0, ws.T1, ms);     // T1 = W A
     hipLaunchKernelGGL((gemm_kernel<false, true>), gg, dim3(256), 0, st, n, ld, ws.T1, ws.W, ws.C0, ms);      // C = T1 W^T
     hipLaunchKernelGGL(symmetrise_kernel, dim3(gx, n, batch), dim3(TPB), 0, st, n, ld, ws.C0, ms);
-    hipLaunchKernelGGL(set_identity_kernel, dim3(gx, ne, batch), dim3(TPB), 0, st, ne, ld, ws.V0, ms);
+    hipLaunchKernelGGL(transpose_kernel, dim3(gx, n, batch), dim3(TPB), 0, st, n, ld, ws.W, ws.X, ms);         // X = W^T Q, Q = I
     hipLaunchKernelGGL(frob2_kernel, dim3(64, 1, batch), dim3(TPB), 0, st, n, ld, ws.C0, ws.acc + 2 * batch, ms);
     std::vector<int> hflag(batch, 0);
     std::vector<double> hacc(3 * batch, 0.0);
@@ -366,24 +569,27 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
         h_status[z] = hflag[z] ? 1 : 0;
         any_bad = any_bad || hflag[z];
     }
+    if (any_bad) {
+        // a failed factorisation leaves W undefined: nothing downstream may consume it
+        (void)hipGetLastError();
+        return apv_fail(h, APV_ERR_NOT_PD, "Matrix is not positive definite");
+    }
     std::vector<double> norm2(hacc.begin() + 2 * batch, hacc.end());
     const int max_pairs = (h->cfg.max_sweeps > 0 ? h->cfg.max_sweeps : 30) / 2 + 1;
-    bool converged = (n == 1);
+    bool converged = false;
     for (int it = 0; it < max_pairs && !converged; ++it) {
         LCHK(hipGraphLaunch(ws.exec, st));
         LCHK(hipMemcpyAsync(hacc.data(), ws.acc, sizeof(double) * 2 * batch, hipMemcpyDeviceToHost, st));
         LCHK(hipStreamSynchronize(st));
         converged = true;                     // judged on the second sweep of the pair
         for (int z = 0; z < batch; ++z)
-            if (!hflag[z] && !(hacc[batch + z] <= 1e-20 * norm2[z])) converged = false;
+            if (!(hacc[batch + z] <= 1e-20 * norm2[z])) converged = false;
     }
     if (!converged)
-        for (int z = 0; z < batch; ++z)
-            if (!hflag[z]) h_status[z] = 2;
-    // after an even number of sweeps the current matrices are back in C0 / V0
+        for (int z = 0; z < batch; ++z) h_status[z] = 2;
+    // after an even number of sweeps the current matrix is back in C0
     hipLaunchKernelGGL(rank_kernel, dim3(gx, 1, batch), dim3(TPB), 0, st, n, ld, ws.C0, d_lam, ws.order, ms, vs);
-    hipLaunchKernelGGL((gemm_kernel<true, false>), gg, dim3(256), 0, st, n, ld, ws.W, ws.V0, ws.T1, ms);       // X = W^T Q
-    hipLaunchKernelGGL(gather_cols_kernel, dim3(gx, n, batch), dim3(TPB), 0, st, n, ld, ws.T1, ws.order, d_U, ms, vs,
+    hipLaunchKernelGGL(gather_cols_kernel, dim3(gx, n, batch), dim3(TPB), 0, st, n, ld, ws.X, ws.order, d_U, ms, vs,
                        (size_t)n * n);
     if (d_r != nullptr && d_w != nullptr && V > 0) {
         hipLaunchKernelGGL(coef_kernel, dim3(gx, 1, batch), dim3(TPB), 0, st, n, d_U, d_lam, d_r, mu, ws.coef, (size_t)n * n, vs);
@@ -392,7 +598,6 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
     }
     LCHK(hipStreamSynchronize(st));
     LCHK(hipGetLastError());
-    if (any_bad) return apv_fail(h, APV_ERR_NOT_PD, "Matrix is not positive definite");
 #undef LCHK
     return APV_OK;
 }

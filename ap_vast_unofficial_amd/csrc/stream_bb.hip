@@ -16,6 +16,10 @@
 // with an ABSOLUTE 1e-7 (apvast.py:23) against entries of order 1e-3, so float statistics would not survive.
 #include "apv_internal.h"
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -334,6 +338,19 @@ int apv_bb_process_block(apv_handle* h, const double* h_in_A, const double* h_in
     hipStream_t st = h->stream;
     const int N = s->N, H = s->H, K = s->K, L = s->L, M = s->M, C = s->C, P = s->P, J = s->J, S = s->S, V = s->V, n = s->n;
     std::string why;
+    // APV_BB_TIMING=1: synchronise at the stage boundaries and print the wall time of each (profiling aid;
+    // rocprofv3 cannot trace this path)
+    static const bool timing = getenv("APV_BB_TIMING") != nullptr;
+    double t_stage[8] = {0};
+    int n_stage = 0;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto stage_done = [&]() {
+        if (!timing) return;
+        (void)hipStreamSynchronize(st);
+        const auto now = std::chrono::steady_clock::now();
+        t_stage[n_stage++] = std::chrono::duration<double, std::milli>(now - t_prev).count();
+        t_prev = now;
+    };
     BCHK(h, hipMemcpyAsync(s->xin, h_in_A, sizeof(double) * H, hipMemcpyHostToDevice, st));
     BCHK(h, hipMemcpyAsync(s->xin + H, h_in_B, sizeof(double) * H, hipMemcpyHostToDevice, st));
     const int nxt = s->cur ^ 1;
@@ -354,6 +371,7 @@ int apv_bb_process_block(apv_handle* h, const double* h_in_A, const double* h_in
     for (int z = 0; z < 2; ++z)
         hipLaunchKernelGGL(fir_f64_kernel, tgd, dim3(64), 0, st, M, P, H, N, s->ring_off, s->trir[z],
                            s->xhist[s->cur][z], s->tresp[z]);
+    stage_done();
     // 2: WOLA (unit weights, apvast.py:326-327, or the perceptual curves) and append the finished hop to the statistics rings
     const bool runA = s->zones & 1, runB = s->zones & 2;
     for (int z = 0; z < 2; ++z)
@@ -384,6 +402,7 @@ int apv_bb_process_block(apv_handle* h, const double* h_in_A, const double* h_in
         hipLaunchKernelGGL(ring_append_f64_kernel, dim3((H + 255) / 256, C), dim3(256), 0, st, S, H, s->stat_off,
                            s->ov[p], (long)N, s->stats[p]);
     }
+    stage_done();
     // 3: statistics.  R order: bright [0] A->A, [1] B->B; dark [2] A->B, [3] B->A
     const int stat_src[4] = {0, 3, 1, 2};
     const dim3 sg((n + 15) / 16, (n + 15) / 16);
@@ -395,6 +414,7 @@ int apv_bb_process_block(apv_handle* h, const double* h_in_A, const double* h_in
     }
     if (runA) hipLaunchKernelGGL(xcorr_hankel_kernel, dim3(n), dim3(256), 0, st, n, J, L, M, S, s->stat_off, 1, s->stats[0], s->tstats[0], s->r);
     if (runB) hipLaunchKernelGGL(xcorr_hankel_kernel, dim3(n), dim3(256), 0, st, n, J, L, M, S, s->stat_off, 1, s->stats[3], s->tstats[1], s->r + n);
+    stage_done();
     // 4: jdiag + filters; both zone programs in one batch when both run
     {
         int32_t status[2] = {0, 0};
@@ -405,6 +425,7 @@ int apv_bb_process_block(apv_handle* h, const double* h_in_A, const double* h_in
                                 s->w + (size_t)first * V * n, status);
         if (rc != APV_OK) return rc;
     }
+    stage_done();
     // 5: filter spectra: channel (v, l) = taps w[v][l*J : (l+1)*J] zero-padded to N, no window
     int oc = 0;
     for (int z = 0; z < 2; ++z) {
@@ -432,6 +453,10 @@ int apv_bb_process_block(apv_handle* h, const double* h_in_A, const double* h_in
     BCHK(h, hipMemcpyAsync(h_out, s->out, sizeof(double) * (size_t)s->n_out * H, hipMemcpyDeviceToHost, st));
     BCHK(h, hipStreamSynchronize(st));
     BCHK(h, hipGetLastError());
+    stage_done();
+    if (timing)
+        fprintf(stderr, "[apv bb] fir %.3f  wola %.3f  stats %.3f  gevd %.3f  out %.3f ms\n", t_stage[0], t_stage[1],
+                t_stage[2], t_stage[3], t_stage[4]);
     return APV_OK;
 }
 
