@@ -21,6 +21,9 @@
 // launches, each dominated by 16 (31 in the first round of a sweep) LDS-synchronised inner rounds.
 #include "apv_internal.h"
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 namespace {
@@ -499,6 +502,7 @@ void apv_gevd_large_free(apv_handle* h) {
 int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const double* d_B, double reg, double* d_U,
                    double* d_lam, const double* d_r, double mu, int V, double* d_w, int32_t* h_status) {
     hipStream_t st = h->stream;
+    const auto t_begin = std::chrono::steady_clock::now();
     const int ne = (n + BT - 1) / BT * BT, ld = ne;          // padded with ghost rows/columns: zero in A and C, unit in B
     const int nbk = ne / BT, nb = ne / BH, np = nb / 2, rounds = nb - 1;
     const size_t ms = (size_t)ne * ne, vs = (size_t)ne;
@@ -574,17 +578,22 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
         (void)hipGetLastError();
         return apv_fail(h, APV_ERR_NOT_PD, "Matrix is not positive definite");
     }
+    static const bool timing = getenv("APV_BB_TIMING") != nullptr;       // profiling aid, see stream_bb.hip
+    const auto t_pre = std::chrono::steady_clock::now();
+    int n_graphs = 0;
     std::vector<double> norm2(hacc.begin() + 2 * batch, hacc.end());
     const int max_pairs = (h->cfg.max_sweeps > 0 ? h->cfg.max_sweeps : 30) / 2 + 1;
     bool converged = false;
     for (int it = 0; it < max_pairs && !converged; ++it) {
         LCHK(hipGraphLaunch(ws.exec, st));
+        ++n_graphs;
         LCHK(hipMemcpyAsync(hacc.data(), ws.acc, sizeof(double) * 2 * batch, hipMemcpyDeviceToHost, st));
         LCHK(hipStreamSynchronize(st));
         converged = true;                     // judged on the second sweep of the pair
         for (int z = 0; z < batch; ++z)
             if (!(hacc[batch + z] <= 1e-20 * norm2[z])) converged = false;
     }
+    const auto t_sweeps = std::chrono::steady_clock::now();
     if (!converged)
         for (int z = 0; z < batch; ++z) h_status[z] = 2;
     // after an even number of sweeps the current matrix is back in C0
@@ -598,6 +607,11 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
     }
     LCHK(hipStreamSynchronize(st));
     LCHK(hipGetLastError());
+    if (timing)
+        fprintf(stderr, "[apv gevd_large] n=%d batch=%d: factor+whiten %.3f ms, %d sweeps %.3f ms, sort+filter %.3f ms\n", n, batch,
+                std::chrono::duration<double, std::milli>(t_pre - t_begin).count(), 2 * n_graphs,
+                std::chrono::duration<double, std::milli>(t_sweeps - t_pre).count(),
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_sweeps).count());
 #undef LCHK
     return APV_OK;
 }

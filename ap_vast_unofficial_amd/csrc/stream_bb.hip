@@ -128,34 +128,127 @@ __device__ __forceinline__ double stat_at(const double* __restrict__ ring, int S
 using d4 = __attribute__((ext_vector_type(4))) double;
 
 // R[rho][sigma] = sum_m sum_ncol Y_m[rho][ncol] Y_m[sigma][ncol], Y_m[(s, i)][ncol] = g_{s,m}[J-1-i+ncol].
-// One wave = one 16x16 tile of R on v_mfma_f64_16x16x4_f64; the operands are gathered straight from the rings.
-__global__ void __launch_bounds__(64) syrk_hankel_kernel(int n, int J, int L, int M, int S, int off, int skip,
-                                                         const double* __restrict__ stats, double* __restrict__ R) {
-    const int lane = threadIdx.x;
-    const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16;
-    const int ra = r0 + (lane & 15), cb = c0 + (lane & 15), kq = lane >> 4;
-    const bool ra_ok = ra < n, cb_ok = cb < n;
-    const int sa = ra_ok ? ra / J : 0, ia = ra_ok ? ra % J : 0;
-    const int sb = cb_ok ? cb / J : 0, ib = cb_ok ? cb % J : 0;
-    const int ncols = S - J;
+//
+// A workgroup of four waves owns a 32 x 32 tile of R (one 16 x 16 v_mfma_f64_16x16x4_f64 accumulator per wave).
+// A row (s, i) of Y is a window of the sequence g_{s,m}, so a tile side only ever needs, per microphone and per
+// chunk of TC columns, one window of TC + 31 samples for each loudspeaker its 32 rows touch: those windows are
+// unwrapped from the rings into LDS once (double-buffered: the next set is fetched into registers while the MFMAs
+// of the current one run) and every operand is then an LDS read at (window base + column).
+constexpr int SY_PER = 10;                      // window doubles staged per thread and step
+constexpr int SY_BUF = 256 * SY_PER;            // doubles per LDS buffer (both sides, all segments)
+struct SyrkJobs {
+    const double* stats[4];
+    double* R[4];
+};
+
+__global__ void __launch_bounds__(256) syrk_hankel_kernel(int n, int J, int L, int M, int S, int off, int skip, int TC,
+                                                          int nseg, SyrkJobs jobs) {
+    extern __shared__ double sy_lds[];           // [2][SY_BUF]
+    const double* __restrict__ stats = jobs.stats[blockIdx.z];
+    double* __restrict__ R = jobs.R[blockIdx.z];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kq = lane >> 4;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int W = TC + 32;
+    const int ncols = S - J, nchunks = (ncols + TC - 1) / TC, iters = M * nchunks;
+    const int tmax = skip ? S - 2 : S - 1;
+    const int slo[2] = {r0 / J, c0 / J};
+    const int t0[2] = {r0, c0};
+    // this lane's rows on the two sides of its wave tile
+    const int ra = r0 + (wave >> 1) * 16 + (lane & 15), cb = c0 + (wave & 1) * 16 + (lane & 15);
+    int offA = -1, offB = -1;
+    if (ra < n) {
+        const int sa = ra / J, ia = ra - sa * J;
+        const int ihi = min(r0 + 31, (sa + 1) * J - 1) - sa * J;
+        offA = (sa - slo[0]) * W + (ihi - ia) + kq;
+    }
+    if (cb < n) {
+        const int sb = cb / J, ib = cb - sb * J;
+        const int ihi = min(c0 + 31, (sb + 1) * J - 1) - sb * J;
+        offB = (nseg + sb - slo[1]) * W + (ihi - ib) + kq;
+    }
+    // staging: element e of the buffer = (side, segment, w)
+    const int total = 2 * nseg * W;
+    double stage[SY_PER];
+    auto fetch = [&](int it) {
+        const int m = it / nchunks, nc0 = (it - m * nchunks) * TC;
+#pragma unroll
+        for (int q = 0; q < SY_PER; ++q) {
+            const int e = tid + q * 256;
+            double v = 0.0;
+            if (e < total) {
+                const int sg = e / W, w = e - sg * W;
+                const int side = sg >= nseg, sp = slo[side] + (side ? sg - nseg : sg);
+                if (sp < L) {
+                    const int ihi = min(t0[side] + 31, (sp + 1) * J - 1) - sp * J;
+                    const int t = nc0 + J - 1 - ihi + w;
+                    if (t <= tmax && ihi >= 0) v = stat_at(stats + (size_t)(m * L + sp) * S, S, off, J, t, skip);
+                }
+            }
+            stage[q] = v;
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < SY_PER; ++q) {
+            const int e = tid + q * 256;
+            if (e < total) sy_lds[buf * SY_BUF + e] = stage[q];
+        }
+    };
     d4 acc = {0, 0, 0, 0};
-    for (int m = 0; m < M; ++m) {
-        const double* ga = stats + (size_t)(m * L + sa) * S;
-        const double* gb = stats + (size_t)(m * L + sb) * S;
-        for (int nc = 0; nc < ncols; nc += 4) {
-            const int col = nc + kq;
-            const bool ok = col < ncols;
-            const double a = (ra_ok && ok) ? stat_at(ga, S, off, J, J - 1 - ia + col, skip) : 0.0;
-            const double b = (cb_ok && ok) ? stat_at(gb, S, off, J, J - 1 - ib + col, skip) : 0.0;
+    fetch(0);
+    commit(0);
+    __syncthreads();
+    for (int it = 0; it < iters; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < iters) fetch(it + 1);
+        const int nc0 = (it % nchunks) * TC;
+        const int steps = (min(TC, ncols - nc0) + 3) >> 2;
+        const double* la = sy_lds + buf * SY_BUF + (offA >= 0 ? offA : 0);
+        const double* lb = sy_lds + buf * SY_BUF + (offB >= 0 ? offB : 0);
+        const bool tail = nc0 + 4 * steps > ncols;          // the last step of the last chunk may run past the columns
+        const int full_steps = tail ? steps - 1 : steps;
+        int k = 0;
+        for (; k + 4 <= full_steps; k += 4) {
+            const double a0 = la[4 * k], a1 = la[4 * k + 4], a2 = la[4 * k + 8], a3 = la[4 * k + 12];
+            const double b0 = lb[4 * k], b1 = lb[4 * k + 4], b2 = lb[4 * k + 8], b3 = lb[4 * k + 12];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(offA >= 0 ? a0 : 0.0, offB >= 0 ? b0 : 0.0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(offA >= 0 ? a1 : 0.0, offB >= 0 ? b1 : 0.0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(offA >= 0 ? a2 : 0.0, offB >= 0 ? b2 : 0.0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(offA >= 0 ? a3 : 0.0, offB >= 0 ? b3 : 0.0, acc, 0, 0, 0);
+        }
+        for (; k < steps; ++k) {
+            const bool ok = nc0 + 4 * k + kq < ncols;
+            const double a = (ok && offA >= 0) ? la[4 * k] : 0.0;
+            const double b = (ok && offB >= 0) ? lb[4 * k] : 0.0;
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
         }
+        if (it + 1 < iters) commit(buf ^ 1);
+        __syncthreads();
     }
     // f64 accumulator: row = (lane>>4) + 4 t, col = lane & 15
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        const int row = r0 + kq + 4 * t, col = c0 + (lane & 15);
+        const int row = r0 + (wave >> 1) * 16 + kq + 4 * t, col = c0 + (wave & 1) * 16 + (lane & 15);
         if (row < n && col < n) R[(size_t)row * n + col] = acc[t];
     }
+}
+
+// window length and segment count that fit the staging buffer for this (J, S)
+static void syrk_plan(int J, int S, int* TC, int* nseg) {
+    *nseg = 31 / J + 2;                                   // loudspeakers a run of 32 rows can touch
+    int W = SY_BUF / (2 * *nseg);
+    int tc = ((W - 32) / 4) * 4;
+    const int ncols4 = ((S - J) + 3) / 4 * 4;
+    if (tc > ncols4) tc = ncols4;
+    if (tc < 4) tc = 4;
+    *TC = tc;
+}
+
+static void launch_syrk(hipStream_t st, int n, int J, int L, int M, int S, int off, int skip, int njobs, const SyrkJobs& jobs) {
+    int TC, nseg;
+    syrk_plan(J, S, &TC, &nseg);
+    hipLaunchKernelGGL(syrk_hankel_kernel, dim3((n + 31) / 32, (n + 31) / 32, njobs), dim3(256), sizeof(double) * 2 * SY_BUF, st, n, J,
+                       L, M, S, off, skip, TC, nseg, jobs);
 }
 
 // r[rho] = sum_m sum_ncol Y_m[rho][ncol] d_m[J + ncol]      (apvast.py:340, 356)
@@ -405,12 +498,16 @@ int apv_bb_process_block(apv_handle* h, const double* h_in_A, const double* h_in
     stage_done();
     // 3: statistics.  R order: bright [0] A->A, [1] B->B; dark [2] A->B, [3] B->A
     const int stat_src[4] = {0, 3, 1, 2};
-    const dim3 sg((n + 15) / 16, (n + 15) / 16);
-    for (int q = 0; q < 4; ++q) {
-        const bool live = (q == 0 || q == 2) ? runA : runB;
-        if (!live) continue;
-        hipLaunchKernelGGL(syrk_hankel_kernel, sg, dim3(64), 0, st, n, J, L, M, S, s->stat_off, 1, s->stats[stat_src[q]],
-                           s->R + (size_t)q * n * n);
+    {
+        SyrkJobs jobs{};
+        int nj = 0;
+        for (int q = 0; q < 4; ++q) {
+            const bool live = (q == 0 || q == 2) ? runA : runB;
+            if (!live) continue;
+            jobs.stats[nj] = s->stats[stat_src[q]];
+            jobs.R[nj++] = s->R + (size_t)q * n * n;
+        }
+        launch_syrk(st, n, J, L, M, S, s->stat_off, 1, nj, jobs);
     }
     if (runA) hipLaunchKernelGGL(xcorr_hankel_kernel, dim3(n), dim3(256), 0, st, n, J, L, M, S, s->stat_off, 1, s->stats[0], s->tstats[0], s->r);
     if (runB) hipLaunchKernelGGL(xcorr_hankel_kernel, dim3(n), dim3(256), 0, st, n, J, L, M, S, s->stat_off, 1, s->stats[3], s->tstats[1], s->r + n);
@@ -553,8 +650,13 @@ int apv_vast_static(apv_handle* h, int32_t Nb, int32_t Nd, int32_t P, int32_t L,
     BCHK(h, hipMemcpyAsync(dsd, sd.data(), sizeof(double) * sd.size(), hipMemcpyHostToDevice, st));
     BCHK(h, hipMemcpyAsync(dtd, td.data(), sizeof(double) * td.size(), hipMemcpyHostToDevice, st));
     const dim3 sg((n + 15) / 16, (n + 15) / 16);
-    hipLaunchKernelGGL(syrk_hankel_kernel, sg, dim3(64), 0, st, n, J, L, Nb, S, 0, 0, dsb, dR);
-    hipLaunchKernelGGL(syrk_hankel_kernel, sg, dim3(64), 0, st, n, J, L, Nd, S, 0, 0, dsd, dR + (size_t)n * n);
+    {
+        SyrkJobs jb{}, jd{};
+        jb.stats[0] = dsb; jb.R[0] = dR;
+        jd.stats[0] = dsd; jd.R[0] = dR + (size_t)n * n;
+        launch_syrk(st, n, J, L, Nb, S, 0, 0, 1, jb);
+        launch_syrk(st, n, J, L, Nd, S, 0, 0, 1, jd);
+    }
     hipLaunchKernelGGL(xcorr_hankel_kernel, dim3(n), dim3(256), 0, st, n, J, L, Nb, S, 0, 0, dsb, dtd, dr);
     // vast.m:71-73 normalises all three by numberOfMics (of the BRIGHT zone) * (rirLength - filterLength)
     const double f = 1.0 / ((double)Nb * (double)(P - J));

@@ -103,3 +103,28 @@ def test_broadband_perceptual_vs_oracle(golden):
             assert np.abs(np.stack(got[q]) - e).max() <= 1e-7 * max(np.abs(e).max(), 1e-30), (h, q)
     assert np.abs(ap.lambda_A[:V] / orc.lambda_A[:V] - 1).max() < 1e-8
     ap.close()
+
+
+@pytest.mark.parametrize("J,S,L,M", [(24, 1664, 3, 2), (5, 700, 4, 3), (40, 300, 2, 2)])
+def test_broadband_statistics_shapes(golden, J, S, L, M):
+    """Implicit-Hankel statistics (apvast.py:329-364) where a 32-row tile spans several loudspeakers (J not a
+    multiple of 16, J < 16) and the columns take several LDS chunks (long statistics buffers)."""
+    from ap_vast_unofficial_amd.apvast import apvast
+    from oracle.broadband import BroadbandOracle
+    rirs = golden("rirs_cfg1")
+    rA, rB = rirs["rirA"][:200, :L, :M], rirs["rirB"][:200, :L, :M]
+    N, H, V = 128, 64, 2
+    ap = apvast(N, rA, rB, J, 3, 0, 1, V, 1.0, S, hop_size=H, perceptual=False, mode="broadband", seed=11)
+    np.random.seed(11)
+    orc = BroadbandOracle(N, rA, rB, J, 3, 0, 1, V, 1.0, S, hop_size=H)
+    x = np.random.default_rng(3).standard_normal((2, 4 * H))
+    try:
+        for h in range(4):
+            ap.process_input_buffers(x[0, h * H:(h + 1) * H], x[1, h * H:(h + 1) * H])
+            orc.process_input_buffers(x[0, h * H:(h + 1) * H], x[1, h * H:(h + 1) * H])
+    except np.linalg.LinAlgError:
+        pass        # short histories can leave the dark matrix numerically singular for both; the statistics stand
+    for got, exp in ((ap.R_A_to_A, orc.R_AA), (ap.R_A_to_B, orc.R_AB), (ap.R_B_to_B, orc.R_BB), (ap.R_B_to_A, orc.R_BA)):
+        assert np.abs(got - exp).max() <= 1e-12 * np.abs(exp).max()
+    assert np.abs(ap.r_A[:, 0] - orc.r_A).max() <= 1e-12 * np.abs(orc.r_A).max()
+    ap.close()
