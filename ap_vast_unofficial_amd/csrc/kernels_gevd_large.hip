@@ -52,6 +52,23 @@ __device__ __forceinline__ void mm32(const double* A, const double* B, int ty, i
     }
 }
 
+using d4 = __attribute__((ext_vector_type(4))) double;
+
+// The same product on v_mfma_f64_16x16x4_f64: four waves, wave w owns the 16 x 16 tile (w >> 1, w & 1).
+// acc[t] is element (row0 + (lane >> 4) + 4 t, col0 + (lane & 15)).
+template <bool TA>
+__device__ __forceinline__ d4 mm32_mfma(const double* A, const double* B, int w, int lane) {
+    const int row0 = (w >> 1) * 16, col0 = (w & 1) * 16, il = lane & 15, kq = lane >> 4;
+    d4 acc = {0, 0, 0, 0};
+#pragma unroll
+    for (int k0 = 0; k0 < BT; k0 += 4) {
+        const double av = TA ? A[(k0 + kq) * LS + row0 + il] : A[(row0 + il) * LS + k0 + kq];
+        const double bv = B[(k0 + kq) * LS + col0 + il];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
 // ---- step 1 ---------------------------------------------------------------------------------------
 // Left-looking Cholesky, column panel k (32 wide); workgroup x handles the row tile I = k + x.  Every workgroup
 // forms the updated diagonal block D = B[K,K] - sum_J L[K,J] L[K,J]^T itself and eliminates [D | I] in LDS (unscaled
@@ -236,34 +253,58 @@ __device__ __forceinline__ void rr_pair(int ne, int r, int a, int& p, int& q) {
     q = u < v ? v : u;
 }
 
+// 1/sqrt(x) to full double precision: v_rsq_f64 (5e-8 on gfx950) and one third-order correction
+__device__ __forceinline__ double rsq_f64(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = __builtin_fma(-(x * y), y, 1.0);
+    return __builtin_fma(y * e, __builtin_fma(0.375, e, 0.5), y);
+}
+
+// Jacobi rotation for [[alpha, beta], [beta, gamma]], branch-free.  The tangent is evaluated in float (the
+// double-precision divide and square root cost ~10x more on the serial path of every inner round); (c, s) are
+// then formed in double from that tangent, so the rotation is orthogonal to 1e-16 but leaves ~1e-7 |beta| in the
+// pivot instead of an exact zero -- the caller keeps the computed pivot, and the sweeps still converge
+// quadratically.  With tau = (gamma - alpha) / (2 beta): t = sign(tau) / (|tau| + sqrt(1 + tau^2)), written on
+// rho = min(|d|, |2 beta|) / max(|d|, |2 beta|) so that nothing overflows.
 __device__ __forceinline__ void sym_rotation(double alpha, double gamma, double beta, double& c, double& s) {
-    c = 1.0;
-    s = 0.0;
     const double b2 = beta * beta;
-    if (b2 > 1e-290 && b2 > 1e-60 * (alpha * alpha + gamma * gamma)) {
-        const double tau = (gamma - alpha) / (2.0 * beta);
-        const double t = copysign(1.0, tau) / (fabs(tau) + sqrt(1.0 + tau * tau));
-        c = 1.0 / sqrt(1.0 + t * t);
-        s = t * c;
-    }
+    const bool rotate = b2 > 1e-290 && b2 > 1e-60 * (alpha * alpha + gamma * gamma);
+    const double d = gamma - alpha, tb = 2.0 * beta;
+    const bool d_big = fabs(d) >= fabs(tb);
+    // only the ratio matters: bring the larger of the two to [0.5, 1) before leaving double range
+    const int ex = __builtin_amdgcn_frexp_exp(d_big ? d : tb);
+    const float fd = (float)__builtin_ldexp(d, -ex), fb = (float)__builtin_ldexp(tb, -ex);
+    const float hi = d_big ? fabsf(fd) : fabsf(fb), lo = d_big ? fabsf(fb) : fabsf(fd);
+    const float rho = lo * __builtin_amdgcn_rcpf(hi);
+    const float h2 = __builtin_fmaf(rho, rho, 1.0f);
+    const float hyp = h2 * __builtin_amdgcn_rsqf(h2);                // sqrt(1 + rho^2), 1 <= h2 <= 2
+    // |d| >= |2 beta|: |t| = rho / (1 + hyp), else |t| = 1 / (rho + hyp)
+    const float mag = (d_big ? rho : 1.0f) * __builtin_amdgcn_rcpf((d_big ? 1.0f : rho) + hyp);
+    const float t = __builtin_copysignf(mag, __builtin_copysignf(1.0f, fd) * fb);
+    const double td = (double)t;
+    const double cc = rsq_f64(__builtin_fma(td, td, 1.0));
+    c = rotate ? cc : 1.0;
+    s = rotate ? td * cc : 0.0;
 }
 
 __device__ __forceinline__ int tile_index(int I, int J, int t) { return t < BH ? I * BH + t : J * BH + t - BH; }
 
 // One block round.  Tile (P, Q), P <= Q, of the pair grid: rows = the two 16-blocks of pair P, columns = those of
-// pair Q.  The workgroup runs the inner sweep on the diagonal tiles (P, P) and (Q, Q) side by side -- thread (a, b)
-// owns the 2 x 2 block rows {p_a, q_a} x columns {p_b, q_b} of each and rows {2a, 2a+1} of the accumulated rotation
-// V -- then writes V_P^T C[P,Q] V_Q (and its transpose) to the other buffer and rotates its two tiles of X in place.
+// pair Q.  The workgroup runs the inner sweep on the diagonal tiles (P, P) and (Q, Q) side by side, one per half of
+// its 512 threads: thread (a, b) of a half owns the 2 x 2 block rows {p_a, q_a} x columns {p_b, q_b} of its tile and
+// rows {2a, 2a+1} of the accumulated rotation V; thread (a, a) derives the rotation of pair a and publishes it.
+// Then V_P^T C[P,Q] V_Q (and its transpose) goes to the other global buffer and the two tiles of X this workgroup
+// owns are rotated in place.
 // `full`: the inner sweep visits all 496 pairs of the 32 indices (first round of a sweep: that is where the pairs
 // inside one 16-block are annihilated); otherwise only the 256 pairs across the two blocks, in 16 rounds.
-__global__ void __launch_bounds__(256) block_jacobi_round_kernel(int ld, int nb, int round, int full,
+__global__ void __launch_bounds__(512) block_jacobi_round_kernel(int ld, int nb, int round, int full,
                                                                  const double* __restrict__ Cin, double* __restrict__ Cout,
                                                                  double* __restrict__ X, double* __restrict__ off,
                                                                  size_t mat_stride) {
-    __shared__ double sm[6 * BT * LS];
+    constexpr int TS = BT * LS;
+    __shared__ double sm[6 * TS];
     __shared__ double2 rot[2][BH];
-    double *SP = sm, *SQ = sm + BT * LS, *VP = sm + 2 * BT * LS, *VQ = sm + 3 * BT * LS, *T = sm + 4 * BT * LS,
-           *U = sm + 5 * BT * LS;
+    double *SP = sm, *SQ = sm + TS, *VP = sm + 2 * TS, *VQ = sm + 3 * TS, *T = sm + 4 * TS, *U = sm + 5 * TS;
     const int z = blockIdx.z;
     Cin += z * mat_stride;
     Cout += z * mat_stride;
@@ -279,8 +320,8 @@ __global__ void __launch_bounds__(256) block_jacobi_round_kernel(int ld, int nb,
     int IP, JP, IQ, JQ;
     rr_pair(nb, round, P, IP, JP);
     rr_pair(nb, round, Q, IQ, JQ);
-    const int tid = threadIdx.x, a = tid >> 4, b = tid & 15;
-    for (int e = tid; e < BT * BT; e += 256) {
+    const int tid = threadIdx.x, half = tid >> 8, a = (tid >> 4) & 15, b = tid & 15;
+    for (int e = tid; e < BT * BT; e += 512) {
         const int t = e >> 5, u = e & 31;
         const size_t gr = (size_t)tile_index(IP, JP, t) * ld;
         SP[t * LS + u] = Cin[gr + tile_index(IP, JP, u)];
@@ -293,47 +334,51 @@ __global__ void __launch_bounds__(256) block_jacobi_round_kernel(int ld, int nb,
     }
     __syncthreads();
     // ---- inner sweep -------------------------------------------------------------------------------
-    const int nm = diag ? 1 : 2;
+    const bool active = half == 0 || !diag;
+    double* const S = half ? SQ : SP;
+    double* const V = half ? VQ : VP;
     const int inner_rounds = full ? BT - 1 : BH;
-    const int mrot = (b == a) ? 0 : ((b == (a ^ 1)) ? 1 : 2);      // which matrix's rotation of pair a this thread derives
+    // round-robin positions of pair a / pair b, advanced incrementally (rr_pair without the modulo)
+    int ua = (a == 0) ? BT - 1 : a, va = (a == 0) ? 0 : BT - 1 - a;
+    int ub = (b == 0) ? BT - 1 : b, vb = (b == 0) ? 0 : BT - 1 - b;
     double offacc = 0.0;
     for (int t = 0; t < inner_rounds; ++t) {
         int pa, qa, pb, qb;
         if (full) {
-            rr_pair(BT, t, a, pa, qa);
-            rr_pair(BT, t, b, pb, qb);
+            pa = min(ua, va); qa = max(ua, va);
+            pb = min(ub, vb); qb = max(ub, vb);
+            if (a != 0) ua = (ua + 1 == BT - 1) ? 0 : ua + 1;
+            va = (va + 1 == BT - 1) ? 0 : va + 1;
+            if (b != 0) ub = (ub + 1 == BT - 1) ? 0 : ub + 1;
+            vb = (vb + 1 == BT - 1) ? 0 : vb + 1;
         } else {
             pa = a;
             qa = BH + ((a + t) & 15);
             pb = b;
             qb = BH + ((b + t) & 15);
         }
-        if (mrot < nm) {
-            const double* S = mrot ? SQ : SP;
+        if (active && a == b) {
             const double beta = S[pa * LS + qa];
             double c, s;
             sym_rotation(S[pa * LS + pa], S[qa * LS + qa], beta, c, s);
-            rot[mrot][a] = make_double2(c, s);
-            if (mrot == 0) offacc += beta * beta;
+            rot[half][a] = make_double2(c, s);
+            if (half == 0) offacc += beta * beta;
         }
         __syncthreads();
-        for (int m = 0; m < nm; ++m) {
-            double* S = m ? SQ : SP;
-            double* V = m ? VQ : VP;
-            const double2 ra = rot[m][a], rb = rot[m][b];
+        if (active) {
+            const double2 ra = rot[half][a], rb = rot[half][b];
             const double ca = ra.x, sa = ra.y, cb = rb.x, sb = rb.y;
             const double xpp = S[pa * LS + pb], xpq = S[pa * LS + qb], xqp = S[qa * LS + pb], xqq = S[qa * LS + qb];
+            const int r0 = 2 * a, r1 = 2 * a + 1;
+            const double v0p = V[r0 * LS + pb], v0q = V[r0 * LS + qb], v1p = V[r1 * LS + pb], v1q = V[r1 * LS + qb];
             // columns: [x_p, x_q] J_b, J = [[c, s], [-s, c]]; rows: J_a^T [y_p; y_q]
             const double ypp = cb * xpp - sb * xpq, ypq = sb * xpp + cb * xpq;
             const double yqp = cb * xqp - sb * xqq, yqq = sb * xqp + cb * xqq;
-            double zpq = ca * ypq - sa * yqq, zqp = sa * ypp + ca * yqp;
-            if (a == b) zpq = zqp = 0.0;
+            const double zpq = ca * ypq - sa * yqq;
             S[pa * LS + pb] = ca * ypp - sa * yqp;
             S[pa * LS + qb] = zpq;
-            S[qa * LS + pb] = zqp;
+            S[qa * LS + pb] = (a == b) ? zpq : sa * ypp + ca * yqp;       // the pivot keeps its (tiny) computed value
             S[qa * LS + qb] = sa * ypq + ca * yqq;
-            const int r0 = 2 * a, r1 = 2 * a + 1;
-            const double v0p = V[r0 * LS + pb], v0q = V[r0 * LS + qb], v1p = V[r1 * LS + pb], v1q = V[r1 * LS + qb];
             V[r0 * LS + pb] = cb * v0p - sb * v0q;
             V[r0 * LS + qb] = sb * v0p + cb * v0q;
             V[r1 * LS + pb] = cb * v1p - sb * v1q;
@@ -341,49 +386,49 @@ __global__ void __launch_bounds__(256) block_jacobi_round_kernel(int ld, int nb,
         }
         __syncthreads();
     }
-    // ---- outer update --------------------------------------------------------------------------------
-    const int ty = a, tx = b;
-    double o[4];
+    // ---- outer update: 32 x 32 x 32 products on the f64 MFMA, one 16 x 16 output tile per wave ------------
+    const int w = (tid >> 6) & 3, lane = tid & 63;
+    const int orow = (w >> 1) * 16 + (lane >> 4), ocol = (w & 1) * 16 + (lane & 15);     // + 4 t on the row
     if (diag) {
         if (offacc != 0.0) atomicAdd(off + z, offacc);
-        for (int e = tid; e < BT * BT; e += 256) {
+        for (int e = tid; e < BT * BT; e += 512) {
             const int t = e >> 5, u = e & 31;
             Cout[(size_t)tile_index(IP, JP, t) * ld + tile_index(IP, JP, u)] = SP[t * LS + u];
             T[t * LS + u] = X[(size_t)(P * BT + t) * ld + tile_index(IP, JP, u)];
         }
         __syncthreads();
-        mm32<false, false>(T, VP, ty, tx, o);
-        for (int i = 0; i < 4; ++i) {
-            const int r = ty + ((i >> 1) << 4), c = tx + ((i & 1) << 4);
-            X[(size_t)(P * BT + r) * ld + tile_index(IP, JP, c)] = o[i];
-        }
+        if (half) return;
+        const d4 o = mm32_mfma<false>(T, VP, w, lane);
+        for (int t = 0; t < 4; ++t) X[(size_t)(P * BT + orow + 4 * t) * ld + tile_index(IP, JP, ocol)] = o[t];
         return;
     }
-    mm32<false, false>(T, VQ, ty, tx, o);                          // U = C[P,Q] V_Q
-    for (int i = 0; i < 4; ++i) U[(ty + ((i >> 1) << 4)) * LS + tx + ((i & 1) << 4)] = o[i];
-    // the rotated diagonal tiles are not needed here any more: their buffers take the X tiles
-    for (int e = tid; e < BT * BT; e += 256) {
+    // half 0: U = C[P,Q] V_Q, then V_P^T U; half 1 meanwhile rotates the two X tiles (staged in the buffers of the
+    // rotated diagonal tiles, which are not needed in an off-diagonal workgroup)
+    if (half == 0) {
+        const d4 o = mm32_mfma<false>(T, VQ, w, lane);
+        for (int t = 0; t < 4; ++t) U[(orow + 4 * t) * LS + ocol] = o[t];
+    }
+    for (int e = tid; e < BT * BT; e += 512) {
         const int t = e >> 5, u = e & 31;
         SP[t * LS + u] = X[(size_t)(Q * BT + t) * ld + tile_index(IP, JP, u)];
         SQ[t * LS + u] = X[(size_t)(P * BT + t) * ld + tile_index(IQ, JQ, u)];
     }
     __syncthreads();
-    mm32<true, false>(VP, U, ty, tx, o);                           // V_P^T U
-    for (int i = 0; i < 4; ++i) {
-        const int r = ty + ((i >> 1) << 4), c = tx + ((i & 1) << 4);
-        Cout[(size_t)tile_index(IP, JP, r) * ld + tile_index(IQ, JQ, c)] = o[i];
-        T[r * LS + c] = o[i];                                       // every thread is past its reads of T
-    }
-    double x1[4], x2[4];
-    mm32<false, false>(SP, VP, ty, tx, x1);
-    mm32<false, false>(SQ, VQ, ty, tx, x2);
-    for (int i = 0; i < 4; ++i) {
-        const int r = ty + ((i >> 1) << 4), c = tx + ((i & 1) << 4);
-        X[(size_t)(Q * BT + r) * ld + tile_index(IP, JP, c)] = x1[i];
-        X[(size_t)(P * BT + r) * ld + tile_index(IQ, JQ, c)] = x2[i];
+    if (half == 0) {
+        const d4 o = mm32_mfma<true>(VP, U, w, lane);
+        for (int t = 0; t < 4; ++t) {
+            Cout[(size_t)tile_index(IP, JP, orow + 4 * t) * ld + tile_index(IQ, JQ, ocol)] = o[t];
+            T[(orow + 4 * t) * LS + ocol] = o[t];                   // every thread is past its reads of T
+        }
+    } else {
+        const d4 x1 = mm32_mfma<false>(SP, VP, w, lane), x2 = mm32_mfma<false>(SQ, VQ, w, lane);
+        for (int t = 0; t < 4; ++t) {
+            X[(size_t)(Q * BT + orow + 4 * t) * ld + tile_index(IP, JP, ocol)] = x1[t];
+            X[(size_t)(P * BT + orow + 4 * t) * ld + tile_index(IQ, JQ, ocol)] = x2[t];
+        }
     }
     __syncthreads();
-    for (int e = tid; e < BT * BT; e += 256) {                     // the mirrored tile, coalesced
+    for (int e = tid; e < BT * BT; e += 512) {                     // the mirrored tile, coalesced
         const int t = e >> 5, u = e & 31;
         Cout[(size_t)tile_index(IQ, JQ, t) * ld + tile_index(IP, JP, u)] = T[u * LS + t];
     }
@@ -527,16 +572,22 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
         LCHK(hipMalloc((void**)&ws.coef, sizeof(double) * vs * batch));
         LCHK(hipMalloc((void**)&ws.flag, sizeof(int) * batch));
         LCHK(hipMalloc((void**)&ws.order, sizeof(int) * vs * batch));
-        // two sweeps as one graph: 2 (nb - 1) block rounds bring the ping-pong buffers back to where they started
-        LCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-        LCHK(hipMemsetAsync(ws.acc, 0, sizeof(double) * 2 * batch, st));
+    }
+    // two sweeps: 2 (nb - 1) block rounds bring the ping-pong buffers back to where they started
+    auto two_sweeps = [&]() {
+        (void)hipMemsetAsync(ws.acc, 0, sizeof(double) * 2 * batch, st);
         double *Cc = ws.C0, *Cn = ws.C1;
         for (int sw = 0; sw < 2; ++sw)
             for (int r = 0; r < rounds; ++r) {
-                hipLaunchKernelGGL(block_jacobi_round_kernel, dim3(tiles, 1, batch), dim3(256), 0, st, ld, nb, r, r == 0 ? 1 : 0,
+                hipLaunchKernelGGL(block_jacobi_round_kernel, dim3(tiles, 1, batch), dim3(512), 0, st, ld, nb, r, r == 0 ? 1 : 0,
                                    Cc, Cn, ws.X, ws.acc + (size_t)sw * batch, ms);
                 double* t = Cc; Cc = Cn; Cn = t;
             }
+    };
+    static const bool no_graph = getenv("APV_NO_GRAPH") != nullptr;      // plain launches: rocprofv3 can then trace the rounds
+    if (!ws.exec && !no_graph) {
+        LCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        two_sweeps();
         LCHK(hipStreamEndCapture(st, &ws.graph));
         LCHK(hipGraphInstantiate(&ws.exec, ws.graph, nullptr, nullptr, 0));
     }
@@ -585,7 +636,8 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
     const int max_pairs = (h->cfg.max_sweeps > 0 ? h->cfg.max_sweeps : 30) / 2 + 1;
     bool converged = false;
     for (int it = 0; it < max_pairs && !converged; ++it) {
-        LCHK(hipGraphLaunch(ws.exec, st));
+        if (ws.exec) LCHK(hipGraphLaunch(ws.exec, st));
+        else two_sweeps();
         ++n_graphs;
         LCHK(hipMemcpyAsync(hacc.data(), ws.acc, sizeof(double) * 2 * batch, hipMemcpyDeviceToHost, st));
         LCHK(hipStreamSynchronize(st));
