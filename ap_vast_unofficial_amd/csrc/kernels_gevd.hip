@@ -47,15 +47,62 @@ template <typename T> struct Tol;
 template <> struct Tol<double> {
     static constexpr double sweep_tol2 = 1e-10;   // quadratic convergence: the sweep that meets it leaves ~tol2^2
     static constexpr int max_sweeps = 16;
-    static constexpr double tiny = 1e-290;
-    static constexpr double skip_rel = 1e-60;
 };
 template <> struct Tol<float> {
     static constexpr float sweep_tol2 = 1e-8f;
     static constexpr int max_sweeps = 14;
-    static constexpr float tiny = 1e-35f;
-    static constexpr float skip_rel = 1e-24f;
 };
+
+// 1/sqrt(x) to the full precision of T (v_rsq_f64 is good to 5e-8 on gfx950: one third-order correction)
+__device__ __forceinline__ double rsq_full(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = __builtin_fma(-(x * y), y, 1.0);
+    return __builtin_fma(y * e, __builtin_fma(0.375, e, 0.5), y);
+}
+__device__ __forceinline__ float rsq_full(float x) {
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float e = __builtin_fmaf(-(x * y), y, 1.0f);
+    return __builtin_fmaf(y * e, 0.5f, y);
+}
+
+// Jacobi rotation J = [[c, s], [-conj(s), c]] for the Hermitian 2x2 [[alpha, beta], [conj(beta), gamma]].
+// The angle t = sign(tau) e^{i arg beta} / (|tau| + sqrt(1 + tau^2)), tau = (gamma - alpha) / (2 |beta|), is
+// evaluated in float on operands brought to [0.5, 1) by a common power of two (the double-precision divides and
+// square roots sat on the serial path of every round); c = 1/sqrt(1 + |t|^2), s = t c are then formed in T, so J
+// is unitary to the precision of T and the pivot drops by ~1e-7 instead of to zero -- the next sweep finishes it.
+// A pivot below 1e-19 of the larger of (|gamma - alpha|, |beta|) underflows in float and is left alone.
+template <typename T>
+__device__ __forceinline__ void rotation_scaled(T alpha, T gamma, T bx, T by, T& c, T& sx, T& sy) {
+    const T d = gamma - alpha;
+    const T m = fmax(fabs(d), fmax(fabs(bx), fabs(by)));
+    float fd, fbx, fby;
+    if constexpr (sizeof(T) == 8) {
+        const int ex = -__builtin_amdgcn_frexp_exp(m);
+        fd = (float)__builtin_ldexp(d, ex);
+        fbx = (float)__builtin_ldexp(bx, ex);
+        fby = (float)__builtin_ldexp(by, ex);
+    } else {
+        const int ex = -__builtin_amdgcn_frexp_expf(m);
+        fd = __builtin_ldexpf(d, ex);
+        fbx = __builtin_ldexpf(bx, ex);
+        fby = __builtin_ldexpf(by, ex);
+    }
+    const float b2 = fbx * fbx + fby * fby;
+    float tx = 0.f, ty = 0.f;
+    if (b2 > 1e-37f) {
+        const float iab = __builtin_amdgcn_rsqf(b2);
+        const float tau = fd * 0.5f * iab;
+        const float h2 = __builtin_fmaf(tau, tau, 1.0f);
+        const float rho = (h2 < 3e38f) ? h2 * __builtin_amdgcn_rsqf(h2) : fabsf(tau);
+        const float t = copysignf(__builtin_amdgcn_rcpf(fabsf(tau) + rho), tau) * iab;
+        tx = fbx * t;
+        ty = fby * t;
+    }
+    const T dx = (T)tx, dy = (T)ty;
+    c = rsq_full((T)1 + dx * dx + dy * dy);
+    sx = dx * c;
+    sy = dy * c;
+}
 
 // Round-robin (tournament) pairing: ne players (even), round r in [0, ne-1), slot a in [0, ne/2).
 __device__ __forceinline__ void rr_pair(int ne, int r, int a, int& p, int& q) {
@@ -322,26 +369,18 @@ __global__ void __launch_bounds__(TPB) gevd_vast_kernel(const GevdParams p) {
         const int max_sweeps = p.max_sweeps > 0 ? p.max_sweeps : Tol<T>::max_sweeps;
         bool converged = (n == 1);
         for (int sweep = 0; sweep < max_sweeps && !converged; ++sweep) {
-            T off = 0;
+            T my_off = 0;                       // pair threads: sum of |pivot|^2 over the sweep
             for (int r = 0; r < rounds; ++r) {
                 if (tid < np) {
                     int pp, qq;
                     rr_pair(ne, r, tid, pp, qq);
-                    T c = 1, o = 0;
+                    T c = 1;
                     C s = mk<T>(0, 0);
                     if (qq < n) {
                         const T alpha = sA[pp * LD + pp].x, gamma = sA[qq * LD + qq].x;
                         const C beta = sA[pp * LD + qq];
-                        const T b2 = cabs2(beta);
-                        o = b2;
-                        if (b2 > Tol<T>::tiny && b2 > Tol<T>::skip_rel * (alpha * alpha + gamma * gamma)) {
-                            const T ab = sqrt(b2);
-                            const T tau = (gamma - alpha) / ((T)2 * ab);
-                            const T t = copysign((T)1, tau) / (fabs(tau) + sqrt((T)1 + tau * tau));
-                            c = (T)1 / sqrt((T)1 + t * t);
-                            const T sc = t * c / ab;
-                            s = mk<T>(beta.x * sc, beta.y * sc);
-                        }
+                        my_off += cabs2(beta);
+                        rotation_scaled<T>(alpha, gamma, beta.x, beta.y, c, s.x, s.y);
                     }
                     // qq == n (odd n): the bye.  Row/column n of C and V are zero ghosts and the
                     // rotation is the identity, so the real index pp still sees its partners' rotations.
@@ -349,10 +388,8 @@ __global__ void __launch_bounds__(TPB) gevd_vast_kernel(const GevdParams p) {
                     rq[tid] = qq;
                     rc[tid] = c;
                     rs[tid] = s;
-                    roff[tid] = o;
                 }
                 __syncthreads();
-                for (int a = 0; a < np; ++a) off += roff[a];
                 // C <- J^H C J on 2x2 blocks
                 for (int idx = tid; idx < np * np; idx += TPB) {
                     const int a = idx / np, b = idx - a * np;
@@ -372,8 +409,8 @@ __global__ void __launch_bounds__(TPB) gevd_vast_kernel(const GevdParams p) {
                     C zqp = cadd(ccmul(sa, ypp), cscale(yqp, ca));
                     C zqq = cadd(ccmul(sa, ypq), cscale(yqq, ca));
                     if (a == b) {
-                        zpq = mk<T>(0, 0);
-                        zqp = mk<T>(0, 0);
+                        // the rotation angle is good to float accuracy: the pivot keeps its (tiny) computed value
+                        zqp = cconj(zpq);
                         zpp.y = 0;
                         zqq.y = 0;
                     }
@@ -394,6 +431,11 @@ __global__ void __launch_bounds__(TPB) gevd_vast_kernel(const GevdParams p) {
                 }
                 __syncthreads();
             }
+            if (tid < np) roff[tid] = my_off;
+            __syncthreads();
+            T off = 0;
+            for (int a = 0; a < np; ++a) off += roff[a];
+            __syncthreads();
             if (off <= (p.sweep_tol2 > 0.0 ? (T)p.sweep_tol2 : Tol<T>::sweep_tol2) * normF2) converged = true;
         }
         if (!converged) status = 2;
@@ -516,11 +558,11 @@ hipError_t apv_launch_gevd(const GevdParams& p, int compute_dtype, bool fused, h
         if (n <= 8) return launch_t<double, 8, 64, false>(p, fused, s);
         if (n <= 16) return launch_t<double, 16, 64, false>(p, fused, s);
         if (n <= 32) return launch_t<double, 32, 256, false>(p, fused, s);
-        return launch_t<double, 64, 256, true>(p, fused, s);
+        return launch_t<double, 64, 1024, true>(p, fused, s);
     } else {
         if (n <= 8) return launch_t<float, 8, 64, false>(p, fused, s);
         if (n <= 16) return launch_t<float, 16, 64, false>(p, fused, s);
         if (n <= 32) return launch_t<float, 32, 256, false>(p, fused, s);
-        return launch_t<float, 64, 256, false>(p, fused, s);
+        return launch_t<float, 64, 1024, false>(p, fused, s);
     }
 }
