@@ -73,7 +73,7 @@ __device__ __forceinline__ d4 mm32_mfma(const double* A, const double* B, int w,
 // Left-looking Cholesky, column panel k (32 wide); workgroup x handles the row tile I = k + x.  Every workgroup
 // forms the updated diagonal block D = B[K,K] - sum_J L[K,J] L[K,J]^T itself and eliminates [D | I] in LDS (unscaled
 // columns of L_D on the left, rows of L_D^-1 up to 1/sqrt(d) on the right), then writes L[I,K] = T L_D^-T.
-// B holds A's lower tiles being replaced by L; LiBuf[k] receives L_D^-1.
+// The strictly lower tiles of B are replaced by L; LiBuf[k] receives L_D^-1 (L_D itself is not kept).
 __global__ void __launch_bounds__(256) chol_panel_kernel(int ld, int k, int nbk, double* __restrict__ B,
                                                          double* __restrict__ LiBuf, int* __restrict__ flag,
                                                          size_t mat_stride) {
@@ -135,9 +135,10 @@ __global__ void __launch_bounds__(256) chol_panel_kernel(int ld, int k, int nbk,
         Wp[r * LS + c] *= rs[r];                                   // L_D^-1 (lower)
     }
     if (I == k) {
+        // only the inverse of the diagonal block is ever used again; B[K,K] itself must stay as it is, the other
+        // workgroups of this launch are still reading it
         for (int i = 0; i < 4; ++i) {
             const int r = ty + ((i >> 1) << 4), c = tx + ((i & 1) << 4);
-            B[(size_t)(k * BT + r) * ld + k * BT + c] = (c <= r) ? Dm[r * LS + c] * rs[c] : 0.0;
             LiBuf[(size_t)k * BT * BT + r * BT + c] = Wp[r * LS + c];
         }
         return;
@@ -192,12 +193,23 @@ __global__ void __launch_bounds__(256) tri_inverse_kernel(int ld, int nbk, const
     }
 }
 
-// B += reg on the diagonal; the ghost rows of the padding get a unit diagonal so that the factorisation runs through
-__global__ void __launch_bounds__(TPB) add_diag_kernel(int n, int ne, int ld, double* __restrict__ B, double reg, size_t mat_stride) {
-    B += blockIdx.z * mat_stride;
-    const int i = blockIdx.x * TPB + threadIdx.x;
-    if (i < n) B[(size_t)i * ld + i] += reg;
-    else if (i < ne) B[(size_t)i * ld + i] = 1.0;
+// Working copies with leading dimension ld >= n: Bw = B + reg I with a unit diagonal on the ghost rows of the padding
+// (so that the factorisation runs through), C0 = A with zero ghosts.                                   apvast.py:24
+__global__ void __launch_bounds__(TPB) load_pair_kernel(int n, int ne, int ld, const double* __restrict__ A,
+                                                        const double* __restrict__ B, double reg, double* __restrict__ C0,
+                                                        double* __restrict__ Bw, size_t mat_stride) {
+    const int z = blockIdx.z, i = blockIdx.y;
+    A += (size_t)z * n * n;
+    B += (size_t)z * n * n;
+    C0 += z * mat_stride;
+    Bw += z * mat_stride;
+    for (int j = blockIdx.x * TPB + threadIdx.x; j < ne; j += gridDim.x * TPB) {
+        const bool in = i < n && j < n;
+        C0[(size_t)i * ld + j] = in ? A[(size_t)i * n + j] : 0.0;
+        double b = in ? B[(size_t)i * n + j] : 0.0;
+        if (i == j) b = in ? b + reg : 1.0;
+        Bw[(size_t)i * ld + j] = b;
+    }
 }
 
 // X = W^T
@@ -591,20 +603,11 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
         LCHK(hipStreamEndCapture(st, &ws.graph));
         LCHK(hipGraphInstantiate(&ws.exec, ws.graph, nullptr, nullptr, 0));
     }
-    LCHK(hipMemsetAsync(ws.Bw, 0, mb, st));
     LCHK(hipMemsetAsync(ws.W, 0, mb, st));
-    LCHK(hipMemsetAsync(ws.C0, 0, mb, st));
-    LCHK(hipMemsetAsync(ws.C1, 0, mb, st));
     LCHK(hipMemsetAsync(ws.X, 0, mb, st));
     LCHK(hipMemsetAsync(ws.flag, 0, sizeof(int) * batch, st));
     LCHK(hipMemsetAsync(ws.acc, 0, sizeof(double) * 3 * batch, st));
-    for (int z = 0; z < batch; ++z) {
-        LCHK(hipMemcpy2DAsync(ws.Bw + z * ms, sizeof(double) * ld, d_B + (size_t)z * n * n, sizeof(double) * n,
-                              sizeof(double) * n, n, hipMemcpyDeviceToDevice, st));
-        LCHK(hipMemcpy2DAsync(ws.C0 + z * ms, sizeof(double) * ld, d_A + (size_t)z * n * n, sizeof(double) * n,
-                              sizeof(double) * n, n, hipMemcpyDeviceToDevice, st));      // C0 holds A for now
-    }
-    hipLaunchKernelGGL(add_diag_kernel, dim3(gx, 1, batch), dim3(TPB), 0, st, n, ne, ld, ws.Bw, reg, ms);      // apvast.py:24
+    hipLaunchKernelGGL(load_pair_kernel, dim3(gx, ne, batch), dim3(TPB), 0, st, n, ne, ld, d_A, d_B, reg, ws.C0, ws.Bw, ms);   // C0 holds A for now
     for (int k = 0; k < nbk; ++k)
         hipLaunchKernelGGL(chol_panel_kernel, dim3(nbk - k, 1, batch), dim3(256), 0, st, ld, k, nbk, ws.Bw, ws.Li, ws.flag, ms);
     hipLaunchKernelGGL(tri_inverse_kernel, dim3(nbk, BT / 8, batch), dim3(256), 0, st, ld, nbk, ws.Bw, ws.Li, ws.W, ws.flag, ms);

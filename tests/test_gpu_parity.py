@@ -252,7 +252,7 @@ def test_jdiag_large_broadband_golden(Engine, golden):
     print(f"jdiag_large n=256: {dt * 1e3:.1f} ms")
 
 
-@pytest.mark.parametrize("n,batch", [(65, 1), (100, 2), (257, 1)])
+@pytest.mark.parametrize("n,batch", [(65, 1), (100, 2), (257, 1), (800, 1)])
 def test_jdiag_large_vs_oracle(Engine, n, batch):
     rng = np.random.default_rng(n)
     Y = rng.standard_normal((batch, 3 * n, n))
