@@ -304,7 +304,8 @@ __device__ __forceinline__ int tile_index(int I, int J, int t) { return t < BH ?
 // One block round.  Tile (P, Q), P <= Q, of the pair grid: rows = the two 16-blocks of pair P, columns = those of
 // pair Q.  The workgroup runs the inner sweep on the diagonal tiles (P, P) and (Q, Q) side by side, one per half of
 // its 512 threads: thread (a, b) of a half owns the 2 x 2 block rows {p_a, q_a} x columns {p_b, q_b} of its tile and
-// rows {2a, 2a+1} of the accumulated rotation V; thread (a, a) derives the rotation of pair a and publishes it.
+// rows {2a, 2a+1} of the accumulated rotation V; thread (0, b) derives the rotation of pair b and publishes it (the
+// inner rounds are bound by instruction issue, so the rotations are worked out in one wave per tile only).
 // Then V_P^T C[P,Q] V_Q (and its transpose) goes to the other global buffer and the two tiles of X this workgroup
 // owns are rotated in place.
 // `full`: the inner sweep visits all 496 pairs of the 32 indices (first round of a sweep: that is where the pairs
@@ -369,11 +370,11 @@ __global__ void __launch_bounds__(512) block_jacobi_round_kernel(int ld, int nb,
             pb = b;
             qb = BH + ((b + t) & 15);
         }
-        if (active && a == b) {
-            const double beta = S[pa * LS + qa];
+        if (active && a == 0) {                  // the 16 leading lanes of one wave per half; the other waves skip
+            const double beta = S[pb * LS + qb];
             double c, s;
-            sym_rotation(S[pa * LS + pa], S[qa * LS + qa], beta, c, s);
-            rot[half][a] = make_double2(c, s);
+            sym_rotation(S[pb * LS + pb], S[qb * LS + qb], beta, c, s);
+            rot[half][b] = make_double2(c, s);
             if (half == 0) offacc += beta * beta;
         }
         __syncthreads();
@@ -402,7 +403,7 @@ __global__ void __launch_bounds__(512) block_jacobi_round_kernel(int ld, int nb,
     const int w = (tid >> 6) & 3, lane = tid & 63;
     const int orow = (w >> 1) * 16 + (lane >> 4), ocol = (w & 1) * 16 + (lane & 15);     // + 4 t on the row
     if (diag) {
-        if (offacc != 0.0) atomicAdd(off + z, offacc);
+        if (tid < 16 && offacc != 0.0) atomicAdd(off + z, offacc);
         for (int e = tid; e < BT * BT; e += 512) {
             const int t = e >> 5, u = e & 31;
             Cout[(size_t)tile_index(IP, JP, t) * ld + tile_index(IP, JP, u)] = SP[t * LS + u];
