@@ -28,7 +28,7 @@ EXPORTS = (
     "apv_update_dev", "apv_update", "apv_corr_dev", "apv_corr_bf16_dev", "apv_to_bf16_dev", "apv_gevd_vast_dev", "apv_jdiag_batched", "apv_jdiag_large",
     "apv_stft_analysis_dev", "apv_istft_ola_dev",
     "apv_stream_init", "apv_stream_set_perceptual", "apv_process_block", "apv_state_bytes", "apv_get_state", "apv_set_state",
-    "apv_bb_init", "apv_bb_set_perceptual", "apv_bb_process_block", "apv_bb_get_state", "apv_bb_set_state",
+    "apv_bb_set_rank_list", "apv_bb_init", "apv_bb_set_perceptual", "apv_bb_process_block", "apv_bb_get_state", "apv_bb_set_state",
     "apv_predict_pressure", "apv_vast_static",
     "apv_comm_unique_id", "apv_comm_init", "apv_allgather_filters_dev",
 )
@@ -41,7 +41,9 @@ class Config(C.Structure):
         ("compute_dtype", C.c_int32), ("out_c128", C.c_int32), ("reg_mode", C.c_int32),
         ("reg_dark", C.c_double), ("reg_bright", C.c_double), ("mu", C.c_double),
         ("max_sweeps", C.c_int32), ("block_size", C.c_int32), ("hop_size", C.c_int32), ("n_zones", C.c_int32),
-        ("reserved", C.c_int32 * 8),
+        ("debug_stop", C.c_int32),
+        ("dialect", C.c_int32),
+        ("reserved", C.c_int32 * 6),
     ]
 
 
@@ -94,6 +96,7 @@ def load():
     lib.apv_get_state.argtypes = [vp, C.c_char_p, vp, sz]
     lib.apv_set_state.argtypes = [vp, C.c_char_p, vp, sz]
     lib.apv_bb_init.argtypes = [vp, i32, vp, vp, i32, i32, i32, i32, i32, i32]
+    lib.apv_bb_set_rank_list.argtypes = [vp, i32, vp]
     lib.apv_bb_set_perceptual.argtypes = [vp, i32, vp, C.c_double, C.c_double, C.c_double, i32]
     lib.apv_bb_process_block.argtypes = [vp, vp, vp, vp]
     lib.apv_bb_get_state.argtypes = [vp, C.c_char_p, vp, sz]
@@ -154,7 +157,7 @@ class Engine:
 
     def __init__(self, n_bins, n_srcs, n_mics, ranks=(1,), mu=1.0, compute_dtype="f64", out_c128=None,
                  reg_mode=REG_ABS, reg_dark=1e-7, reg_bright=0.0, device=0, max_sweeps=0,
-                 block_size=0, hop_size=0, n_zones=1, debug_stop=0):
+                 block_size=0, hop_size=0, n_zones=1, debug_stop=0, dialect="python"):
         self.lib = load()
         self.h = None
         ranks = [int(v) for v in ranks]
@@ -174,7 +177,8 @@ class Engine:
         cfg.reg_mode, cfg.reg_dark, cfg.reg_bright, cfg.mu = reg_mode, reg_dark, reg_bright, mu
         cfg.max_sweeps = max_sweeps
         cfg.block_size, cfg.hop_size, cfg.n_zones = block_size, hop_size, n_zones
-        cfg.reserved[0] = debug_stop          # profiling aid (kernels_gevd16.hip), 0 in normal use
+        cfg.debug_stop = debug_stop           # profiling aid (kernels_gevd16m.hip), 0 in normal use
+        cfg.dialect = 1 if dialect == "matlab" else 0
         self.cfg = cfg
         self.K, self.L, self.M, self.nV = cfg.n_bins, cfg.n_srcs, cfg.n_mics, cfg.n_ranks
         h = C.c_void_p()
@@ -400,6 +404,10 @@ class Engine:
         self._chk(self.lib.apv_bb_init(self.h, rir_A.shape[0], _ptr(rir_A), _ptr(rir_B), int(reference_index_A),
                                        int(reference_index_B), int(modeling_delay), int(filter_length),
                                        int(statistics_buffer_length), int(number_of_eigenvectors)))
+
+    def bb_set_rank_list(self, ranks):
+        r = np.ascontiguousarray(ranks, dtype=np.int32)
+        self._chk(self.lib.apv_bb_set_rank_list(self.h, int(r.size), _ptr(r) if r.size else None))
 
     def bb_set_perceptual(self, tables, normalisation):
         G2 = np.ascontiguousarray(tables.G2, dtype=np.float64)

@@ -130,10 +130,10 @@ class apvast:
         self.window = np.sin(np.pi / self.block_size * np.arange(self.block_size)).reshape(-1, 1)   # apvast.py:94
         self.rir_length, self.number_of_srcs, self.number_of_mics = rir_A.shape  # apvast.py:97-99
         L, M, N, H = self.number_of_srcs, self.number_of_mics, self.block_size, self.hop_size
-        V = int(number_of_eigenvectors)
         if mode == "broadband":
             self._init_broadband(device, seed)
             return
+        V = int(number_of_eigenvectors)
         if not 1 <= V <= L:
             raise ValueError("subband mode: number_of_eigenvectors must be in 1..number_of_srcs")
         self._ranks = list(range(1, V + 1))            # the reference emits every rank 1..V (apvast.py:406-422)
@@ -169,28 +169,40 @@ class apvast:
 
     # ---- broadband mode: the reference's own time-domain algorithm, float64 on the device ----------
     def _init_broadband(self, device, seed):
-        if self.dialect != "python":
-            raise NotImplementedError("broadband mode implements the Python dialect (SURVEY.md section 3.4)")
-        if not EXPERIMENTAL_REGULARIZATION:
-            raise NotImplementedError("broadband mode implements the absolute dark loading (apvast.py:22-24)")
         L, M, N, H = self.number_of_srcs, self.number_of_mics, self.block_size, self.hop_size
-        V, J, S = int(self.number_of_eigenvectors), int(self.filter_length), int(self.statistics_buffer_length)
-        self._ranks = list(range(1, V + 1))
+        J, S = int(self.filter_length), int(self.statistics_buffer_length)
+        matlab = self.dialect == "matlab"
+        if matlab:
+            # apVast.m: a vector of ranks, one solution per entry (527-549); hop fixed to half a block (138); loading
+            # relative to the spectral norm, bright 1e-8 and dark 5e-3 (552-569); zero initial buffers (175-180).
+            # Indices stay 0-based here (make_python_test.m:9-10 passes 7 where Python takes 6).
+            self._ranks = [int(v) for v in np.atleast_1d(self.number_of_eigenvectors)]
+            if H * 2 != N:
+                raise ValueError("MATLAB dialect: the hop is half a block (apVast.m:138)")
+            reg = dict(reg_mode=_capi.REG_REL, reg_dark=5e-3, reg_bright=1e-8)
+        else:
+            if not EXPERIMENTAL_REGULARIZATION:
+                raise NotImplementedError("broadband mode, Python dialect: the absolute dark loading only (apvast.py:22-24)")
+            self._ranks = list(range(1, int(self.number_of_eigenvectors) + 1))
+            reg = dict(reg_mode=_capi.REG_ABS, reg_dark=1e-7)
+        V = len(self._ranks)
         self._K = N // 2 + 1
         zones = (1 if self.run_A else 0) | (2 if self.run_B else 0)
-        self._eng = _capi.Engine(self._K, L, M, ranks=(1,), mu=self.mu, compute_dtype="f64", reg_mode=_capi.REG_ABS,
-                                 reg_dark=1e-7, device=device, block_size=N, hop_size=H, n_zones=zones)
+        self._eng = _capi.Engine(self._K, L, M, ranks=(1,), mu=self.mu, compute_dtype="f64", device=device, block_size=N,
+                                 hop_size=H, n_zones=zones, dialect=self.dialect, **reg)
+        self._eng.bb_set_rank_list(self._ranks if matlab else [])
         self._eng.bb_init(self.rir_A, self.rir_B, self.reference_index_A, self.reference_index_B, self.modeling_delay,
-                          J, S, V)
+                          J, S, max(self._ranks))
         self._n_out = (int(self.run_A) + int(self.run_B)) * V * L + 2 * L
         if self.perceptual:
             from .perceptual import PerceptualTables
             self.model = PerceptualTables(N, self.sampling_rate, self._fullscale_db_spl)
-            self._eng.bb_set_perceptual(self.model, "python")                 # apvast.py:322-324 normalisation
-        rs = np.random if seed is None else np.random.RandomState(seed)      # apvast.py:124-129
-        resp = [1e-3 * rs.randn(N, L, M) for _ in range(4)]
-        tresp = [1e-3 * rs.randn(N, M) for _ in range(2)]
-        self.set_state({"response": np.stack(resp), "target_response": np.stack(tresp)})
+            self._eng.bb_set_perceptual(self.model, self.dialect)             # apvast.py:322-324 / apVast.m:396-406
+        if not matlab:
+            rs = np.random if seed is None else np.random.RandomState(seed)  # apvast.py:124-129
+            resp = [1e-3 * rs.randn(N, L, M) for _ in range(4)]
+            tresp = [1e-3 * rs.randn(N, M) for _ in range(2)]
+            self.set_state({"response": np.stack(resp), "target_response": np.stack(tresp)})
         self.w_A = self.w_B = None
         self.lambda_A = self.lambda_B = None
 

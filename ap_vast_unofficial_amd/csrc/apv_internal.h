@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <vector>
 
 #include "../../include/apvast_hip.h"
 
@@ -62,6 +63,7 @@ struct apv_handle {
     size_t rscratch_bytes;
     struct apv_stream* st;   // streaming state (apv_stream_init), owned
     struct apv_bb* bb;       // broadband streaming state (apv_bb_init), owned
+    std::vector<int> bb_rank_list;   // apv_bb_set_rank_list: ranks of the next apv_bb_init (empty = 1..V)
     void* gl_ws;             // workspace + captured sweep graph of apv_gevd_large, owned
     void* comm;       // ncclComm_t
     int comm_rank, comm_world;
@@ -87,7 +89,7 @@ hipError_t apv_launch_gevd16m(const GevdParams& p, int compute_dtype, bool fused
 
 // kernels_gevd_large.hip: real symmetric pairs of broadband order, f64, device pointers (see the file header)
 int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const double* d_B, double reg, double* d_U,
-                   double* d_lam, const double* d_r, double mu, int V, double* d_w, int32_t* h_status);
+                   double* d_lam, const double* d_r, double mu, int V, const int* d_ranks, double* d_w, int32_t* h_status);
 
 // kernels_corr.hip
 hipError_t apv_launch_corr(int compute_dtype, int K, int M, int L, const float2* XB, const float2* XD,

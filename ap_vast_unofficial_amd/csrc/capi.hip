@@ -57,7 +57,7 @@ GevdParams apv_base_params(const apv_handle* h) {
     p.reg_bright = c.reg_bright;
     p.reg_mode = c.reg_mode;
     p.max_sweeps = c.max_sweeps;
-    p.debug_stop = c.reserved[0];
+    p.debug_stop = c.debug_stop;
     p.out_c128 = c.out_c128;
     p.Lspill = h->d_Lspill;
     return p;
@@ -470,7 +470,7 @@ int apv_jdiag_large(apv_handle* h, int32_t n, int32_t batch, const double* h_A, 
         for (void* b : tofree) (void)hipFree(b);
         return fail(h, APV_ERR_ARG, "apv_jdiag_large supports absolute loading only (EXPERIMENTAL_REGULARIZATION=True)");
     }
-    int rc = apv_gevd_large(h, n, batch, dA, dB, reg, dU, dl, nullptr, 0.0, 0, nullptr, st);
+    int rc = apv_gevd_large(h, n, batch, dA, dB, reg, dU, dl, nullptr, 0.0, 0, nullptr, nullptr, st);
     if (rc == APV_OK || rc == APV_ERR_NOT_PD) {
         (void)hipMemcpyAsync(h_U, dU, mat, hipMemcpyDeviceToHost, h->stream);
         (void)hipMemcpyAsync(h_lam, dl, (size_t)batch * n * sizeof(double), hipMemcpyDeviceToHost, h->stream);

@@ -510,19 +510,23 @@ __global__ void __launch_bounds__(TPB) coef_kernel(int n, const double* __restri
     coef[c] = s / (lam[c] + mu);
 }
 
-// w[v][i] = sum_{c <= v} coef[c] U[i][c], v = 0..V-1 (the reference keeps every rank, apvast.py:406-414)
-__global__ void __launch_bounds__(TPB) vast_prefix_kernel(int n, int V, const double* __restrict__ U,
-                                                          const double* __restrict__ coef, double* __restrict__ w,
-                                                          size_t out_stride, size_t vec_stride, size_t w_stride) {
+// w[q][i] = sum_{c < ranks[q]} coef[c] U[i][c] for the ascending rank list (ranks == nullptr: every rank 1..V, the
+// reference keeps them all, apvast.py:406-414; a list is apVast.m:527-549)
+__global__ void __launch_bounds__(TPB) vast_prefix_kernel(int n, int V, const int* __restrict__ ranks,
+                                                          const double* __restrict__ U, const double* __restrict__ coef,
+                                                          double* __restrict__ w, size_t out_stride, size_t vec_stride,
+                                                          size_t w_stride) {
     U += blockIdx.z * out_stride;
     coef += blockIdx.z * vec_stride;
     w += blockIdx.z * w_stride;
     const int i = blockIdx.x * TPB + threadIdx.x;
     if (i >= n) return;
     double acc = 0.0;
-    for (int v = 0; v < V; ++v) {
-        acc += coef[v] * U[(size_t)i * n + v];
-        w[(size_t)v * n + i] = acc;
+    int c = 0;
+    for (int q = 0; q < V; ++q) {
+        const int upto = ranks ? ranks[q] : q + 1;
+        for (; c < upto && c < n; ++c) acc += coef[c] * U[(size_t)i * n + c];
+        w[(size_t)q * n + i] = acc;
     }
 }
 
@@ -556,9 +560,9 @@ void apv_gevd_large_free(apv_handle* h) {
 
 // Everything above, for `batch` independent pairs.  d_A, d_B: [batch][n][n] f64 (row-major, device, B is loaded
 // with +reg on its diagonal here); outputs d_U [batch][n][n] (sorted columns), d_lam [batch][n]; optional
-// d_r [batch][n] -> d_w [batch][V][n].  h_status[batch]: 0 ok, 1 not positive definite, 2 sweep cap.
+// d_r [batch][n] -> d_w [batch][V][n] for the ranks d_ranks[0..V) (device; nullptr = 1..V).  h_status[batch]: 0 ok, 1 not positive definite, 2 sweep cap.
 int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const double* d_B, double reg, double* d_U,
-                   double* d_lam, const double* d_r, double mu, int V, double* d_w, int32_t* h_status) {
+                   double* d_lam, const double* d_r, double mu, int V, const int* d_ranks, double* d_w, int32_t* h_status) {
     hipStream_t st = h->stream;
     const auto t_begin = std::chrono::steady_clock::now();
     const int ne = (n + BT - 1) / BT * BT, ld = ne;          // padded with ghost rows/columns: zero in A and C, unit in B
@@ -658,7 +662,7 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
                        (size_t)n * n);
     if (d_r != nullptr && d_w != nullptr && V > 0) {
         hipLaunchKernelGGL(coef_kernel, dim3(gx, 1, batch), dim3(TPB), 0, st, n, d_U, d_lam, d_r, mu, ws.coef, (size_t)n * n, vs);
-        hipLaunchKernelGGL(vast_prefix_kernel, dim3(gx, 1, batch), dim3(TPB), 0, st, n, V, d_U, ws.coef, d_w, (size_t)n * n, vs,
+        hipLaunchKernelGGL(vast_prefix_kernel, dim3(gx, 1, batch), dim3(TPB), 0, st, n, V, d_ranks, d_U, ws.coef, d_w, (size_t)n * n, vs,
                            (size_t)V * n);
     }
     LCHK(hipStreamSynchronize(st));

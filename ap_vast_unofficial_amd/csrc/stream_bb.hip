@@ -25,7 +25,10 @@
 #include <vector>
 
 struct apv_bb {
-    int N, H, K, L, M, C, P, J, S, V, n, zones, pad;
+    int N, H, K, L, M, C, P, J, S, V, n, zones, pad;      // V = number of solutions (ranks kept)
+    int dialect, skip, ncols, toff, rel_loading;          // statistics conventions of the dialect
+    int* d_ranks;          // [V] ascending
+    double* nrm;           // [4] ||R_q||_2 for the relative loading
     int ring_off, stat_off, cur;
     int n_out;
     double* rir[2];        // [P][C]
@@ -176,15 +179,15 @@ struct SyrkJobs {
     double* R[4];
 };
 
-__global__ void __launch_bounds__(256) syrk_hankel_kernel(int n, int J, int L, int M, int S, int off, int skip, int TC,
-                                                          int nseg, SyrkJobs jobs) {
+__global__ void __launch_bounds__(256) syrk_hankel_kernel(int n, int J, int L, int M, int S, int off, int skip, int ncols,
+                                                          int TC, int nseg, SyrkJobs jobs) {
     extern __shared__ double sy_lds[];           // [2][SY_BUF]
     const double* __restrict__ stats = jobs.stats[blockIdx.z];
     double* __restrict__ R = jobs.R[blockIdx.z];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kq = lane >> 4;
     const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
     const int W = TC + 32;
-    const int ncols = S - J, nchunks = (ncols + TC - 1) / TC, iters = M * nchunks;
+    const int nchunks = (ncols + TC - 1) / TC, iters = M * nchunks;
     const int tmax = skip ? S - 2 : S - 1;
     const int slo[2] = {r0 / J, c0 / J};
     const int t0[2] = {r0, c0};
@@ -269,35 +272,35 @@ __global__ void __launch_bounds__(256) syrk_hankel_kernel(int n, int J, int L, i
 }
 
 // window length and segment count that fit the staging buffer for this (J, S)
-static void syrk_plan(int J, int S, int* TC, int* nseg) {
+static void syrk_plan(int J, int ncols, int* TC, int* nseg) {
     *nseg = 31 / J + 2;                                   // loudspeakers a run of 32 rows can touch
     int W = SY_BUF / (2 * *nseg);
     int tc = ((W - 32) / 4) * 4;
-    const int ncols4 = ((S - J) + 3) / 4 * 4;
+    const int ncols4 = (ncols + 3) / 4 * 4;
     if (tc > ncols4) tc = ncols4;
     if (tc < 4) tc = 4;
     *TC = tc;
 }
 
-static void launch_syrk(hipStream_t st, int n, int J, int L, int M, int S, int off, int skip, int njobs, const SyrkJobs& jobs) {
+static void launch_syrk(hipStream_t st, int n, int J, int L, int M, int S, int off, int skip, int ncols, int njobs,
+                        const SyrkJobs& jobs) {
     int TC, nseg;
-    syrk_plan(J, S, &TC, &nseg);
+    syrk_plan(J, ncols, &TC, &nseg);
     hipLaunchKernelGGL(syrk_hankel_kernel, dim3((n + 31) / 32, (n + 31) / 32, njobs), dim3(256), sizeof(double) * 2 * SY_BUF, st, n, J,
-                       L, M, S, off, skip, TC, nseg, jobs);
+                       L, M, S, off, skip, ncols, TC, nseg, jobs);
 }
 
-// r[rho] = sum_m sum_ncol Y_m[rho][ncol] d_m[J + ncol]      (apvast.py:340, 356)
-__global__ void __launch_bounds__(256) xcorr_hankel_kernel(int n, int J, int L, int M, int S, int off, int skip,
-                                                           const double* __restrict__ stats,
+// r[rho] = sum_m sum_ncol Y_m[rho][ncol] d_m[toff + ncol]      (apvast.py:340, 356: toff = J; apVast.m:425: J - 1)
+__global__ void __launch_bounds__(256) xcorr_hankel_kernel(int n, int J, int L, int M, int S, int off, int skip, int ncols,
+                                                           int toff, const double* __restrict__ stats,
                                                            const double* __restrict__ tstats, double* __restrict__ r) {
     const int rho = blockIdx.x;
     const int s = rho / J, i = rho % J;
-    const int ncols = S - J;
     double acc = 0.0;
     for (int idx = threadIdx.x; idx < M * ncols; idx += 256) {
         const int m = idx / ncols, nc = idx - m * ncols;
         const double y = stat_at(stats + (size_t)(m * L + s) * S, S, off, J, J - 1 - i + nc, skip);
-        int ph = J + nc + off;
+        int ph = toff + nc + off;
         if (ph >= S) ph -= S;
         acc += y * tstats[(size_t)m * S + ph];
     }
@@ -309,6 +312,133 @@ __global__ void __launch_bounds__(256) xcorr_hankel_kernel(int n, int J, int L, 
         __syncthreads();
     }
     if (threadIdx.x == 0) r[rho] = red[0];
+}
+
+// lambda_max of a symmetric positive semi-definite n x n matrix (= norm(R), apVast.m:559-566): KL Lanczos steps and
+// the largest eigenvalue of the resulting tridiagonal matrix by 1024-way multisection on Sturm counts.  One workgroup
+// per matrix; in the matrix-vector product a wave takes a row at a time so that the loads run along it.  (Plain power
+// iteration needs thousands of steps when the leading eigenvalues cluster, which they do right after start-up.)
+constexpr int KL = 96;
+struct NormJobs {
+    const double* m[4];
+};
+__global__ void __launch_bounds__(1024) norm2_lanczos_kernel(int n, NormJobs jobs, double* __restrict__ out) {
+    extern __shared__ double pw[];               // v [n], vp [n], w [n], alpha [KL], beta [KL + 1], red [32], flag [1025]
+    const double* __restrict__ Rm = jobs.m[blockIdx.x];
+    double *v = pw, *vp = pw + n, *w = pw + 2 * n, *alpha = pw + 3 * n, *beta = alpha + KL, *red = beta + KL + 1;
+    int* flag = reinterpret_cast<int*>(red + 32);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    auto block_sum = [&](double a) {             // sum over the workgroup, result in every thread
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) a += __shfl_xor(a, o, 64);
+        __syncthreads();
+        if (lane == 0) red[wave] = a;
+        __syncthreads();
+        double t = 0.0;
+        for (int q = 0; q < 16; ++q) t += red[q];
+        return t;
+    };
+    double nrm0 = 0.0;
+    for (int i = tid; i < n; i += 1024) {
+        const double x = 1.0 + 0.37 * (double)((i * 7) % 11);
+        v[i] = x;
+        vp[i] = 0.0;
+        nrm0 += x * x;
+    }
+    nrm0 = block_sum(nrm0);
+    const double inv0 = 1.0 / sqrt(nrm0);
+    for (int i = tid; i < n; i += 1024) v[i] *= inv0;
+    if (tid == 0) beta[0] = 0.0;
+    __syncthreads();
+    const int kmax = n < KL ? n : KL;
+    int k = 0;
+    for (int j = 0; j < kmax; ++j) {
+        for (int row = wave; row < n; row += 16) {
+            double a = 0.0;
+            for (int c = lane; c < n; c += 64) a += Rm[(size_t)row * n + c] * v[c];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) a += __shfl_xor(a, o, 64);
+            if (lane == 0) w[row] = a;
+        }
+        __syncthreads();
+        double d = 0.0;
+        for (int i = tid; i < n; i += 1024) d += v[i] * w[i];
+        const double aj = block_sum(d);
+        const double bj = beta[j];
+        double nn2 = 0.0;
+        for (int i = tid; i < n; i += 1024) {
+            const double x = w[i] - aj * v[i] - bj * vp[i];
+            w[i] = x;
+            nn2 += x * x;
+        }
+        nn2 = block_sum(nn2);
+        const double bn = sqrt(nn2);
+        if (tid == 0) {
+            alpha[j] = aj;
+            beta[j + 1] = bn;
+        }
+        k = j + 1;
+        if (!(bn > 1e-14 * fabs(aj)) || !(bn > 1e-300)) break;          // invariant subspace found (uniform)
+        const double ib = 1.0 / bn;
+        for (int i = tid; i < n; i += 1024) {
+            vp[i] = v[i];
+            v[i] = w[i] * ib;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    // Gershgorin bracket of the tridiagonal matrix, then multisection: count(x) = number of eigenvalues below x
+    double lo = alpha[0], hi = alpha[0];
+    for (int i = 0; i < k; ++i) {
+        const double rad = (i > 0 ? fabs(beta[i]) : 0.0) + (i + 1 < k ? fabs(beta[i + 1]) : 0.0);
+        lo = fmin(lo, alpha[i] - rad);
+        hi = fmax(hi, alpha[i] + rad);
+    }
+    for (int round = 0; round < 7; ++round) {
+        const double x = lo + (hi - lo) * (double)(tid + 1) / 1025.0;
+        int cnt = 0;
+        double dd = 1.0;
+        for (int i = 0; i < k; ++i) {
+            const double b2 = i > 0 ? beta[i] * beta[i] : 0.0;
+            dd = (alpha[i] - x) - (i > 0 ? b2 / dd : 0.0);
+            if (dd == 0.0) dd = -1e-300;
+            cnt += dd < 0.0;
+        }
+        flag[tid + 1] = cnt >= k;                  // every eigenvalue lies below x
+        if (tid == 0) flag[0] = 0;
+        __syncthreads();
+        // the largest eigenvalue sits between the last x that is not above all of them and the first that is
+        const double step = (hi - lo) / 1025.0;
+        double nlo = lo, nhi = hi;
+        int first = 1025;
+        for (int q = wave * 64 + lane; q < 1024; q += 1024) first = (flag[q + 1] && !flag[q]) ? q : first;
+        // reduce `first` (exactly one boundary exists since the counts are monotone)
+        red[0] = 0;
+        __syncthreads();
+        if (first < 1025) {
+            red[0] = (double)first;
+            red[1] = 1.0;
+        }
+        if (tid == 0 && !flag[1024]) red[1] = 0.0;
+        __syncthreads();
+        if (flag[1024]) {
+            const int f = (int)red[0];
+            nlo = lo + step * (double)f;
+            nhi = lo + step * (double)(f + 1);
+        } else {
+            nlo = lo + step * 1024.0;              // numerically above the bracket: keep the top slice
+        }
+        __syncthreads();
+        lo = nlo;
+        hi = nhi;
+    }
+    if (tid == 0) out[blockIdx.x] = 0.5 * (lo + hi);
+}
+
+// R[i][i] += coef * nrm[q]
+__global__ void __launch_bounds__(256) add_rel_diag_kernel(int n, double* __restrict__ R, double coef, const double* __restrict__ nrm) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) R[(size_t)i * n + i] += coef * nrm[0];
 }
 
 // out[ch][k] = in[k] * filt[ch][k]   (complex, channel-major)
@@ -355,14 +485,23 @@ void apv_bb_free(apv_handle* h) {
                       s->xhist[1][1], s->xin, s->resp[0], s->resp[1], s->resp[2], s->resp[3], s->tresp[0], s->tresp[1],
                       s->inblk, s->spec, s->ov[0], s->ov[1], s->ov[2], s->ov[3], s->tov[0], s->tov[1], s->stats[0],
                       s->stats[1], s->stats[2], s->stats[3], s->tstats[0], s->tstats[1], s->R, s->r, s->U, s->lam, s->w,
-                      s->fspec, s->inspec, s->outov, s->out, s->G2, s->G2T, s->tspec[0], s->tspec[1], s->Wgt[0], s->Wgt[1]};
+                      s->fspec, s->inspec, s->outov, s->out, s->G2, s->G2T, s->tspec[0], s->tspec[1], s->Wgt[0], s->Wgt[1], s->nrm};
     for (double* b : bufs)
         if (b) (void)hipFree(b);
+    if (s->d_ranks) (void)hipFree(s->d_ranks);
     delete s;
     h->bb = nullptr;
 }
 
 extern "C" {
+
+// Ranks of the solutions the next apv_bb_init keeps (apVast.m:527-549 takes a vector of ranks); n_ranks = 0 restores
+// "every rank 1..number_of_eigenvectors" (apvast.py:406-422).
+int apv_bb_set_rank_list(apv_handle* h, int32_t n_ranks, const int32_t* ranks) {
+    if (!h || n_ranks < 0 || (n_ranks > 0 && !ranks)) return apv_fail(h, APV_ERR_ARG, "bad rank list");
+    h->bb_rank_list.assign(ranks, ranks + n_ranks);
+    return APV_OK;
+}
 
 int apv_bb_init(apv_handle* h, int32_t rir_len, const double* h_rir_A, const double* h_rir_B,
                 int32_t reference_index_A, int32_t reference_index_B, int32_t modeling_delay,
@@ -381,21 +520,37 @@ int apv_bb_init(apv_handle* h, int32_t rir_len, const double* h_rir_A, const dou
     const int n = J * L;
     if (n > 2048) return apv_fail(h, APV_ERR_ARG, "broadband mode: filter_length * loudspeakers <= 2048");
     if (V < 1 || V > n) return apv_fail(h, APV_ERR_ARG, "number_of_eigenvectors must be in 1..filter_length*loudspeakers");
+    // ranks kept: every rank 1..V (apvast.py:406-422) unless a list was registered (apVast.m:527-549)
+    std::vector<int> ranks = h->bb_rank_list;
+    if (ranks.empty())
+        for (int v = 1; v <= V; ++v) ranks.push_back(v);
+    for (size_t i = 0; i < ranks.size(); ++i)
+        if (ranks[i] < 1 || ranks[i] > n || (i && ranks[i] <= ranks[i - 1]))
+            return apv_fail(h, APV_ERR_ARG, "rank list must be ascending and within 1..filter_length*loudspeakers");
+    const int dialect = c.dialect;
+    if (dialect != APV_DIALECT_PYTHON && dialect != APV_DIALECT_MATLAB) return apv_fail(h, APV_ERR_ARG, "unknown dialect");
     if (rir_len < 1 || modeling_delay < 0 || modeling_delay >= rir_len || modeling_delay >= J)
         return apv_fail(h, APV_ERR_ARG, "modeling_delay must be < rir_len and < filter_length");
     if (reference_index_A < 0 || reference_index_A >= L || reference_index_B < 0 || reference_index_B >= L)
         return apv_fail(h, APV_ERR_ARG, "reference index out of range");
     if (c.n_zones < 1 || c.n_zones > 3) return apv_fail(h, APV_ERR_ARG, "n_zones is a bit mask: 1 = A, 2 = B, 3 = both");
-    if (c.reg_mode != APV_REG_ABS) return apv_fail(h, APV_ERR_ARG, "broadband mode supports the absolute dark loading only");
     BCHK(h, hipSetDevice(h->device));
     apv_bb_free(h);
     apv_bb* s = new apv_bb();
     std::memset(static_cast<void*>(s), 0, sizeof(apv_bb));
     h->bb = s;
-    s->N = N; s->H = H; s->K = N / 2 + 1; s->L = L; s->M = M; s->C = L * M; s->P = rir_len; s->J = J; s->S = S; s->V = V;
+    const int nsol = (int)ranks.size();
+    s->N = N; s->H = H; s->K = N / 2 + 1; s->L = L; s->M = M; s->C = L * M; s->P = rir_len; s->J = J; s->S = S; s->V = nsol;
     s->n = n; s->zones = c.n_zones; s->pad = TN;
+    s->dialect = dialect;
+    s->skip = dialect == APV_DIALECT_PYTHON;                 // scipy's toeplitz drops sample J (apvast.py:336-338)
+    s->ncols = S - J + (s->skip ? 0 : 1);                    // apvast.py:334 / apVast.m:420
+    s->toff = s->skip ? J : J - 1;                           // apvast.py:340 d[J:] / apVast.m:425 d(J:end)
+    s->rel_loading = c.reg_mode == APV_REG_REL;              // apVast.m:552-569
     const int nz = ((s->zones & 1) ? 1 : 0) + ((s->zones & 2) ? 1 : 0);
-    s->n_out = nz * V * L + 2 * L;
+    s->n_out = nz * nsol * L + 2 * L;
+    BCHK(h, hipMalloc((void**)&s->d_ranks, sizeof(int) * nsol));
+    BCHK(h, hipMemcpy(s->d_ranks, ranks.data(), sizeof(int) * nsol, hipMemcpyHostToDevice));
     const int C = s->C, P = s->P, K = s->K;
     int rc;
     std::vector<double> tmp((size_t)P * C), ttmp((size_t)P * M);
@@ -437,22 +592,25 @@ int apv_bb_init(apv_handle* h, int32_t rir_len, const double* h_rir_A, const dou
     if ((rc = dalloc(h, &s->r, (size_t)2 * n))) return rc;
     if ((rc = dalloc(h, &s->U, (size_t)2 * n * n))) return rc;
     if ((rc = dalloc(h, &s->lam, (size_t)2 * n))) return rc;
-    if ((rc = dalloc(h, &s->w, (size_t)2 * V * n))) return rc;
+    if ((rc = dalloc(h, &s->w, (size_t)2 * nsol * n))) return rc;
+    if ((rc = dalloc(h, &s->nrm, 4))) return rc;
     if ((rc = dalloc(h, &s->fspec, (size_t)s->n_out * K * 2))) return rc;
     if ((rc = dalloc(h, &s->inspec, (size_t)2 * K * 2))) return rc;
     if ((rc = dalloc(h, &s->outov, (size_t)s->n_out * N))) return rc;
     if ((rc = dalloc(h, &s->out, (size_t)s->n_out * H))) return rc;
-    // target filter spectra (apvast.py:389-390, 418, 422): the same delta filter for A_t and B_t
+    // target filter spectra: the Python class uses the zone-A reference for both A_t and B_t (apvast.py:389-390, 418,
+    // 422), the MATLAB class one reference per zone (apVast.m:597-602)
     std::vector<double> tg((size_t)2 * L * K * 2, 0.0);
     const double PI = 3.14159265358979323846;
     for (int z = 0; z < 2; ++z)
         for (int k = 0; k < K; ++k) {
             const double ph = -2.0 * PI * (double)k * (double)modeling_delay / (double)N;
-            const size_t o = (((size_t)z * L + reference_index_A) * K + k) * 2;
+            const int ref = (z == 1 && dialect == APV_DIALECT_MATLAB) ? reference_index_B : reference_index_A;
+            const size_t o = (((size_t)z * L + ref) * K + k) * 2;
             tg[o] = std::cos(ph);
             tg[o + 1] = std::sin(ph);
         }
-    BCHK(h, hipMemcpy(s->fspec + (size_t)nz * V * L * K * 2, tg.data(), sizeof(double) * tg.size(), hipMemcpyHostToDevice));
+    BCHK(h, hipMemcpy(s->fspec + (size_t)nz * nsol * L * K * 2, tg.data(), sizeof(double) * tg.size(), hipMemcpyHostToDevice));
     BCHK(h, apv_stft_prepare(N, 1));
     BCHK(h, hipStreamSynchronize(h->stream));
     return APV_OK;
@@ -552,18 +710,40 @@ int apv_bb_process_block(apv_handle* h, const double* h_in_A, const double* h_in
             jobs.stats[nj] = s->stats[stat_src[q]];
             jobs.R[nj++] = s->R + (size_t)q * n * n;
         }
-        launch_syrk(st, n, J, L, M, S, s->stat_off, 1, nj, jobs);
+        launch_syrk(st, n, J, L, M, S, s->stat_off, s->skip, s->ncols, nj, jobs);
     }
-    if (runA) hipLaunchKernelGGL(xcorr_hankel_kernel, dim3(n), dim3(256), 0, st, n, J, L, M, S, s->stat_off, 1, s->stats[0], s->tstats[0], s->r);
-    if (runB) hipLaunchKernelGGL(xcorr_hankel_kernel, dim3(n), dim3(256), 0, st, n, J, L, M, S, s->stat_off, 1, s->stats[3], s->tstats[1], s->r + n);
+    if (runA) hipLaunchKernelGGL(xcorr_hankel_kernel, dim3(n), dim3(256), 0, st, n, J, L, M, S, s->stat_off, s->skip, s->ncols, s->toff, s->stats[0], s->tstats[0], s->r);
+    if (runB) hipLaunchKernelGGL(xcorr_hankel_kernel, dim3(n), dim3(256), 0, st, n, J, L, M, S, s->stat_off, s->skip, s->ncols, s->toff, s->stats[3], s->tstats[1], s->r + n);
+    const size_t nn = (size_t)n * n;
+    if (s->dialect == APV_DIALECT_MATLAB) {
+        // apVast.m:448-456: everything / ((S - J + 1) M)
+        const double f = 1.0 / ((double)s->ncols * (double)M);
+        for (int q = 0; q < 4; ++q) {
+            const bool live = (q == 0 || q == 2) ? runA : runB;
+            if (live) hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, nn, s->R + q * nn, f);
+        }
+        hipLaunchKernelGGL(scale_kernel, dim3((2 * n + 255) / 256), dim3(256), 0, st, (size_t)2 * n, s->r, f);
+    }
+    if (s->rel_loading) {
+        // apVast.m:552-569: bright += reg_bright ||R||_2, dark += reg_dark ||R||_2, in place like the reference
+        NormJobs nj{};
+        for (int q = 0; q < 4; ++q) nj.m[q] = s->R + q * nn;
+        hipLaunchKernelGGL(norm2_lanczos_kernel, dim3(4), dim3(1024), sizeof(double) * (3 * (size_t)n + 2 * KL + 33 + 520), st, n, nj,
+                           s->nrm);
+        for (int q = 0; q < 4; ++q) {
+            const bool live = (q == 0 || q == 2) ? runA : runB;
+            if (!live) continue;
+            const double coef = q < 2 ? h->cfg.reg_bright : h->cfg.reg_dark;
+            hipLaunchKernelGGL(add_rel_diag_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, s->R + q * nn, coef, s->nrm + q);
+        }
+    }
     stage_done();
     // 4: jdiag + filters; both zone programs in one batch when both run
     {
         int32_t status[2] = {0, 0};
         const int first = runA ? 0 : 1, batch = (runA && runB) ? 2 : 1;
-        const size_t nn = (size_t)n * n;
-        int rc = apv_gevd_large(h, n, batch, s->R + first * nn, s->R + (2 + first) * nn, h->cfg.reg_dark, s->U + first * nn,
-                                s->lam + (size_t)first * n, s->r + (size_t)first * n, h->cfg.mu, V,
+        int rc = apv_gevd_large(h, n, batch, s->R + first * nn, s->R + (2 + first) * nn, s->rel_loading ? 0.0 : h->cfg.reg_dark,
+                                s->U + first * nn, s->lam + (size_t)first * n, s->r + (size_t)first * n, h->cfg.mu, V, s->d_ranks,
                                 s->w + (size_t)first * V * n, status);
         if (rc != APV_OK) return rc;
     }
@@ -699,17 +879,17 @@ int apv_vast_static(apv_handle* h, int32_t Nb, int32_t Nd, int32_t P, int32_t L,
         SyrkJobs jb{}, jd{};
         jb.stats[0] = dsb; jb.R[0] = dR;
         jd.stats[0] = dsd; jd.R[0] = dR + (size_t)n * n;
-        launch_syrk(st, n, J, L, Nb, S, 0, 0, 1, jb);
-        launch_syrk(st, n, J, L, Nd, S, 0, 0, 1, jd);
+        launch_syrk(st, n, J, L, Nb, S, 0, 0, S - J, 1, jb);
+        launch_syrk(st, n, J, L, Nd, S, 0, 0, S - J, 1, jd);
     }
-    hipLaunchKernelGGL(xcorr_hankel_kernel, dim3(n), dim3(256), 0, st, n, J, L, Nb, S, 0, 0, dsb, dtd, dr);
+    hipLaunchKernelGGL(xcorr_hankel_kernel, dim3(n), dim3(256), 0, st, n, J, L, Nb, S, 0, 0, S - J, J, dsb, dtd, dr);
     // vast.m:71-73 normalises all three by numberOfMics (of the BRIGHT zone) * (rirLength - filterLength)
     const double f = 1.0 / ((double)Nb * (double)(P - J));
     const size_t nn = (size_t)n * n;
     hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((2 * nn + 255) / 256)), dim3(256), 0, st, 2 * nn, dR, f);
     hipLaunchKernelGGL(scale_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (size_t)n, dr, f);
     int32_t status = 0;
-    int rc = apv_gevd_large(h, n, 1, dR, dR + nn, 0.0, dU, dl, dr, mu, V, dw, &status);     // jdiag(RB, RD, 'vector', true): no loading
+    int rc = apv_gevd_large(h, n, 1, dR, dR + nn, 0.0, dU, dl, dr, mu, V, nullptr, dw, &status);     // jdiag(RB, RD, 'vector', true): no loading
     if (rc == APV_OK) {
         (void)hipMemcpyAsync(h_w, dw + (size_t)(V - 1) * n, sizeof(double) * n, hipMemcpyDeviceToHost, st);
         (void)hipStreamSynchronize(st);

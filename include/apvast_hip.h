@@ -66,6 +66,9 @@ extern "C" {
 
 typedef struct apv_handle apv_handle;
 
+#define APV_DIALECT_PYTHON 0   /* apvast.py: skipped sample in the data matrix, no normalisation, absolute dark loading, ranks 1..V */
+#define APV_DIALECT_MATLAB 1   /* apVast.m: contiguous Hankel matrix, R and r / ((S-J+1) M), loading relative to ||R||_2, rank list */
+
 typedef struct apv_config {
     int32_t abi_version;      /* APV_ABI_VERSION */
     int32_t device;           /* HIP device ordinal */
@@ -84,7 +87,9 @@ typedef struct apv_config {
     int32_t block_size;       /* N : STFT length for the streaming entry points (0 = kernel-level use only) */
     int32_t hop_size;         /* H */
     int32_t n_zones;          /* streaming: bit mask of zone programs, 1 = A, 2 = B (run_A/run_B, apvast.py:53-54) */
-    int32_t reserved[8];
+    int32_t debug_stop;       /* profiling aid: stop the fused kernel after stage n (0 = run everything) */
+    int32_t dialect;          /* APV_DIALECT_PYTHON | APV_DIALECT_MATLAB: the broadband stream's statistics/loading/rank conventions */
+    int32_t reserved[6];
 } apv_config;
 
 /* ---- lifetime ---------------------------------------------------------- */
@@ -179,6 +184,12 @@ int  apv_get_state(apv_handle* h, const char* name, void* h_dst, size_t bytes);
 int  apv_set_state(apv_handle* h, const char* name, const void* h_src, size_t bytes);
 
 /* ---- broadband (time-domain) mode: the reference's own algorithm, float64 ---------------------------- */
+/* Rank list of the next apv_bb_init: apVast.m:527-549 takes a vector of ranks and emits one solution per entry
+ * (ascending, each 1..J L); n_ranks = 0 restores "every rank 1..number_of_eigenvectors" (apvast.py:406-422).
+ * With cfg.dialect = APV_DIALECT_MATLAB the stream also follows apVast.m:410-456 (contiguous data matrix, R and r
+ * divided by (S-J+1) M), apVast.m:597-602 (one target reference per zone) and, with cfg.reg_mode = APV_REG_REL,
+ * apVast.m:552-569 (bright += reg_bright ||R||_2, dark += reg_dark ||R||_2, spectral norm by power iteration). */
+int  apv_bb_set_rank_list(apv_handle* h, int32_t n_ranks, const int32_t* ranks);
 /* One real (J L) x (J L) pair per zone per hop from `statistics_buffer_length` samples, J-tap filters, every rank
  * 1..V (apvast.py:329-422).  The handle needs block_size, hop_size, n_srcs, n_mics, n_zones, mu, reg_dark and
  * reg_mode = APV_REG_ABS; n_bins / ranks are not used.  J L <= 2048, block_size <= 4096.

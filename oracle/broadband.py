@@ -54,6 +54,8 @@ def hankel_rows(buf, J):
 
 
 class BroadbandOracle:
+    normalisation = "python"          # of the perceptual curves (apvast.py:322-324)
+
     def __init__(self, block_size, rir_A, rir_B, filter_length, modeling_delay,
                  reference_index_A, reference_index_B, number_of_eigenvectors, mu,
                  statistics_buffer_length, hop_size=None, sampling_rate=48000,
@@ -137,7 +139,7 @@ class BroadbandOracle:
         if self.model is not None:                   # apvast.py:313-324 with the MATLAB twin's model
             for z in range(2):
                 tspec = np.fft.rfft(self.window[:, None] * self.target_response[z], axis=0)
-                wts[z] = np.stack([self.model.weights(tspec[:, m], "python") for m in range(self.M)], axis=1)
+                wts[z] = np.stack([self.model.weights(tspec[:, m], self.normalisation) for m in range(self.M)], axis=1)
             self.weights = wts
         for z in range(2):
             self._wola(self.target_response[z], self.target_overlap[z], self.target_stats[z], wts[z])

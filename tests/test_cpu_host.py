@@ -62,8 +62,9 @@ def test_reference_error_messages_without_gpu(golden):
         apvast(255, g["rirA"], g["rirB"], 32, 16, 0, 0, 8, 1.0, 512, perceptual=False)
     with pytest.raises(RuntimeError, match=str(e["unequal"])):
         apvast(256, g["rirA"], g["rirB"][:, :, :7], 32, 16, 0, 0, 8, 1.0, 512, perceptual=False)
-    with pytest.raises(NotImplementedError, match="Python dialect"):
-        apvast(256, g["rirA"], g["rirB"], 32, 16, 0, 0, 8, 1.0, 512, mode="broadband", dialect="matlab", perceptual=False)
+    with pytest.raises(ValueError, match="half a block"):
+        apvast(256, g["rirA"], g["rirB"], 32, 16, 0, 0, [1, 8], 1.0, 512, hop_size=64, mode="broadband", dialect="matlab",
+               perceptual=False)
 
 
 def test_perceptual_tables_calibration():

@@ -128,3 +128,40 @@ def test_broadband_statistics_shapes(golden, J, S, L, M):
         assert np.abs(got - exp).max() <= 1e-12 * np.abs(exp).max()
     assert np.abs(ap.r_A[:, 0] - orc.r_A).max() <= 1e-12 * np.abs(orc.r_A).max()
     ap.close()
+
+
+@pytest.mark.parametrize("perceptual", [False, True])
+def test_broadband_matlab_dialect_vs_oracle(golden, perceptual):
+    """dialect='matlab' in broadband mode against the restatement of apVast.m (unpinned): contiguous data
+    matrix, normalised statistics, loading relative to the spectral norm, rank list, per-zone target reference."""
+    from ap_vast_unofficial_amd.apvast import apvast
+    from oracle.broadband_matlab import MatlabBroadbandOracle
+    from oracle.perceptual import Model
+    rirs = golden("rirs_cfg1")
+    rA, rB = rirs["rirA"][:, :4, :6], rirs["rirB"][:, :4, :6]
+    N, H, J, S, ranks = 256, 128, 16, 384, [1, 3, 8, 20]
+    ap = apvast(N, rA, rB, J, 8, 1, 2, ranks, 1.0, S, sampling_rate=16000, perceptual=perceptual, mode="broadband",
+                dialect="matlab", fullscale_db_spl=100.0)
+    orc = MatlabBroadbandOracle(N, rA, rB, J, 8, 1, 2, ranks, 1.0, S, sampling_rate=16000,
+                                model=Model(N, 16000, 100.0) if perceptual else None)
+    # The MATLAB class starts from all-zero buffers (apVast.m:175-180), so its first hop factorises matrices made of
+    # FFT rounding noise (1e-38) -- nothing to compare there.  Start both sides from the same small noise instead.
+    rng = np.random.default_rng(21)
+    orc.response[:] = 1e-3 * rng.standard_normal(orc.response.shape)
+    orc.target_response[:] = 1e-3 * rng.standard_normal(orc.target_response.shape)
+    ap.set_state({"response": orc.response, "target_response": orc.target_response})
+    x = np.random.default_rng(8).standard_normal((2, 5 * H))
+    for h in range(5):
+        got = ap.process_input_buffers(x[0, h * H:(h + 1) * H], x[1, h * H:(h + 1) * H])
+        exp = orc.process_input_buffers(x[0, h * H:(h + 1) * H], x[1, h * H:(h + 1) * H])
+        for q in range(4):
+            e = exp[q]
+            assert np.abs(np.stack(got[q]) - e).max() <= 1e-6 * max(np.abs(e).max(), 1e-30), (h, q)
+    # statistics after normalisation and in-place loading; the spectral norm comes from a Lanczos iteration
+    for gotR, expR in ((ap.R_A_to_A, orc.R_AA), (ap.R_A_to_B, orc.R_AB), (ap.R_B_to_B, orc.R_BB), (ap.R_B_to_A, orc.R_BA)):
+        assert np.abs(gotR - expR).max() <= 1e-7 * np.abs(expR).max()
+    assert np.abs(ap.r_A[:, 0] - orc.r_A).max() <= 1e-12 * np.abs(orc.r_A).max()
+    assert np.abs(ap.lambda_A[:20] / orc.lambda_A[:20] - 1).max() < 1e-6
+    for i in range(len(ranks)):
+        assert np.linalg.norm(ap.w_A[i, :, 0] - orc.w_A[i]) <= 1e-6 * np.linalg.norm(orc.w_A[i])
+    ap.close()

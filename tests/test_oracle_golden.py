@@ -163,3 +163,27 @@ def test_hankel_rows_matches_scipy_toeplitz():
     J = 7
     T = scipy.linalg.toeplitz(np.flipud(buf[:J]), buf[J:])
     assert np.array_equal(T, broadband.hankel_rows(buf, J))
+
+
+def test_matlab_broadband_oracle_invariants(golden):
+    """The MATLAB-dialect restatement (apVast.m) has no fixture: KA-3 (joint diagonalisation of the loaded pair) and
+    KA-4 (rank n = pressure matching with the loaded matrices), and the zero start state (apVast.m:175-180)."""
+    from oracle.broadband_matlab import MatlabBroadbandOracle
+    rirs = golden("rirs_cfg1")
+    rA, rB = rirs["rirA"][:200, :3, :4], rirs["rirB"][:200, :3, :4]
+    n = 36
+    o = MatlabBroadbandOracle(128, rA, rB, 12, 3, 0, 1, [1, 4, n], 1.0, 300)
+    assert not o.response.any() and not o.target_response.any()
+    x = np.random.default_rng(0).standard_normal((2, 64 * 4))
+    for h in range(4):
+        out = o.process_input_buffers(x[0, h * 64:(h + 1) * 64], x[1, h * 64:(h + 1) * 64])
+    assert [a.shape for a in out] == [(3, 64, 3)] * 4
+    for U, lam, RB_, RD_, r, w in ((o.U_A, o.lambda_A, o.R_AA, o.R_AB, o.r_A, o.w_A), (o.U_B, o.lambda_B, o.R_BB, o.R_BA, o.r_B, o.w_B)):
+        assert np.abs(U.T @ RD_ @ U - np.eye(n)).max() < 1e-12
+        assert np.abs(U.T @ RB_ @ U - np.diag(lam)).max() < 1e-12 * lam[0]
+        assert np.all(np.diff(lam) <= 0)
+        wpm = np.linalg.solve(RB_ + 1.0 * RD_, r)
+        assert np.linalg.norm(w[-1] - wpm) < 1e-12 * np.linalg.norm(wpm)
+    # the B target filter uses the zone-B reference (apVast.m:597-602): only that loudspeaker carries signal
+    tB = out[3][0]
+    assert np.abs(tB[:, 1]).max() > 0 and not tB[:, [0, 2]].any()
