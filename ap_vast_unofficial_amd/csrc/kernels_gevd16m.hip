@@ -76,6 +76,7 @@ __global__ void __launch_bounds__(64) gevd16m_kernel(const GevdParams p) {
     __shared__ C scoef[N];
     __shared__ T sLam[N];
     __shared__ int sOrder[N];
+    __shared__ T srot[8][4];       // Jacobi: (c, s.x, s.y) of the eight rotations of a round
 
     const int lane = threadIdx.x;
     const int k = blockIdx.x;
@@ -216,9 +217,22 @@ __global__ void __launch_bounds__(64) gevd16m_kernel(const GevdParams p) {
                 if (diag) off += tb.x * tb.x + tb.y * tb.y;
                 T c, sx, sy;
                 rotation<T>(tt.x, bb.x, tb.x, tb.y, c, sx, sy);
-                const int da = 9 * a, db = 9 * b;
-                const T ca = __shfl(c, da, 64), sax = __shfl(sx, da, 64), say = __shfl(sy, da, 64);
-                const T cb = __shfl(c, db, 64), sbx = __shfl(sx, db, 64), sby = __shfl(sy, db, 64);
+                T ca, sax, say, cb, sbx, sby;
+                if constexpr (sizeof(T) == 8) {
+                    // double: the eight rotations go through LDS (two wide reads per lane instead of twelve ds_bpermute)
+                    if (diag) {
+                        srot[a][0] = c;
+                        srot[a][1] = sx;
+                        srot[a][2] = sy;
+                    }
+                    wsync();
+                    ca = srot[a][0]; sax = srot[a][1]; say = srot[a][2];
+                    cb = srot[b][0]; sbx = srot[b][1]; sby = srot[b][2];
+                } else {
+                    const int da = 9 * a, db = 9 * b;
+                    ca = __shfl(c, da, 64); sax = __shfl(sx, da, 64); say = __shfl(sy, da, 64);
+                    cb = __shfl(c, db, 64); sbx = __shfl(sx, db, 64); sby = __shfl(sy, db, 64);
+                }
                 C ypp, ypq, yqp, yqq;
                 ypp.x = cb * tt.x - (sbx * tb.x + sby * tb.y);
                 ypp.y = cb * tt.y - (sbx * tb.y - sby * tb.x);
