@@ -74,9 +74,11 @@ __global__ void __launch_bounds__(64) gevd16m_kernel(const GevdParams p) {
     __shared__ C swr[2][N];        // Cholesky: current row of W
     __shared__ C sr[N];
     __shared__ C scoef[N];
-    __shared__ T sLam[N];
-    __shared__ int sOrder[N];
-    __shared__ T srot[8][4];       // Jacobi: (c, s.x, s.y) of the eight rotations of a round
+    // The Cholesky staging is dead after stage 1; the later stages' small arrays live in it, which keeps the
+    // workgroup at 10 240 B of LDS = exactly 16 workgroups (4 waves per SIMD) per CU.
+    T* const sLam = reinterpret_cast<T*>(&scol[0][0]);                 // [N]
+    int* const sOrder = reinterpret_cast<int*>(&scol[1][0]);           // [N]
+    T (*const srot)[4] = reinterpret_cast<T(*)[4]>(&swr[0][0]);        // Jacobi: (c, s.x, s.y) of the eight rotations of a round
 
     const int lane = threadIdx.x;
     const int k = blockIdx.x;
