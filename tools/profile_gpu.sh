@@ -8,7 +8,7 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--steps 10 --warmup 2 --no-cpu-baseline $*"
+ARGS="--steps 100 --warmup 20 --no-cpu-baseline $*"
 echo "[profile] kernel trace"; 
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$REPO/bench.py" $ARGS > "$OUT/trace.log" 2>&1
 echo "[profile] pmc FETCH_SIZE"
