@@ -124,16 +124,22 @@ def main():
     dw_all = None
     t_w = t_all = None
     if multi:
-        try:
-            uid = [Engine.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            eng.comm_init(uid[0], rank, world)
-            dw_all = eng.alloc(w_bytes * world)
-            collective = "rccl all-gather (C ABI, ncclAllGather over xGMI)"
-            ok = 1
-        except Exception as ex:  # keep the job alive: same collective through torch's process group
-            print(f"[bench] rank {rank}: C-ABI communicator failed ({ex}); using torch.distributed", file=sys.stderr)
-            ok = 0
+        uid = [None]
+        if rank == 0:
+            try:
+                uid[0] = Engine.comm_unique_id()
+            except Exception as ex:
+                print(f"[bench] rank 0: ncclGetUniqueId failed ({ex})", file=sys.stderr)
+        dist.broadcast_object_list(uid, src=0)          # every rank reaches this, whatever happened on rank 0
+        ok = 0
+        if uid[0] is not None:
+            try:
+                eng.comm_init(uid[0], rank, world)
+                dw_all = eng.alloc(w_bytes * world)
+                collective = "rccl all-gather (C ABI, ncclAllGather over xGMI)"
+                ok = 1
+            except Exception as ex:  # keep the job alive: same collective through torch's process group
+                print(f"[bench] rank {rank}: C-ABI communicator failed ({ex}); using torch.distributed", file=sys.stderr)
         flag = torch.tensor([ok], device="cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
