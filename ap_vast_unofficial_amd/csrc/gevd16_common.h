@@ -150,10 +150,9 @@ template <int D> __device__ __forceinline__ int dpp_xor_lo(int v);       // lane
 // full permutations: no `old` operand, so no copy in front of the DPP move
 template <> __device__ __forceinline__ int dpp_xor_lo<1>(int v) { return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, false); }  // quad_perm [1,0,3,2]
 template <> __device__ __forceinline__ int dpp_xor_lo<2>(int v) { return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, false); }  // quad_perm [2,3,0,1]
-template <> __device__ __forceinline__ int dpp_xor_lo<4>(int v) {
-    const int t = __builtin_amdgcn_update_dpp(v, v, 0x104, 0xf, 0x5, false);      // row_shl:4 into banks 0,2
-    return __builtin_amdgcn_update_dpp(t, v, 0x114, 0xf, 0xa, false);             // row_shr:4 into banks 1,3
-}
+// lane ^ 4 has no single DPP pattern (it takes row_shl:4 + row_shr:4 under bank masks plus copies); ds_swizzle in
+// bit-mask mode (and 0x1f, or 0, xor 4) is one crossbar operation and keeps the VALU, the bound unit, free
+template <> __device__ __forceinline__ int dpp_xor_lo<4>(int v) { return __builtin_amdgcn_ds_swizzle(v, 0x101F); }
 __device__ __forceinline__ int dpp_xor8(int v) { return __builtin_amdgcn_mov_dpp(v, 0x128, 0xf, 0xf, false); }  // row_ror:8
 
 template <int D> __device__ __forceinline__ float xcol(float v) { return __int_as_float(dpp_xor_lo<D>(__float_as_int(v))); }
@@ -172,6 +171,66 @@ template <int D> __device__ __forceinline__ double xrow(double v, int lane) {
                                 __builtin_amdgcn_ds_bpermute(addr, __double2loint(v)));
     }
 }
+// ---- top/bottom exchanges of the schedule's transitions as single-instruction lane swaps ----
+// Rows (lane bits 3, 4, 5): the lanes whose bit is set give their top and take the partner's bottom.
+//   bit 3: row_ror:8 under bank masks; bit 4: v_permlane16_swap (odd 16-lane rows of `top` <-> even rows of `bot`);
+//   bit 5: v_permlane32_swap (upper half of `top` <-> lower half of `bot`)
+template <int TB> __device__ __forceinline__ void xswap_row(int& top, int& bot) {
+    if constexpr (TB == 0) {
+        const int nt = __builtin_amdgcn_update_dpp(top, bot, 0x128, 0xf, 0xc, false);
+        bot = __builtin_amdgcn_update_dpp(bot, top, 0x128, 0xf, 0x3, false);
+        top = nt;
+    } else if constexpr (TB == 1) {
+        const auto r = __builtin_amdgcn_permlane16_swap((unsigned)top, (unsigned)bot, false, false);
+        top = (int)r[0];
+        bot = (int)r[1];
+    } else {
+        const auto r = __builtin_amdgcn_permlane32_swap((unsigned)top, (unsigned)bot, false, false);
+        top = (int)r[0];
+        bot = (int)r[1];
+    }
+}
+// Columns, lane bit 2: row_shr:4 / row_shl:4 under bank masks (bits 0 and 1 have no masked form: generic xchg)
+__device__ __forceinline__ void xswap_col4(int& top, int& bot) {
+    const int nt = __builtin_amdgcn_update_dpp(top, bot, 0x114, 0xf, 0xa, false);
+    bot = __builtin_amdgcn_update_dpp(bot, top, 0x104, 0xf, 0x5, false);
+    top = nt;
+}
+template <int TB> __device__ __forceinline__ void xswap_row(float& t, float& b) {
+    int ti = __float_as_int(t), bi = __float_as_int(b);
+    xswap_row<TB>(ti, bi);
+    t = __int_as_float(ti);
+    b = __int_as_float(bi);
+}
+template <int TB> __device__ __forceinline__ void xswap_row(double& t, double& b) {
+    int tl = __double2loint(t), th = __double2hiint(t), bl = __double2loint(b), bh = __double2hiint(b);
+    xswap_row<TB>(tl, bl);
+    xswap_row<TB>(th, bh);
+    t = __hiloint2double(th, tl);
+    b = __hiloint2double(bh, bl);
+}
+__device__ __forceinline__ void xswap_col4(float& t, float& b) {
+    int ti = __float_as_int(t), bi = __float_as_int(b);
+    xswap_col4(ti, bi);
+    t = __int_as_float(ti);
+    b = __int_as_float(bi);
+}
+__device__ __forceinline__ void xswap_col4(double& t, double& b) {
+    int tl = __double2loint(t), th = __double2hiint(t), bl = __double2loint(b), bh = __double2hiint(b);
+    xswap_col4(tl, bl);
+    xswap_col4(th, bh);
+    t = __hiloint2double(th, tl);
+    b = __hiloint2double(bh, bl);
+}
+template <int TB, typename T> __device__ __forceinline__ void cxswap_row(Cx<T>& t, Cx<T>& b) {
+    xswap_row<TB>(t.x, b.x);
+    xswap_row<TB>(t.y, b.y);
+}
+template <typename T> __device__ __forceinline__ void cxswap_col4(Cx<T>& t, Cx<T>& b) {
+    xswap_col4(t.x, b.x);
+    xswap_col4(t.y, b.y);
+}
+
 template <int D, typename T> __device__ __forceinline__ Cx<T> cxcol(Cx<T> v) { return mk<T>(xcol<D>(v.x), xcol<D>(v.y)); }
 template <int D, typename T> __device__ __forceinline__ Cx<T> cxrow(Cx<T> v, int lane) { return mk<T>(xrow<D>(v.x, lane), xrow<D>(v.y, lane)); }
 

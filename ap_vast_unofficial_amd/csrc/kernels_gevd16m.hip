@@ -201,14 +201,29 @@ __global__ void __launch_bounds__(64) gevd16m_kernel(const GevdParams p) {
             for (int r = 0; r < 15; ++r) {
                 const int delta = (int)((dseq >> (4 * r)) & 15), tbit = (int)((tseq >> (4 * r)) & 15) - 1;
                 if (tbit >= 0) {
-                    const bool cb_ = (b >> tbit) & 1, ab_ = (a >> tbit) & 1;
-                    const int pc = lane ^ (1 << tbit), pr = lane ^ (8 << tbit);
-                    xchg(tt, tb, cb_, pc);
-                    xchg(bt, bb, cb_, pc);
-                    xchg(v0t, v0b, cb_, pc);
-                    xchg(v1t, v1b, cb_, pc);
-                    xchg(tt, bt, ab_, pr);
-                    xchg(tb, bb, ab_, pr);
+                    // columns first, then rows; the row exchanges and the bit-2 column exchange are masked lane swaps
+                    if (tbit == 2) {
+                        cxswap_col4(tt, tb);
+                        cxswap_col4(bt, bb);
+                        cxswap_col4(v0t, v0b);
+                        cxswap_col4(v1t, v1b);
+                        cxswap_row<2>(tt, bt);
+                        cxswap_row<2>(tb, bb);
+                    } else {
+                        const bool cb_ = (b >> tbit) & 1;
+                        const int pc = lane ^ (1 << tbit);
+                        xchg(tt, tb, cb_, pc);
+                        xchg(bt, bb, cb_, pc);
+                        xchg(v0t, v0b, cb_, pc);
+                        xchg(v1t, v1b, cb_, pc);
+                        if (tbit == 1) {
+                            cxswap_row<1>(tt, bt);
+                            cxswap_row<1>(tb, bb);
+                        } else {
+                            cxswap_row<0>(tt, bt);
+                            cxswap_row<0>(tb, bb);
+                        }
+                    }
                 }
                 switch (delta) {
                     case 1: move_bottoms<1>(tb, bt, bb, v0b, v1b, lane); break;
