@@ -58,18 +58,27 @@ __device__ __forceinline__ void correlate16<double>(const float2* __restrict__ X
     d4 re = {0, 0, 0, 0}, im = {0, 0, 0, 0};
     double rx = 0, ry = 0;
     const int msub = lane >> 4;
-    for (int m0 = 0; m0 < M; m0 += 4) {
-        const bool ok = (m0 + msub) < M;
-        const float2 xv = ok ? X[(size_t)m0 * N + lane] : make_float2(0.f, 0.f);
-        const double xr = xv.x, xi = xv.y;
-        re = __builtin_amdgcn_mfma_f64_16x16x4f64(xr, xr, re, 0, 0, 0);
-        re = __builtin_amdgcn_mfma_f64_16x16x4f64(xi, xi, re, 0, 0, 0);
-        im = __builtin_amdgcn_mfma_f64_16x16x4f64(xr, xi, im, 0, 0, 0);
-        im = __builtin_amdgcn_mfma_f64_16x16x4f64(-xi, xr, im, 0, 0, 0);
-        if (dvec != nullptr) {
-            const float2 dv = ok ? dvec[m0 + msub] : make_float2(0.f, 0.f);
-            rx += xr * (double)dv.x + xi * (double)dv.y;        // conj(x) * d
-            ry += xr * (double)dv.y - xi * (double)dv.x;
+    // 32 control points (8 k-steps) at a time: all the loads of a chunk are in flight before its first MFMA
+    for (int mc = 0; mc < M; mc += 32) {
+        float2 xv[8], dv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int m = mc + 4 * q + msub;
+            const bool ok = m < M;
+            xv[q] = ok ? X[(size_t)(mc + 4 * q) * N + lane] : make_float2(0.f, 0.f);
+            dv[q] = (ok && dvec != nullptr) ? dvec[m] : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const double xr = xv[q].x, xi = xv[q].y;
+            re = __builtin_amdgcn_mfma_f64_16x16x4f64(xr, xr, re, 0, 0, 0);
+            re = __builtin_amdgcn_mfma_f64_16x16x4f64(xi, xi, re, 0, 0, 0);
+            im = __builtin_amdgcn_mfma_f64_16x16x4f64(xr, xi, im, 0, 0, 0);
+            im = __builtin_amdgcn_mfma_f64_16x16x4f64(-xi, xr, im, 0, 0, 0);
+            if (dvec != nullptr) {
+                rx += xr * (double)dv[q].x + xi * (double)dv[q].y;        // conj(x) * d
+                ry += xr * (double)dv[q].y - xi * (double)dv[q].x;
+            }
         }
     }
     // f64 16x16x4 accumulator: row = (lane>>4) + 4*reg, col = lane&15
@@ -89,18 +98,26 @@ __device__ __forceinline__ void correlate16<float>(const float2* __restrict__ X,
     f4 re = {0, 0, 0, 0}, im = {0, 0, 0, 0};
     float rx = 0, ry = 0;
     const int msub = lane >> 4;
-    for (int m0 = 0; m0 < M; m0 += 4) {
-        const bool ok = (m0 + msub) < M;
-        const float2 xv = ok ? X[(size_t)m0 * N + lane] : make_float2(0.f, 0.f);
-        const float xr = xv.x, xi = xv.y;
-        re = __builtin_amdgcn_mfma_f32_16x16x4f32(xr, xr, re, 0, 0, 0);
-        re = __builtin_amdgcn_mfma_f32_16x16x4f32(xi, xi, re, 0, 0, 0);
-        im = __builtin_amdgcn_mfma_f32_16x16x4f32(xr, xi, im, 0, 0, 0);
-        im = __builtin_amdgcn_mfma_f32_16x16x4f32(-xi, xr, im, 0, 0, 0);
-        if (dvec != nullptr) {
-            const float2 dv = ok ? dvec[m0 + msub] : make_float2(0.f, 0.f);
-            rx += xr * dv.x + xi * dv.y;
-            ry += xr * dv.y - xi * dv.x;
+    for (int mc = 0; mc < M; mc += 32) {
+        float2 xv[8], dv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int m = mc + 4 * q + msub;
+            const bool ok = m < M;
+            xv[q] = ok ? X[(size_t)(mc + 4 * q) * N + lane] : make_float2(0.f, 0.f);
+            dv[q] = (ok && dvec != nullptr) ? dvec[m] : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float xr = xv[q].x, xi = xv[q].y;
+            re = __builtin_amdgcn_mfma_f32_16x16x4f32(xr, xr, re, 0, 0, 0);
+            re = __builtin_amdgcn_mfma_f32_16x16x4f32(xi, xi, re, 0, 0, 0);
+            im = __builtin_amdgcn_mfma_f32_16x16x4f32(xr, xi, im, 0, 0, 0);
+            im = __builtin_amdgcn_mfma_f32_16x16x4f32(-xi, xr, im, 0, 0, 0);
+            if (dvec != nullptr) {
+                rx += xr * dv[q].x + xi * dv[q].y;
+                ry += xr * dv[q].y - xi * dv[q].x;
+            }
         }
     }
     // f32 16x16x4 accumulator: row = 4*(lane>>4) + reg, col = lane&15
