@@ -188,17 +188,21 @@ int  apv_set_state(apv_handle* h, const char* name, const void* h_src, size_t by
  * (ascending, each 1..J L); n_ranks = 0 restores "every rank 1..number_of_eigenvectors" (apvast.py:406-422).
  * With cfg.dialect = APV_DIALECT_MATLAB the stream also follows apVast.m:410-456 (contiguous data matrix, R and r
  * divided by (S-J+1) M), apVast.m:597-602 (one target reference per zone) and, with cfg.reg_mode = APV_REG_REL,
- * apVast.m:552-569 (bright += reg_bright ||R||_2, dark += reg_dark ||R||_2, spectral norm by power iteration). */
+ * apVast.m:552-569 (bright += reg_bright ||R||_2, dark += reg_dark ||R||_2 in place; spectral norm = largest Ritz
+ * value of 96 Lanczos steps). */
 int  apv_bb_set_rank_list(apv_handle* h, int32_t n_ranks, const int32_t* ranks);
 /* One real (J L) x (J L) pair per zone per hop from `statistics_buffer_length` samples, J-tap filters, every rank
- * 1..V (apvast.py:329-422).  The handle needs block_size, hop_size, n_srcs, n_mics, n_zones, mu, reg_dark and
- * reg_mode = APV_REG_ABS; n_bins / ranks are not used.  J L <= 2048, block_size <= 4096.
+ * 1..V (apvast.py:329-422) or the registered rank list.  The handle needs block_size, hop_size, n_srcs, n_mics,
+ * n_zones, mu, dialect, reg_mode and reg_dark (reg_mode = APV_REG_ABS: dark + reg_dark I inside the joint
+ * diagonalisation, apvast.py:22-24; APV_REG_REL: see above); n_bins / ranks are not used.  J L <= 2048,
+ * block_size <= 4096.  A failed factorisation (APV_ERR_NOT_PD) leaves the input/response/statistics buffers
+ * advanced by the hop and the output overlap buffers untouched.
  *                                                         replaces apvast.__init__, apvast.py:40-151 */
 int  apv_bb_init(apv_handle* h, int32_t rir_len, const double* h_rir_A, const double* h_rir_B,
                  int32_t reference_index_A, int32_t reference_index_B, int32_t modeling_delay,
                  int32_t filter_length, int32_t statistics_buffer_length, int32_t number_of_eigenvectors);
 /* One hop (H float64 samples per signal).  h_out: [n_out][H] float64, channels as for apv_process_block with
- * nV = V.                                                 replaces process_input_buffers, apvast.py:153-165 */
+ * nV = the number of ranks kept.                          replaces process_input_buffers, apvast.py:153-165 */
 int  apv_bb_process_block(apv_handle* h, const double* h_in_A, const double* h_in_B, double* h_out);
 /* perceptual weighting for the broadband stream; arguments as for apv_stream_set_perceptual */
 int  apv_bb_set_perceptual(apv_handle* h, int32_t n_channels, const double* h_G2, double Cs, double Ca, double Leff,
