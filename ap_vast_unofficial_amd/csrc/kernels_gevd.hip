@@ -163,11 +163,20 @@ __global__ void __launch_bounds__(TPB) gevd_vast_kernel(const GevdParams p) {
     // ---------------- stage 0: load or correlate ----------------
     if constexpr (FUSED) {
         const int M = p.M;
+        // float64 with enough waves: the contraction runs on v_mfma_f64_16x16x4_f64, one 16 x 16 tile of R per wave
+        // (re and im accumulators), operands read from the staged rows; otherwise one element of R per thread on the VALU
+        constexpr bool MFMA_CORR = sizeof(T) == 8 && NMAX >= 16 && (NMAX / 16) * (NMAX / 16) <= TPB / 64;
         for (int which = 0; which < 2; ++which) {
             const float2* X = (which ? pXD : pXB) + (size_t)k * M * n;
             C acc[NACC];
 #pragma unroll
             for (int a = 0; a < NACC; ++a) acc[a] = mk<T>(0, 0);
+            using d4v = __attribute__((ext_vector_type(4))) double;
+            d4v mre = {0, 0, 0, 0}, mim = {0, 0, 0, 0};
+            const int wave = tid >> 6, lane = tid & 63, il = lane & 15, kq = lane >> 4;
+            const int ntile = (n + 15) >> 4;
+            const int ti = wave / ntile, tj = wave - ti * ntile;
+            const bool tile_ok = wave < ntile * ntile;
             C racc = mk<T>(0, 0);
             for (int m0 = 0; m0 < M; m0 += MT) {
                 const int rows = (M - m0) < MT ? (M - m0) : MT;
@@ -175,19 +184,37 @@ __global__ void __launch_bounds__(TPB) gevd_vast_kernel(const GevdParams p) {
                 if (which == 0)
                     for (int idx = tid; idx < rows; idx += TPB) sd[idx] = pd[(size_t)k * M + m0 + idx];
                 __syncthreads();
+                if constexpr (MFMA_CORR) {
+                    if (tile_ok) {
+                        const int ia = 16 * ti + il, jb = 16 * tj + il;
 #pragma unroll
-                for (int a = 0; a < NACC; ++a) {
-                    const int idx = tid + a * TPB;
-                    if (idx < n * n) {
-                        const int i = idx / n, j = idx - i * n;
-                        C s = acc[a];
-                        for (int m = 0; m < rows; ++m) {
-                            const float2 xi = sX[m * n + i], xj = sX[m * n + j];
-                            // conj(xi) * xj, products exact in T=double
-                            s.x += (T)xi.x * (T)xj.x + (T)xi.y * (T)xj.y;
-                            s.y += (T)xi.x * (T)xj.y - (T)xi.y * (T)xj.x;
+                        for (int m = 0; m < MT; m += 4) {
+                            const bool ok = m + kq < rows;
+                            const float2 xa = (ok && ia < n) ? sX[(m + kq) * n + ia] : make_float2(0.f, 0.f);
+                            const float2 xb = (ok && jb < n) ? sX[(m + kq) * n + jb] : make_float2(0.f, 0.f);
+                            const double ar = xa.x, ai = xa.y, br = xb.x, bi = xb.y;
+                            // conj(x_i) x_j: re = ar br + ai bi, im = ar bi - ai br
+                            mre = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, mre, 0, 0, 0);
+                            mre = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bi, mre, 0, 0, 0);
+                            mim = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, mim, 0, 0, 0);
+                            mim = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, br, mim, 0, 0, 0);
                         }
-                        acc[a] = s;
+                    }
+                } else {
+#pragma unroll
+                    for (int a = 0; a < NACC; ++a) {
+                        const int idx = tid + a * TPB;
+                        if (idx < n * n) {
+                            const int i = idx / n, j = idx - i * n;
+                            C s = acc[a];
+                            for (int m = 0; m < rows; ++m) {
+                                const float2 xi = sX[m * n + i], xj = sX[m * n + j];
+                                // conj(xi) * xj, products exact in T=double
+                                s.x += (T)xi.x * (T)xj.x + (T)xi.y * (T)xj.y;
+                                s.y += (T)xi.x * (T)xj.y - (T)xi.y * (T)xj.x;
+                            }
+                            acc[a] = s;
+                        }
                     }
                 }
                 if (which == 0 && tid < n) {
@@ -200,12 +227,23 @@ __global__ void __launch_bounds__(TPB) gevd_vast_kernel(const GevdParams p) {
                 __syncthreads();
             }
             C* dst = which ? sB : sA;
+            if constexpr (MFMA_CORR) {
+                // f64 16x16x4 accumulator: row = (lane >> 4) + 4 t, col = lane & 15
+                if (tile_ok) {
 #pragma unroll
-            for (int a = 0; a < NACC; ++a) {
-                const int idx = tid + a * TPB;
-                if (idx < n * n) {
-                    const int i = idx / n, j = idx - i * n;
-                    dst[i * LD + j] = acc[a];
+                    for (int t = 0; t < 4; ++t) {
+                        const int i = 16 * ti + kq + 4 * t, j = 16 * tj + il;
+                        if (i < n && j < n) dst[i * LD + j] = mk<T>((T)mre[t], (T)mim[t]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int a = 0; a < NACC; ++a) {
+                    const int idx = tid + a * TPB;
+                    if (idx < n * n) {
+                        const int i = idx / n, j = idx - i * n;
+                        dst[i * LD + j] = acc[a];
+                    }
                 }
             }
             if (which == 0 && tid < n) sr[tid] = racc;
