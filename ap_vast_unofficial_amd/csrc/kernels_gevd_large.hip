@@ -221,29 +221,44 @@ __global__ void __launch_bounds__(TPB) transpose_kernel(int n, int ld, const dou
     for (int j = blockIdx.x * TPB + threadIdx.x; j < n; j += gridDim.x * TPB) X[(size_t)i * ld + j] = W[(size_t)j * ld + i];
 }
 
-// ---- step 2: C = op(A) op(B), 16x16 tiles ---------------------------------------------------------
+// ---- step 2: C = op(A) op(B) on the f64 MFMA: a workgroup owns a 32 x 32 tile of C, the operands pass through LDS in
+// 32-deep slices, each of the four waves accumulates one 16 x 16 quarter ------------------------------------------
 template <bool TA, bool TB>
 __global__ void __launch_bounds__(256) gemm_kernel(int n, int ld, const double* __restrict__ A,
                                                    const double* __restrict__ Bm, double* __restrict__ C,
                                                    size_t mat_stride) {
-    __shared__ double sa[16][17], sb[16][17];
+    __shared__ double sa[BT * LS], sb[BT * LS];          // sa[i][k] = op(A)[row0 + i][k0 + k], sb[k][j] = op(B)[k0 + k][col0 + j]
     const int z = blockIdx.z;
     A += z * mat_stride;
     Bm += z * mat_stride;
     C += z * mat_stride;
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int row = blockIdx.y * 16 + ty, col = blockIdx.x * 16 + tx;
-    double acc = 0.0;
-    for (int k0 = 0; k0 < n; k0 += 16) {
-        const int ka = k0 + tx, kb = k0 + ty;
-        sa[ty][tx] = (row < n && ka < n) ? (TA ? A[(size_t)ka * ld + row] : A[(size_t)row * ld + ka]) : 0.0;
-        sb[ty][tx] = (kb < n && col < n) ? (TB ? Bm[(size_t)col * ld + kb] : Bm[(size_t)kb * ld + col]) : 0.0;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int row0 = blockIdx.y * BT, col0 = blockIdx.x * BT;
+    d4 acc = {0, 0, 0, 0};
+    for (int k0 = 0; k0 < n; k0 += BT) {
+        for (int e = tid; e < BT * BT; e += 256) {
+            const int r = e >> 5, c = e & 31;            // c runs along the contiguous dimension of the source
+            {
+                const int i = TA ? c : r, kk = TA ? r : c;                 // source element (r, c) of A's 32 x 32 window
+                const int gi = row0 + i, gk = k0 + kk;
+                const double v = (gi < n && gk < n) ? (TA ? A[(size_t)gk * ld + gi] : A[(size_t)gi * ld + gk]) : 0.0;
+                sa[i * LS + kk] = v;
+            }
+            {
+                const int kk = TB ? c : r, j = TB ? r : c;
+                const int gk = k0 + kk, gj = col0 + j;
+                const double v = (gk < n && gj < n) ? (TB ? Bm[(size_t)gj * ld + gk] : Bm[(size_t)gk * ld + gj]) : 0.0;
+                sb[kk * LS + j] = v;
+            }
+        }
         __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 16; ++k) acc += sa[ty][k] * sb[k][tx];
+        const d4 part = mm32_mfma<false>(sa, sb, w, lane);
+        for (int t = 0; t < 4; ++t) acc[t] += part[t];
         __syncthreads();
     }
-    if (row < n && col < n) C[(size_t)row * ld + col] = acc;
+    const int orow = row0 + (w >> 1) * 16 + (lane >> 4), ocol = col0 + (w & 1) * 16 + (lane & 15);
+    for (int t = 0; t < 4; ++t)
+        if (orow + 4 * t < n && ocol < n) C[(size_t)(orow + 4 * t) * ld + ocol] = acc[t];
 }
 
 __global__ void __launch_bounds__(TPB) symmetrise_kernel(int n, int ld, double* __restrict__ C, size_t mat_stride) {
@@ -616,7 +631,7 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
     for (int k = 0; k < nbk; ++k)
         hipLaunchKernelGGL(chol_panel_kernel, dim3(nbk - k, 1, batch), dim3(256), 0, st, ld, k, nbk, ws.Bw, ws.Li, ws.flag, ms);
     hipLaunchKernelGGL(tri_inverse_kernel, dim3(nbk, BT / 8, batch), dim3(256), 0, st, ld, nbk, ws.Bw, ws.Li, ws.W, ws.flag, ms);
-    const dim3 gg((n + 15) / 16, (n + 15) / 16, batch);
+    const dim3 gg((n + BT - 1) / BT, (n + BT - 1) / BT, batch);
     hipLaunchKernelGGL((gemm_kernel<false, false>), gg, dim3(256), 0, st, n, ld, ws.W, ws.C0, ws.T1, ms);     // T1 = W A
     hipLaunchKernelGGL((gemm_kernel<false, true>), gg, dim3(256), 0, st, n, ld, ws.T1, ws.W, ws.C0, ms);      // C = T1 W^T
     hipLaunchKernelGGL(symmetrise_kernel, dim3(gx, n, batch), dim3(TPB), 0, st, n, ld, ws.C0, ms);
