@@ -319,3 +319,35 @@ def test_corr_bf16_exact_on_rounded_inputs(Engine):
             assert np.array_equal(first, r)
         first = r
     eng.close()
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_degenerate_spectra(Engine, dtype):
+    """Edge cases of the eigen-iteration at the headline shape: an all-zero bright slab (every pivot is exactly zero:
+    no rotation may be attempted on 0/0), a bright matrix proportional to the identity with an identity dark matrix
+    (fully degenerate spectrum) and already-diagonal matrices (nothing to rotate); no NaN, status 0, filters as the
+    oracle's."""
+    L, M = 16, 32
+    rng = np.random.default_rng(5)
+    XB, XD, d = cn(rng, 4, M, L), cn(rng, 4, M, L), cn(rng, 4, M)
+    XB[0] = 0                                            # R_B = 0: all eigenvalues 0, r = 0, w = 0
+    Q = np.linalg.qr(cn(rng, M, L).astype(np.complex128))[0]
+    XB[1] = (3.0 * Q).astype(np.complex64)               # R_B = 9 I
+    XD[1] = np.linalg.qr(cn(rng, M, L).astype(np.complex128))[0].astype(np.complex64)     # R_D = I
+    XB[2] = 0
+    XB[2, :L, :] = np.diag(np.arange(1, L + 1)).astype(np.complex64)                      # diagonal R_B
+    XD[2] = 0
+    XD[2, :L, :] = np.diag(np.linspace(2, 3, L)).astype(np.complex64)                     # diagonal R_D
+    eng = Engine(4, L, M, ranks=(1, 8, 16), mu=1.0, compute_dtype=dtype)
+    w, lam, status = eng.update(XB, XD, d)
+    eng.close()
+    assert not status.any() and np.isfinite(w).all() and np.isfinite(lam).all()
+    w_ref, lam_ref, _ = subband.update(XB, XD, d, 1.0, [1, 8, 16])
+    assert np.abs(lam[0]).max() < 1e-6 and np.abs(w[0]).max() < 1e-6
+    # sixteen eigenvalues inside a 1e-7-wide cluster (c64 rounding of the orthonormal columns): the sweep criterion is
+    # relative to ||C||, so the members are resolved to a fraction of the cluster width, not to 1e-9
+    assert np.abs(lam[1] / lam_ref[1] - 1).max() < max(TOL[dtype]["lam"] * 10, 1e-7)
+    assert np.abs(lam[2:] / lam_ref[2:] - 1).max() < TOL[dtype]["lam"] * 10
+    # degenerate eigenvalues: only the full-rank filter (and the projector it implies) is unique
+    assert w_err(w[1:2, 2], w_ref[1:2, 2]) < TOL[dtype]["w"] * 10
+    assert w_err(w[2:, :], w_ref[2:, :]) < TOL[dtype]["w"] * 10
