@@ -114,6 +114,34 @@ def g1_broadband(ref):
     return ap
 
 
+G4_HOPS = (0, 3, 7)
+
+
+def g4_stft_stage(ref):
+    """G4: the spectra of the RIR-convolved control-point signals -- the per-bin control-point matrices the subband
+    mode consumes -- from the reference's own response buffers of the G1 run, by the reference's
+    formulas (apvast.py:202-203 targets, 246-255 loudspeaker responses; weights are ones, 326-327)."""
+    rirA, rirB = cfg1_rirs()
+    ap = make_ref_obj(ref, rirA, rirB, seed=0)
+    H, N = CFG1["hop_size"], CFG1["block_size"]
+    x = np.random.default_rng(7).standard_normal((2, G1_HOPS * H))     # the G1 inputs
+    spectra = np.zeros((len(G4_HOPS), 4, N // 2 + 1, 8, 8), dtype=np.complex64)
+    tspectra = np.zeros((len(G4_HOPS), 2, N // 2 + 1, 8), dtype=np.complex64)
+    for h in range(max(G4_HOPS) + 1):
+        ap.process_input_buffers(x[0, h * H:(h + 1) * H], x[1, h * H:(h + 1) * H])
+        if h in G4_HOPS:
+            i = G4_HOPS.index(h)
+            bufs = (ap.loudspeaker_response_A_to_A_buffer, ap.loudspeaker_response_A_to_B_buffer,
+                    ap.loudspeaker_response_B_to_A_buffer, ap.loudspeaker_response_B_to_B_buffer)
+            for p, b in enumerate(bufs):                     # (N, L, M) -> (K, L, M)
+                spectra[i, p] = np.fft.rfft(ap.window[:, :, None] * b, n=N, axis=0)
+            for z, b in enumerate((ap.loudspeaker_target_response_A_to_A_buffer,
+                                   ap.loudspeaker_target_response_B_to_B_buffer)):
+                tspectra[i, z] = np.fft.rfft(ap.window * b, n=N, axis=0)
+    np.savez_compressed(os.path.join(OUT, "g4_stft_stage.npz"), hops=np.array(G4_HOPS), spectra=spectra,
+                        target_spectra=tspectra)
+
+
 def g1b_single_zone(ref):
     """run_B=False variant (apvast.py:53-54, 433-443): B output is None."""
     rirA, rirB = cfg1_rirs()
@@ -227,7 +255,11 @@ def g6_errors(ref):
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     ref = load_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "g4":        # add the fixture without regenerating the others
+        g4_stft_stage(ref)
+        sys.exit(0)
     g1_broadband(ref)
+    g4_stft_stage(ref)
     g1b_single_zone(ref)
     g2_jdiag_real(ref)
     g3_jdiag_complex(ref)

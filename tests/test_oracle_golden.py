@@ -187,3 +187,26 @@ def test_matlab_broadband_oracle_invariants(golden):
     # the B target filter uses the zone-B reference (apVast.m:597-602): only that loudspeaker carries signal
     tB = out[3][0]
     assert np.abs(tB[:, 1]).max() > 0 and not tB[:, [0, 2]].any()
+
+
+def test_g4_stft_stage_of_the_oracle(golden):
+    """Fixture G4 (spectra of the reference's response buffers, apvast.py:202-203, 246-255) against the oracle's
+    response buffers and its subband analysis stage."""
+    from oracle.broadband import BroadbandOracle
+    from oracle.subband import sine_window
+    g1, g4, rirs = golden("g1_broadband_cfg1"), golden("g4_stft_stage"), golden("rirs_cfg1")
+    N, H = 256, 128
+    np.random.seed(0)
+    orc = BroadbandOracle(N, rirs["rirA"], rirs["rirB"], 32, 16, 0, 0, 8, 1.0, 512, hop_size=H)
+    orc.response[:] = g1["init_response"]
+    orc.target_response[:] = g1["init_target_response"]
+    x, hops = g1["x"], list(g4["hops"])
+    w = sine_window(N)
+    for h in range(max(hops) + 1):
+        orc._update_response_buffers(x[0, h * H:(h + 1) * H], x[1, h * H:(h + 1) * H])
+        if h in hops:
+            i = hops.index(h)
+            spec = np.fft.rfft(w[None, :, None, None] * orc.response, axis=1)            # (4, K, L, M)
+            tspec = np.fft.rfft(w[None, :, None] * orc.target_response, axis=1)
+            assert np.abs(spec - g4["spectra"][i]).max() < 2e-7 * np.abs(g4["spectra"][i]).max()      # fixture is c64
+            assert np.abs(tspec - g4["target_spectra"][i]).max() < 2e-7 * np.abs(g4["target_spectra"][i]).max()
