@@ -262,6 +262,49 @@ __device__ __forceinline__ void move_bottoms(Cx<T>& tb, Cx<T>& bt, Cx<T>& bb, Cx
     bb = cxrow<D>(bb, lane);
 }
 
+// ---- applying a rotation J = [[c, s], [-conj(s), c]] to a pair of complex numbers ----
+//   columns  [p, q] J      : p' = c p - conj(s) q,  q' = c q + s p
+//   rows     J^H [p; q]    : p' = c p - s q,        q' = c q + conj(s) p
+// double: scalar FMAs.  float: the (re, im) pair is one 64-bit operand of v_pk_mul_f32 / v_pk_fma_f32 (the op_sel and
+// neg modifiers supply the swaps and sign flips of a complex product), which halves the instruction count.
+template <typename T>
+__device__ __forceinline__ void rot_cols(T c, Cx<T> s, Cx<T> p, Cx<T> q, Cx<T>& po, Cx<T>& qo) {
+    po.x = c * p.x - (s.x * q.x + s.y * q.y);
+    po.y = c * p.y - (s.x * q.y - s.y * q.x);
+    qo.x = c * q.x + (s.x * p.x - s.y * p.y);
+    qo.y = c * q.y + (s.x * p.y + s.y * p.x);
+}
+template <typename T>
+__device__ __forceinline__ void rot_rows(T c, Cx<T> s, Cx<T> p, Cx<T> q, Cx<T>& po, Cx<T>& qo) {
+    po.x = c * p.x - (s.x * q.x - s.y * q.y);
+    po.y = c * p.y - (s.x * q.y + s.y * q.x);
+    qo.x = c * q.x + (s.x * p.x + s.y * p.y);
+    qo.y = c * q.y + (s.x * p.y - s.y * p.x);
+}
+using f2v = __attribute__((ext_vector_type(2))) float;
+__device__ __forceinline__ f2v pk_cmul(f2v s, f2v z) {          // s z
+    const f2v t = {-s.y, s.y};
+    return __builtin_elementwise_fma((f2v){s.x, s.x}, z, t * (f2v){z.y, z.x});
+}
+__device__ __forceinline__ f2v pk_cmulc(f2v s, f2v z) {         // conj(s) z
+    const f2v t = {s.y, -s.y};
+    return __builtin_elementwise_fma((f2v){s.x, s.x}, z, t * (f2v){z.y, z.x});
+}
+template <>
+__device__ __forceinline__ void rot_cols<float>(float c, Cx<float> s, Cx<float> p, Cx<float> q, Cx<float>& po, Cx<float>& qo) {
+    const f2v cc = {c, c}, sv = {s.x, s.y}, pv = {p.x, p.y}, qv = {q.x, q.y};
+    const f2v a = cc * pv - pk_cmulc(sv, qv), b = cc * qv + pk_cmul(sv, pv);
+    po = mk<float>(a.x, a.y);
+    qo = mk<float>(b.x, b.y);
+}
+template <>
+__device__ __forceinline__ void rot_rows<float>(float c, Cx<float> s, Cx<float> p, Cx<float> q, Cx<float>& po, Cx<float>& qo) {
+    const f2v cc = {c, c}, sv = {s.x, s.y}, pv = {p.x, p.y}, qv = {q.x, q.y};
+    const f2v a = cc * pv - pk_cmul(sv, qv), b = cc * qv + pk_cmulc(sv, pv);
+    po = mk<float>(a.x, a.y);
+    qo = mk<float>(b.x, b.y);
+}
+
 // Jacobi rotation J = [[c, s], [-conj(s), c]] for the Hermitian 2x2 [[alpha, beta], [conj(beta), gamma]].
 // Any complex t gives an exactly unitary J once c = 1/sqrt(1+|t|^2), s = t c are formed in T, so the
 // angle t = sign(tau) e^{i arg beta} / (|tau| + sqrt(1+tau^2)) is evaluated in float (relative 1e-7: the pair's

@@ -250,36 +250,19 @@ __global__ void __launch_bounds__(64) gevd16m_kernel(const GevdParams p) {
                     ca = __shfl(c, da, 64); sax = __shfl(sx, da, 64); say = __shfl(sy, da, 64);
                     cb = __shfl(c, db, 64); sbx = __shfl(sx, db, 64); sby = __shfl(sy, db, 64);
                 }
+                const C sa = mk<T>(sax, say), sb = mk<T>(sbx, sby);
                 C ypp, ypq, yqp, yqq;
-                ypp.x = cb * tt.x - (sbx * tb.x + sby * tb.y);
-                ypp.y = cb * tt.y - (sbx * tb.y - sby * tb.x);
-                ypq.x = cb * tb.x + (sbx * tt.x - sby * tt.y);
-                ypq.y = cb * tb.y + (sbx * tt.y + sby * tt.x);
-                yqp.x = cb * bt.x - (sbx * bb.x + sby * bb.y);
-                yqp.y = cb * bt.y - (sbx * bb.y - sby * bb.x);
-                yqq.x = cb * bb.x + (sbx * bt.x - sby * bt.y);
-                yqq.y = cb * bb.y + (sbx * bt.y + sby * bt.x);
-                tt.x = ca * ypp.x - (sax * yqp.x - say * yqp.y);
-                tt.y = ca * ypp.y - (sax * yqp.y + say * yqp.x);
-                tb.x = ca * ypq.x - (sax * yqq.x - say * yqq.y);
-                tb.y = ca * ypq.y - (sax * yqq.y + say * yqq.x);
-                bt.x = ca * yqp.x + (sax * ypp.x + say * ypp.y);
-                bt.y = ca * yqp.y + (sax * ypp.y - say * ypp.x);
-                bb.x = ca * yqq.x + (sax * ypq.x + say * ypq.y);
-                bb.y = ca * yqq.y + (sax * ypq.y - say * ypq.x);
+                rot_cols<T>(cb, sb, tt, tb, ypp, ypq);
+                rot_cols<T>(cb, sb, bt, bb, yqp, yqq);
+                rot_rows<T>(ca, sa, ypp, yqp, tt, bt);
+                rot_rows<T>(ca, sa, ypq, yqq, tb, bb);
                 if (diag) {         // the angle is float-accurate: the residual beta' ~ 1e-7 beta is real data, keep it
                     tt.y = 0;
                     bb.y = 0;
                 }
                 C w0p, w0q, w1p, w1q;
-                w0p.x = cb * v0t.x - (sbx * v0b.x + sby * v0b.y);
-                w0p.y = cb * v0t.y - (sbx * v0b.y - sby * v0b.x);
-                w0q.x = cb * v0b.x + (sbx * v0t.x - sby * v0t.y);
-                w0q.y = cb * v0b.y + (sbx * v0t.y + sby * v0t.x);
-                w1p.x = cb * v1t.x - (sbx * v1b.x + sby * v1b.y);
-                w1p.y = cb * v1t.y - (sbx * v1b.y - sby * v1b.x);
-                w1q.x = cb * v1b.x + (sbx * v1t.x - sby * v1t.y);
-                w1q.y = cb * v1b.y + (sbx * v1t.y + sby * v1t.x);
+                rot_cols<T>(cb, sb, v0t, v0b, w0p, w0q);
+                rot_cols<T>(cb, sb, v1t, v1b, w1p, w1q);
                 v0t = w0p; v0b = w0q; v1t = w1p; v1b = w1q;
             }
             ++sweeps_done;
