@@ -57,8 +57,103 @@ __device__ __forceinline__ void cmm16(FA fa, FB fb, int lane, Cx<float> out[4]) 
     for (int t = 0; t < 4; ++t) out[t] = mk<float>(re[t], im[t]);
 }
 
+// The register-resident cyclic Jacobi of stage 3 on the 2 x 2 blocks (tt, tb; bt, bb) of this lane and its two rows
+// of V, in precision TT.  Runs sweeps until one of them meets sum |pivot|^2 <= tol2 normS2 (that sweep is the last) or
+// max_sweeps is reached; returns the number of sweeps done (its parity says which slot layout the blocks are left in).
+template <typename TT>
+__device__ __forceinline__ int jacobi16_sweeps(Cx<TT>& tt_, Cx<TT>& tb_, Cx<TT>& bt_, Cx<TT>& bb_, Cx<TT>& v0t_, Cx<TT>& v0b_,
+                                               Cx<TT>& v1t_, Cx<TT>& v1b_, TT (*srot)[4], int lane, TT tol2, TT normS2,
+                                               int max_sweeps, bool& converged_) {
+    using CC = Cx<TT>;
+    const int a = lane >> 3, b = lane & 7;
+    const bool diag = (a == b);
+    int sweeps_done = 0;
+    bool converged = false;
+    // work on local copies: the blocks must stay in registers (by-reference structs end up in scratch otherwise)
+    CC tt = tt_, tb = tb_, bt = bt_, bb = bb_, v0t = v0t_, v0b = v0b_, v1t = v1t_, v1b = v1b_;
+    for (int sweep = 0; sweep < max_sweeps && !converged; ++sweep) {
+        TT off = 0;
+        // the schedule as two nibble strings in scalar registers (a table in memory costs a load per round)
+        const unsigned long long dseq = (sweep & 1) ? XS_DELTA1 : XS_DELTA0;
+        const unsigned long long tseq = (sweep & 1) ? XS_TBIT1 : XS_TBIT0;
+        for (int r = 0; r < 15; ++r) {
+            const int delta = (int)((dseq >> (4 * r)) & 15), tbit = (int)((tseq >> (4 * r)) & 15) - 1;
+            if (tbit >= 0) {
+                // columns first, then rows; the row exchanges and the bit-2 column exchange are masked lane swaps
+                if (tbit == 2) {
+                    cxswap_col4(tt, tb);
+                    cxswap_col4(bt, bb);
+                    cxswap_col4(v0t, v0b);
+                    cxswap_col4(v1t, v1b);
+                    cxswap_row<2>(tt, bt);
+                    cxswap_row<2>(tb, bb);
+                } else {
+                    const bool cb_ = (b >> tbit) & 1;
+                    const int pc = lane ^ (1 << tbit);
+                    xchg(tt, tb, cb_, pc);
+                    xchg(bt, bb, cb_, pc);
+                    xchg(v0t, v0b, cb_, pc);
+                    xchg(v1t, v1b, cb_, pc);
+                    if (tbit == 1) {
+                        cxswap_row<1>(tt, bt);
+                        cxswap_row<1>(tb, bb);
+                    } else {
+                        cxswap_row<0>(tt, bt);
+                        cxswap_row<0>(tb, bb);
+                    }
+                }
+            }
+            switch (delta) {
+                case 1: move_bottoms<1>(tb, bt, bb, v0b, v1b, lane); break;
+                case 2: move_bottoms<2>(tb, bt, bb, v0b, v1b, lane); break;
+                case 4: move_bottoms<4>(tb, bt, bb, v0b, v1b, lane); break;
+                default: break;
+            }
+            if (diag) off += tb.x * tb.x + tb.y * tb.y;
+            TT c, sx, sy;
+            rotation<TT>(tt.x, bb.x, tb.x, tb.y, c, sx, sy);
+            TT ca, sax, say, cb, sbx, sby;
+            if constexpr (sizeof(TT) == 8) {
+                // double: the eight rotations go through LDS (two wide reads per lane instead of twelve ds_bpermute)
+                if (diag) {
+                    srot[a][0] = c;
+                    srot[a][1] = sx;
+                    srot[a][2] = sy;
+                }
+                wsync();
+                ca = srot[a][0]; sax = srot[a][1]; say = srot[a][2];
+                cb = srot[b][0]; sbx = srot[b][1]; sby = srot[b][2];
+            } else {
+                const int da = 9 * a, db = 9 * b;
+                ca = __shfl(c, da, 64); sax = __shfl(sx, da, 64); say = __shfl(sy, da, 64);
+                cb = __shfl(c, db, 64); sbx = __shfl(sx, db, 64); sby = __shfl(sy, db, 64);
+            }
+            const CC sa = mk<TT>(sax, say), sb = mk<TT>(sbx, sby);
+            CC ypp, ypq, yqp, yqq;
+            rot_cols<TT>(cb, sb, tt, tb, ypp, ypq);
+            rot_cols<TT>(cb, sb, bt, bb, yqp, yqq);
+            rot_rows<TT>(ca, sa, ypp, yqp, tt, bt);
+            rot_rows<TT>(ca, sa, ypq, yqq, tb, bb);
+            if (diag) {         // the angle is float-accurate: the residual beta' ~ 1e-7 beta is real data, keep it
+                tt.y = 0;
+                bb.y = 0;
+            }
+            CC w0p, w0q, w1p, w1q;
+            rot_cols<TT>(cb, sb, v0t, v0b, w0p, w0q);
+            rot_cols<TT>(cb, sb, v1t, v1b, w1p, w1q);
+            v0t = w0p; v0b = w0q; v1t = w1p; v1b = w1q;
+        }
+        ++sweeps_done;
+        const TT tot = wave_sum(off);
+        if (tot <= tol2 * normS2) converged = true;
+    }
+    tt_ = tt; tb_ = tb; bt_ = bt; bb_ = bb; v0t_ = v0t; v0b_ = v0b; v1t_ = v1t; v1b_ = v1b;
+    converged_ = converged;
+    return sweeps_done;
+}
+
 template <typename T, bool FUSED>
-__global__ void __launch_bounds__(64) gevd16m_kernel(const GevdParams p) {
+__device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
     // zone program of a two-zone launch (blockIdx.y); the argument block itself stays in scalar registers
     const bool z1 = (blockIdx.y == 1);
     const float2* const pXB = z1 ? p.XB1 : p.XB;
@@ -185,90 +280,95 @@ __global__ void __launch_bounds__(64) gevd16m_kernel(const GevdParams p) {
         bool converged = false;
         const int sexp = (normF2 > (T)0) ? -(ilogb((double)normF2) / 2) : 0;
         const T scl = (T)ldexp(1.0, sexp), iscl = (T)ldexp(1.0, -sexp);
+        const T normS2 = normF2 * scl * scl;
+        bool v_in_lds = false;
+        if constexpr (sizeof(T) == 8) {
+            // ---- float32 pre-solve (debug_stop == 4 skips it: double sweeps only, for A/B timing) -------------------
+            // The sweeps are the cost of the kernel and the packed-float ones are less than half as expensive, so C is
+            // first diagonalised in float: V32 with V32^H C V32 diagonal to ~1e-7.  V32 is unitary only to 1e-7, so it is
+            // not used as it is: with E = V32^H V32 - I,  V' = V32 (I - E/2) is unitary to E^2 ~ 1e-14 and
+            // C' = V'^H C V' = C1 - (E C1 + C1 E)/2,  C1 = V32^H C V32  (five complex 16 x 16 x 16 MFMA products).  The
+            // double sweeps then start from (C', V'): one is enough for the default tolerance.  W waits in registers.
+            if (p.debug_stop != 4) {
+                using CF = Cx<float>;
+                auto ldf = [&](int r, int c) { const C v = sA[r * LD + c]; return mk<float>((float)(v.x * scl), (float)(v.y * scl)); };
+                CF ftt = ldf(a, b), ftb = ldf(a, 8 + b), fbt = ldf(8 + a, b), fbb = ldf(8 + a, 8 + b);
+                CF f0t = mk<float>((2 * a == b) ? 1.f : 0.f, 0.f), f0b = mk<float>((2 * a == 8 + b) ? 1.f : 0.f, 0.f);
+                CF f1t = mk<float>((2 * a + 1 == b) ? 1.f : 0.f, 0.f), f1b = mk<float>((2 * a + 1 == 8 + b) ? 1.f : 0.f, 0.f);
+                bool fconv = false;
+                const int fs = jacobi16_sweeps<float>(ftt, ftb, fbt, fbb, f0t, f0b, f1t, f1b, (float (*)[4]) nullptr, lane,
+                                                      Prec<float>::sweep_tol2, (float)normS2, Prec<float>::max_sweeps, fconv);
+                const bool fnat = fs & 1;
+                const int fit = fnat ? 2 * b : b, fib = fnat ? 2 * b + 1 : 8 + b;
+                const int mcol = lane & 15;
+                auto cj = [](C w) { return mk<T>(w.x, -w.y); };
+                wsync();
+                sB[(2 * a) * LD + fit] = mk<T>((T)f0t.x, (T)f0t.y);                 // V32 takes W's place
+                sB[(2 * a) * LD + fib] = mk<T>((T)f0b.x, (T)f0b.y);
+                sB[(2 * a + 1) * LD + fit] = mk<T>((T)f1t.x, (T)f1t.y);
+                sB[(2 * a + 1) * LD + fib] = mk<T>((T)f1b.x, (T)f1b.y);
+                wsync();
+                C accT[4], accG[4], accC[4], accV[4], accE[4];
+                cmm16([&](int r, int kx) { return sA[r * LD + kx]; }, [&](int kx, int c) { return sB[kx * LD + c]; }, lane, accT);       // C V
+                cmm16([&](int r, int kx) { return cj(sB[kx * LD + r]); }, [&](int kx, int c) { return sB[kx * LD + c]; }, lane, accG);   // V^H V
+                wsync();
+#pragma unroll
+                for (int t = 0; t < 4; ++t) sA[mfma_row<T>(lane, t) * LD + mcol] = accT[t];
+                wsync();
+                cmm16([&](int r, int kx) { return cj(sB[kx * LD + r]); }, [&](int kx, int c) { return sA[kx * LD + c]; }, lane, accC);   // C1 = V^H C V
+                wsync();
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int row = mfma_row<T>(lane, t);
+                    sA[row * LD + mcol] = mk<T>(accG[t].x - (row == mcol ? (T)1 : (T)0), accG[t].y);                                     // E
+                }
+                wsync();
+                cmm16([&](int r, int kx) { return sB[r * LD + kx]; }, [&](int kx, int c) { return sA[kx * LD + c]; }, lane, accV);       // V E
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const C v = sB[mfma_row<T>(lane, t) * LD + mcol];
+                    accV[t] = mk<T>(v.x - (T)0.5 * accV[t].x, v.y - (T)0.5 * accV[t].y);                                                 // V'
+                }
+                wsync();
+#pragma unroll
+                for (int t = 0; t < 4; ++t) sB[mfma_row<T>(lane, t) * LD + mcol] = accC[t];
+                wsync();
+                cmm16([&](int r, int kx) { return sA[r * LD + kx]; }, [&](int kx, int c) { return sB[kx * LD + c]; }, lane, accE);       // E C1
+                wsync();
+#pragma unroll
+                for (int t = 0; t < 4; ++t) sA[mfma_row<T>(lane, t) * LD + mcol] = accE[t];
+                wsync();
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int row = mfma_row<T>(lane, t);
+                    const C h = cj(sA[mcol * LD + row]);                                                                                // (E C1)^H = C1 E
+                    accC[t] = mk<T>(accC[t].x - (T)0.5 * (accE[t].x + h.x), accC[t].y - (T)0.5 * (accE[t].y + h.y));
+                    if (row == mcol) accC[t].y = 0;
+                }
+                wsync();
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    sA[mfma_row<T>(lane, t) * LD + mcol] = accC[t];                                                                     // C'
+                    sB[mfma_row<T>(lane, t) * LD + mcol] = accV[t];                                                                     // V'
+                }
+                wsync();
+                v_in_lds = true;
+            }
+        }
         C tt = sA[a * LD + b], tb = sA[a * LD + 8 + b], bt = sA[(8 + a) * LD + b], bb = sA[(8 + a) * LD + 8 + b];
         tt = mk<T>(tt.x * scl, tt.y * scl); tb = mk<T>(tb.x * scl, tb.y * scl);
         bt = mk<T>(bt.x * scl, bt.y * scl); bb = mk<T>(bb.x * scl, bb.y * scl);
-        const T normS2 = normF2 * scl * scl;
         C v0t = mk<T>((2 * a == b) ? (T)1 : (T)0, 0), v0b = mk<T>((2 * a == 8 + b) ? (T)1 : (T)0, 0);
         C v1t = mk<T>((2 * a + 1 == b) ? (T)1 : (T)0, 0), v1b = mk<T>((2 * a + 1 == 8 + b) ? (T)1 : (T)0, 0);
-        const bool diag = (a == b);
-        int sweeps_done = 0;
-        for (int sweep = 0; sweep < max_sweeps && !converged; ++sweep) {
-            T off = 0;
-            // the schedule as two nibble strings in scalar registers (a table in memory costs a load per round)
-            const unsigned long long dseq = (sweep & 1) ? XS_DELTA1 : XS_DELTA0;
-            const unsigned long long tseq = (sweep & 1) ? XS_TBIT1 : XS_TBIT0;
-            for (int r = 0; r < 15; ++r) {
-                const int delta = (int)((dseq >> (4 * r)) & 15), tbit = (int)((tseq >> (4 * r)) & 15) - 1;
-                if (tbit >= 0) {
-                    // columns first, then rows; the row exchanges and the bit-2 column exchange are masked lane swaps
-                    if (tbit == 2) {
-                        cxswap_col4(tt, tb);
-                        cxswap_col4(bt, bb);
-                        cxswap_col4(v0t, v0b);
-                        cxswap_col4(v1t, v1b);
-                        cxswap_row<2>(tt, bt);
-                        cxswap_row<2>(tb, bb);
-                    } else {
-                        const bool cb_ = (b >> tbit) & 1;
-                        const int pc = lane ^ (1 << tbit);
-                        xchg(tt, tb, cb_, pc);
-                        xchg(bt, bb, cb_, pc);
-                        xchg(v0t, v0b, cb_, pc);
-                        xchg(v1t, v1b, cb_, pc);
-                        if (tbit == 1) {
-                            cxswap_row<1>(tt, bt);
-                            cxswap_row<1>(tb, bb);
-                        } else {
-                            cxswap_row<0>(tt, bt);
-                            cxswap_row<0>(tb, bb);
-                        }
-                    }
-                }
-                switch (delta) {
-                    case 1: move_bottoms<1>(tb, bt, bb, v0b, v1b, lane); break;
-                    case 2: move_bottoms<2>(tb, bt, bb, v0b, v1b, lane); break;
-                    case 4: move_bottoms<4>(tb, bt, bb, v0b, v1b, lane); break;
-                    default: break;
-                }
-                if (diag) off += tb.x * tb.x + tb.y * tb.y;
-                T c, sx, sy;
-                rotation<T>(tt.x, bb.x, tb.x, tb.y, c, sx, sy);
-                T ca, sax, say, cb, sbx, sby;
-                if constexpr (sizeof(T) == 8) {
-                    // double: the eight rotations go through LDS (two wide reads per lane instead of twelve ds_bpermute)
-                    if (diag) {
-                        srot[a][0] = c;
-                        srot[a][1] = sx;
-                        srot[a][2] = sy;
-                    }
-                    wsync();
-                    ca = srot[a][0]; sax = srot[a][1]; say = srot[a][2];
-                    cb = srot[b][0]; sbx = srot[b][1]; sby = srot[b][2];
-                } else {
-                    const int da = 9 * a, db = 9 * b;
-                    ca = __shfl(c, da, 64); sax = __shfl(sx, da, 64); say = __shfl(sy, da, 64);
-                    cb = __shfl(c, db, 64); sbx = __shfl(sx, db, 64); sby = __shfl(sy, db, 64);
-                }
-                const C sa = mk<T>(sax, say), sb = mk<T>(sbx, sby);
-                C ypp, ypq, yqp, yqq;
-                rot_cols<T>(cb, sb, tt, tb, ypp, ypq);
-                rot_cols<T>(cb, sb, bt, bb, yqp, yqq);
-                rot_rows<T>(ca, sa, ypp, yqp, tt, bt);
-                rot_rows<T>(ca, sa, ypq, yqq, tb, bb);
-                if (diag) {         // the angle is float-accurate: the residual beta' ~ 1e-7 beta is real data, keep it
-                    tt.y = 0;
-                    bb.y = 0;
-                }
-                C w0p, w0q, w1p, w1q;
-                rot_cols<T>(cb, sb, v0t, v0b, w0p, w0q);
-                rot_cols<T>(cb, sb, v1t, v1b, w1p, w1q);
-                v0t = w0p; v0b = w0q; v1t = w1p; v1b = w1q;
-            }
-            ++sweeps_done;
-            const T tot = wave_sum(off);
-            if (tot <= tol2 * normS2) converged = true;
+        if (v_in_lds) {
+            v0t = sB[(2 * a) * LD + b]; v0b = sB[(2 * a) * LD + 8 + b];
+            v1t = sB[(2 * a + 1) * LD + b]; v1b = sB[(2 * a + 1) * LD + 8 + b];
+            wsync();
+#pragma unroll
+            for (int t = 0; t < 4; ++t) sB[i * LD + jq + 4 * t] = wrow[t];          // W back in place for stage 5
         }
+        const bool diag = (a == b);
+        const int sweeps_done = jacobi16_sweeps<T>(tt, tb, bt, bb, v0t, v0b, v1t, v1b, srot, lane, tol2, normS2, max_sweeps, converged);
         if (!converged) status = 2;
         // after an odd number of sweeps slot s holds (2s, 2s+1), after an even number (s, 8+s)
         const bool nat = sweeps_done & 1;
@@ -354,6 +454,15 @@ __global__ void __launch_bounds__(64) gevd16m_kernel(const GevdParams p) {
     if (pstatus != nullptr && lane == 0) pstatus[k] = status;
 }
 
+// The double kernel is held to four waves per SIMD (its float32 pre-solve and the re-orthonormalisation products would
+// otherwise raise the register count past 128 and cost a wave); the float kernel is left to the compiler.
+template <typename T, bool FUSED>
+__global__ void __launch_bounds__(64) gevd16m_kernel(const GevdParams p) { gevd16m_body<T, FUSED>(p); }
+template <bool FUSED>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) gevd16m_kernel_f64(const GevdParams p) {
+    gevd16m_body<double, FUSED>(p);
+}
+
 }  // namespace
 
 hipError_t apv_launch_gevd16m(const GevdParams& p, int compute_dtype, bool fused, hipStream_t s) {
@@ -361,8 +470,8 @@ hipError_t apv_launch_gevd16m(const GevdParams& p, int compute_dtype, bool fused
     if (p.K <= 0) return hipSuccess;
     const dim3 grid(p.K, p.n_zones > 1 ? 2 : 1);
     if (compute_dtype == APV_F64) {
-        if (fused) hipLaunchKernelGGL((gevd16m_kernel<double, true>), grid, dim3(64), 0, s, p);
-        else hipLaunchKernelGGL((gevd16m_kernel<double, false>), grid, dim3(64), 0, s, p);
+        if (fused) hipLaunchKernelGGL((gevd16m_kernel_f64<true>), grid, dim3(64), 0, s, p);
+        else hipLaunchKernelGGL((gevd16m_kernel_f64<false>), grid, dim3(64), 0, s, p);
     } else {
         if (fused) hipLaunchKernelGGL((gevd16m_kernel<float, true>), grid, dim3(64), 0, s, p);
         else hipLaunchKernelGGL((gevd16m_kernel<float, false>), grid, dim3(64), 0, s, p);

@@ -223,7 +223,7 @@ def main():
                        "collective": collective},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved * 1e9 / HBM_PEAK, "traffic": traffic,
-                         "kernel": "gevd16m_kernel<%s, fused>" % ("double" if args.dtype == "f64" else "float"), "kernel_ms": kern_ms,
+                         "kernel": "gevd16m_kernel_f64<fused>" if args.dtype == "f64" else "gevd16m_kernel<float, fused>", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_update": bpu, "updates_per_launch": K,
                          "alu": {"flop_per_update": FLOP_PER_UPDATE, "achieved_tflops": alu / 1e12,
                                  "peak_tflops": PEAK_FLOPS[args.dtype] / 1e12,
