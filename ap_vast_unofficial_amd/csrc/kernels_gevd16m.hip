@@ -291,13 +291,16 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
             // double sweeps then start from (C', V'): one is enough for the default tolerance.  W waits in registers.
             if (p.debug_stop != 4) {
                 using CF = Cx<float>;
+                // looser than the float kernel's own 1e-8: a double sweep follows anyway, so the float sweep that would only
+                // confirm convergence is not run (1e-6 measured best; 1e-5 leaves more bins needing a second double sweep)
+                constexpr float kPresolveTol2 = 1e-6f;
                 auto ldf = [&](int r, int c) { const C v = sA[r * LD + c]; return mk<float>((float)(v.x * scl), (float)(v.y * scl)); };
                 CF ftt = ldf(a, b), ftb = ldf(a, 8 + b), fbt = ldf(8 + a, b), fbb = ldf(8 + a, 8 + b);
                 CF f0t = mk<float>((2 * a == b) ? 1.f : 0.f, 0.f), f0b = mk<float>((2 * a == 8 + b) ? 1.f : 0.f, 0.f);
                 CF f1t = mk<float>((2 * a + 1 == b) ? 1.f : 0.f, 0.f), f1b = mk<float>((2 * a + 1 == 8 + b) ? 1.f : 0.f, 0.f);
                 bool fconv = false;
                 const int fs = jacobi16_sweeps<float>(ftt, ftb, fbt, fbb, f0t, f0b, f1t, f1b, (float (*)[4]) nullptr, lane,
-                                                      Prec<float>::sweep_tol2, (float)normS2, Prec<float>::max_sweeps, fconv);
+                                                      kPresolveTol2, (float)normS2, Prec<float>::max_sweeps, fconv);
                 const bool fnat = fs & 1;
                 const int fit = fnat ? 2 * b : b, fib = fnat ? 2 * b + 1 : 8 + b;
                 const int mcol = lane & 15;
