@@ -6,6 +6,8 @@
 //            live in registers, one column / one row is broadcast through LDS per step      apvast.py:22-27
 //   stage 2  C = W R_B W^H                         two complex MFMA products                 apvast.py:28-29
 //   stage 3  cyclic Jacobi, register resident, XOR pairing schedule (gevd16_common.h)        apvast.py:30
+//            float64: a float32 pre-solve on packed math, its eigenvector matrix re-orthonormalised to first order
+//            and C re-formed on the f64 MFMA, then the double sweeps (one, at the default tolerance)
 //   stage 4  sort                                                                            apvast.py:32-35
 //   stage 5  X = W^H Q                             one complex MFMA product                  apvast.py:31
 //   stage 6  w_V = sum_{i<V} (x_i^H r)/(lam_i+mu) x_i                                        apvast.py:406-414
