@@ -104,6 +104,9 @@ hipError_t apv_launch_to_bf16(size_t count, const float2* in, uint32_t* out, hip
 hipError_t apv_launch_stft_analysis(int N, int n_ch, const float* x, float2* spec, hipStream_t s, std::string* why);
 hipError_t apv_launch_istft_ola(int N, int H, int n_ch, const float2* spec, float* overlap, float* out,
                                 hipStream_t s, std::string* why);
+hipError_t apv_launch_stft_analysis_jobs(int N, int n_jobs, const float* const* x, const int* n_ch, float2* const* spec,
+                                         const long* stride_c, const long* stride_k, int ring_off, hipStream_t s,
+                                         std::string* why);
 hipError_t apv_launch_stft_analysis_strided(int N, int n_ch, const float* x, int ring_off, float2* spec,
                                             long stride_c, long stride_k, hipStream_t s, std::string* why);
 hipError_t apv_launch_istft_ola_strided(int N, int H, int n_ch, const float2* spec, long stride_c, long stride_k,

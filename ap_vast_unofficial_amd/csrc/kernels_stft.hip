@@ -148,20 +148,15 @@ __device__ __forceinline__ C2<T>* fft_forward(const FftPlan& plan, C2<T>* a, C2<
     return src;
 }
 
-// x is a ring: logical sample n of channel c lives at x[c*x_stride + (n + ring_off) mod N]; samples
-// n >= in_len read as zero (zero padding, apvast.py:417: rfft(taps, N)); use_win = 0 skips the window
 template <typename T>
-__global__ void __launch_bounds__(STFT_TPB) stft_analysis_kernel(FftPlan plan, const T* __restrict__ x, long x_stride,
-                                                                 int in_len, int ring_off, int use_win,
-                                                                 C2<T>* __restrict__ spec, long stride_c, long stride_k,
-                                                                 const C2<T>* __restrict__ tw,
-                                                                 const T* __restrict__ win) {
+__device__ __forceinline__ void stft_analysis_body(const FftPlan& plan, const T* __restrict__ xin, int in_len, int ring_off,
+                                                   int use_win, C2<T>* __restrict__ out, long stride_k,
+                                                   const C2<T>* __restrict__ tw, const T* __restrict__ win) {
     extern __shared__ unsigned char smem_raw[];
     C2<T>* za = reinterpret_cast<C2<T>*>(smem_raw);
     const int N = plan.N, Nh = plan.Nh;
     C2<T>* zb = za + Nh;
-    const int c = blockIdx.x, tid = threadIdx.x;
-    const T* xin = x + (size_t)c * x_stride;
+    const int tid = threadIdx.x;
     for (int n = tid; n < Nh; n += STFT_TPB) {
         int i0 = 2 * n + ring_off, i1 = i0 + 1;
         if (i0 >= N) i0 -= N;
@@ -176,7 +171,6 @@ __global__ void __launch_bounds__(STFT_TPB) stft_analysis_kernel(FftPlan plan, c
     __syncthreads();
     const C2<T>* z = fft_forward<T>(plan, za, zb, tw);
     // even/odd split: X[k] = E[k] + e^{-2 pi i k/N} O[k]
-    C2<T>* out = spec + (size_t)c * stride_c;
     for (int k = tid; k <= Nh; k += STFT_TPB) {
         const C2<T> a = z[k == Nh ? 0 : k];
         const C2<T> bq = z[k == 0 ? 0 : Nh - k];
@@ -187,6 +181,37 @@ __global__ void __launch_bounds__(STFT_TPB) stft_analysis_kernel(FftPlan plan, c
         const C2<T> ow = cmul(o, tw[k]);                                 // tw[Nh] = -1
         out[(size_t)k * stride_k] = c2<T>(e.x + ow.x, e.y + ow.y);
     }
+}
+
+// x is a ring: logical sample n of channel c lives at x[c*x_stride + (n + ring_off) mod N]; samples
+// n >= in_len read as zero (zero padding, apvast.py:417: rfft(taps, N)); use_win = 0 skips the window
+template <typename T>
+__global__ void __launch_bounds__(STFT_TPB) stft_analysis_kernel(FftPlan plan, const T* __restrict__ x, long x_stride,
+                                                                 int in_len, int ring_off, int use_win,
+                                                                 C2<T>* __restrict__ spec, long stride_c, long stride_k,
+                                                                 const C2<T>* __restrict__ tw,
+                                                                 const T* __restrict__ win) {
+    const int c = blockIdx.x;
+    stft_analysis_body<T>(plan, x + (size_t)c * x_stride, in_len, ring_off, use_win, spec + (size_t)c * stride_c, stride_k, tw, win);
+}
+
+// several channel sets (full-length, windowed, one shared ring offset) in one launch: the streaming hop has seven
+constexpr int STFT_MAX_JOBS = 8;
+struct StftJobsF {
+    const float* x[STFT_MAX_JOBS];
+    C2<float>* spec[STFT_MAX_JOBS];
+    long stride_c[STFT_MAX_JOBS], stride_k[STFT_MAX_JOBS];
+    int ch0[STFT_MAX_JOBS + 1];                  // first workgroup of each job
+    int n;
+};
+__global__ void __launch_bounds__(STFT_TPB) stft_analysis_jobs_kernel(FftPlan plan, StftJobsF jobs, int ring_off,
+                                                                      const C2<float>* __restrict__ tw,
+                                                                      const float* __restrict__ win) {
+    int j = 0;
+    while (j + 1 < jobs.n && (int)blockIdx.x >= jobs.ch0[j + 1]) ++j;
+    const int c = (int)blockIdx.x - jobs.ch0[j];
+    stft_analysis_body<float>(plan, jobs.x[j] + (size_t)c * plan.N, plan.N, ring_off, 1, jobs.spec[j] + (size_t)c * jobs.stride_c[j],
+                              jobs.stride_k[j], tw, win);
 }
 
 template <typename T>
@@ -296,6 +321,35 @@ hipError_t launch_synthesis(int N, int H, int n_ch, const void* spec, long strid
 }
 
 }  // namespace
+
+hipError_t apv_launch_stft_analysis_jobs(int N, int n_jobs, const float* const* x, const int* n_ch, float2* const* spec,
+                                         const long* stride_c, const long* stride_k, int ring_off, hipStream_t s,
+                                         std::string* why) {
+    FftPlan plan;
+    if (!make_plan(N, &plan, why)) return hipErrorInvalidValue;
+    if (n_jobs < 1 || n_jobs > STFT_MAX_JOBS) return hipErrorInvalidValue;
+    Tables<float> t;
+    hipError_t e = get_tables<float>(N, &t);
+    if (e != hipSuccess) return e;
+    StftJobsF jobs{};
+    int total = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        jobs.x[j] = x[j];
+        jobs.spec[j] = (C2<float>*)spec[j];
+        jobs.stride_c[j] = stride_c[j];
+        jobs.stride_k[j] = stride_k[j];
+        jobs.ch0[j] = total;
+        total += n_ch[j];
+    }
+    jobs.ch0[n_jobs] = total;
+    jobs.n = n_jobs;
+    if (total <= 0) return hipSuccess;
+    int off = ring_off % N;
+    if (off < 0) off += N;
+    hipLaunchKernelGGL(stft_analysis_jobs_kernel, dim3(total), dim3(STFT_TPB), sizeof(C2<float>) * 2 * plan.Nh, s, plan, jobs, off,
+                       t.tw, t.win);
+    return hipGetLastError();
+}
 
 // build (or find) the twiddle / window tables now, so that no allocation happens on the per-hop path
 hipError_t apv_stft_prepare(int N, int f64) {

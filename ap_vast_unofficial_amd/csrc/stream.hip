@@ -235,14 +235,22 @@ static int enqueue_hop(apv_handle* h) {
     }
     // K2: analysis, bin-major output
     const bool runA = s->zones & 1, runB = s->zones & 2;
-    for (int p = 0; p < 4; ++p) {
-        const bool need = (p < 2) ? runA : runB;       // A->A, A->B feed zone program A; B->A, B->B feed B
-        if (!need) continue;
-        SCHK(h, apv_launch_stft_analysis_strided(N, C, s->resp[p], s->ring_off, s->X[p], 1, C, st, &why));
+    {
+        // every analysis transform of the hop in one launch: the live response paths, both targets, the two inputs
+        const float* jx[7];
+        float2* jspec[7];
+        int jch[7], nj = 0;
+        long jsc[7], jsk[7];
+        for (int p = 0; p < 4; ++p) {
+            const bool need = (p < 2) ? runA : runB;       // A->A, A->B feed zone program A; B->A, B->B feed B
+            if (!need) continue;
+            jx[nj] = s->resp[p]; jspec[nj] = s->X[p]; jch[nj] = C; jsc[nj] = 1; jsk[nj] = C; ++nj;
+        }
+        for (int z = 0; z < 2; ++z) { jx[nj] = s->tresp[z]; jspec[nj] = s->tspec[z]; jch[nj] = M; jsc[nj] = 1; jsk[nj] = M; ++nj; }
+        jx[nj] = s->inblk; jspec[nj] = s->inspec; jch[nj] = 2; jsc[nj] = K; jsk[nj] = 1; ++nj;
+        hipError_t e = apv_launch_stft_analysis_jobs(N, nj, jx, jch, jspec, jsc, jsk, s->ring_off, st, &why);
+        if (e != hipSuccess) return apv_fail(h, APV_ERR_HIP, why.empty() ? hipGetErrorString(e) : why);
     }
-    for (int z = 0; z < 2; ++z)
-        SCHK(h, apv_launch_stft_analysis_strided(N, M, s->tresp[z], s->ring_off, s->tspec[z], 1, M, st, &why));
-    SCHK(h, apv_launch_stft_analysis_strided(N, 2, s->inblk, s->ring_off, s->inspec, K, 1, st, &why));
     if (s->nch > 0) {
         // weights from the UNWEIGHTED target spectra (apvast.py:205), then spectra x weights (apvast.py:208-209,
         // 258-262): A->A and B->A take zone A's curve, A->B and B->B zone B's
