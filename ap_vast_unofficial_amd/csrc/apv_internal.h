@@ -136,9 +136,8 @@ hipError_t apv_launch_perceptual_weights_f64(int K, int M, int nch, const double
                                              const double* G2T, double Cs, double Ca, double Leff, int N, int norm_mode,
                                              double* W, hipStream_t s);
 hipError_t apv_launch_scale_spectra_cm_f64(int K, int C, int L, double2* spec, const double* W, hipStream_t s);
-hipError_t apv_launch_hist_update(int P, int H, int pad, const float* old_hist, const float* x, float* new_hist,
-                                  hipStream_t s);
-hipError_t apv_launch_ring_append(int N, int H, int ring_off, const float* x, float* ring, hipStream_t s);
+hipError_t apv_launch_input_update(int P, int H, int pad, int N, int ring_off, const float* const old_hist[2],
+                                   float* const new_hist[2], const float* xin, float* inblk, hipStream_t s);
 int apv_fir_pad();
 // out[ch][k] = in_spec[k] * filt(ch, k): ch < n_filt channels taken from the bin-major filter bank
 // w[k][n_filt] (c64 or c128), remaining channels from the channel-major table tgt[ch - n_filt][k]

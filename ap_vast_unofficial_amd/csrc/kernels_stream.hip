@@ -118,21 +118,21 @@ __global__ void __launch_bounds__(256) fir_mfma_kernel(FirJobs jobs, int P, int 
     }
 }
 
-// new_hist = [old_hist[H : H+P-1], x[0:H], zero pad]
-__global__ void __launch_bounds__(256) hist_update_kernel(int P, int H, int pad, const float* __restrict__ old_hist,
-                                                          const float* __restrict__ x, float* __restrict__ new_hist) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+// both input signals of a hop in one launch (blockIdx.y = signal): new history = [old[H:], x, zeros(pad)] and the hop
+// appended to the input-block ring
+struct InputUpdate {
+    const float* old_hist[2];
+    float* new_hist[2];
+};
+__global__ void __launch_bounds__(256) input_update_kernel(int P, int H, int pad, int N, int ring_off, InputUpdate u,
+                                                           const float* __restrict__ xin, float* __restrict__ inblk) {
+    const int g = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    const float* x = xin + (size_t)g * H;
     const int keep = P - 1;
-    if (i < keep) new_hist[i] = old_hist[i + H];
-    else if (i < keep + H) new_hist[i] = x[i - keep];
-    else if (i < keep + H + pad) new_hist[i] = 0.f;
-}
-
-// ring[(N-H+n + ring_off) & (N-1)] = x[n]
-__global__ void __launch_bounds__(256) ring_append_kernel(int N, int H, int ring_off, const float* __restrict__ x,
-                                                          float* __restrict__ ring) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n < H) ring[(N - H + n + ring_off) % N] = x[n];
+    if (i < keep) u.new_hist[g][i] = u.old_hist[g][i + H];
+    else if (i < keep + H) u.new_hist[g][i] = x[i - keep];
+    else if (i < keep + H + pad) u.new_hist[g][i] = 0.f;
+    if (i < H) inblk[(size_t)g * N + (N - H + i + ring_off) % N] = x[i];
 }
 
 // ---- perceptual weighting (van de Par 2005, Matlab/ControlMethods/perceptualModel.m:118-139, 177-190) --------
@@ -289,15 +289,11 @@ hipError_t apv_launch_scale_spectra(int K, int C, int L, float2* spec, const flo
     return hipGetLastError();
 }
 
-hipError_t apv_launch_hist_update(int P, int H, int pad, const float* old_hist, const float* x, float* new_hist,
-                                  hipStream_t s) {
+hipError_t apv_launch_input_update(int P, int H, int pad, int N, int ring_off, const float* const old_hist[2],
+                                   float* const new_hist[2], const float* xin, float* inblk, hipStream_t s) {
+    InputUpdate u{{old_hist[0], old_hist[1]}, {new_hist[0], new_hist[1]}};
     const int total = P - 1 + H + pad;
-    hipLaunchKernelGGL(hist_update_kernel, dim3((total + 255) / 256), dim3(256), 0, s, P, H, pad, old_hist, x, new_hist);
-    return hipGetLastError();
-}
-
-hipError_t apv_launch_ring_append(int N, int H, int ring_off, const float* x, float* ring, hipStream_t s) {
-    hipLaunchKernelGGL(ring_append_kernel, dim3((H + 255) / 256), dim3(256), 0, s, N, H, ring_off % N, x, ring);
+    hipLaunchKernelGGL(input_update_kernel, dim3((total + 255) / 256, 2), dim3(256), 0, s, P, H, pad, N, ring_off % N, u, xin, inblk);
     return hipGetLastError();
 }
 

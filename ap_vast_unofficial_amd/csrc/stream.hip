@@ -209,14 +209,14 @@ static int enqueue_hop(apv_handle* h) {
     SCHK(h, hipMemcpyAsync(s->xin, h_in_A, sizeof(float) * H, hipMemcpyHostToDevice, st));
     SCHK(h, hipMemcpyAsync(s->xin + H, h_in_B, sizeof(float) * H, hipMemcpyHostToDevice, st));
     const int nxt = s->cur ^ 1;
-    for (int g = 0; g < 2; ++g) {
-        SCHK(h, apv_launch_hist_update(P, H, s->pad, s->xhist[s->cur][g], s->xin + (size_t)g * H, s->xhist[nxt][g], st));
-    }
-    s->cur = nxt;
     // all rings advance by one hop: logical sample n now lives H further on
     s->ring_off = (s->ring_off + H) % N;
-    for (int g = 0; g < 2; ++g)
-        SCHK(h, apv_launch_ring_append(N, H, s->ring_off, s->xin + (size_t)g * H, s->inblk + (size_t)g * N, st));
+    {
+        const float* oh[2] = {s->xhist[s->cur][0], s->xhist[s->cur][1]};
+        float* nh[2] = {s->xhist[nxt][0], s->xhist[nxt][1]};
+        SCHK(h, apv_launch_input_update(P, H, s->pad, N, s->ring_off, oh, nh, s->xin, s->inblk, st));   // histories + input-block rings
+    }
+    s->cur = nxt;
     // K1: RIR convolution into the response rings (one MFMA launch for all six filter banks)
     {
         static const bool valu_fir = (getenv("APV_FIR_VALU") != nullptr);     // A/B switch: direct-form VALU kernel
