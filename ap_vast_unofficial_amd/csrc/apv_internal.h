@@ -141,5 +141,5 @@ hipError_t apv_launch_input_update(int P, int H, int pad, int N, int ring_off, c
 int apv_fir_pad();
 // out[ch][k] = in_spec[k] * filt(ch, k): ch < n_filt channels taken from the bin-major filter bank
 // w[k][n_filt] (c64 or c128), remaining channels from the channel-major table tgt[ch - n_filt][k]
-hipError_t apv_launch_apply_filters(int K, int n_filt, int n_tgt, const float2* in_spec, const void* w, int w_c128,
-                                    const float2* tgt, float2* out, hipStream_t s);
+hipError_t apv_launch_apply_jobs(int K, int n_jobs, const float2* const* in_spec, const void* const* w, const float2* const* tgt,
+                                 float2* const* out, const int* n_filt, const int* n_tgt, int w_c128, hipStream_t s);

@@ -215,14 +215,30 @@ __global__ void __launch_bounds__(256) scale_spectra_cm_f64_kernel(int K, int C,
     spec[idx] = v;
 }
 
+// Output spectra of a hop in one launch: job j multiplies the input spectrum in[j] with n_filt[j] filters of the bin-major
+// bank w[j] (c64 or c128) and/or n_tgt[j] channel-major target filters tgt[j]; blockIdx.y walks the 16-channel tiles of
+// all jobs.
+constexpr int APPLY_MAX_JOBS = 4;
+struct ApplyJobs {
+    const float2* in[APPLY_MAX_JOBS];
+    const void* w[APPLY_MAX_JOBS];
+    const float2* tgt[APPLY_MAX_JOBS];
+    float2* out[APPLY_MAX_JOBS];
+    int n_filt[APPLY_MAX_JOBS], n_tgt[APPLY_MAX_JOBS], tile0[APPLY_MAX_JOBS + 1];
+    int n;
+};
 template <typename W>
-__global__ void __launch_bounds__(256) apply_filters_kernel(int K, int n_filt, int n_tgt,
-                                                            const float2* __restrict__ in_spec,
-                                                            const W* __restrict__ w, const float2* __restrict__ tgt,
-                                                            float2* __restrict__ out) {
+__global__ void __launch_bounds__(256) apply_filters_kernel(int K, ApplyJobs jobs) {
     // grid: x over k, y over channels (tiles of 16 channels x 16 bins so both sides stay reasonably coalesced)
     __shared__ float2 tile[16][17];
-    const int k0 = blockIdx.x * 16, c0 = blockIdx.y * 16;
+    int j = 0;
+    while (j + 1 < jobs.n && (int)blockIdx.y >= jobs.tile0[j + 1]) ++j;
+    const int n_filt = jobs.n_filt[j], n_tgt = jobs.n_tgt[j];
+    const W* __restrict__ w = reinterpret_cast<const W*>(jobs.w[j]);
+    const float2* __restrict__ tgt = jobs.tgt[j];
+    const float2* __restrict__ in_spec = jobs.in[j];
+    float2* __restrict__ out = jobs.out[j];
+    const int k0 = blockIdx.x * 16, c0 = ((int)blockIdx.y - jobs.tile0[j]) * 16;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int n_ch = n_filt + n_tgt;
     {   // load: channel fastest (bin-major filter bank)
@@ -311,16 +327,22 @@ hipError_t apv_launch_fir_jobs(const FirJobs& jobs, int P, int H, int N, int rin
     return hipGetLastError();
 }
 
-hipError_t apv_launch_apply_filters(int K, int n_filt, int n_tgt, const float2* in_spec, const void* w,
-                                    int w_c128, const float2* tgt, float2* out, hipStream_t s) {
-    const int n_ch = n_filt + n_tgt;
-    if (n_ch <= 0 || K <= 0) return hipSuccess;
-    dim3 grid((K + 15) / 16, (n_ch + 15) / 16);
-    if (w_c128)
-        hipLaunchKernelGGL(apply_filters_kernel<double2>, grid, dim3(256), 0, s, K, n_filt, n_tgt, in_spec,
-                           (const double2*)w, tgt, out);
-    else
-        hipLaunchKernelGGL(apply_filters_kernel<float2>, grid, dim3(256), 0, s, K, n_filt, n_tgt, in_spec,
-                           (const float2*)w, tgt, out);
+hipError_t apv_launch_apply_jobs(int K, int n_jobs, const float2* const* in_spec, const void* const* w, const float2* const* tgt,
+                                 float2* const* out, const int* n_filt, const int* n_tgt, int w_c128, hipStream_t s) {
+    if (n_jobs < 1 || n_jobs > APPLY_MAX_JOBS || K <= 0) return hipErrorInvalidValue;
+    ApplyJobs jobs{};
+    int tiles = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        jobs.in[j] = in_spec[j]; jobs.w[j] = w[j]; jobs.tgt[j] = tgt[j]; jobs.out[j] = out[j];
+        jobs.n_filt[j] = n_filt[j]; jobs.n_tgt[j] = n_tgt[j];
+        jobs.tile0[j] = tiles;
+        tiles += (n_filt[j] + n_tgt[j] + 15) / 16;
+    }
+    jobs.tile0[n_jobs] = tiles;
+    jobs.n = n_jobs;
+    if (tiles == 0) return hipSuccess;
+    const dim3 grid((K + 15) / 16, tiles);
+    if (w_c128) hipLaunchKernelGGL(apply_filters_kernel<double2>, grid, dim3(256), 0, s, K, jobs);
+    else hipLaunchKernelGGL(apply_filters_kernel<float2>, grid, dim3(256), 0, s, K, jobs);
     return hipGetLastError();
 }

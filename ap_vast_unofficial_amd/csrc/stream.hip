@@ -283,19 +283,27 @@ static int enqueue_hop(apv_handle* h) {
         hipError_t e = apv_launch_gevd(p, h->cfg.compute_dtype, true, st, &why);
         if (e != hipSuccess) return apv_fail(h, APV_ERR_HIP, why.empty() ? hipGetErrorString(e) : why);
     }
-    for (int z = 0; z < 2; ++z) {
-        if (!(z ? runB : runA)) continue;
-        // K3: filtered output spectra for this zone's nV*L channels
-        SCHK(h, apv_launch_apply_filters(K, s->nV * L, 0, s->inspec + (size_t)z * K, s->w[z], h->cfg.out_c128, nullptr,
-                                         s->outspec + (size_t)oc * K, st));
-        SCHK(h, hipMemcpyAsync(s->pin_status + (size_t)z * K, s->status[z], sizeof(int32_t) * K,
-                               hipMemcpyDeviceToHost, st));
-        oc += s->nV * L;
-    }
-    for (int z = 0; z < 2; ++z) {       // target paths A_t, B_t
-        SCHK(h, apv_launch_apply_filters(K, 0, L, s->inspec + (size_t)z * K, nullptr, 0, s->tgt,
-                                         s->outspec + (size_t)oc * K, st));
-        oc += L;
+    {
+        // K3: output spectra in one launch: each live zone's nV*L filtered channels, then the target paths A_t, B_t
+        const float2* jin[4];
+        const void* jw[4];
+        const float2* jt[4];
+        float2* jout[4];
+        int jf[4], jtg[4], nj = 0;
+        for (int z = 0; z < 2; ++z) {
+            if (!(z ? runB : runA)) continue;
+            jin[nj] = s->inspec + (size_t)z * K; jw[nj] = s->w[z]; jt[nj] = nullptr; jout[nj] = s->outspec + (size_t)oc * K;
+            jf[nj] = s->nV * L; jtg[nj] = 0; ++nj;
+            SCHK(h, hipMemcpyAsync(s->pin_status + (size_t)z * K, s->status[z], sizeof(int32_t) * K,
+                                   hipMemcpyDeviceToHost, st));
+            oc += s->nV * L;
+        }
+        for (int z = 0; z < 2; ++z) {
+            jin[nj] = s->inspec + (size_t)z * K; jw[nj] = nullptr; jt[nj] = s->tgt; jout[nj] = s->outspec + (size_t)oc * K;
+            jf[nj] = 0; jtg[nj] = L; ++nj;
+            oc += L;
+        }
+        SCHK(h, apv_launch_apply_jobs(K, nj, jin, jw, jt, jout, jf, jtg, h->cfg.out_c128, st));
     }
     // K4: synthesis + overlap-add + emit
     SCHK(h, apv_launch_istft_ola_strided(N, H, s->n_out, s->outspec, K, 1, s->outov, s->out, st, &why));
