@@ -85,7 +85,7 @@ void apv_stream_free(apv_handle* h) {
     void* bufs[] = {s->rir[0], s->rir[1], s->trir[0], s->trir[1], s->xhist[0][0], s->xhist[0][1], s->xhist[1][0],
                     s->xhist[1][1], s->xin, s->resp[0], s->resp[1], s->resp[2], s->resp[3], s->tresp[0], s->tresp[1],
                     s->inblk, s->X[0], s->X[1], s->X[2], s->X[3], s->tspec[0], s->tspec[1], s->inspec, s->w[0],
-                    s->w[1], s->lam[0], s->lam[1], s->status[0], s->status[1], s->tgt, s->outspec, s->outov, s->out,
+                    s->w[1], s->lam[0], s->lam[1], s->status[0], s->tgt, s->outspec, s->outov, s->out,
                     s->G2, s->G2T, s->Wgt[0], s->Wgt[1]};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -158,8 +158,9 @@ int apv_stream_init(apv_handle* h, int32_t rir_len, const double* h_rir_A, const
         if ((rc = dalloc(h, &s->tspec[z], (size_t)K * M))) return rc;
         if ((rc = dalloc(h, (char**)&s->w[z], (size_t)K * s->nV * L * wsz(h)))) return rc;
         if ((rc = dalloc(h, (char**)&s->lam[z], (size_t)K * L * lsz(h)))) return rc;
-        if ((rc = dalloc(h, &s->status[z], (size_t)K))) return rc;
     }
+    if ((rc = dalloc(h, &s->status[0], (size_t)2 * K))) return rc;       // [zone A | zone B]: one copy back per hop
+    s->status[1] = s->status[0] + K;
     if ((rc = dalloc(h, &s->inblk, (size_t)2 * N))) return rc;
     if ((rc = dalloc(h, &s->inspec, (size_t)2 * K))) return rc;
     if ((rc = dalloc(h, &s->tgt, (size_t)L * K))) return rc;
@@ -201,13 +202,11 @@ static int enqueue_hop(apv_handle* h) {
     apv_stream* s = h->st;
     hipStream_t st = h->stream;
     const float* h_in_A = s->pin_in;
-    const float* h_in_B = s->pin_in + s->H;
     float* h_out = s->pin_out;
     const int N = s->N, H = s->H, K = s->K, L = s->L, M = s->M, C = s->C, P = s->P;
     std::string why;
     // hop -> device, input history and input-block rings
-    SCHK(h, hipMemcpyAsync(s->xin, h_in_A, sizeof(float) * H, hipMemcpyHostToDevice, st));
-    SCHK(h, hipMemcpyAsync(s->xin + H, h_in_B, sizeof(float) * H, hipMemcpyHostToDevice, st));
+    SCHK(h, hipMemcpyAsync(s->xin, h_in_A, sizeof(float) * 2 * H, hipMemcpyHostToDevice, st));     // [A | B], contiguous on both sides
     const int nxt = s->cur ^ 1;
     // all rings advance by one hop: logical sample n now lives H further on
     s->ring_off = (s->ring_off + H) % N;
@@ -294,8 +293,6 @@ static int enqueue_hop(apv_handle* h) {
             if (!(z ? runB : runA)) continue;
             jin[nj] = s->inspec + (size_t)z * K; jw[nj] = s->w[z]; jt[nj] = nullptr; jout[nj] = s->outspec + (size_t)oc * K;
             jf[nj] = s->nV * L; jtg[nj] = 0; ++nj;
-            SCHK(h, hipMemcpyAsync(s->pin_status + (size_t)z * K, s->status[z], sizeof(int32_t) * K,
-                                   hipMemcpyDeviceToHost, st));
             oc += s->nV * L;
         }
         for (int z = 0; z < 2; ++z) {
@@ -304,6 +301,8 @@ static int enqueue_hop(apv_handle* h) {
             oc += L;
         }
         SCHK(h, apv_launch_apply_jobs(K, nj, jin, jw, jt, jout, jf, jtg, h->cfg.out_c128, st));
+        const int zf = runA ? 0 : 1, zn = (runA && runB) ? 2 : 1;
+        SCHK(h, hipMemcpyAsync(s->pin_status + (size_t)zf * K, s->status[zf], sizeof(int32_t) * K * zn, hipMemcpyDeviceToHost, st));
     }
     // K4: synthesis + overlap-add + emit
     SCHK(h, apv_launch_istft_ola_strided(N, H, s->n_out, s->outspec, K, 1, s->outov, s->out, st, &why));
