@@ -5,6 +5,7 @@
 // split of the C ABI, the stage-level parity tests, and the fp32-vs-bf16 accumulation study of BASELINE config 5.
 //
 //   corr_kernel<T>            any L <= 64, any M: LDS-staged VALU (f32 or f64 accumulation)
+//   corr_mfma_f64_kernel      L in {16, 32, 48, 64}: v_mfma_f64_16x16x4_f64, float64 accumulation, one wave per 16x16 tile
 //   corr_mfma_f32_kernel      L in {32, 64}: v_mfma_f32_32x32x2_f32, exact f32 products, one wave per (bin, matrix)
 //   corr_mfma_bf16_kernel     L in {32, 64}: v_mfma_f32_32x32x16_bf16 on bf16 inputs, f32 accumulation
 //
@@ -71,6 +72,57 @@ __global__ void __launch_bounds__(256) corr_kernel(int M, int L, const float2* _
             r[((size_t)k * L + tid) * 2] = rx;
             r[((size_t)k * L + tid) * 2 + 1] = ry;
         }
+    }
+}
+
+using d4c = __attribute__((ext_vector_type(4))) double;
+
+// float64 accumulation on v_mfma_f64_16x16x4_f64: one workgroup per (bin, matrix), one wave per 16 x 16 tile of R
+// (NT = L / 16 tiles per side).  Lane (c = lane & 15, h = lane >> 4) supplies A[i = c][k = h] = conj(X[m0+h][16 ta + c])
+// and B[k = h][j = c] = X[m0+h][16 tb + c]; the products of float32 inputs are exact in double.  Rows are taken eight
+// k-steps (32 control points) at a time with every load of the chunk in flight before its first MFMA.
+template <int NT>
+__global__ void __launch_bounds__(64 * NT * NT) corr_mfma_f64_kernel(int M, const float2* __restrict__ XB,
+                                                                     const float2* __restrict__ XD,
+                                                                     const float2* __restrict__ d, double2* __restrict__ RB,
+                                                                     double2* __restrict__ RD, double2* __restrict__ r) {
+    constexpr int L = 16 * NT;
+    const int k = blockIdx.x, which = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ta = wave / NT, tb = wave % NT;
+    const float2* X = (which ? XD : XB) + (size_t)k * M * L;
+    const int c = lane & 15, h = lane >> 4;
+    const bool want_r = (which == 0) && (tb == 0);          // the waves of tile column 0 cover every loudspeaker once
+    d4c re = {0, 0, 0, 0}, im = {0, 0, 0, 0};
+    double rx = 0.0, ry = 0.0;
+    for (int mc = 0; mc < M; mc += 32) {
+        float2 xa[8], xb[8], dv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int m = mc + 4 * q + h;
+            const bool ok = m < M;
+            xa[q] = ok ? X[(size_t)m * L + 16 * ta + c] : make_float2(0.f, 0.f);
+            xb[q] = ok ? X[(size_t)m * L + 16 * tb + c] : make_float2(0.f, 0.f);
+            dv[q] = (ok && want_r) ? d[(size_t)k * M + m] : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const double ar = xa[q].x, ai = xa[q].y, br = xb[q].x, bi = xb[q].y;
+            re = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, re, 0, 0, 0);
+            re = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bi, re, 0, 0, 0);
+            im = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, im, 0, 0, 0);
+            im = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, br, im, 0, 0, 0);
+            rx += ar * (double)dv[q].x + ai * (double)dv[q].y;
+            ry += ar * (double)dv[q].y - ai * (double)dv[q].x;
+        }
+    }
+    // f64 16x16x4 accumulator: row = (lane >> 4) + 4 t, col = lane & 15
+    double2* R = (which ? RD : RB) + (size_t)k * L * L;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) R[(size_t)(16 * ta + h + 4 * t) * L + 16 * tb + c] = make_double2(re[t], im[t]);
+    if (want_r) {
+        rx += __shfl_xor(rx, 16, 64); ry += __shfl_xor(ry, 16, 64);
+        rx += __shfl_xor(rx, 32, 64); ry += __shfl_xor(ry, 32, 64);
+        if (h == 0) r[(size_t)k * L + 16 * ta + c] = make_double2(rx, ry);
     }
 }
 
@@ -248,7 +300,13 @@ hipError_t apv_launch_corr(int compute_dtype, int K, int M, int L, const float2*
                            const float2* d, void* RB, void* RD, void* r, hipStream_t s) {
     if (K <= 0) return hipSuccess;
     if (L < 1 || L > APV_MAX_N || M < 1) return hipErrorInvalidValue;
-    if (compute_dtype == APV_F64) {
+    if (compute_dtype == APV_F64 && (L == 16 || L == 32 || L == 48 || L == 64)) {
+        double2 *rb = (double2*)RB, *rd = (double2*)RD, *rr = (double2*)r;
+        if (L == 16) hipLaunchKernelGGL(corr_mfma_f64_kernel<1>, dim3(K, 2), dim3(64), 0, s, M, XB, XD, d, rb, rd, rr);
+        else if (L == 32) hipLaunchKernelGGL(corr_mfma_f64_kernel<2>, dim3(K, 2), dim3(256), 0, s, M, XB, XD, d, rb, rd, rr);
+        else if (L == 48) hipLaunchKernelGGL(corr_mfma_f64_kernel<3>, dim3(K, 2), dim3(576), 0, s, M, XB, XD, d, rb, rd, rr);
+        else hipLaunchKernelGGL(corr_mfma_f64_kernel<4>, dim3(K, 2), dim3(1024), 0, s, M, XB, XD, d, rb, rd, rr);
+    } else if (compute_dtype == APV_F64) {
         hipLaunchKernelGGL(corr_kernel<double>, dim3(K), dim3(256), 0, s, M, L, XB, XD, d, (double*)RB,
                            (double*)RD, (double*)r);
     } else if (L == 64 && (M % 2) == 0 && M >= 8) {
