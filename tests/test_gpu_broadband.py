@@ -165,3 +165,14 @@ def test_broadband_matlab_dialect_vs_oracle(golden, perceptual):
     for i in range(len(ranks)):
         assert np.linalg.norm(ap.w_A[i, :, 0] - orc.w_A[i]) <= 1e-6 * np.linalg.norm(orc.w_A[i])
     ap.close()
+
+
+def test_broadband_rank_list_validation(golden):
+    """apVast.m:527-549 takes an ascending vector of ranks: a descending or out-of-range list is refused."""
+    from ap_vast_unofficial_amd.apvast import apvast
+    from ap_vast_unofficial_amd._capi import ApvError
+    rirs = golden("rirs_cfg1")
+    rA, rB = rirs["rirA"][:, :4, :6], rirs["rirB"][:, :4, :6]
+    for bad in ([8, 3], [0, 2], [1, 16 * 4 + 1]):
+        with pytest.raises((ApvError, ValueError, RuntimeError)):
+            apvast(256, rA, rB, 16, 8, 1, 2, bad, 1.0, 384, perceptual=False, mode="broadband", dialect="matlab")
