@@ -351,3 +351,20 @@ def test_degenerate_spectra(Engine, dtype):
     # degenerate eigenvalues: only the full-rank filter (and the projector it implies) is unique
     assert w_err(w[1:2, 2], w_ref[1:2, 2]) < TOL[dtype]["w"] * 10
     assert w_err(w[2:, :], w_ref[2:, :]) < TOL[dtype]["w"] * 10
+
+
+@pytest.mark.parametrize("scale", [1e-8, 1e8])
+def test_input_scale_robustness(Engine, scale):
+    """The float32 pre-solve works on a copy of C brought to unit norm by a power of two: inputs far from unit scale
+    (R of order 1e-16 or 1e+16) must give the oracle's answer all the same."""
+    rng = np.random.default_rng(77)
+    K, L, M = 32, 16, 32
+    XB, XD, d = (cn(rng, K, M, L) * np.float32(scale)), (cn(rng, K, M, L) * np.float32(scale)), cn(rng, K, M) * np.float32(scale)
+    reg = 1e-7 * scale * scale                      # keep the loading proportionate so that the problem stays the same
+    eng = Engine(K, L, M, ranks=(1, 8, 16), mu=1.0, compute_dtype="f64", reg_dark=reg)
+    w, lam, status = eng.update(XB, XD, d)
+    eng.close()
+    w_ref, lam_ref, _ = subband.update(XB, XD, d, 1.0, [1, 8, 16], reg=reg)
+    assert not status.any()
+    assert np.abs(lam / lam_ref - 1).max() < 1e-9
+    assert w_err(w, w_ref) < 1e-7
