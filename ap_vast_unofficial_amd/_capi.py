@@ -27,10 +27,11 @@ EXPORTS = (
     "apv_timer_start", "apv_timer_stop",
     "apv_update_dev", "apv_update", "apv_corr_dev", "apv_corr_bf16_dev", "apv_to_bf16_dev", "apv_gevd_vast_dev", "apv_jdiag_batched", "apv_jdiag_large",
     "apv_stft_analysis_dev", "apv_istft_ola_dev",
-    "apv_stream_init", "apv_stream_set_perceptual", "apv_process_block", "apv_state_bytes", "apv_get_state", "apv_set_state",
+    "apv_stream_init", "apv_stream_set_perceptual", "apv_process_block", "apv_process_block_f64", "apv_stream_is_f64", "apv_state_bytes", "apv_get_state", "apv_set_state",
     "apv_bb_set_rank_list", "apv_bb_init", "apv_bb_set_perceptual", "apv_bb_process_block", "apv_bb_get_state", "apv_bb_set_state",
     "apv_predict_pressure", "apv_vast_static",
-    "apv_comm_unique_id", "apv_comm_init", "apv_allgather_filters_dev",
+    "apv_comm_unique_id", "apv_comm_init", "apv_allgather_filters_dev", "apv_comm_last_gather", "apv_comm_barrier",
+    "apv_device_sync", "apv_device_info",
 )
 
 
@@ -43,7 +44,8 @@ class Config(C.Structure):
         ("max_sweeps", C.c_int32), ("block_size", C.c_int32), ("hop_size", C.c_int32), ("n_zones", C.c_int32),
         ("debug_stop", C.c_int32),
         ("dialect", C.c_int32),
-        ("reserved", C.c_int32 * 6),
+        ("frontend", C.c_int32),
+        ("reserved", C.c_int32 * 5),
     ]
 
 
@@ -92,6 +94,8 @@ def load():
     lib.apv_stream_init.argtypes = [vp, i32, vp, vp, i32, i32, i32]
     lib.apv_stream_set_perceptual.argtypes = [vp, i32, vp, C.c_double, C.c_double, C.c_double, i32]
     lib.apv_process_block.argtypes = [vp, vp, vp, vp]
+    lib.apv_process_block_f64.argtypes = [vp, vp, vp, vp]
+    lib.apv_stream_is_f64.argtypes = [vp]
     lib.apv_state_bytes.argtypes = [vp, C.c_char_p, C.POINTER(sz)]
     lib.apv_get_state.argtypes = [vp, C.c_char_p, vp, sz]
     lib.apv_set_state.argtypes = [vp, C.c_char_p, vp, sz]
@@ -106,6 +110,10 @@ def load():
     lib.apv_comm_unique_id.argtypes = [C.c_char_p]
     lib.apv_comm_init.argtypes = [vp, C.c_char_p, i32, i32]
     lib.apv_allgather_filters_dev.argtypes = [vp, vp, vp]
+    lib.apv_comm_last_gather.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(sz)]
+    lib.apv_comm_barrier.argtypes = [vp]
+    lib.apv_device_sync.argtypes = [vp]
+    lib.apv_device_info.argtypes = [vp, C.c_char_p, C.POINTER(i32), C.POINTER(i32)]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name != "apv_last_error":
@@ -157,7 +165,7 @@ class Engine:
 
     def __init__(self, n_bins, n_srcs, n_mics, ranks=(1,), mu=1.0, compute_dtype="f64", out_c128=None,
                  reg_mode=REG_ABS, reg_dark=1e-7, reg_bright=0.0, device=0, max_sweeps=0,
-                 block_size=0, hop_size=0, n_zones=1, debug_stop=0, dialect="python"):
+                 block_size=0, hop_size=0, n_zones=1, debug_stop=0, dialect="python", frontend=None):
         self.lib = load()
         self.h = None
         ranks = [int(v) for v in ranks]
@@ -179,6 +187,9 @@ class Engine:
         cfg.block_size, cfg.hop_size, cfg.n_zones = block_size, hop_size, n_zones
         cfg.debug_stop = debug_stop           # profiling aid (kernels_gevd16m.hip), 0 in normal use
         cfg.dialect = 1 if dialect == "matlab" else 0
+        # streaming front-end precision: None follows compute_dtype; "f32" / "f64" force it
+        cfg.frontend = {None: 0, "f32": 1, "f64": 2}[frontend]
+        self.frontend_f64 = self.f64 if frontend is None else frontend == "f64"
         self.cfg = cfg
         self.K, self.L, self.M, self.nV = cfg.n_bins, cfg.n_srcs, cfg.n_mics, cfg.n_ranks
         h = C.c_void_p()
@@ -192,8 +203,9 @@ class Engine:
         if rc == OK:
             return
         msg = self.lib.apv_last_error(self.h).decode()
-        if rc == ERR_NOT_PD:
-            raise np.linalg.LinAlgError(msg)          # apvast.py:21,24
+        if rc in (ERR_NOT_PD, ERR_NO_CONVERGE):
+            # apvast.py:21,24 (cholesky); LAPACK's eigensolvers raise the same class when they do not converge
+            raise np.linalg.LinAlgError(msg)
         raise ApvError(rc, msg)
 
     def close(self):
@@ -381,11 +393,25 @@ class Engine:
                                                      float(tables.Leff), 1 if normalisation == "matlab" else 0))
 
     def process_block(self, in_A, in_B, n_out):
-        in_A = np.ascontiguousarray(in_A, dtype=np.float32).ravel()
-        in_B = np.ascontiguousarray(in_B, dtype=np.float32).ravel()
-        out = np.empty((n_out, self.cfg.hop_size), dtype=np.float32)
-        self._chk(self.lib.apv_process_block(self.h, _ptr(in_A), _ptr(in_B), _ptr(out)))
+        """One hop; samples cross the boundary in the front-end's own precision (float64 in, float64 out with the
+        float64 front-end)."""
+        dt = np.float64 if self.frontend_f64 else np.float32
+        in_A = np.ascontiguousarray(in_A, dtype=dt).ravel()
+        in_B = np.ascontiguousarray(in_B, dtype=dt).ravel()
+        out = np.empty((n_out, self.cfg.hop_size), dtype=dt)
+        fn = self.lib.apv_process_block_f64 if self.frontend_f64 else self.lib.apv_process_block
+        self._chk(fn(self.h, _ptr(in_A), _ptr(in_B), _ptr(out)))
         return out
+
+    @property
+    def s_dtype(self):
+        """dtype of the stream's real state arrays."""
+        return np.float64 if self.frontend_f64 else np.float32
+
+    @property
+    def sc_dtype(self):
+        """dtype of the stream's spectra."""
+        return np.complex128 if self.frontend_f64 else np.complex64
 
     def get_state(self, name, shape, dtype):
         out = np.empty(shape, dtype=dtype)
@@ -470,3 +496,21 @@ class Engine:
 
     def allgather_filters_dev(self, dw_shard, dw_all):
         self._chk(self.lib.apv_allgather_filters_dev(self.h, dw_shard.ptr, dw_all.ptr))
+
+    def comm_last_gather(self):
+        """(device milliseconds, bytes contributed by this rank) of the latest all-gather."""
+        ms, nb = C.c_float(), C.c_size_t()
+        self._chk(self.lib.apv_comm_last_gather(self.h, C.byref(ms), C.byref(nb)))
+        return ms.value, nb.value
+
+    def comm_barrier(self):
+        self._chk(self.lib.apv_comm_barrier(self.h))
+
+    def device_sync(self):
+        self._chk(self.lib.apv_device_sync(self.h))
+
+    def device_info(self):
+        buf = C.create_string_buffer(128)
+        cus, mhz = C.c_int32(), C.c_int32()
+        self._chk(self.lib.apv_device_info(self.h, buf, C.byref(cus), C.byref(mhz)))
+        return {"name": buf.value.decode(), "compute_units": cus.value, "clock_mhz": mhz.value}

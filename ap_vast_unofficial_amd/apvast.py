@@ -16,7 +16,9 @@ What is the same as the reference
 What is different (keyword-only, after ``perceptual``)
   * ``mode="subband"`` (default): one (R_B, R_D) pair, one GEVD and one filter PER FREQUENCY BIN from the
     current block's control-point spectra -- the fast path (``filter_length`` and
-    ``statistics_buffer_length`` are accepted and stored, not used).
+    ``statistics_buffer_length`` are accepted and stored, not used).  ``dtype="f64"`` (default) runs every stage in
+    float64 like the reference's lfilter / rfft / irfft (apvast.py:171-192, 202-203, 461-496); ``"f32"`` runs every
+    stage in float32; ``"mixed"`` keeps the float32 FIR / STFT / overlap-add around a float64 joint diagonalisation.
   * ``mode="broadband"``: the reference's own time-domain algorithm (one (J L) x (J L) pair per zone from
     ``statistics_buffer_length`` samples, apvast.py:329-422), float64 on the device, checked against the
     golden outputs of the reference (tests/test_gpu_broadband.py).
@@ -123,6 +125,9 @@ class apvast:
             raise ValueError("mode must be 'subband' or 'broadband'")
         if dialect not in ("python", "matlab"):
             raise ValueError("dialect must be 'python' or 'matlab'")
+        if dtype not in ("f64", "f32", "mixed"):
+            raise ValueError("dtype must be 'f64' (float64 end to end, the reference's arithmetic), 'f32' (float32 end to "
+                             "end) or 'mixed' (float32 FIR/STFT/overlap-add around a float64 joint diagonalisation)")
         if not (run_A or run_B):
             raise ValueError("at least one of run_A / run_B must be True")
 
@@ -145,9 +150,9 @@ class apvast:
         else:
             reg_mode, reg_dark, reg_bright = _capi.REG_REL, 5e-3, 1e-8        # apVast.m:552-569
         zones = (1 if run_A else 0) | (2 if run_B else 0)
-        self._eng = _capi.Engine(self._K, L, M, ranks=self._ranks, mu=mu, compute_dtype=dtype,
+        self._eng = _capi.Engine(self._K, L, M, ranks=self._ranks, mu=mu, compute_dtype="f32" if dtype == "f32" else "f64",
                                  reg_mode=reg_mode, reg_dark=reg_dark, reg_bright=reg_bright, device=device,
-                                 block_size=N, hop_size=H, n_zones=zones)
+                                 block_size=N, hop_size=H, n_zones=zones, frontend="f32" if dtype == "mixed" else None)
         self._eng.stream_init(rir_A, rir_B, reference_index_A, reference_index_B, modeling_delay)
         if perceptual:
             # the masking model carried by the MATLAB twin (perceptualModel.m); per-block curves are formed on the
@@ -259,7 +264,7 @@ class apvast:
 
     def _refresh_attributes(self):
         e, K, L, V = self._eng, self._K, self.number_of_srcs, len(self._ranks)
-        spec = e.get_state("input_spectrum", (2, K), np.complex64)
+        spec = e.get_state("input_spectrum", (2, K), e.sc_dtype)
         self.input_spectrum_A = spec[0].astype(np.complex128).reshape(-1, 1)   # apvast.py:430-431
         self.input_spectrum_B = spec[1].astype(np.complex128).reshape(-1, 1)
         for z, run in (("A", self.run_A), ("B", self.run_B)):
@@ -282,15 +287,16 @@ class apvast:
                 "stats": np.stack([e.bb_get_state(f"stats{p}", (M, L, S)) for p in range(4)]).transpose(0, 3, 2, 1),
                 "target_stats": np.stack([e.bb_get_state(f"target_stats{z}", (M, S)) for z in range(2)]).transpose(0, 2, 1),
             }
-        resp = np.stack([e.get_state(f"response{p}", (M, L, N), np.float32) for p in range(4)])
-        tresp = np.stack([e.get_state(f"target_response{z}", (M, N), np.float32) for z in range(2)])
+        sd = e.s_dtype                      # float32, or float64 with the float64 front-end (dtype="f64")
+        resp = np.stack([e.get_state(f"response{p}", (M, L, N), sd) for p in range(4)])
+        tresp = np.stack([e.get_state(f"target_response{z}", (M, N), sd) for z in range(2)])
         return {
             "response": resp.transpose(0, 3, 2, 1).astype(np.float64),           # (4, N, L, M)
             "target_response": tresp.transpose(0, 2, 1).astype(np.float64),      # (2, N, M)
-            "input_block": e.get_state("input_block", (2, N), np.float32).astype(np.float64),
+            "input_block": e.get_state("input_block", (2, N), sd).astype(np.float64),
             "input_history": np.stack([e.get_state(f"input_history{g}", (self.rir_length - 1 + self.hop_size,),
-                                                   np.float32) for g in range(2)]).astype(np.float64),
-            "out_overlap": e.get_state("out_overlap", (self._n_out, N), np.float32).astype(np.float64),
+                                                   sd) for g in range(2)]).astype(np.float64),
+            "out_overlap": e.get_state("out_overlap", (self._n_out, N), sd).astype(np.float64),
         }
 
     def set_state(self, state):
@@ -305,22 +311,23 @@ class apvast:
                 for z in range(2):
                     e.bb_set_state(f"target_response{z}", np.ascontiguousarray(t[z].T))
             return
+        sd = e.s_dtype
         if "response" in state:
-            r = np.asarray(state["response"], dtype=np.float32)                  # (4, N, L, M) -> [M][L][N]
+            r = np.asarray(state["response"], dtype=sd)                          # (4, N, L, M) -> [M][L][N]
             for p in range(4):
                 e.set_state(f"response{p}", np.ascontiguousarray(r[p].transpose(2, 1, 0)))
         if "target_response" in state:
-            t = np.asarray(state["target_response"], dtype=np.float32)           # (2, N, M) -> [M][N]
+            t = np.asarray(state["target_response"], dtype=sd)                   # (2, N, M) -> [M][N]
             for z in range(2):
                 e.set_state(f"target_response{z}", np.ascontiguousarray(t[z].T))
         if "input_block" in state:
-            e.set_state("input_block", np.asarray(state["input_block"], dtype=np.float32))
+            e.set_state("input_block", np.asarray(state["input_block"], dtype=sd))
         if "input_history" in state:
-            hst = np.asarray(state["input_history"], dtype=np.float32)
+            hst = np.asarray(state["input_history"], dtype=sd)
             for g in range(2):
                 e.set_state(f"input_history{g}", hst[g])
         if "out_overlap" in state:
-            e.set_state("out_overlap", np.asarray(state["out_overlap"], dtype=np.float32))
+            e.set_state("out_overlap", np.asarray(state["out_overlap"], dtype=sd))
 
     def close(self):
         self._eng.close()

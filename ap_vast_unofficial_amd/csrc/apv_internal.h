@@ -21,10 +21,11 @@ struct GevdParams {
     int debug_stop;    // profiling aid: return after stage N (1 = correlate, 2 = Cholesky, 3 = whitening); 0 = run everything
     double sweep_tol2; // Jacobi stop threshold on off^2/||C||_F^2 seen during a sweep; 0 = per-dtype default
     int out_c128;
-    // fused input (c64)
-    const float2* XB;
-    const float2* XD;
-    const float2* d;
+    // fused input: c64, or c128 when x_c128 is set (the float64 streaming front-end)
+    int x_c128;
+    const void* XB;
+    const void* XD;
+    const void* d;
     // explicit input (complex of the compute dtype), row-major n x n
     const void* RB;
     const void* RD;
@@ -37,9 +38,9 @@ struct GevdParams {
     void* Lspill;     // [K][n][n]   complex of compute dtype (SPILL instances only)
     // optional second zone program in the same launch (blockIdx.y == 1), fused path only
     int n_zones;
-    const float2* XB1;
-    const float2* XD1;
-    const float2* d1;
+    const void* XB1;
+    const void* XD1;
+    const void* d1;
     void* w1;
     void* lam1;
     int32_t* status1;
@@ -70,6 +71,10 @@ struct apv_handle {
     hipStream_t comm_stream;      // the all-gather runs here so that it overlaps the next block's kernels
     hipEvent_t ev_ready;          // compute -> comm: the shard is written
     struct { const void* ptr; hipEvent_t ev; } gather_done[4];   // comm -> compute: shard buffer may be rewritten
+    int gather_next;              // slot recycled next when all four track live buffers
+    hipEvent_t ev_ag0, ev_ag1;    // timing events around the latest all-gather (comm stream)
+    size_t ag_bytes;              // bytes this rank contributed to it
+    int32_t* d_bar;               // one device word for apv_comm_barrier
     std::string err;
 };
 
@@ -104,7 +109,7 @@ hipError_t apv_launch_to_bf16(size_t count, const float2* in, uint32_t* out, hip
 hipError_t apv_launch_stft_analysis(int N, int n_ch, const float* x, float2* spec, hipStream_t s, std::string* why);
 hipError_t apv_launch_istft_ola(int N, int H, int n_ch, const float2* spec, float* overlap, float* out,
                                 hipStream_t s, std::string* why);
-hipError_t apv_launch_stft_analysis_jobs(int N, int n_jobs, const float* const* x, const int* n_ch, float2* const* spec,
+hipError_t apv_launch_stft_analysis_jobs(int f64, int N, int n_jobs, const void* const* x, const int* n_ch, void* const* spec,
                                          const long* stride_c, const long* stride_k, int ring_off, hipStream_t s,
                                          std::string* why);
 hipError_t apv_launch_stft_analysis_strided(int N, int n_ch, const float* x, int ring_off, float2* spec,
@@ -129,17 +134,29 @@ struct FirJob { const float* rir; const float* xh; float* resp; int C; };
 struct FirJobs { FirJob j[6]; int n; };
 // all FIR jobs of a hop in one launch, on the matrix cores (v_mfma_f32_32x32x2_f32, implicit Toeplitz operand)
 hipError_t apv_launch_fir_jobs(const FirJobs& jobs, int P, int H, int N, int ring_off, hipStream_t s);
-hipError_t apv_launch_perceptual_weights(int K, int M, int nch, const float2* spec, const double* G2, const double* G2T,
-                                         double Cs, double Ca, double Leff, int N, int norm_mode, float* W, hipStream_t s);
-hipError_t apv_launch_scale_spectra(int K, int C, int L, float2* spec, const float* W, hipStream_t s);
+// float64 jobs of one hop on v_mfma_f64_16x16x4_f64 (both stream modes); tile0 is filled by the launcher
+constexpr int FIR_JOBS_D = 6;
+struct FirJobsD {
+    const double* rir[FIR_JOBS_D];     // [P][C_j]
+    const double* xh[FIR_JOBS_D];      // input history of the job's signal
+    double* resp[FIR_JOBS_D];          // [C_j][N] ring
+    int C[FIR_JOBS_D];
+    int tile0[FIR_JOBS_D + 1];         // first channel tile of each job
+};
+hipError_t apv_launch_fir_jobs_f64(FirJobsD jobs, int njobs, int P, int H, int N, int ring_off, hipStream_t s);
+int apv_fir_pad_f64();
+// f64 = 0: c64 spectra / float weights; 1: c128 spectra / double weights (bin-major [K][M])
+hipError_t apv_launch_perceptual_weights(int f64, int K, int M, int nch, const void* spec, const double* G2, const double* G2T,
+                                         double Cs, double Ca, double Leff, int N, int norm_mode, void* W, hipStream_t s);
+hipError_t apv_launch_scale_spectra(int f64, int K, int C, int L, void* spec, const void* W, hipStream_t s);
 hipError_t apv_launch_perceptual_weights_f64(int K, int M, int nch, const double2* spec, const double* G2,
                                              const double* G2T, double Cs, double Ca, double Leff, int N, int norm_mode,
                                              double* W, hipStream_t s);
 hipError_t apv_launch_scale_spectra_cm_f64(int K, int C, int L, double2* spec, const double* W, hipStream_t s);
-hipError_t apv_launch_input_update(int P, int H, int pad, int N, int ring_off, const float* const old_hist[2],
-                                   float* const new_hist[2], const float* xin, float* inblk, hipStream_t s);
+hipError_t apv_launch_input_update(int f64, int P, int H, int pad, int N, int ring_off, const void* const old_hist[2],
+                                   void* const new_hist[2], const void* xin, void* inblk, hipStream_t s);
 int apv_fir_pad();
 // out[ch][k] = in_spec[k] * filt(ch, k): ch < n_filt channels taken from the bin-major filter bank
 // w[k][n_filt] (c64 or c128), remaining channels from the channel-major table tgt[ch - n_filt][k]
-hipError_t apv_launch_apply_jobs(int K, int n_jobs, const float2* const* in_spec, const void* const* w, const float2* const* tgt,
-                                 float2* const* out, const int* n_filt, const int* n_tgt, int w_c128, hipStream_t s);
+hipError_t apv_launch_apply_jobs(int K, int n_jobs, const void* const* in_spec, const void* const* w, const void* const* tgt,
+                                 void* const* out, const int* n_filt, const int* n_tgt, int w_c128, int spec_f64, hipStream_t s);

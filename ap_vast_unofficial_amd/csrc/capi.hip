@@ -135,6 +135,10 @@ int apv_create(const apv_config* cfg, apv_handle** out) {
     h->comm_stream = nullptr;
     h->ev_ready = nullptr;
     for (auto& g : h->gather_done) { g.ptr = nullptr; g.ev = nullptr; }
+    h->gather_next = 0;
+    h->ev_ag0 = h->ev_ag1 = nullptr;
+    h->ag_bytes = 0;
+    h->d_bar = nullptr;
     h->comm = nullptr;
     h->comm_rank = 0;
     h->comm_world = 1;
@@ -174,6 +178,9 @@ int apv_destroy(apv_handle* h) {
     for (auto& g : h->gather_done)
         if (g.ev) (void)hipEventDestroy(g.ev);
     if (h->ev_ready) (void)hipEventDestroy(h->ev_ready);
+    if (h->ev_ag0) (void)hipEventDestroy(h->ev_ag0);
+    if (h->ev_ag1) (void)hipEventDestroy(h->ev_ag1);
+    if (h->d_bar) (void)hipFree(h->d_bar);
     if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
     void* bufs[] = {h->d_XB, h->d_XD, h->d_d, h->d_w, h->d_lam, h->d_status, h->d_Lspill, h->d_Rscratch};
     for (void* b : bufs)
@@ -531,6 +538,10 @@ int apv_comm_init(apv_handle* h, const char id[128], int32_t rank, int32_t world
         HIPCHK(h, hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
         HIPCHK(h, hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming));
         for (auto& g : h->gather_done) HIPCHK(h, hipEventCreateWithFlags(&g.ev, hipEventDisableTiming));
+        HIPCHK(h, hipEventCreate(&h->ev_ag0));
+        HIPCHK(h, hipEventCreate(&h->ev_ag1));
+        HIPCHK(h, hipMalloc((void**)&h->d_bar, sizeof(int32_t)));
+        HIPCHK(h, hipMemset(h->d_bar, 0, sizeof(int32_t)));
     }
     return APV_OK;
 }
@@ -545,13 +556,63 @@ int apv_allgather_filters_dev(apv_handle* h, const void* d_w_shard, void* d_w_al
     // on its own stream: the next block's update (into another shard buffer) overlaps it
     HIPCHK(h, hipEventRecord(h->ev_ready, h->stream));
     HIPCHK(h, hipStreamWaitEvent(h->comm_stream, h->ev_ready, 0));
+    HIPCHK(h, hipEventRecord(h->ev_ag0, h->comm_stream));
     ncclResult_t r = ncclAllGather(d_w_shard, d_w_all, bytes, ncclChar, (ncclComm_t)h->comm, h->comm_stream);
     if (r != ncclSuccess) return fail(h, APV_ERR_RCCL, std::string("ncclAllGather: ") + ncclGetErrorString(r));
-    int slot = 0;
-    for (int i = 0; i < 4; ++i)
-        if (h->gather_done[i].ptr == d_w_shard || h->gather_done[i].ptr == nullptr) { slot = i; break; }
+    HIPCHK(h, hipEventRecord(h->ev_ag1, h->comm_stream));
+    h->ag_bytes = bytes;
+    // remember "this shard buffer is being read until <event>": the slot already tracking this buffer, else a free one,
+    // else the oldest -- whose gather the compute stream then waits for here, so no later update can overtake it
+    int slot = -1;
+    for (int i = 0; i < 4 && slot < 0; ++i)
+        if (h->gather_done[i].ptr == d_w_shard) slot = i;
+    for (int i = 0; i < 4 && slot < 0; ++i)
+        if (h->gather_done[i].ptr == nullptr) slot = i;
+    if (slot < 0) {
+        slot = h->gather_next;
+        h->gather_next = (h->gather_next + 1) & 3;
+        HIPCHK(h, hipStreamWaitEvent(h->stream, h->gather_done[slot].ev, 0));
+    }
     h->gather_done[slot].ptr = d_w_shard;
     HIPCHK(h, hipEventRecord(h->gather_done[slot].ev, h->comm_stream));
+    return APV_OK;
+}
+
+int apv_comm_last_gather(apv_handle* h, float* elapsed_ms, size_t* bytes_per_rank) {
+    if (!h || !elapsed_ms) return fail(h, APV_ERR_ARG, "null argument");
+    if (!h->comm || h->ag_bytes == 0) return fail(h, APV_ERR_RCCL, "no all-gather has run on this handle");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipEventSynchronize(h->ev_ag1));
+    HIPCHK(h, hipEventElapsedTime(elapsed_ms, h->ev_ag0, h->ev_ag1));
+    if (bytes_per_rank) *bytes_per_rank = h->ag_bytes;
+    return APV_OK;
+}
+
+int apv_comm_barrier(apv_handle* h) {
+    if (!h) return APV_ERR_ARG;
+    if (!h->comm) return fail(h, APV_ERR_RCCL, "communicator not initialised (apv_comm_init)");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    ncclResult_t r = ncclAllReduce(h->d_bar, h->d_bar, 1, ncclInt32, ncclSum, (ncclComm_t)h->comm, h->comm_stream);
+    if (r != ncclSuccess) return fail(h, APV_ERR_RCCL, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+    HIPCHK(h, hipStreamSynchronize(h->comm_stream));
+    return APV_OK;
+}
+
+int apv_device_sync(apv_handle* h) {
+    if (!h) return APV_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    return APV_OK;
+}
+
+int apv_device_info(apv_handle* h, char name_out[128], int32_t* n_cus, int32_t* clock_mhz) {
+    if (!h || !name_out) return APV_ERR_ARG;
+    hipDeviceProp_t prop;
+    HIPCHK(h, hipGetDeviceProperties(&prop, h->device));
+    std::snprintf(name_out, 128, "%s (%s)", prop.name, prop.gcnArchName);
+    if (n_cus) *n_cus = prop.multiProcessorCount;
+    if (clock_mhz) *clock_mhz = prop.clockRate / 1000;
     return APV_OK;
 }
 

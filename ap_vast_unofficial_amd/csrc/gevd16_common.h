@@ -47,87 +47,63 @@ template <typename T> __device__ __forceinline__ T wave_sum(T v) {
 using d4 = __attribute__((ext_vector_type(4))) double;
 using f4 = __attribute__((ext_vector_type(4))) float;
 
-// R = X^H X for one [M][16] c64 slab, result written to dst (LDS, row stride LD); optional r = X^H d -> sr
-template <typename T>
-__device__ __forceinline__ void correlate16(const float2* __restrict__ X, const float2* __restrict__ dvec, int M,
-                                            Cx<T>* dst, Cx<T>* sr, int lane);
+// R = X^H X for one [M][16] slab of c64 (XT = float2) or c128 (XT = double2) elements, result written to dst (LDS, row
+// stride LD); optional r = X^H d -> sr.  Lane l loads slab element 64 s + l: fully coalesced, and that one register is
+// both the A (X^H) and the B (X) operand of the 16x16x4 MFMA.
+template <typename T> struct Mfma16;
+template <> struct Mfma16<double> {
+    using V = d4;
+    static __device__ __forceinline__ V mac(double a, double b, V c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    // f64 16x16x4 accumulator: row = (lane>>4) + 4*reg, col = lane&15
+    static __device__ __forceinline__ int row(int lane, int t) { return (lane >> 4) + 4 * t; }
+};
+template <> struct Mfma16<float> {
+    using V = f4;
+    static __device__ __forceinline__ V mac(float a, float b, V c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    // f32 16x16x4 accumulator: row = 4*(lane>>4) + reg, col = lane&15
+    static __device__ __forceinline__ int row(int lane, int t) { return 4 * (lane >> 4) + t; }
+};
 
-template <>
-__device__ __forceinline__ void correlate16<double>(const float2* __restrict__ X, const float2* __restrict__ dvec,
-                                                    int M, Cx<double>* dst, Cx<double>* sr, int lane) {
-    d4 re = {0, 0, 0, 0}, im = {0, 0, 0, 0};
-    double rx = 0, ry = 0;
+template <typename T, typename XT>
+__device__ __forceinline__ void correlate16(const XT* __restrict__ X, const XT* __restrict__ dvec, int M,
+                                            Cx<T>* dst, Cx<T>* sr, int lane) {
+    using MM = Mfma16<T>;
+    typename MM::V re = {0, 0, 0, 0}, im = {0, 0, 0, 0};
+    T rx = 0, ry = 0;
     const int msub = lane >> 4;
+    XT zero;
+    zero.x = 0;
+    zero.y = 0;
     // 32 control points (8 k-steps) at a time: all the loads of a chunk are in flight before its first MFMA
     for (int mc = 0; mc < M; mc += 32) {
-        float2 xv[8], dv[8];
+        XT xv[8], dv[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int m = mc + 4 * q + msub;
             const bool ok = m < M;
-            xv[q] = ok ? X[(size_t)(mc + 4 * q) * N + lane] : make_float2(0.f, 0.f);
-            dv[q] = (ok && dvec != nullptr) ? dvec[m] : make_float2(0.f, 0.f);
+            xv[q] = ok ? X[(size_t)(mc + 4 * q) * N + lane] : zero;
+            dv[q] = (ok && dvec != nullptr) ? dvec[m] : zero;
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const double xr = xv[q].x, xi = xv[q].y;
-            re = __builtin_amdgcn_mfma_f64_16x16x4f64(xr, xr, re, 0, 0, 0);
-            re = __builtin_amdgcn_mfma_f64_16x16x4f64(xi, xi, re, 0, 0, 0);
-            im = __builtin_amdgcn_mfma_f64_16x16x4f64(xr, xi, im, 0, 0, 0);
-            im = __builtin_amdgcn_mfma_f64_16x16x4f64(-xi, xr, im, 0, 0, 0);
+            const T xr = (T)xv[q].x, xi = (T)xv[q].y;
+            re = MM::mac(xr, xr, re);
+            re = MM::mac(xi, xi, re);
+            im = MM::mac(xr, xi, im);
+            im = MM::mac(-xi, xr, im);
             if (dvec != nullptr) {
-                rx += xr * (double)dv[q].x + xi * (double)dv[q].y;        // conj(x) * d
-                ry += xr * (double)dv[q].y - xi * (double)dv[q].x;
+                rx += xr * (T)dv[q].x + xi * (T)dv[q].y;        // conj(x) * d
+                ry += xr * (T)dv[q].y - xi * (T)dv[q].x;
             }
         }
     }
-    // f64 16x16x4 accumulator: row = (lane>>4) + 4*reg, col = lane&15
     const int col = lane & 15;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) dst[(msub + 4 * t) * LD + col] = mk<double>(re[t], im[t]);
+    for (int t = 0; t < 4; ++t) dst[MM::row(lane, t) * LD + col] = mk<T>(re[t], im[t]);
     if (dvec != nullptr) {
         rx += __shfl_xor(rx, 16, 64); ry += __shfl_xor(ry, 16, 64);
         rx += __shfl_xor(rx, 32, 64); ry += __shfl_xor(ry, 32, 64);
-        if (lane < N) sr[lane] = mk<double>(rx, ry);
-    }
-}
-
-template <>
-__device__ __forceinline__ void correlate16<float>(const float2* __restrict__ X, const float2* __restrict__ dvec,
-                                                   int M, Cx<float>* dst, Cx<float>* sr, int lane) {
-    f4 re = {0, 0, 0, 0}, im = {0, 0, 0, 0};
-    float rx = 0, ry = 0;
-    const int msub = lane >> 4;
-    for (int mc = 0; mc < M; mc += 32) {
-        float2 xv[8], dv[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int m = mc + 4 * q + msub;
-            const bool ok = m < M;
-            xv[q] = ok ? X[(size_t)(mc + 4 * q) * N + lane] : make_float2(0.f, 0.f);
-            dv[q] = (ok && dvec != nullptr) ? dvec[m] : make_float2(0.f, 0.f);
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float xr = xv[q].x, xi = xv[q].y;
-            re = __builtin_amdgcn_mfma_f32_16x16x4f32(xr, xr, re, 0, 0, 0);
-            re = __builtin_amdgcn_mfma_f32_16x16x4f32(xi, xi, re, 0, 0, 0);
-            im = __builtin_amdgcn_mfma_f32_16x16x4f32(xr, xi, im, 0, 0, 0);
-            im = __builtin_amdgcn_mfma_f32_16x16x4f32(-xi, xr, im, 0, 0, 0);
-            if (dvec != nullptr) {
-                rx += xr * dv[q].x + xi * dv[q].y;
-                ry += xr * dv[q].y - xi * dv[q].x;
-            }
-        }
-    }
-    // f32 16x16x4 accumulator: row = 4*(lane>>4) + reg, col = lane&15
-    const int col = lane & 15;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) dst[(4 * msub + t) * LD + col] = mk<float>(re[t], im[t]);
-    if (dvec != nullptr) {
-        rx += __shfl_xor(rx, 16, 64); ry += __shfl_xor(ry, 16, 64);
-        rx += __shfl_xor(rx, 32, 64); ry += __shfl_xor(ry, 32, 64);
-        if (lane < N) sr[lane] = mk<float>(rx, ry);
+        if (lane < N) sr[lane] = mk<T>(rx, ry);
     }
 }
 

@@ -119,13 +119,14 @@ __device__ __forceinline__ void rr_pair(int ne, int r, int a, int& p, int& q) {
     q = u < v ? v : u;
 }
 
-template <typename T, int NMAX, int TPB, bool FUSED, bool SPILL, bool EXACT>
+// XT: element type of the fused input slabs (float2 = c64, double2 = c128: the float64 streaming front-end)
+template <typename T, int NMAX, int TPB, bool FUSED, bool SPILL, bool EXACT, typename XT>
 __global__ void __launch_bounds__(TPB) gevd_vast_kernel(const GevdParams p) {
     // zone program of a two-zone launch (blockIdx.y); the argument block itself stays in scalar registers
     const bool z1 = (blockIdx.y == 1);
-    const float2* const pXB = z1 ? p.XB1 : p.XB;
-    const float2* const pXD = z1 ? p.XD1 : p.XD;
-    const float2* const pd = z1 ? p.d1 : p.d;
+    const XT* const pXB = reinterpret_cast<const XT*>(z1 ? p.XB1 : p.XB);
+    const XT* const pXD = reinterpret_cast<const XT*>(z1 ? p.XD1 : p.XD);
+    const XT* const pd = reinterpret_cast<const XT*>(z1 ? p.d1 : p.d);
     void* const pw = z1 ? p.w1 : p.w;
     void* const plam = z1 ? p.lam1 : p.lam;
     int32_t* const pstatus = z1 ? p.status1 : p.status;
@@ -138,8 +139,8 @@ __global__ void __launch_bounds__(TPB) gevd_vast_kernel(const GevdParams p) {
     __shared__ C sA[NMAX * LD];
     __shared__ C sB[NMAX * LD];
     __shared__ C sVstore[SPILL ? 1 : NMAX * LD];
-    __shared__ float2 sX[FUSED ? MT * NMAX : 1];
-    __shared__ float2 sd[FUSED ? MT : 1];
+    __shared__ XT sX[FUSED ? MT * NMAX : 1];
+    __shared__ XT sd[FUSED ? MT : 1];
     __shared__ C sr[NMAX];
     __shared__ C scoef[NMAX];
     __shared__ T sDiag[NMAX];
@@ -167,7 +168,7 @@ __global__ void __launch_bounds__(TPB) gevd_vast_kernel(const GevdParams p) {
         // (re and im accumulators), operands read from the staged rows; otherwise one element of R per thread on the VALU
         constexpr bool MFMA_CORR = sizeof(T) == 8 && NMAX >= 16 && (NMAX / 16) * (NMAX / 16) <= TPB / 64;
         for (int which = 0; which < 2; ++which) {
-            const float2* X = (which ? pXD : pXB) + (size_t)k * M * n;
+            const XT* X = (which ? pXD : pXB) + (size_t)k * M * n;
             C acc[NACC];
 #pragma unroll
             for (int a = 0; a < NACC; ++a) acc[a] = mk<T>(0, 0);
@@ -190,8 +191,11 @@ __global__ void __launch_bounds__(TPB) gevd_vast_kernel(const GevdParams p) {
 #pragma unroll
                         for (int m = 0; m < MT; m += 4) {
                             const bool ok = m + kq < rows;
-                            const float2 xa = (ok && ia < n) ? sX[(m + kq) * n + ia] : make_float2(0.f, 0.f);
-                            const float2 xb = (ok && jb < n) ? sX[(m + kq) * n + jb] : make_float2(0.f, 0.f);
+                            XT xzero;
+                            xzero.x = 0;
+                            xzero.y = 0;
+                            const XT xa = (ok && ia < n) ? sX[(m + kq) * n + ia] : xzero;
+                            const XT xb = (ok && jb < n) ? sX[(m + kq) * n + jb] : xzero;
                             const double ar = xa.x, ai = xa.y, br = xb.x, bi = xb.y;
                             // conj(x_i) x_j: re = ar br + ai bi, im = ar bi - ai br
                             mre = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, mre, 0, 0, 0);
@@ -208,7 +212,7 @@ __global__ void __launch_bounds__(TPB) gevd_vast_kernel(const GevdParams p) {
                             const int i = idx / n, j = idx - i * n;
                             C s = acc[a];
                             for (int m = 0; m < rows; ++m) {
-                                const float2 xi = sX[m * n + i], xj = sX[m * n + j];
+                                const XT xi = sX[m * n + i], xj = sX[m * n + j];
                                 // conj(xi) * xj, products exact in T=double
                                 s.x += (T)xi.x * (T)xj.x + (T)xi.y * (T)xj.y;
                                 s.y += (T)xi.x * (T)xj.y - (T)xi.y * (T)xj.x;
@@ -219,7 +223,7 @@ __global__ void __launch_bounds__(TPB) gevd_vast_kernel(const GevdParams p) {
                 }
                 if (which == 0 && tid < n) {
                     for (int m = 0; m < rows; ++m) {
-                        const float2 xi = sX[m * n + tid], dm = sd[m];
+                        const XT xi = sX[m * n + tid], dm = sd[m];
                         racc.x += (T)xi.x * (T)dm.x + (T)xi.y * (T)dm.y;
                         racc.y += (T)xi.x * (T)dm.y - (T)xi.y * (T)dm.x;
                     }
@@ -564,12 +568,15 @@ template <typename T, int NMAX, int TPB, bool SPILL>
 hipError_t launch_t(const GevdParams& p, bool fused, hipStream_t s) {
     if (p.K <= 0) return hipSuccess;
     const dim3 grid(p.K, p.n_zones > 1 ? 2 : 1);
+    const bool xd = fused && p.x_c128;
     if (p.n == NMAX) {
-        if (fused) hipLaunchKernelGGL((gevd_vast_kernel<T, NMAX, TPB, true, SPILL, true>), grid, dim3(TPB), 0, s, p);
-        else hipLaunchKernelGGL((gevd_vast_kernel<T, NMAX, TPB, false, SPILL, true>), grid, dim3(TPB), 0, s, p);
+        if (xd) hipLaunchKernelGGL((gevd_vast_kernel<T, NMAX, TPB, true, SPILL, true, double2>), grid, dim3(TPB), 0, s, p);
+        else if (fused) hipLaunchKernelGGL((gevd_vast_kernel<T, NMAX, TPB, true, SPILL, true, float2>), grid, dim3(TPB), 0, s, p);
+        else hipLaunchKernelGGL((gevd_vast_kernel<T, NMAX, TPB, false, SPILL, true, float2>), grid, dim3(TPB), 0, s, p);
     } else {
-        if (fused) hipLaunchKernelGGL((gevd_vast_kernel<T, NMAX, TPB, true, SPILL, false>), grid, dim3(TPB), 0, s, p);
-        else hipLaunchKernelGGL((gevd_vast_kernel<T, NMAX, TPB, false, SPILL, false>), grid, dim3(TPB), 0, s, p);
+        if (xd) hipLaunchKernelGGL((gevd_vast_kernel<T, NMAX, TPB, true, SPILL, false, double2>), grid, dim3(TPB), 0, s, p);
+        else if (fused) hipLaunchKernelGGL((gevd_vast_kernel<T, NMAX, TPB, true, SPILL, false, float2>), grid, dim3(TPB), 0, s, p);
+        else hipLaunchKernelGGL((gevd_vast_kernel<T, NMAX, TPB, false, SPILL, false, float2>), grid, dim3(TPB), 0, s, p);
     }
     return hipGetLastError();
 }

@@ -154,13 +154,14 @@ __device__ __forceinline__ int jacobi16_sweeps(Cx<TT>& tt_, Cx<TT>& tb_, Cx<TT>&
     return sweeps_done;
 }
 
-template <typename T, bool FUSED>
+// XT: element type of the fused input slabs (float2 = c64, double2 = c128: the float64 streaming front-end)
+template <typename T, bool FUSED, typename XT>
 __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
     // zone program of a two-zone launch (blockIdx.y); the argument block itself stays in scalar registers
     const bool z1 = (blockIdx.y == 1);
-    const float2* const pXB = z1 ? p.XB1 : p.XB;
-    const float2* const pXD = z1 ? p.XD1 : p.XD;
-    const float2* const pd = z1 ? p.d1 : p.d;
+    const XT* const pXB = reinterpret_cast<const XT*>(z1 ? p.XB1 : p.XB);
+    const XT* const pXD = reinterpret_cast<const XT*>(z1 ? p.XD1 : p.XD);
+    const XT* const pd = reinterpret_cast<const XT*>(z1 ? p.d1 : p.d);
     void* const pw = z1 ? p.w1 : p.w;
     void* const plam = z1 ? p.lam1 : p.lam;
     int32_t* const pstatus = z1 ? p.status1 : p.status;
@@ -184,8 +185,8 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
     // ---------------- stage 0 ----------------
     if constexpr (FUSED) {
         const size_t slab = (size_t)k * p.M * N;
-        correlate16<T>(pXB + slab, pd + (size_t)k * p.M, p.M, sA, sr, lane);
-        correlate16<T>(pXD + slab, nullptr, p.M, sB, sr, lane);
+        correlate16<T, XT>(pXB + slab, pd + (size_t)k * p.M, p.M, sA, sr, lane);
+        correlate16<T, XT>(pXD + slab, (const XT*)nullptr, p.M, sB, sr, lane);
     } else {
         const C* RB = reinterpret_cast<const C*>(p.RB) + (size_t)k * N * N;
         const C* RD = reinterpret_cast<const C*>(p.RD) + (size_t)k * N * N;
@@ -461,11 +462,11 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
 
 // The double kernel is held to four waves per SIMD (its float32 pre-solve and the re-orthonormalisation products would
 // otherwise raise the register count past 128 and cost a wave); the float kernel is left to the compiler.
-template <typename T, bool FUSED>
-__global__ void __launch_bounds__(64) gevd16m_kernel(const GevdParams p) { gevd16m_body<T, FUSED>(p); }
-template <bool FUSED>
+template <typename T, bool FUSED, typename XT>
+__global__ void __launch_bounds__(64) gevd16m_kernel(const GevdParams p) { gevd16m_body<T, FUSED, XT>(p); }
+template <bool FUSED, typename XT>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) gevd16m_kernel_f64(const GevdParams p) {
-    gevd16m_body<double, FUSED>(p);
+    gevd16m_body<double, FUSED, XT>(p);
 }
 
 }  // namespace
@@ -474,12 +475,15 @@ hipError_t apv_launch_gevd16m(const GevdParams& p, int compute_dtype, bool fused
     if (p.n != 16 || p.reg_mode != APV_REG_ABS || p.reg_bright != 0.0) return hipErrorNotSupported;
     if (p.K <= 0) return hipSuccess;
     const dim3 grid(p.K, p.n_zones > 1 ? 2 : 1);
+    const bool xd = fused && p.x_c128;
     if (compute_dtype == APV_F64) {
-        if (fused) hipLaunchKernelGGL((gevd16m_kernel_f64<true>), grid, dim3(64), 0, s, p);
-        else hipLaunchKernelGGL((gevd16m_kernel_f64<false>), grid, dim3(64), 0, s, p);
+        if (xd) hipLaunchKernelGGL((gevd16m_kernel_f64<true, double2>), grid, dim3(64), 0, s, p);
+        else if (fused) hipLaunchKernelGGL((gevd16m_kernel_f64<true, float2>), grid, dim3(64), 0, s, p);
+        else hipLaunchKernelGGL((gevd16m_kernel_f64<false, float2>), grid, dim3(64), 0, s, p);
     } else {
-        if (fused) hipLaunchKernelGGL((gevd16m_kernel<float, true>), grid, dim3(64), 0, s, p);
-        else hipLaunchKernelGGL((gevd16m_kernel<float, false>), grid, dim3(64), 0, s, p);
+        if (xd) hipLaunchKernelGGL((gevd16m_kernel<float, true, double2>), grid, dim3(64), 0, s, p);
+        else if (fused) hipLaunchKernelGGL((gevd16m_kernel<float, true, float2>), grid, dim3(64), 0, s, p);
+        else hipLaunchKernelGGL((gevd16m_kernel<float, false, float2>), grid, dim3(64), 0, s, p);
     }
     return hipGetLastError();
 }

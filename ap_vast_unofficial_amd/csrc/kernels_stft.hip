@@ -197,21 +197,23 @@ __global__ void __launch_bounds__(STFT_TPB) stft_analysis_kernel(FftPlan plan, c
 
 // several channel sets (full-length, windowed, one shared ring offset) in one launch: the streaming hop has seven
 constexpr int STFT_MAX_JOBS = 8;
-struct StftJobsF {
-    const float* x[STFT_MAX_JOBS];
-    C2<float>* spec[STFT_MAX_JOBS];
+template <typename T>
+struct StftJobs {
+    const T* x[STFT_MAX_JOBS];
+    C2<T>* spec[STFT_MAX_JOBS];
     long stride_c[STFT_MAX_JOBS], stride_k[STFT_MAX_JOBS];
     int ch0[STFT_MAX_JOBS + 1];                  // first workgroup of each job
     int n;
 };
-__global__ void __launch_bounds__(STFT_TPB) stft_analysis_jobs_kernel(FftPlan plan, StftJobsF jobs, int ring_off,
-                                                                      const C2<float>* __restrict__ tw,
-                                                                      const float* __restrict__ win) {
+template <typename T>
+__global__ void __launch_bounds__(STFT_TPB) stft_analysis_jobs_kernel(FftPlan plan, StftJobs<T> jobs, int ring_off,
+                                                                      const C2<T>* __restrict__ tw,
+                                                                      const T* __restrict__ win) {
     int j = 0;
     while (j + 1 < jobs.n && (int)blockIdx.x >= jobs.ch0[j + 1]) ++j;
     const int c = (int)blockIdx.x - jobs.ch0[j];
-    stft_analysis_body<float>(plan, jobs.x[j] + (size_t)c * plan.N, plan.N, ring_off, 1, jobs.spec[j] + (size_t)c * jobs.stride_c[j],
-                              jobs.stride_k[j], tw, win);
+    stft_analysis_body<T>(plan, jobs.x[j] + (size_t)c * plan.N, plan.N, ring_off, 1, jobs.spec[j] + (size_t)c * jobs.stride_c[j],
+                          jobs.stride_k[j], tw, win);
 }
 
 template <typename T>
@@ -322,20 +324,18 @@ hipError_t launch_synthesis(int N, int H, int n_ch, const void* spec, long strid
 
 }  // namespace
 
-hipError_t apv_launch_stft_analysis_jobs(int N, int n_jobs, const float* const* x, const int* n_ch, float2* const* spec,
-                                         const long* stride_c, const long* stride_k, int ring_off, hipStream_t s,
-                                         std::string* why) {
-    FftPlan plan;
-    if (!make_plan(N, &plan, why)) return hipErrorInvalidValue;
-    if (n_jobs < 1 || n_jobs > STFT_MAX_JOBS) return hipErrorInvalidValue;
-    Tables<float> t;
-    hipError_t e = get_tables<float>(N, &t);
+namespace {
+template <typename T>
+hipError_t launch_analysis_jobs(const FftPlan& plan, int n_jobs, const void* const* x, const int* n_ch, void* const* spec,
+                                const long* stride_c, const long* stride_k, int ring_off, hipStream_t s) {
+    Tables<T> t;
+    hipError_t e = get_tables<T>(plan.N, &t);
     if (e != hipSuccess) return e;
-    StftJobsF jobs{};
+    StftJobs<T> jobs{};
     int total = 0;
     for (int j = 0; j < n_jobs; ++j) {
-        jobs.x[j] = x[j];
-        jobs.spec[j] = (C2<float>*)spec[j];
+        jobs.x[j] = (const T*)x[j];
+        jobs.spec[j] = (C2<T>*)spec[j];
         jobs.stride_c[j] = stride_c[j];
         jobs.stride_k[j] = stride_k[j];
         jobs.ch0[j] = total;
@@ -344,11 +344,22 @@ hipError_t apv_launch_stft_analysis_jobs(int N, int n_jobs, const float* const* 
     jobs.ch0[n_jobs] = total;
     jobs.n = n_jobs;
     if (total <= 0) return hipSuccess;
-    int off = ring_off % N;
-    if (off < 0) off += N;
-    hipLaunchKernelGGL(stft_analysis_jobs_kernel, dim3(total), dim3(STFT_TPB), sizeof(C2<float>) * 2 * plan.Nh, s, plan, jobs, off,
+    int off = ring_off % plan.N;
+    if (off < 0) off += plan.N;
+    hipLaunchKernelGGL(stft_analysis_jobs_kernel<T>, dim3(total), dim3(STFT_TPB), sizeof(C2<T>) * 2 * plan.Nh, s, plan, jobs, off,
                        t.tw, t.win);
     return hipGetLastError();
+}
+}  // namespace
+
+hipError_t apv_launch_stft_analysis_jobs(int f64, int N, int n_jobs, const void* const* x, const int* n_ch, void* const* spec,
+                                         const long* stride_c, const long* stride_k, int ring_off, hipStream_t s,
+                                         std::string* why) {
+    FftPlan plan;
+    if (!make_plan(N, &plan, why)) return hipErrorInvalidValue;
+    if (n_jobs < 1 || n_jobs > STFT_MAX_JOBS) return hipErrorInvalidValue;
+    return f64 ? launch_analysis_jobs<double>(plan, n_jobs, x, n_ch, spec, stride_c, stride_k, ring_off, s)
+               : launch_analysis_jobs<float>(plan, n_jobs, x, n_ch, spec, stride_c, stride_k, ring_off, s);
 }
 
 // build (or find) the twiddle / window tables now, so that no allocation happens on the per-hop path

@@ -120,19 +120,92 @@ __global__ void __launch_bounds__(256) fir_mfma_kernel(FirJobs jobs, int P, int 
 
 // both input signals of a hop in one launch (blockIdx.y = signal): new history = [old[H:], x, zeros(pad)] and the hop
 // appended to the input-block ring
+template <typename T>
 struct InputUpdate {
-    const float* old_hist[2];
-    float* new_hist[2];
+    const T* old_hist[2];
+    T* new_hist[2];
 };
-__global__ void __launch_bounds__(256) input_update_kernel(int P, int H, int pad, int N, int ring_off, InputUpdate u,
-                                                           const float* __restrict__ xin, float* __restrict__ inblk) {
+template <typename T>
+__global__ void __launch_bounds__(256) input_update_kernel(int P, int H, int pad, int N, int ring_off, InputUpdate<T> u,
+                                                           const T* __restrict__ xin, T* __restrict__ inblk) {
     const int g = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
-    const float* x = xin + (size_t)g * H;
+    const T* x = xin + (size_t)g * H;
     const int keep = P - 1;
     if (i < keep) u.new_hist[g][i] = u.old_hist[g][i + H];
     else if (i < keep + H) u.new_hist[g][i] = x[i - keep];
-    else if (i < keep + H + pad) u.new_hist[g][i] = 0.f;
+    else if (i < keep + H + pad) u.new_hist[g][i] = (T)0;
     if (i < H) inblk[(size_t)g * N + (N - H + i + ring_off) % N] = x[i];
+}
+
+// ---- K1 in float64 on v_mfma_f64_16x16x4_f64 (both stream modes) ---------------------------------
+//   y[n][c] = sum_p xh[P-1+n-p] rir[p][c]                                           apvast.py:171-192 (lfilter)
+// A workgroup owns NT x 16 samples x 16 channels; its four waves split the taps, each streaming its share of the RIR
+// slab straight into MFMA B operands (one load serves all NT sample tiles) while the A operands are windows of the
+// input history held in LDS; the four partial tiles are summed through LDS.  All paths and targets of the hop are one
+// launch (job table).
+using d4 = __attribute__((ext_vector_type(4))) double;
+
+template <int NT>
+__global__ void __launch_bounds__(256) fir_f64_mfma_kernel(int P, int H, int N, int ring_off, int njobs, FirJobsD jobs) {
+    extern __shared__ double fir_lds[];          // [P - 1 + 16 NT] history window, then [4][NT][264] partial tiles
+    int j = 0;
+    while (j + 1 < njobs && (int)blockIdx.y >= jobs.tile0[j + 1]) ++j;
+    const int C = jobs.C[j];
+    const double* __restrict__ rir = jobs.rir[j];
+    const double* __restrict__ xh = jobs.xh[j];
+    const int c0 = ((int)blockIdx.y - jobs.tile0[j]) * 16, n0 = blockIdx.x * 16 * NT;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, il = lane & 15, kq = lane >> 4;
+    constexpr int SPAN = 16 * NT - 1;
+    double* xw = fir_lds;
+    double* part = fir_lds + ((P + SPAN + 1) & ~1);
+    for (int i = tid; i < P + SPAN; i += 256) xw[i] = xh[n0 + i];
+    const int steps_total = (P + 3) >> 2, spw = (steps_total + 3) >> 2;
+    const int s_begin = wave * spw, s_end = min(s_begin + spw, steps_total);
+    const int c = c0 + il;
+    const bool c_ok = c < C;
+    __syncthreads();
+    d4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (d4){0, 0, 0, 0};
+    constexpr int G = NT > 1 ? 8 : 32;           // k-steps whose taps are in flight together
+    for (int s0 = s_begin; s0 < s_end; s0 += G) {
+        double bv[G];
+#pragma unroll
+        for (int q = 0; q < G; ++q) {
+            const int pt = 4 * (s0 + q) + kq;
+            bv[q] = (s0 + q < s_end && pt < P && c_ok) ? rir[(size_t)pt * C + c] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < G; ++q) {
+            const int pt = 4 * (s0 + q) + kq;
+            const int wi = P - 1 + il - pt;                  // taps past P carry a zero B operand
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int wj = wi + 16 * t;
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(xw[wj > 0 ? wj : 0], bv[q], acc[t], 0, 0, 0);
+            }
+        }
+    }
+    // partial tiles -> LDS (row stride RS keeps the transposed read below off a single bank), then each thread sums the four
+    // waves for NT consecutive samples of one channel: the ring is written in runs of 16 NT samples per channel
+    constexpr int RS = 66, TS = 4 * RS;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[(wave * NT + t) * TS + r * RS + lane] = acc[t][r];
+    __syncthreads();
+    // accumulator element (r, lane) of sample tile t: sample 16 t + (lane >> 4) + 4 r, channel lane & 15
+    const int ch = tid >> 4, qs = tid & 15;
+    const bool ch_ok = c0 + ch < C;
+    double* __restrict__ dst = jobs.resp[j] + (size_t)(c0 + ch) * N;
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        const int sm = qs * NT + u, t = sm >> 4, wi = sm & 15;
+        const int e = t * TS + (wi >> 2) * RS + (wi & 3) * 16 + ch;
+        const double v = part[e] + part[NT * TS + e] + part[2 * NT * TS + e] + part[3 * NT * TS + e];
+        const int n = n0 + sm;
+        if (n < H && ch_ok) dst[(N - H + n + ring_off) % N] = v;
+    }
 }
 
 // ---- perceptual weighting (van de Par 2005, Matlab/ControlMethods/perceptualModel.m:118-139, 177-190) --------
@@ -190,13 +263,14 @@ __global__ void __launch_bounds__(256) perceptual_weights_kernel(int K, int M, i
 }
 
 // spec[k][c] *= W[k][c / L]   (bin-major c64; L = 1 scales the target spectra themselves)
-__global__ void __launch_bounds__(256) scale_spectra_kernel(int K, int C, int L, float2* __restrict__ spec,
-                                                            const float* __restrict__ W) {
+template <typename S2, typename WT>
+__global__ void __launch_bounds__(256) scale_spectra_kernel(int K, int C, int L, S2* __restrict__ spec,
+                                                            const WT* __restrict__ W) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (size_t)K * C) return;
     const int k = (int)(idx / C), c = (int)(idx - (size_t)k * C);
-    const float w = W[(size_t)k * (C / L) + c / L];
-    float2 v = spec[idx];
+    const WT w = W[(size_t)k * (C / L) + c / L];
+    S2 v = spec[idx];
     v.x *= w;
     v.y *= w;
     spec[idx] = v;
@@ -220,34 +294,39 @@ __global__ void __launch_bounds__(256) scale_spectra_cm_f64_kernel(int K, int C,
 // all jobs.
 constexpr int APPLY_MAX_JOBS = 4;
 struct ApplyJobs {
-    const float2* in[APPLY_MAX_JOBS];
+    const void* in[APPLY_MAX_JOBS];
     const void* w[APPLY_MAX_JOBS];
-    const float2* tgt[APPLY_MAX_JOBS];
-    float2* out[APPLY_MAX_JOBS];
+    const void* tgt[APPLY_MAX_JOBS];
+    void* out[APPLY_MAX_JOBS];
     int n_filt[APPLY_MAX_JOBS], n_tgt[APPLY_MAX_JOBS], tile0[APPLY_MAX_JOBS + 1];
     int n;
 };
-template <typename W>
+// W: element type of the filter bank (float2 | double2); S2: element type of the spectra (float2 | double2)
+template <typename W, typename S2>
 __global__ void __launch_bounds__(256) apply_filters_kernel(int K, ApplyJobs jobs) {
     // grid: x over k, y over channels (tiles of 16 channels x 16 bins so both sides stay reasonably coalesced)
-    __shared__ float2 tile[16][17];
+    using R = decltype(S2::x);
+    __shared__ S2 tile[16][17];
     int j = 0;
     while (j + 1 < jobs.n && (int)blockIdx.y >= jobs.tile0[j + 1]) ++j;
     const int n_filt = jobs.n_filt[j], n_tgt = jobs.n_tgt[j];
     const W* __restrict__ w = reinterpret_cast<const W*>(jobs.w[j]);
-    const float2* __restrict__ tgt = jobs.tgt[j];
-    const float2* __restrict__ in_spec = jobs.in[j];
-    float2* __restrict__ out = jobs.out[j];
+    const S2* __restrict__ tgt = reinterpret_cast<const S2*>(jobs.tgt[j]);
+    const S2* __restrict__ in_spec = reinterpret_cast<const S2*>(jobs.in[j]);
+    S2* __restrict__ out = reinterpret_cast<S2*>(jobs.out[j]);
     const int k0 = blockIdx.x * 16, c0 = ((int)blockIdx.y - jobs.tile0[j]) * 16;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int n_ch = n_filt + n_tgt;
     {   // load: channel fastest (bin-major filter bank)
         const int k = k0 + ty, ch = c0 + tx;
-        float2 f = make_float2(0.f, 0.f);
+        S2 f;
+        f.x = (R)0;
+        f.y = (R)0;
         if (k < K && ch < n_ch) {
             if (ch < n_filt) {
                 const W v = w[(size_t)k * n_filt + ch];
-                f = make_float2((float)v.x, (float)v.y);
+                f.x = (R)v.x;
+                f.y = (R)v.y;
             } else {
                 f = tgt[(size_t)(ch - n_filt) * K + k];
             }
@@ -258,9 +337,12 @@ __global__ void __launch_bounds__(256) apply_filters_kernel(int K, ApplyJobs job
     {   // store: bin fastest (channel-major spectra for the synthesis kernel)
         const int k = k0 + tx, ch = c0 + ty;
         if (k < K && ch < n_ch) {
-            const float2 f = tile[tx][ty];
-            const float2 x = in_spec[k];
-            out[(size_t)ch * K + k] = make_float2(x.x * f.x - x.y * f.y, x.x * f.y + x.y * f.x);
+            const S2 f = tile[tx][ty];
+            const S2 x = in_spec[k];
+            S2 y;
+            y.x = x.x * f.x - x.y * f.y;
+            y.y = x.x * f.y + x.y * f.x;
+            out[(size_t)ch * K + k] = y;
         }
     }
 }
@@ -275,11 +357,17 @@ hipError_t apv_launch_fir_hop(int C, int P, int H, int N, int ring_off, const fl
     return hipGetLastError();
 }
 
-hipError_t apv_launch_perceptual_weights(int K, int M, int nch, const float2* spec, const double* G2, const double* G2T,
-                                         double Cs, double Ca, double Leff, int N, int norm_mode, float* W, hipStream_t s) {
+// f64 = 0: c64 bin-major spectra [K][M] -> float weights [K][M]; f64 = 1: c128 spectra -> double weights
+hipError_t apv_launch_perceptual_weights(int f64, int K, int M, int nch, const void* spec, const double* G2, const double* G2T,
+                                         double Cs, double Ca, double Leff, int N, int norm_mode, void* W, hipStream_t s) {
     const size_t lds = sizeof(double) * ((size_t)K + nch + 256);
-    hipLaunchKernelGGL((perceptual_weights_kernel<float2, float>), dim3(M), dim3(256), lds, s, K, M, nch, spec, (long)M, 1L,
-                       G2, G2T, Cs, Ca, Leff, 2.0 / ((double)N * (double)N), norm_mode, W, (long)M, 1L);
+    const double fs2 = 2.0 / ((double)N * (double)N);
+    if (f64)
+        hipLaunchKernelGGL((perceptual_weights_kernel<double2, double>), dim3(M), dim3(256), lds, s, K, M, nch, (const double2*)spec,
+                           (long)M, 1L, G2, G2T, Cs, Ca, Leff, fs2, norm_mode, (double*)W, (long)M, 1L);
+    else
+        hipLaunchKernelGGL((perceptual_weights_kernel<float2, float>), dim3(M), dim3(256), lds, s, K, M, nch, (const float2*)spec,
+                           (long)M, 1L, G2, G2T, Cs, Ca, Leff, fs2, norm_mode, (float*)W, (long)M, 1L);
     return hipGetLastError();
 }
 
@@ -299,17 +387,25 @@ hipError_t apv_launch_scale_spectra_cm_f64(int K, int C, int L, double2* spec, c
     return hipGetLastError();
 }
 
-hipError_t apv_launch_scale_spectra(int K, int C, int L, float2* spec, const float* W, hipStream_t s) {
+hipError_t apv_launch_scale_spectra(int f64, int K, int C, int L, void* spec, const void* W, hipStream_t s) {
     const size_t total = (size_t)K * C;
-    hipLaunchKernelGGL(scale_spectra_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, K, C, L, spec, W);
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (f64) hipLaunchKernelGGL((scale_spectra_kernel<double2, double>), grid, dim3(256), 0, s, K, C, L, (double2*)spec, (const double*)W);
+    else hipLaunchKernelGGL((scale_spectra_kernel<float2, float>), grid, dim3(256), 0, s, K, C, L, (float2*)spec, (const float*)W);
     return hipGetLastError();
 }
 
-hipError_t apv_launch_input_update(int P, int H, int pad, int N, int ring_off, const float* const old_hist[2],
-                                   float* const new_hist[2], const float* xin, float* inblk, hipStream_t s) {
-    InputUpdate u{{old_hist[0], old_hist[1]}, {new_hist[0], new_hist[1]}};
+hipError_t apv_launch_input_update(int f64, int P, int H, int pad, int N, int ring_off, const void* const old_hist[2],
+                                   void* const new_hist[2], const void* xin, void* inblk, hipStream_t s) {
     const int total = P - 1 + H + pad;
-    hipLaunchKernelGGL(input_update_kernel, dim3((total + 255) / 256, 2), dim3(256), 0, s, P, H, pad, N, ring_off % N, u, xin, inblk);
+    const dim3 grid((total + 255) / 256, 2);
+    if (f64) {
+        InputUpdate<double> u{{(const double*)old_hist[0], (const double*)old_hist[1]}, {(double*)new_hist[0], (double*)new_hist[1]}};
+        hipLaunchKernelGGL(input_update_kernel<double>, grid, dim3(256), 0, s, P, H, pad, N, ring_off % N, u, (const double*)xin, (double*)inblk);
+    } else {
+        InputUpdate<float> u{{(const float*)old_hist[0], (const float*)old_hist[1]}, {(float*)new_hist[0], (float*)new_hist[1]}};
+        hipLaunchKernelGGL(input_update_kernel<float>, grid, dim3(256), 0, s, P, H, pad, N, ring_off % N, u, (const float*)xin, (float*)inblk);
+    }
     return hipGetLastError();
 }
 
@@ -327,8 +423,36 @@ hipError_t apv_launch_fir_jobs(const FirJobs& jobs, int P, int H, int N, int rin
     return hipGetLastError();
 }
 
-hipError_t apv_launch_apply_jobs(int K, int n_jobs, const float2* const* in_spec, const void* const* w, const float2* const* tgt,
-                                 float2* const* out, const int* n_filt, const int* n_tgt, int w_c128, hipStream_t s) {
+// float64 jobs: fills tile0 from C; the input histories must be readable up to P - 1 + roundup(H, 64) samples
+// (zero tail: apv_fir_pad_f64())
+int apv_fir_pad_f64() { return 64; }
+
+hipError_t apv_launch_fir_jobs_f64(FirJobsD jobs, int njobs, int P, int H, int N, int ring_off, hipStream_t s) {
+    if (njobs <= 0 || H <= 0) return hipSuccess;
+    if (njobs > FIR_JOBS_D) return hipErrorInvalidValue;
+    int tiles = 0;
+    for (int j = 0; j < njobs; ++j) {
+        jobs.tile0[j] = tiles;
+        tiles += (jobs.C[j] + 15) / 16;
+    }
+    jobs.tile0[njobs] = tiles;
+    if (tiles == 0) return hipSuccess;
+    // four sample tiles per workgroup once the hop is long enough to still fill the chip: every tap load then feeds four MFMAs
+    if (H >= 256) {
+        constexpr int NT = 4;
+        const size_t lds = sizeof(double) * (((size_t)P + 16 * NT) + 4 * NT * 264);
+        hipLaunchKernelGGL(fir_f64_mfma_kernel<NT>, dim3((H + 16 * NT - 1) / (16 * NT), tiles), dim3(256), lds, s, P, H, N,
+                           ring_off % N, njobs, jobs);
+    } else {
+        const size_t lds = sizeof(double) * (((size_t)P + 16) + 4 * 264);
+        hipLaunchKernelGGL(fir_f64_mfma_kernel<1>, dim3((H + 15) / 16, tiles), dim3(256), lds, s, P, H, N, ring_off % N, njobs, jobs);
+    }
+    return hipGetLastError();
+}
+
+// spec_f64 = 0: c64 spectra (in, tgt, out), 1: c128; w_c128: element type of the bin-major filter banks
+hipError_t apv_launch_apply_jobs(int K, int n_jobs, const void* const* in_spec, const void* const* w, const void* const* tgt,
+                                 void* const* out, const int* n_filt, const int* n_tgt, int w_c128, int spec_f64, hipStream_t s) {
     if (n_jobs < 1 || n_jobs > APPLY_MAX_JOBS || K <= 0) return hipErrorInvalidValue;
     ApplyJobs jobs{};
     int tiles = 0;
@@ -342,7 +466,12 @@ hipError_t apv_launch_apply_jobs(int K, int n_jobs, const float2* const* in_spec
     jobs.n = n_jobs;
     if (tiles == 0) return hipSuccess;
     const dim3 grid((K + 15) / 16, tiles);
-    if (w_c128) hipLaunchKernelGGL(apply_filters_kernel<double2>, grid, dim3(256), 0, s, K, jobs);
-    else hipLaunchKernelGGL(apply_filters_kernel<float2>, grid, dim3(256), 0, s, K, jobs);
+    if (spec_f64) {
+        if (w_c128) hipLaunchKernelGGL((apply_filters_kernel<double2, double2>), grid, dim3(256), 0, s, K, jobs);
+        else hipLaunchKernelGGL((apply_filters_kernel<float2, double2>), grid, dim3(256), 0, s, K, jobs);
+    } else {
+        if (w_c128) hipLaunchKernelGGL((apply_filters_kernel<double2, float2>), grid, dim3(256), 0, s, K, jobs);
+        else hipLaunchKernelGGL((apply_filters_kernel<float2, float2>), grid, dim3(256), 0, s, K, jobs);
+    }
     return hipGetLastError();
 }

@@ -19,38 +19,41 @@
 
 struct apv_stream {
     int N, H, K, L, M, C, P, nV, zones, pad;
+    int f64;                      // precision of the whole front-end: RIRs, rings, spectra, overlap buffers, outputs
+    size_t esz;                   // bytes per real sample (4 | 8); a complex spectrum element is 2 esz
     int ring_off;                 // physical index of logical sample 0 in every ring
     int cur;                      // which input-history buffer is current
     int n_out;                    // synthesis channels: zones*nV*L filtered + 2*L target
-    float* rir[2];                // [P][C]  zone A, zone B
-    float* trir[2];               // [P][M]  target RIRs (reference loudspeaker, delayed)
-    float* xhist[2][2];           // [buf][signal][P-1+H+pad]
-    float* xin;                   // [2][H] staging of the hop
-    float* resp[4];               // [C][N] rings: A->A, A->B, B->A, B->B
-    float* tresp[2];              // [M][N] rings: target A, target B
-    float* inblk;                 // [2][N] rings: input blocks
-    float2* X[4];                 // [K][C] bin-major control-point spectra
-    float2* tspec[2];             // [K][M]
-    float2* inspec;               // [2][K]
+    void* rir[2];                 // [P][C]  zone A, zone B
+    void* trir[2];                // [P][M]  target RIRs (reference loudspeaker, delayed)
+    void* xhist[2][2];            // [buf][signal][P-1+H+pad]
+    void* xin;                    // [2][H] staging of the hop
+    void* resp[4];                // [C][N] rings: A->A, A->B, B->A, B->B
+    void* tresp[2];               // [M][N] rings: target A, target B
+    void* inblk;                  // [2][N] rings: input blocks
+    void* X[4];                   // [K][C] bin-major control-point spectra
+    void* tspec[2];               // [K][M]
+    void* inspec;                 // [2][K]
     void* w[2];                   // [K][nV][L] per zone
     void* lam[2];                 // [K][L]
     int32_t* status[2];           // [K]
-    float2* tgt;                  // [L][K] target filter spectra (shared by A_t and B_t, apvast.py:389-390)
-    float2* outspec;              // [n_out][K]
-    float* outov;                 // [n_out][N]
-    float* out;                   // [n_out][H]
+    void* tgt;                    // [L][K] target filter spectra (shared by A_t and B_t, apvast.py:389-390)
+    void* outspec;                // [n_out][K]
+    void* outov;                  // [n_out][N]
+    void* out;                    // [n_out][H]
     // perceptual weighting (off when nch == 0)
     int nch, norm_mode;
     double Cs, Ca, Leff;
     double* G2;                   // [K][nch]
     double* G2T;                  // [nch][K]
-    float* Wgt[2];                // [K][M] per zone
+    void* Wgt[2];                 // [K][M] per zone
     // pinned staging + one captured hipGraph per phase of the (ring offset, history buffer) cycle
-    float* pin_in;                // [2][H]
-    float* pin_out;               // [n_out][H]
+    void* pin_in;                 // [2][H]
+    void* pin_out;                // [n_out][H]
     int32_t* pin_status;          // [2][K]
     int period;                   // hops after which (ring_off, cur) repeat; 0 = graphs off
     long hop;                     // hops processed
+    long not_converged;           // hops in which some bin hit the sweep cap (status 2)
     std::vector<hipGraphExec_t> execs;
     std::vector<int32_t> h_status;
 };
@@ -63,11 +66,29 @@ namespace {
         if (_e != hipSuccess) return apv_fail(h, APV_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_e)); \
     } while (0)
 
+// `count` elements of `esz` bytes, zeroed
 template <typename T>
-int dalloc(apv_handle* h, T** p, size_t count) {
-    SCHK(h, hipMalloc((void**)p, sizeof(T) * (count ? count : 1)));
-    SCHK(h, hipMemsetAsync(*p, 0, sizeof(T) * (count ? count : 1), h->stream));
+int dalloc(apv_handle* h, T** p, size_t count, size_t esz = sizeof(T)) {
+    SCHK(h, hipMalloc((void**)p, esz * (count ? count : 1)));
+    SCHK(h, hipMemsetAsync(*p, 0, esz * (count ? count : 1), h->stream));
     return APV_OK;
+}
+
+// front-end precision of a streaming handle: cfg.frontend = 0 follows compute_dtype, 1 forces float32, 2 float64
+int frontend_f64(const apv_config& c) {
+    if (c.frontend == 1) return 0;
+    if (c.frontend == 2) return 1;
+    return c.compute_dtype == APV_F64;
+}
+
+template <typename T>
+int upload_as(apv_handle* h, void* dst, const std::vector<double>& src) {
+    std::vector<T> tmp(src.begin(), src.end());
+    SCHK(h, hipMemcpy(dst, tmp.data(), sizeof(T) * tmp.size(), hipMemcpyHostToDevice));
+    return APV_OK;
+}
+int upload(apv_handle* h, int f64, void* dst, const std::vector<double>& src) {
+    return f64 ? upload_as<double>(h, dst, src) : upload_as<float>(h, dst, src);
 }
 
 size_t wsz(const apv_handle* h) { return h->cfg.out_c128 ? 16 : 8; }
@@ -98,137 +119,53 @@ void apv_stream_free(apv_handle* h) {
     h->st = nullptr;
 }
 
-extern "C" {
-
-int apv_stream_init(apv_handle* h, int32_t rir_len, const double* h_rir_A, const double* h_rir_B,
-                    int32_t reference_index_A, int32_t reference_index_B, int32_t modeling_delay) {
-    if (!h || !h_rir_A || !h_rir_B) return apv_fail(h, APV_ERR_ARG, "null argument");
-    const apv_config& c = h->cfg;
-    const int N = c.block_size, H = c.hop_size;
-    {
-        std::string why;
-        if (!apv_stft_size_ok(N, &why)) return apv_fail(h, APV_ERR_ARG, why);
-    }
-    if (H < 1 || H > N) return apv_fail(h, APV_ERR_ARG, "hop_size must be in 1..block_size");
-    if (c.n_bins != N / 2 + 1) return apv_fail(h, APV_ERR_ARG, "streaming handle needs n_bins == block_size/2 + 1");
-    if (rir_len < 1 || modeling_delay < 0 || modeling_delay >= rir_len) return apv_fail(h, APV_ERR_ARG, "rir_len / modeling_delay out of range");
-    if (reference_index_A < 0 || reference_index_A >= c.n_srcs || reference_index_B < 0 || reference_index_B >= c.n_srcs)
-        return apv_fail(h, APV_ERR_ARG, "reference index out of range");
-    if (c.n_zones < 1 || c.n_zones > 3) return apv_fail(h, APV_ERR_ARG, "n_zones is a bit mask: 1 = A, 2 = B, 3 = both");
-    SCHK(h, hipSetDevice(h->device));
-    apv_stream_free(h);
-    apv_stream* s = new apv_stream();
-    std::memset(static_cast<void*>(s), 0, offsetof(apv_stream, execs));
-    h->st = s;
-    s->N = N; s->H = H; s->K = N / 2 + 1; s->L = c.n_srcs; s->M = c.n_mics; s->C = s->L * s->M;
-    s->P = rir_len; s->nV = c.n_ranks; s->zones = c.n_zones; s->pad = apv_fir_pad();
-    s->ring_off = 0; s->cur = 0;
-    const int nz = ((s->zones & 1) ? 1 : 0) + ((s->zones & 2) ? 1 : 0);
-    s->n_out = nz * s->nV * s->L + 2 * s->L;
-    const int L = s->L, M = s->M, C = s->C, P = s->P, K = s->K;
-    int rc;
-    // RIRs: host (P, L, M) float64 C-order -> device [P][m*L + l] float32
-    std::vector<float> tmp((size_t)P * C), ttmp((size_t)P * M);
-    for (int z = 0; z < 2; ++z) {
-        const double* src = z ? h_rir_B : h_rir_A;
-        const int ref = z ? reference_index_B : reference_index_A;
-        for (int p = 0; p < P; ++p)
-            for (int l = 0; l < L; ++l)
-                for (int m = 0; m < M; ++m) tmp[(size_t)p * C + m * L + l] = (float)src[((size_t)p * L + l) * M + m];
-        // target RIR: reference loudspeaker delayed by modeling_delay (apvast.py:102-112)
-        std::fill(ttmp.begin(), ttmp.end(), 0.f);
-        for (int p = modeling_delay; p < P; ++p)
-            for (int m = 0; m < M; ++m) ttmp[(size_t)p * M + m] = (float)src[((size_t)(p - modeling_delay) * L + ref) * M + m];
-        if ((rc = dalloc(h, &s->rir[z], (size_t)P * C))) return rc;
-        if ((rc = dalloc(h, &s->trir[z], (size_t)P * M))) return rc;
-        SCHK(h, hipMemcpy(s->rir[z], tmp.data(), sizeof(float) * tmp.size(), hipMemcpyHostToDevice));
-        SCHK(h, hipMemcpy(s->trir[z], ttmp.data(), sizeof(float) * ttmp.size(), hipMemcpyHostToDevice));
-    }
-    const size_t hist = (size_t)P - 1 + H + s->pad;
-    for (int b = 0; b < 2; ++b)
-        for (int g = 0; g < 2; ++g)
-            if ((rc = dalloc(h, &s->xhist[b][g], hist))) return rc;
-    if ((rc = dalloc(h, &s->xin, (size_t)2 * H))) return rc;
-    for (int p = 0; p < 4; ++p) {
-        if ((rc = dalloc(h, &s->resp[p], (size_t)C * N))) return rc;
-        if ((rc = dalloc(h, &s->X[p], (size_t)K * C))) return rc;
-    }
-    for (int z = 0; z < 2; ++z) {
-        if ((rc = dalloc(h, &s->tresp[z], (size_t)M * N))) return rc;
-        if ((rc = dalloc(h, &s->tspec[z], (size_t)K * M))) return rc;
-        if ((rc = dalloc(h, (char**)&s->w[z], (size_t)K * s->nV * L * wsz(h)))) return rc;
-        if ((rc = dalloc(h, (char**)&s->lam[z], (size_t)K * L * lsz(h)))) return rc;
-    }
-    if ((rc = dalloc(h, &s->status[0], (size_t)2 * K))) return rc;       // [zone A | zone B]: one copy back per hop
-    s->status[1] = s->status[0] + K;
-    if ((rc = dalloc(h, &s->inblk, (size_t)2 * N))) return rc;
-    if ((rc = dalloc(h, &s->inspec, (size_t)2 * K))) return rc;
-    if ((rc = dalloc(h, &s->tgt, (size_t)L * K))) return rc;
-    if ((rc = dalloc(h, &s->outspec, (size_t)s->n_out * K))) return rc;
-    if ((rc = dalloc(h, &s->outov, (size_t)s->n_out * N))) return rc;
-    if ((rc = dalloc(h, &s->out, (size_t)s->n_out * H))) return rc;
-    // target filter spectra: rfft of a unit impulse at tap modeling_delay of the A reference loudspeaker
-    // (apvast.py:389-390, 418, 422: the same filter serves A_t and B_t)
-    std::vector<float2> tg((size_t)L * K, make_float2(0.f, 0.f));
-    const double PI = 3.14159265358979323846;
-    for (int k = 0; k < K; ++k) {
-        const double ph = -2.0 * PI * (double)k * (double)modeling_delay / (double)N;
-        tg[(size_t)reference_index_A * K + k] = make_float2((float)std::cos(ph), (float)std::sin(ph));
-    }
-    SCHK(h, hipMemcpy(s->tgt, tg.data(), sizeof(float2) * tg.size(), hipMemcpyHostToDevice));
-    s->h_status.assign((size_t)2 * K, 0);
-    SCHK(h, hipHostMalloc((void**)&s->pin_in, sizeof(float) * 2 * H, hipHostMallocDefault));
-    SCHK(h, hipHostMalloc((void**)&s->pin_out, sizeof(float) * (size_t)s->n_out * H, hipHostMallocDefault));
-    SCHK(h, hipHostMalloc((void**)&s->pin_status, sizeof(int32_t) * 2 * K, hipHostMallocDefault));
-    std::memset(s->pin_status, 0, sizeof(int32_t) * 2 * K);
-    // the launch sequence of a hop depends on (ring_off, cur) only: ring_off has period N / gcd(N, H), cur period 2
-    {
-        int a = N, b = H;
-        while (b) { const int t = a % b; a = b; b = t; }
-        int per = N / a;
-        if (per % 2) per *= 2;
-        s->period = (per <= 16 && getenv("APV_NO_GRAPH") == nullptr) ? per : 0;
-        s->execs.assign(s->period > 0 ? s->period : 0, nullptr);
-    }
-    s->hop = 0;
-    SCHK(h, apv_stft_prepare(N, 0));
-    SCHK(h, hipStreamSynchronize(h->stream));
-    return APV_OK;
-}
-
 // everything one hop puts on the stream, from the pinned input staging to the pinned output staging; advances
 // (ring_off, cur) on the host.  Pure enqueue: also used under stream capture.
 static int enqueue_hop(apv_handle* h) {
     apv_stream* s = h->st;
     hipStream_t st = h->stream;
-    const float* h_in_A = s->pin_in;
-    float* h_out = s->pin_out;
-    const int N = s->N, H = s->H, K = s->K, L = s->L, M = s->M, C = s->C, P = s->P;
+    const int N = s->N, H = s->H, K = s->K, L = s->L, M = s->M, C = s->C, P = s->P, f64 = s->f64;
+    const size_t e1 = s->esz, e2 = 2 * s->esz;
     std::string why;
     // hop -> device, input history and input-block rings
-    SCHK(h, hipMemcpyAsync(s->xin, h_in_A, sizeof(float) * 2 * H, hipMemcpyHostToDevice, st));     // [A | B], contiguous on both sides
+    SCHK(h, hipMemcpyAsync(s->xin, s->pin_in, e1 * 2 * H, hipMemcpyHostToDevice, st));     // [A | B], contiguous on both sides
     const int nxt = s->cur ^ 1;
     // all rings advance by one hop: logical sample n now lives H further on
     s->ring_off = (s->ring_off + H) % N;
     {
-        const float* oh[2] = {s->xhist[s->cur][0], s->xhist[s->cur][1]};
-        float* nh[2] = {s->xhist[nxt][0], s->xhist[nxt][1]};
-        SCHK(h, apv_launch_input_update(P, H, s->pad, N, s->ring_off, oh, nh, s->xin, s->inblk, st));   // histories + input-block rings
+        const void* oh[2] = {s->xhist[s->cur][0], s->xhist[s->cur][1]};
+        void* nh[2] = {s->xhist[nxt][0], s->xhist[nxt][1]};
+        SCHK(h, apv_launch_input_update(f64, P, H, s->pad, N, s->ring_off, oh, nh, s->xin, s->inblk, st));   // histories + input-block rings
     }
     s->cur = nxt;
     // K1: RIR convolution into the response rings (one MFMA launch for all six filter banks)
-    {
+    if (f64) {
+        FirJobsD jobs{};
+        for (int p = 0; p < 4; ++p) {
+            jobs.rir[p] = (const double*)s->rir[path_zone(p)]; jobs.xh[p] = (const double*)s->xhist[s->cur][path_sig(p)];
+            jobs.resp[p] = (double*)s->resp[p]; jobs.C[p] = C;
+        }
+        for (int z = 0; z < 2; ++z) {
+            jobs.rir[4 + z] = (const double*)s->trir[z]; jobs.xh[4 + z] = (const double*)s->xhist[s->cur][z];
+            jobs.resp[4 + z] = (double*)s->tresp[z]; jobs.C[4 + z] = M;
+        }
+        SCHK(h, apv_launch_fir_jobs_f64(jobs, 6, P, H, N, s->ring_off, st));
+    } else {
         static const bool valu_fir = (getenv("APV_FIR_VALU") != nullptr);     // A/B switch: direct-form VALU kernel
         if (valu_fir) {
             for (int p = 0; p < 4; ++p)
-                SCHK(h, apv_launch_fir_hop(C, P, H, N, s->ring_off, s->rir[path_zone(p)], s->xhist[s->cur][path_sig(p)], s->resp[p], st));
+                SCHK(h, apv_launch_fir_hop(C, P, H, N, s->ring_off, (const float*)s->rir[path_zone(p)],
+                                           (const float*)s->xhist[s->cur][path_sig(p)], (float*)s->resp[p], st));
             for (int z = 0; z < 2; ++z)
-                SCHK(h, apv_launch_fir_hop(M, P, H, N, s->ring_off, s->trir[z], s->xhist[s->cur][z], s->tresp[z], st));
+                SCHK(h, apv_launch_fir_hop(M, P, H, N, s->ring_off, (const float*)s->trir[z], (const float*)s->xhist[s->cur][z],
+                                           (float*)s->tresp[z], st));
         } else {
             FirJobs jobs;
             jobs.n = 6;
-            for (int p = 0; p < 4; ++p) jobs.j[p] = FirJob{s->rir[path_zone(p)], s->xhist[s->cur][path_sig(p)], s->resp[p], C};
-            for (int z = 0; z < 2; ++z) jobs.j[4 + z] = FirJob{s->trir[z], s->xhist[s->cur][z], s->tresp[z], M};
+            for (int p = 0; p < 4; ++p)
+                jobs.j[p] = FirJob{(const float*)s->rir[path_zone(p)], (const float*)s->xhist[s->cur][path_sig(p)], (float*)s->resp[p], C};
+            for (int z = 0; z < 2; ++z)
+                jobs.j[4 + z] = FirJob{(const float*)s->trir[z], (const float*)s->xhist[s->cur][z], (float*)s->tresp[z], M};
             SCHK(h, apv_launch_fir_jobs(jobs, P, H, N, s->ring_off, st));
         }
     }
@@ -236,8 +173,8 @@ static int enqueue_hop(apv_handle* h) {
     const bool runA = s->zones & 1, runB = s->zones & 2;
     {
         // every analysis transform of the hop in one launch: the live response paths, both targets, the two inputs
-        const float* jx[7];
-        float2* jspec[7];
+        const void* jx[7];
+        void* jspec[7];
         int jch[7], nj = 0;
         long jsc[7], jsk[7];
         for (int p = 0; p < 4; ++p) {
@@ -247,20 +184,20 @@ static int enqueue_hop(apv_handle* h) {
         }
         for (int z = 0; z < 2; ++z) { jx[nj] = s->tresp[z]; jspec[nj] = s->tspec[z]; jch[nj] = M; jsc[nj] = 1; jsk[nj] = M; ++nj; }
         jx[nj] = s->inblk; jspec[nj] = s->inspec; jch[nj] = 2; jsc[nj] = K; jsk[nj] = 1; ++nj;
-        hipError_t e = apv_launch_stft_analysis_jobs(N, nj, jx, jch, jspec, jsc, jsk, s->ring_off, st, &why);
+        hipError_t e = apv_launch_stft_analysis_jobs(f64, N, nj, jx, jch, jspec, jsc, jsk, s->ring_off, st, &why);
         if (e != hipSuccess) return apv_fail(h, APV_ERR_HIP, why.empty() ? hipGetErrorString(e) : why);
     }
     if (s->nch > 0) {
         // weights from the UNWEIGHTED target spectra (apvast.py:205), then spectra x weights (apvast.py:208-209,
         // 258-262): A->A and B->A take zone A's curve, A->B and B->B zone B's
         for (int z = 0; z < 2; ++z)
-            SCHK(h, apv_launch_perceptual_weights(K, M, s->nch, s->tspec[z], s->G2, s->G2T, s->Cs, s->Ca, s->Leff, N,
+            SCHK(h, apv_launch_perceptual_weights(f64, K, M, s->nch, s->tspec[z], s->G2, s->G2T, s->Cs, s->Ca, s->Leff, N,
                                                   s->norm_mode, s->Wgt[z], st));
         for (int p = 0; p < 4; ++p) {
             const bool need = (p < 2) ? runA : runB;
-            if (need) SCHK(h, apv_launch_scale_spectra(K, C, L, s->X[p], s->Wgt[path_zone(p)], st));
+            if (need) SCHK(h, apv_launch_scale_spectra(f64, K, C, L, s->X[p], s->Wgt[path_zone(p)], st));
         }
-        for (int z = 0; z < 2; ++z) SCHK(h, apv_launch_scale_spectra(K, M, 1, s->tspec[z], s->Wgt[z], st));
+        for (int z = 0; z < 2; ++z) SCHK(h, apv_launch_scale_spectra(f64, K, M, 1, s->tspec[z], s->Wgt[z], st));
     }
     // per-bin update per zone program: A: bright A->A, dark A->B, target A;  B: bright B->B, dark B->A, target B
     int oc = 0;     // output channel cursor
@@ -268,6 +205,7 @@ static int enqueue_hop(apv_handle* h) {
         // both zone programs go out in ONE launch (blockIdx.y = zone): K = N/2+1 bins alone cannot fill the chip
         GevdParams p = apv_base_params(h);
         const int first = runA ? 0 : 1;
+        p.x_c128 = f64;
         p.XB = first ? s->X[3] : s->X[0];
         p.XD = first ? s->X[2] : s->X[1];
         p.d = s->tspec[first];
@@ -284,42 +222,42 @@ static int enqueue_hop(apv_handle* h) {
     }
     {
         // K3: output spectra in one launch: each live zone's nV*L filtered channels, then the target paths A_t, B_t
-        const float2* jin[4];
+        const void* jin[4];
         const void* jw[4];
-        const float2* jt[4];
-        float2* jout[4];
+        const void* jt[4];
+        void* jout[4];
         int jf[4], jtg[4], nj = 0;
         for (int z = 0; z < 2; ++z) {
             if (!(z ? runB : runA)) continue;
-            jin[nj] = s->inspec + (size_t)z * K; jw[nj] = s->w[z]; jt[nj] = nullptr; jout[nj] = s->outspec + (size_t)oc * K;
+            jin[nj] = (const char*)s->inspec + (size_t)z * K * e2; jw[nj] = s->w[z]; jt[nj] = nullptr;
+            jout[nj] = (char*)s->outspec + (size_t)oc * K * e2;
             jf[nj] = s->nV * L; jtg[nj] = 0; ++nj;
             oc += s->nV * L;
         }
         for (int z = 0; z < 2; ++z) {
-            jin[nj] = s->inspec + (size_t)z * K; jw[nj] = nullptr; jt[nj] = s->tgt; jout[nj] = s->outspec + (size_t)oc * K;
+            jin[nj] = (const char*)s->inspec + (size_t)z * K * e2; jw[nj] = nullptr; jt[nj] = s->tgt;
+            jout[nj] = (char*)s->outspec + (size_t)oc * K * e2;
             jf[nj] = 0; jtg[nj] = L; ++nj;
             oc += L;
         }
-        SCHK(h, apv_launch_apply_jobs(K, nj, jin, jw, jt, jout, jf, jtg, h->cfg.out_c128, st));
+        SCHK(h, apv_launch_apply_jobs(K, nj, jin, jw, jt, jout, jf, jtg, h->cfg.out_c128, f64, st));
         const int zf = runA ? 0 : 1, zn = (runA && runB) ? 2 : 1;
         SCHK(h, hipMemcpyAsync(s->pin_status + (size_t)zf * K, s->status[zf], sizeof(int32_t) * K * zn, hipMemcpyDeviceToHost, st));
     }
     // K4: synthesis + overlap-add + emit
-    SCHK(h, apv_launch_istft_ola_strided(N, H, s->n_out, s->outspec, K, 1, s->outov, s->out, st, &why));
-    SCHK(h, hipMemcpyAsync(h_out, s->out, sizeof(float) * (size_t)s->n_out * H, hipMemcpyDeviceToHost, st));
+    {
+        hipError_t e = apv_launch_synthesis(f64, N, H, s->n_out, s->outspec, K, 1, s->outov, s->out, st, &why);
+        if (e != hipSuccess) return apv_fail(h, APV_ERR_HIP, why.empty() ? hipGetErrorString(e) : why);
+    }
+    SCHK(h, hipMemcpyAsync(s->pin_out, s->out, e1 * (size_t)s->n_out * H, hipMemcpyDeviceToHost, st));
     return APV_OK;
 }
 
-int apv_process_block(apv_handle* h, const float* h_in_A, const float* h_in_B, float* h_out) {
-    if (!h || !h_in_A || !h_in_B || !h_out) return apv_fail(h, APV_ERR_ARG, "null argument");
+// run one hop whose input is already in the pinned staging; the output is left in the pinned staging
+static int run_hop(apv_handle* h) {
     apv_stream* s = h->st;
-    if (!s) return apv_fail(h, APV_ERR_ARG, "apv_stream_init has not been called");
-    SCHK(h, hipSetDevice(h->device));
     hipStream_t st = h->stream;
-    const int H = s->H, K = s->K;
-    const bool runA = s->zones & 1, runB = s->zones & 2;
-    std::memcpy(s->pin_in, h_in_A, sizeof(float) * H);
-    std::memcpy(s->pin_in + H, h_in_B, sizeof(float) * H);
+    const int H = s->H;
     if (s->period > 0) {
         // replay the captured launch sequence of this phase; capture it the first time the phase comes up
         const int phase = (int)(s->hop % s->period);
@@ -333,7 +271,7 @@ int apv_process_block(apv_handle* h, const float* h_in_A, const float* h_in_B, f
                 if (graph) (void)hipGraphDestroy(graph);
                 s->ring_off = ring_before;
                 s->cur = cur_before;
-                s->period = 0;                       // fall back to eager launches for good
+                s->period = 0;                       // launch eagerly from now on
                 rc = enqueue_hop(h);
                 if (rc != APV_OK) return rc;
             } else {
@@ -353,7 +291,15 @@ int apv_process_block(apv_handle* h, const float* h_in_A, const float* h_in_B, f
     }
     s->hop++;
     SCHK(h, hipStreamSynchronize(st));
-    std::memcpy(h_out, s->pin_out, sizeof(float) * (size_t)s->n_out * H);
+    return APV_OK;
+}
+
+// scan the per-bin status words of the hop: 1 = not positive definite (error, apvast.py:21-24), 2 = sweep cap reached
+static int scan_hop_status(apv_handle* h) {
+    apv_stream* s = h->st;
+    const int K = s->K;
+    const bool runA = s->zones & 1, runB = s->zones & 2;
+    int slow_zone = -1, slow_bin = -1;
     for (int z = 0; z < 2; ++z) {
         if (!(z ? runB : runA)) continue;
         for (int k = 0; k < K; ++k) {
@@ -363,10 +309,166 @@ int apv_process_block(apv_handle* h, const float* h_in_A, const float* h_in_B, f
                 std::snprintf(buf, sizeof(buf), "Matrix is not positive definite (zone %c, bin %d)", z ? 'B' : 'A', k);
                 return apv_fail(h, APV_ERR_NOT_PD, buf);
             }
+            if (v == 2 && slow_zone < 0) { slow_zone = z; slow_bin = k; }
         }
+    }
+    if (slow_zone >= 0) {
+        s->not_converged++;
+        char buf[112];
+        std::snprintf(buf, sizeof(buf), "eigen-iteration did not converge (zone %c, bin %d); the outputs of this hop were written",
+                      slow_zone ? 'B' : 'A', slow_bin);
+        return apv_fail(h, APV_ERR_NO_CONVERGE, buf);
     }
     return APV_OK;
 }
+
+template <typename TI>
+static int process_block_t(apv_handle* h, const TI* h_in_A, const TI* h_in_B, TI* h_out) {
+    if (!h || !h_in_A || !h_in_B || !h_out) return apv_fail(h, APV_ERR_ARG, "null argument");
+    apv_stream* s = h->st;
+    if (!s) return apv_fail(h, APV_ERR_ARG, "apv_stream_init has not been called");
+    SCHK(h, hipSetDevice(h->device));
+    const int H = s->H;
+    const size_t nout = (size_t)s->n_out * H;
+    if (s->f64) {
+        double* pi = (double*)s->pin_in;
+        for (int i = 0; i < H; ++i) { pi[i] = (double)h_in_A[i]; pi[H + i] = (double)h_in_B[i]; }
+    } else {
+        float* pi = (float*)s->pin_in;
+        for (int i = 0; i < H; ++i) { pi[i] = (float)h_in_A[i]; pi[H + i] = (float)h_in_B[i]; }
+    }
+    int rc = run_hop(h);
+    if (rc != APV_OK) return rc;
+    if (s->f64) {
+        const double* po = (const double*)s->pin_out;
+        for (size_t i = 0; i < nout; ++i) h_out[i] = (TI)po[i];
+    } else {
+        const float* po = (const float*)s->pin_out;
+        for (size_t i = 0; i < nout; ++i) h_out[i] = (TI)po[i];
+    }
+    return scan_hop_status(h);
+}
+
+extern "C" {
+
+int apv_stream_init(apv_handle* h, int32_t rir_len, const double* h_rir_A, const double* h_rir_B,
+                    int32_t reference_index_A, int32_t reference_index_B, int32_t modeling_delay) {
+    if (!h || !h_rir_A || !h_rir_B) return apv_fail(h, APV_ERR_ARG, "null argument");
+    const apv_config& c = h->cfg;
+    const int N = c.block_size, H = c.hop_size;
+    {
+        std::string why;
+        if (!apv_stft_size_ok(N, &why)) return apv_fail(h, APV_ERR_ARG, why);
+    }
+    if (c.frontend < 0 || c.frontend > 2) return apv_fail(h, APV_ERR_ARG, "cfg.frontend must be 0 (follow compute_dtype), 1 (float32) or 2 (float64)");
+    const int f64 = frontend_f64(c);
+    if (f64 && N > 4096) return apv_fail(h, APV_ERR_ARG, "float64 front-end: block_size <= 4096 (double-precision FFT in LDS)");
+    if (H < 1 || H > N) return apv_fail(h, APV_ERR_ARG, "hop_size must be in 1..block_size");
+    if (c.n_bins != N / 2 + 1) return apv_fail(h, APV_ERR_ARG, "streaming handle needs n_bins == block_size/2 + 1");
+    if (rir_len < 1 || modeling_delay < 0 || modeling_delay >= rir_len) return apv_fail(h, APV_ERR_ARG, "rir_len / modeling_delay out of range");
+    if (reference_index_A < 0 || reference_index_A >= c.n_srcs || reference_index_B < 0 || reference_index_B >= c.n_srcs)
+        return apv_fail(h, APV_ERR_ARG, "reference index out of range");
+    if (c.n_zones < 1 || c.n_zones > 3) return apv_fail(h, APV_ERR_ARG, "n_zones is a bit mask: 1 = A, 2 = B, 3 = both");
+    SCHK(h, hipSetDevice(h->device));
+    apv_stream_free(h);
+    apv_stream* s = new apv_stream();
+    std::memset(static_cast<void*>(s), 0, offsetof(apv_stream, execs));
+    h->st = s;
+    s->N = N; s->H = H; s->K = N / 2 + 1; s->L = c.n_srcs; s->M = c.n_mics; s->C = s->L * s->M;
+    s->P = rir_len; s->nV = c.n_ranks; s->zones = c.n_zones; s->pad = apv_fir_pad();
+    s->f64 = f64; s->esz = f64 ? 8 : 4;
+    s->ring_off = 0; s->cur = 0;
+    const int nz = ((s->zones & 1) ? 1 : 0) + ((s->zones & 2) ? 1 : 0);
+    s->n_out = nz * s->nV * s->L + 2 * s->L;
+    const int L = s->L, M = s->M, C = s->C, P = s->P, K = s->K;
+    const size_t e1 = s->esz, e2 = 2 * s->esz;
+    int rc;
+    // RIRs: host (P, L, M) float64 C-order -> device [P][m*L + l] in the front-end precision
+    std::vector<double> tmp((size_t)P * C), ttmp((size_t)P * M);
+    for (int z = 0; z < 2; ++z) {
+        const double* src = z ? h_rir_B : h_rir_A;
+        const int ref = z ? reference_index_B : reference_index_A;
+        for (int p = 0; p < P; ++p)
+            for (int l = 0; l < L; ++l)
+                for (int m = 0; m < M; ++m) tmp[(size_t)p * C + m * L + l] = src[((size_t)p * L + l) * M + m];
+        // target RIR: reference loudspeaker delayed by modeling_delay (apvast.py:102-112)
+        std::fill(ttmp.begin(), ttmp.end(), 0.0);
+        for (int p = modeling_delay; p < P; ++p)
+            for (int m = 0; m < M; ++m) ttmp[(size_t)p * M + m] = src[((size_t)(p - modeling_delay) * L + ref) * M + m];
+        if ((rc = dalloc(h, &s->rir[z], (size_t)P * C, e1))) return rc;
+        if ((rc = dalloc(h, &s->trir[z], (size_t)P * M, e1))) return rc;
+        if ((rc = upload(h, f64, s->rir[z], tmp))) return rc;
+        if ((rc = upload(h, f64, s->trir[z], ttmp))) return rc;
+    }
+    const size_t hist = (size_t)P - 1 + H + s->pad;
+    for (int b = 0; b < 2; ++b)
+        for (int g = 0; g < 2; ++g)
+            if ((rc = dalloc(h, &s->xhist[b][g], hist, e1))) return rc;
+    if ((rc = dalloc(h, &s->xin, (size_t)2 * H, e1))) return rc;
+    for (int p = 0; p < 4; ++p) {
+        if ((rc = dalloc(h, &s->resp[p], (size_t)C * N, e1))) return rc;
+        if ((rc = dalloc(h, &s->X[p], (size_t)K * C, e2))) return rc;
+    }
+    for (int z = 0; z < 2; ++z) {
+        if ((rc = dalloc(h, &s->tresp[z], (size_t)M * N, e1))) return rc;
+        if ((rc = dalloc(h, &s->tspec[z], (size_t)K * M, e2))) return rc;
+        if ((rc = dalloc(h, &s->w[z], (size_t)K * s->nV * L, wsz(h)))) return rc;
+        if ((rc = dalloc(h, &s->lam[z], (size_t)K * L, lsz(h)))) return rc;
+    }
+    if ((rc = dalloc(h, &s->status[0], (size_t)2 * K))) return rc;       // [zone A | zone B]: one copy back per hop
+    s->status[1] = s->status[0] + K;
+    if ((rc = dalloc(h, &s->inblk, (size_t)2 * N, e1))) return rc;
+    if ((rc = dalloc(h, &s->inspec, (size_t)2 * K, e2))) return rc;
+    if ((rc = dalloc(h, &s->tgt, (size_t)L * K, e2))) return rc;
+    if ((rc = dalloc(h, &s->outspec, (size_t)s->n_out * K, e2))) return rc;
+    if ((rc = dalloc(h, &s->outov, (size_t)s->n_out * N, e1))) return rc;
+    if ((rc = dalloc(h, &s->out, (size_t)s->n_out * H, e1))) return rc;
+    // target filter spectra: rfft of a unit impulse at tap modeling_delay of the A reference loudspeaker
+    // (apvast.py:389-390, 418, 422: the same filter serves A_t and B_t)
+    std::vector<double> tg((size_t)L * K * 2, 0.0);
+    const double PI = 3.14159265358979323846;
+    for (int k = 0; k < K; ++k) {
+        // exact at the multiples of a quarter turn, like an FFT of the unit impulse
+        const long q = ((long)k * modeling_delay) % N;
+        double cr = std::cos(-2.0 * PI * (double)q / (double)N), ci = std::sin(-2.0 * PI * (double)q / (double)N);
+        if ((4 * q) % N == 0) {
+            const int quarter = (int)((4 * q) / N);
+            cr = quarter == 0 ? 1.0 : quarter == 2 ? -1.0 : 0.0;
+            ci = quarter == 1 ? -1.0 : quarter == 3 ? 1.0 : 0.0;
+        }
+        tg[((size_t)reference_index_A * K + k) * 2] = cr;
+        tg[((size_t)reference_index_A * K + k) * 2 + 1] = ci;
+    }
+    if ((rc = upload(h, f64, s->tgt, tg))) return rc;
+    s->h_status.assign((size_t)2 * K, 0);
+    SCHK(h, hipHostMalloc((void**)&s->pin_in, e1 * 2 * H, hipHostMallocDefault));
+    SCHK(h, hipHostMalloc((void**)&s->pin_out, e1 * (size_t)s->n_out * H, hipHostMallocDefault));
+    SCHK(h, hipHostMalloc((void**)&s->pin_status, sizeof(int32_t) * 2 * K, hipHostMallocDefault));
+    std::memset(s->pin_status, 0, sizeof(int32_t) * 2 * K);
+    // the launch sequence of a hop depends on (ring_off, cur) only: ring_off has period N / gcd(N, H), cur period 2
+    {
+        int a = N, b = H;
+        while (b) { const int t = a % b; a = b; b = t; }
+        int per = N / a;
+        if (per % 2) per *= 2;
+        s->period = (per <= 16 && getenv("APV_NO_GRAPH") == nullptr) ? per : 0;
+        s->execs.assign(s->period > 0 ? s->period : 0, nullptr);
+    }
+    s->hop = 0;
+    SCHK(h, apv_stft_prepare(N, f64));
+    SCHK(h, hipStreamSynchronize(h->stream));
+    return APV_OK;
+}
+
+int apv_process_block(apv_handle* h, const float* h_in_A, const float* h_in_B, float* h_out) {
+    return process_block_t<float>(h, h_in_A, h_in_B, h_out);
+}
+
+int apv_process_block_f64(apv_handle* h, const double* h_in_A, const double* h_in_B, double* h_out) {
+    return process_block_t<double>(h, h_in_A, h_in_B, h_out);
+}
+
+int apv_stream_is_f64(apv_handle* h) { return (h && h->st) ? h->st->f64 : -1; }
 
 // Enable (n_channels > 0) or disable (0) the perceptual weighting.  h_G2 [K][n_channels]: squared
 // outer/middle-ear x gammatone responses (perceptualModel.m:52-54); Cs, Ca, Leff: perceptualModel.m:57, 114-115;
@@ -399,36 +501,38 @@ int apv_stream_set_perceptual(apv_handle* h, int32_t n_channels, const double* h
         for (int i = 0; i < n_channels; ++i) gt[(size_t)i * K + k] = h_G2[(size_t)k * n_channels + i];
     SCHK(h, hipMalloc((void**)&s->G2, sizeof(double) * (size_t)K * n_channels));
     SCHK(h, hipMalloc((void**)&s->G2T, sizeof(double) * (size_t)K * n_channels));
-    for (int z = 0; z < 2; ++z) SCHK(h, hipMalloc((void**)&s->Wgt[z], sizeof(float) * (size_t)K * s->M));
+    for (int z = 0; z < 2; ++z) SCHK(h, hipMalloc((void**)&s->Wgt[z], s->esz * (size_t)K * s->M));
     SCHK(h, hipMemcpy(s->G2, h_G2, sizeof(double) * (size_t)K * n_channels, hipMemcpyHostToDevice));
     SCHK(h, hipMemcpy(s->G2T, gt.data(), sizeof(double) * gt.size(), hipMemcpyHostToDevice));
     s->nch = n_channels; s->Cs = Cs; s->Ca = Ca; s->Leff = Leff; s->norm_mode = normalisation;
     return APV_OK;
 }
 
-// Named state arrays (host float32/complex as stored on the device; rings are returned in LOGICAL order):
-//   "response"        [4][C][N] f32    "target_response" [2][M][N] f32    "input_block" [2][N] f32
-//   "input_history"   [2][P-1]  f32    "out_overlap"     [n_out][N] f32
-//   "spectra"         [4][K][C] c64    "target_spectra"  [2][K][M] c64    "input_spectrum" [2][K] c64
-//   "w_A" / "w_B"     [K][nV][L] c64|c128        "lambda_A" / "lambda_B" [K][L] f32|f64
+// Named state arrays, as stored on the device: real samples are float32 (float64 with the float64 front-end),
+// spectra the matching complex type; rings are returned in LOGICAL order:
+//   "response<p>"     [C][N]           "target_response<z>" [M][N]       "input_block" [2][N]
+//   "input_history<g>" [P-1+H]         "out_overlap"        [n_out][N]
+//   "spectra<p>"      [K][C] complex   "target_spectra<z>"  [K][M] complex   "input_spectrum" [2][K] complex
+//   "weights<z>"      [K][M]
+//   "w_A" / "w_B"     [K][nV][L] c64|c128        "lambda_A" / "lambda_B" [K][L] f32|f64   (cfg.out_c128)
 static int state_lookup(apv_handle* h, const char* name, void** dptr, size_t* bytes, int* ring_rows) {
     apv_stream* s = h->st;
     *ring_rows = 0;
     const std::string n(name);
-    const size_t N = s->N, K = s->K, C = s->C, M = s->M, L = s->L;
+    const size_t N = s->N, K = s->K, C = s->C, M = s->M, L = s->L, e1 = s->esz, e2 = 2 * s->esz;
     if (n.rfind("response", 0) == 0 && n.size() == 9 && n[8] >= '0' && n[8] <= '3') {
-        *dptr = s->resp[n[8] - '0']; *bytes = C * N * 4; *ring_rows = (int)C; return APV_OK; }
+        *dptr = s->resp[n[8] - '0']; *bytes = C * N * e1; *ring_rows = (int)C; return APV_OK; }
     if (n == "target_response0" || n == "target_response1") {
-        *dptr = s->tresp[n.back() - '0']; *bytes = M * N * 4; *ring_rows = (int)M; return APV_OK; }
-    if (n == "input_block") { *dptr = s->inblk; *bytes = 2 * N * 4; *ring_rows = 2; return APV_OK; }
+        *dptr = s->tresp[n.back() - '0']; *bytes = M * N * e1; *ring_rows = (int)M; return APV_OK; }
+    if (n == "input_block") { *dptr = s->inblk; *bytes = 2 * N * e1; *ring_rows = 2; return APV_OK; }
     if (n == "input_history0" || n == "input_history1") {
-        *dptr = s->xhist[s->cur][n.back() - '0']; *bytes = (size_t)(s->P - 1 + s->H) * 4; return APV_OK; }
-    if (n == "out_overlap") { *dptr = s->outov; *bytes = (size_t)s->n_out * N * 4; return APV_OK; }
+        *dptr = s->xhist[s->cur][n.back() - '0']; *bytes = (size_t)(s->P - 1 + s->H) * e1; return APV_OK; }
+    if (n == "out_overlap") { *dptr = s->outov; *bytes = (size_t)s->n_out * N * e1; return APV_OK; }
     if (n.rfind("spectra", 0) == 0 && n.size() == 8 && n[7] >= '0' && n[7] <= '3') {
-        *dptr = s->X[n[7] - '0']; *bytes = K * C * 8; return APV_OK; }
-    if (n == "target_spectra0" || n == "target_spectra1") { *dptr = s->tspec[n.back() - '0']; *bytes = K * M * 8; return APV_OK; }
-    if (n == "input_spectrum") { *dptr = s->inspec; *bytes = 2 * K * 8; return APV_OK; }
-    if ((n == "weights0" || n == "weights1") && s->nch > 0) { *dptr = s->Wgt[n.back() - '0']; *bytes = K * M * 4; return APV_OK; }
+        *dptr = s->X[n[7] - '0']; *bytes = K * C * e2; return APV_OK; }
+    if (n == "target_spectra0" || n == "target_spectra1") { *dptr = s->tspec[n.back() - '0']; *bytes = K * M * e2; return APV_OK; }
+    if (n == "input_spectrum") { *dptr = s->inspec; *bytes = 2 * K * e2; return APV_OK; }
+    if ((n == "weights0" || n == "weights1") && s->nch > 0) { *dptr = s->Wgt[n.back() - '0']; *bytes = K * M * e1; return APV_OK; }
     if (n == "w_A" || n == "w_B") { *dptr = s->w[n == "w_B"]; *bytes = K * s->nV * L * wsz(h); return APV_OK; }
     if (n == "lambda_A" || n == "lambda_B") { *dptr = s->lam[n == "lambda_B"]; *bytes = K * L * lsz(h); return APV_OK; }
     return apv_fail(h, APV_ERR_STATE, std::string("unknown state name: ") + name);
@@ -453,12 +557,15 @@ int apv_get_state(apv_handle* h, const char* name, void* h_dst, size_t bytes) {
         return APV_OK;
     }
     // ring: rotate rows into logical order
-    const int N = h->st->N, off = h->st->ring_off;
-    std::vector<float> tmp((size_t)rr * N);
+    const size_t N = h->st->N, off = h->st->ring_off, e1 = h->st->esz;
+    std::vector<char> tmp(need);
     SCHK(h, hipMemcpy(tmp.data(), d, need, hipMemcpyDeviceToHost));
-    float* out = (float*)h_dst;
-    for (int r = 0; r < rr; ++r)
-        for (int n = 0; n < N; ++n) out[(size_t)r * N + n] = tmp[(size_t)r * N + ((n + off) % N)];
+    char* out = (char*)h_dst;
+    for (int r = 0; r < rr; ++r) {
+        // logical [0, N - off) = physical [off, N); logical [N - off, N) = physical [0, off)
+        std::memcpy(out + ((size_t)r * N) * e1, tmp.data() + ((size_t)r * N + off) * e1, (N - off) * e1);
+        std::memcpy(out + ((size_t)r * N + (N - off)) * e1, tmp.data() + ((size_t)r * N) * e1, off * e1);
+    }
     return APV_OK;
 }
 
@@ -474,11 +581,13 @@ int apv_set_state(apv_handle* h, const char* name, const void* h_src, size_t byt
         SCHK(h, hipMemcpy(d, h_src, need, hipMemcpyHostToDevice));
         return APV_OK;
     }
-    const int N = h->st->N, off = h->st->ring_off;
-    std::vector<float> tmp((size_t)rr * N);
-    const float* in = (const float*)h_src;
-    for (int r = 0; r < rr; ++r)
-        for (int n = 0; n < N; ++n) tmp[(size_t)r * N + ((n + off) % N)] = in[(size_t)r * N + n];
+    const size_t N = h->st->N, off = h->st->ring_off, e1 = h->st->esz;
+    std::vector<char> tmp(need);
+    const char* in = (const char*)h_src;
+    for (int r = 0; r < rr; ++r) {
+        std::memcpy(tmp.data() + ((size_t)r * N + off) * e1, in + ((size_t)r * N) * e1, (N - off) * e1);
+        std::memcpy(tmp.data() + ((size_t)r * N) * e1, in + ((size_t)r * N + (N - off)) * e1, off * e1);
+    }
     SCHK(h, hipMemcpy(d, tmp.data(), need, hipMemcpyHostToDevice));
     return APV_OK;
 }

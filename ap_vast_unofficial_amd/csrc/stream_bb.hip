@@ -75,66 +75,7 @@ int dalloc(apv_handle* h, double** p, size_t count) {
     return APV_OK;
 }
 
-constexpr int TN = 16;          // zero tail of the input history (a sample tile may read that far)
-
 using d4 = __attribute__((ext_vector_type(4))) double;
-
-// RIR convolution of one hop as an implicit-Toeplitz product on v_mfma_f64_16x16x4_f64:
-//   y[n][c] = sum_p xh[P-1+n-p] rir[p][c]                                           apvast.py:171-192 (lfilter)
-// A workgroup owns 16 samples x 16 channels; its four waves split the taps, each streaming its share of the RIR
-// slab straight into MFMA B operands while the A operands are windows of the input history held in LDS; the four
-// partial tiles are summed through LDS.  All paths and targets of the hop are one launch (job table).
-constexpr int FIR_JOBS = 6;
-struct FirJobsD {
-    const double* rir[FIR_JOBS];     // [P][C_j]
-    const double* xh[FIR_JOBS];      // input history of the job's signal
-    double* resp[FIR_JOBS];          // [C_j][N] ring
-    int C[FIR_JOBS];
-    int tile0[FIR_JOBS + 1];         // first channel tile of each job
-};
-
-__global__ void __launch_bounds__(256) fir_f64_mfma_kernel(int P, int H, int N, int ring_off, int njobs, FirJobsD jobs) {
-    extern __shared__ double fir_lds[];          // [P + 15] history window, then [4][256] partial tiles
-    int j = 0;
-    while (j + 1 < njobs && (int)blockIdx.y >= jobs.tile0[j + 1]) ++j;
-    const int C = jobs.C[j];
-    const double* __restrict__ rir = jobs.rir[j];
-    const double* __restrict__ xh = jobs.xh[j];
-    const int c0 = ((int)blockIdx.y - jobs.tile0[j]) * 16, n0 = blockIdx.x * 16;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, il = lane & 15, kq = lane >> 4;
-    double* xw = fir_lds;
-    double* part = fir_lds + ((P + 15 + 1) & ~1);
-    for (int i = tid; i < P + 15; i += 256) xw[i] = xh[n0 + i];
-    const int steps_total = (P + 3) >> 2, spw = (steps_total + 3) >> 2;
-    const int s_begin = wave * spw, s_end = min(s_begin + spw, steps_total);
-    const int c = c0 + il;
-    const bool c_ok = c < C;
-    __syncthreads();
-    d4 acc = {0, 0, 0, 0};
-    for (int s0 = s_begin; s0 < s_end; s0 += 32) {
-        double bv[32];
-#pragma unroll
-        for (int q = 0; q < 32; ++q) {
-            const int pt = 4 * (s0 + q) + kq;
-            bv[q] = (s0 + q < s_end && pt < P && c_ok) ? rir[(size_t)pt * C + c] : 0.0;
-        }
-#pragma unroll
-        for (int q = 0; q < 32; ++q) {
-            const int pt = 4 * (s0 + q) + kq;
-            const int wi = P - 1 + il - pt;
-            const double av = xw[wi > 0 ? wi : 0];       // taps past P carry a zero B operand
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[q], acc, 0, 0, 0);
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) part[wave * 256 + t * 64 + lane] = acc[t];
-    __syncthreads();
-    // element e = t * 64 + lane: sample n0 + (lane >> 4) + 4 t, channel c0 + (lane & 15)
-    const double v = part[tid] + part[256 + tid] + part[512 + tid] + part[768 + tid];
-    const int t = tid >> 6;
-    const int n = n0 + kq + 4 * t;
-    if (n < H && c_ok) jobs.resp[j][(size_t)c * N + (N - H + n + ring_off) % N] = v;
-}
 
 // new_hist = [old_hist[H:], x, zeros(pad)]: the last P-1 inputs, this hop, and the zero tail
 __global__ void __launch_bounds__(256) hist_f64_kernel(int P, int H, int pad, const double* __restrict__ old_hist,
@@ -541,7 +482,7 @@ int apv_bb_init(apv_handle* h, int32_t rir_len, const double* h_rir_A, const dou
     h->bb = s;
     const int nsol = (int)ranks.size();
     s->N = N; s->H = H; s->K = N / 2 + 1; s->L = L; s->M = M; s->C = L * M; s->P = rir_len; s->J = J; s->S = S; s->V = nsol;
-    s->n = n; s->zones = c.n_zones; s->pad = TN;
+    s->n = n; s->zones = c.n_zones; s->pad = apv_fir_pad_f64();
     s->dialect = dialect;
     s->skip = dialect == APV_DIALECT_PYTHON;                 // scipy's toeplitz drops sample J (apvast.py:336-338)
     s->ncols = S - J + (s->skip ? 0 : 1);                    // apvast.py:334 / apVast.m:420
@@ -652,20 +593,16 @@ int apv_bb_process_block(apv_handle* h, const double* h_in_A, const double* h_in
     // 1: RIR convolution
     {
         FirJobsD jobs{};
-        int nj = 0, tiles = 0;
+        int nj = 0;
         for (int p = 0; p < 4; ++p) {
             jobs.rir[nj] = s->rir[path_zone(p)]; jobs.xh[nj] = s->xhist[s->cur][path_sig(p)]; jobs.resp[nj] = s->resp[p];
-            jobs.C[nj] = C; jobs.tile0[nj++] = tiles;
-            tiles += (C + 15) / 16;
+            jobs.C[nj++] = C;
         }
         for (int z = 0; z < 2; ++z) {
             jobs.rir[nj] = s->trir[z]; jobs.xh[nj] = s->xhist[s->cur][z]; jobs.resp[nj] = s->tresp[z];
-            jobs.C[nj] = M; jobs.tile0[nj++] = tiles;
-            tiles += (M + 15) / 16;
+            jobs.C[nj++] = M;
         }
-        jobs.tile0[nj] = tiles;
-        const size_t lds = sizeof(double) * (((size_t)P + 16) + 4 * 256);
-        hipLaunchKernelGGL(fir_f64_mfma_kernel, dim3((H + 15) / 16, tiles), dim3(256), lds, st, P, H, N, s->ring_off, nj, jobs);
+        BCHK(h, apv_launch_fir_jobs_f64(jobs, nj, P, H, N, s->ring_off, st));
     }
     stage_done();
     // 2: WOLA (unit weights, apvast.py:326-327, or the perceptual curves) and append the finished hop to the statistics rings

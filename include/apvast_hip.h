@@ -89,7 +89,10 @@ typedef struct apv_config {
     int32_t n_zones;          /* streaming: bit mask of zone programs, 1 = A, 2 = B (run_A/run_B, apvast.py:53-54) */
     int32_t debug_stop;       /* profiling aid: stop the fused kernel after stage n (0 = run everything) */
     int32_t dialect;          /* APV_DIALECT_PYTHON | APV_DIALECT_MATLAB: the broadband stream's statistics/loading/rank conventions */
-    int32_t reserved[6];
+    int32_t frontend;         /* streaming (subband) front-end precision -- RIRs, FIR, rings, STFT, spectra, overlap-add:
+                                 0 = follow compute_dtype (APV_F64: everything float64, as the reference's lfilter / rfft /
+                                 irfft are, apvast.py:171-192, 202-203, 461-496), 1 = float32, 2 = float64 */
+    int32_t reserved[5];
 } apv_config;
 
 /* ---- lifetime ---------------------------------------------------------- */
@@ -172,13 +175,20 @@ int  apv_stream_init(apv_handle* h, int32_t rir_len, const double* h_rir_A, cons
  * [zone A: nV x L][zone B: nV x L] (zones that run) followed by [A_t: L][B_t: L].
  *                                                         replaces process_input_buffers, apvast.py:153-165 */
 int  apv_process_block(apv_handle* h, const float* h_in_A, const float* h_in_B, float* h_out);
+/* The same with float64 samples on the host side (lossless with the float64 front-end; either entry point works
+ * with either front-end, converting on the host).  A hop in which some bin reached the Jacobi sweep cap returns
+ * APV_ERR_NO_CONVERGE after h_out has been written.      replaces process_input_buffers, apvast.py:153-165 */
+int  apv_process_block_f64(apv_handle* h, const double* h_in_A, const double* h_in_B, double* h_out);
+/* 1 if the stream's front-end (and therefore its named state arrays) is float64, 0 if float32, -1 without a stream */
+int  apv_stream_is_f64(apv_handle* h);
 /* Perceptual ("AP") weighting of the control-point and target spectra, evaluated per block on the device from the
  * target spectra (van de Par 2005 model as carried by the reference's MATLAB twin).  h_G2 [K][n_channels] float64
  * = squared outer/middle-ear x gammatone responses; n_channels = 0 switches it off (all-ones, apvast.py:326-327).
  *                         replaces update_perceptual_weighting, apvast.py:313-324 / apVast.m:386-408 */
 int  apv_stream_set_perceptual(apv_handle* h, int32_t n_channels, const double* h_G2, double Cs, double Ca,
                                double Leff, int32_t normalisation);
-/* Named state arrays for fixtures / checkpoint-resume (names: see stream.hip).   apvast.py:115-151 */
+/* Named state arrays for fixtures / checkpoint-resume (names: see stream.hip), in the front-end precision:
+ * float32 / complex64, or float64 / complex128 with the float64 front-end.          apvast.py:115-151 */
 int  apv_state_bytes(apv_handle* h, const char* name, size_t* bytes);
 int  apv_get_state(apv_handle* h, const char* name, void* h_dst, size_t bytes);
 int  apv_set_state(apv_handle* h, const char* name, const void* h_src, size_t bytes);
@@ -230,6 +240,13 @@ int  apv_comm_init(apv_handle* h, const char id[128], int32_t rank, int32_t worl
  * next apv_update_dev (into a different shard buffer) overlaps it; an update into the SAME shard buffer waits
  * for the gather.  apv_sync() waits for both streams. */
 int  apv_allgather_filters_dev(apv_handle* h, const void* d_w_shard, void* d_w_all);
+/* device time of the latest all-gather (HIP events on the communication stream) and the bytes this rank sent */
+int  apv_comm_last_gather(apv_handle* h, float* elapsed_ms, size_t* bytes_per_rank);
+/* all ranks of the communicator meet here (one-word ncclAllReduce); also drains the handle's compute stream */
+int  apv_comm_barrier(apv_handle* h);
+/* hipDeviceSynchronize on the handle's device, and what that device is */
+int  apv_device_sync(apv_handle* h);
+int  apv_device_info(apv_handle* h, char name_out[128], int32_t* n_cus, int32_t* clock_mhz);
 
 #ifdef __cplusplus
 }

@@ -156,3 +156,43 @@ def test_two_rank_gloo_reassembly(tmp_path, K):
         got = np.load(tmp_path / f"w_{r}.npy")
         assert got.shape == (K, 2, L)
         assert np.abs(got - w_ref.astype(np.complex64)).max() == 0.0
+
+
+def _rz_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    from ap_vast_unofficial_amd.rendezvous import Rendezvous
+    rz = Rendezvous(rank, world, "127.0.0.1", port, timeout=30.0)
+    uid = rz.broadcast(bytes(range(128)) if rank == 0 else None)        # the shape of the RCCL id exchange
+    rz.barrier()
+    worst = rz.allreduce(1.0 + rank, max)
+    gathered = rz.gather(("rank", rank))
+    rz.close()
+    q.put((rank, uid, worst, gathered))
+
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_rendezvous_without_torch(world):
+    """bench.py's multi-GPU bootstrap (no MPI, no PyTorch): id broadcast, barrier and max over a TCP hub."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rz_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=60) for _ in range(world))
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    for rank, uid, worst, gathered in res:
+        assert uid == bytes(range(128)) and worst == float(world)
+        assert gathered == ([("rank", r) for r in range(world)] if rank == 0 else None)
+
+
+def test_bench_and_package_do_not_import_torch():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "import torch" not in src
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r); import ap_vast_unofficial_amd, ap_vast_unofficial_amd.rendezvous, "
+            "ap_vast_unofficial_amd.sharding; assert 'torch' not in sys.modules" % ROOT)
+    assert subprocess.run([sys.executable, "-c", code]).returncode == 0

@@ -1,7 +1,12 @@
 """GPU parity: the HIP path (through the C ABI) against the CPU oracle and the golden
 fixtures captured from the reference.  Run on the MI355X box with `-m gpu`."""
+import os
+import sys
+
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -368,3 +373,19 @@ def test_input_scale_robustness(Engine, scale):
     assert not status.any()
     assert np.abs(lam / lam_ref - 1).max() < 1e-9
     assert w_err(w, w_ref) < 1e-7
+
+
+def test_bench_distributed_rehearsal_without_torch():
+    """The whole multi-rank code path of bench.py (TCP rendezvous, RCCL communicator, cfg4 shard, all-gather on the side
+    stream, RCCL barrier) at world size 1, in a fresh interpreter that must never import torch."""
+    import json
+    import subprocess
+    code = ("import sys, runpy; sys.argv = ['bench.py', '--steps', '4', '--warmup', '2', '--prespin', '0.05', '--no-cpu-baseline'];"
+            "runpy.run_path(%r, run_name='__main__'); assert 'torch' not in sys.modules" % os.path.join(ROOT, "bench.py"))
+    env = dict(os.environ, APV_BENCH_FORCE_DIST="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29655")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["config"]["workload"].startswith("cfg4") and line["collective_us"] > 0
+    assert line["collective_bytes_per_rank"] == 32768 * 16 * 8 and line["value"] > 1e6
