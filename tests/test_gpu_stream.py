@@ -14,13 +14,17 @@ def synth_rirs(P, L, M, seed):
 
 
 # Tolerances of the streaming subband composition against the float64 oracle, which always receives the UNROUNDED
-# impulse responses, start buffers and inputs.  "f64": every stage in float64 like the reference (w <= 1e-7 |w|,
-# outputs <= 1e-9..1e-7 max|y|).  "mixed" / "f32": the float32 FIR + FFT front-end feeds an ill-conditioned solve, so its
-# rounding (1e-7 relative on the spectra) is amplified by cond(R_D) in the filters.
+# impulse responses, start buffers and inputs.  Errors are relative to the largest reference value of the run (outputs),
+# of the tensor (spectra), to |w| per bin and rank (filters) and to the bin's largest eigenvalue.
+#   "f64": every stage in float64 like the reference (lambda 1e-9, w 1e-7 |w|, outputs 1e-9 max|y|).
+#          Measured at cfg3's shape (tools/probes/stream_err_probe.py): spectra 4e-16, w 3e-9 (median 1e-12),
+#          lambda 1e-11, outputs 1e-10, target path 4e-12.
+#   "mixed" / "f32": float32 FIR + FFT front-end (1e-7 on the spectra), amplified by cond(R_D) in the filters.
+#          Measured: spectra 2e-7, w 1.2e-3 (median 5e-6), lambda 3e-5, outputs 3e-6.
 TOL = {
-    "f64": dict(spec=1e-12, w_med=1e-10, w_max=1e-7, out=1e-7, tgt=1e-12),
-    "mixed": dict(spec=5e-6, w_med=1e-4, w_max=2e-2, out=5e-3, tgt=5e-5),
-    "f32": dict(spec=5e-6, w_med=2e-4, w_max=5e-2, out=1e-2, tgt=5e-5),
+    "f64": dict(spec=1e-13, w_med=1e-10, w_max=1e-7, lam=1e-9, out=1e-9, tgt=1e-11),
+    "mixed": dict(spec=1e-6, w_med=5e-5, w_max=1e-2, lam=3e-4, out=5e-5, tgt=1e-5),
+    "f32": dict(spec=1e-6, w_med=5e-5, w_max=1e-2, lam=3e-4, out=5e-5, tgt=1e-5),
 }
 
 
@@ -48,16 +52,17 @@ def run_pair(block, hop, rirA, rirB, delay, refA, refB, V, mu, hops, run_A=True,
 
 
 def check_outputs(got, exp, tol, tol_target=None):
-    for h, (g, e) in enumerate(zip(got, exp)):
-        for q in range(4):
-            if e[q] is None:
-                assert g[q] is None
-                continue
+    """every hop's outputs against the oracle's, relative to the largest reference sample of the run"""
+    for q in range(4):
+        if exp[0][q] is None:
+            assert all(g[q] is None for g in got)
+            continue
+        scale = max(max(np.abs(e[q]).max() for e in exp), 1e-30)
+        t = tol if (q < 2 or tol_target is None) else tol_target
+        for h, (g, e) in enumerate(zip(got, exp)):
             ref = e[q] if q < 2 else np.broadcast_to(e[q], (len(g[q]),) + e[q].shape)
-            arr = np.stack(g[q])
-            scale = max(np.abs(ref).max(), 1e-30)
-            t = tol if (q < 2 or tol_target is None) else tol_target
-            assert np.abs(arr - ref).max() <= t * scale, (h, q, np.abs(arr - ref).max() / scale)
+            err = np.abs(np.stack(g[q]) - ref).max()
+            assert err <= t * scale, (h, q, err / scale)
 
 
 def check_last_hop_state(ap, orc, tol, K, L, M, zones=(0, 1)):
@@ -77,7 +82,7 @@ def check_last_hop_state(ap, orc, tol, K, L, M, zones=(0, 1)):
         lam, lr = getattr(ap, "lambda_" + name), orc.lam[z]
         V = w.shape[0]
         lerr = np.abs(lam[:, :V] - lr[:, :V]).max(axis=1) / lr[:, 0]
-        assert lerr.max() < max(tol["w_max"] * 1e-2, 1e-9), (name, lerr.max())
+        assert lerr.max() < tol["lam"], (name, lerr.max())
 
 
 @pytest.mark.parametrize("dtype", ["f64", "mixed", "f32"])
@@ -171,7 +176,7 @@ def test_stream_single_zone_and_errors(golden):
     # cfg1 is square (8 loudspeakers x 8 control points): the loaded dark matrix R_D + 1e-7 I is ill-conditioned, so the
     # float64 bounds are scaled by its condition number per bin, the rule of test_gpu_parity.py (kappa / 100 x the
     # well-conditioned bounds: lambda 1e-9 relative to the largest, w 1e-7 |w|); the target path does not depend on it
-    check_outputs([(None, None, g_[2], g_[3]) for g_ in got], [(None, None, e[2], e[3]) for e in exp], 1e-12)
+    check_outputs([(None, None, g_[2], g_[3]) for g_ in got], [(None, None, e[2], e[3]) for e in exp], TOL["f64"]["tgt"])
     XD = orc.spectra[1].transpose(0, 2, 1)
     RD = np.einsum("kmi,kmj->kij", XD.conj(), XD) + 1e-7 * np.eye(8)
     amp = np.maximum(1.0, np.linalg.cond(RD) / 1e2)
@@ -251,7 +256,7 @@ def test_stream_perceptual_weighting(dialect):
             W = ap._eng.get_state(f"weights{z}", (N // 2 + 1, M), np.float64)
             assert np.abs(W - orc.weights[z]).max() < 1e-9 * np.abs(orc.weights[z]).max(), (h, z)
         if dialect == "python":
-            check_outputs([got], [exp], 1e-6, 1e-12)
+            check_outputs([got], [exp], 1e-6, 1e-9)
     assert abs(np.linalg.norm(W[:, 0]) - (1.0 if dialect == "python" else np.linalg.norm(W[:, 0]))) < 1e-5
     ap.close()
 
