@@ -27,7 +27,7 @@ EXPORTS = (
     "apv_timer_start", "apv_timer_stop",
     "apv_update_dev", "apv_update", "apv_corr_dev", "apv_corr_bf16_dev", "apv_to_bf16_dev", "apv_gevd_vast_dev", "apv_jdiag_batched", "apv_jdiag_large",
     "apv_stft_analysis_dev", "apv_istft_ola_dev",
-    "apv_stream_init", "apv_stream_set_perceptual", "apv_process_block", "apv_process_block_f64", "apv_stream_is_f64", "apv_state_bytes", "apv_get_state", "apv_set_state",
+    "apv_stream_init", "apv_stream_set_perceptual", "apv_process_block", "apv_process_block_f64", "apv_stream_is_f64", "apv_stream_get_statistics", "apv_stream_not_converged", "apv_state_bytes", "apv_get_state", "apv_set_state",
     "apv_bb_set_rank_list", "apv_bb_init", "apv_bb_set_perceptual", "apv_bb_process_block", "apv_bb_get_state", "apv_bb_set_state",
     "apv_predict_pressure", "apv_vast_static",
     "apv_comm_unique_id", "apv_comm_init", "apv_allgather_filters_dev", "apv_comm_last_gather", "apv_comm_barrier",
@@ -96,6 +96,8 @@ def load():
     lib.apv_process_block.argtypes = [vp, vp, vp, vp]
     lib.apv_process_block_f64.argtypes = [vp, vp, vp, vp]
     lib.apv_stream_is_f64.argtypes = [vp]
+    lib.apv_stream_get_statistics.argtypes = [vp, i32, vp, vp, vp, vp, vp]
+    lib.apv_stream_not_converged.argtypes = [vp]
     lib.apv_state_bytes.argtypes = [vp, C.c_char_p, C.POINTER(sz)]
     lib.apv_get_state.argtypes = [vp, C.c_char_p, vp, sz]
     lib.apv_set_state.argtypes = [vp, C.c_char_p, vp, sz]
@@ -116,7 +118,9 @@ def load():
     lib.apv_device_info.argtypes = [vp, C.c_char_p, C.POINTER(i32), C.POINTER(i32)]
     for name in EXPORTS:
         fn = getattr(lib, name)
-        if name != "apv_last_error":
+        if name == "apv_stream_not_converged":
+            fn.restype = C.c_long
+        elif name != "apv_last_error":
             fn.restype = C.c_int
     if lib.apv_abi_version() != ABI_VERSION:
         raise RuntimeError("libapvast_hip.so ABI version mismatch; rebuild it")
@@ -402,6 +406,16 @@ class Engine:
         fn = self.lib.apv_process_block_f64 if self.frontend_f64 else self.lib.apv_process_block
         self._chk(fn(self.h, _ptr(in_A), _ptr(in_B), _ptr(out)))
         return out
+
+    def stream_statistics(self, zone, want_U=True):
+        """R_B, R_D (K, L, L), r (K, L), U (K, L, L), lam (K, L) of the current hop for zone 0 (A) / 1 (B), float64."""
+        K, L = self.K, self.L
+        RB, RD = np.empty((K, L, L), np.complex128), np.empty((K, L, L), np.complex128)
+        r = np.empty((K, L), np.complex128)
+        U = np.empty((K, L, L), np.complex128) if want_U else None
+        lam = np.empty((K, L)) if want_U else None
+        self._chk(self.lib.apv_stream_get_statistics(self.h, int(zone), _ptr(RB), _ptr(RD), _ptr(r), _ptr(U), _ptr(lam)))
+        return RB, RD, r, U, lam
 
     @property
     def s_dtype(self):

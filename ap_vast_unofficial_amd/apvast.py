@@ -11,8 +11,9 @@ What is the same as the reference
     ``number_of_eigenvectors`` arrays of shape (hop_size, number_of_srcs), one per rank 1..V
     (apvast.py:406-422, 498-506); ``None`` for a zone that does not run (apvast.py:433-443)
   * ``rirs.mat`` ingest: ``rirA``/``rirB`` of shape (rir_len, L, M) (make_python_test.m:4, 18)
-  * readable attributes: hop_size, window, number_of_srcs, number_of_mics, w_A/w_B,
-    lambda_A/lambda_B, filter_spectra_*, input_spectrum_A/B
+  * readable attributes: hop_size, window, number_of_srcs, number_of_mics, w_A/w_B, lambda_A/lambda_B, U_A/U_B,
+    R_A_to_A/R_A_to_B/R_B_to_B/R_B_to_A, r_A/r_B, filter_spectra_A/B/A_t/B_t, input_spectrum_A/B (apvast.py:368-403);
+    in subband mode they are per bin (leading axis K)
 What is different (keyword-only, after ``perceptual``)
   * ``mode="subband"`` (default): one (R_B, R_D) pair, one GEVD and one filter PER FREQUENCY BIN from the
     current block's control-point spectra -- the fast path (``filter_length`` and
@@ -58,9 +59,10 @@ def jdiag(A, B, device=0):
     if A.shape != (n, n) or B.shape != (n, n):
         raise ValueError("jdiag expects two square matrices of equal size")
     cplx = np.iscomplexobj(A) or np.iscomplexobj(B)
-    if n > _capi.MAX_N and (cplx or n > 2048 or not EXPERIMENTAL_REGULARIZATION):
-        raise NotImplementedError("GPU jdiag: complex pairs up to n = 64; real symmetric pairs (the reference's "
-                                  "broadband call sites, apvast.py:380-382) up to n = 2048 with absolute loading")
+    if n > _capi.MAX_N and (cplx or n > 2048):
+        # stated limit of the boundary (include/apvast_hip.h): complex Hermitian pairs are the per-bin problems, whose
+        # order is the loudspeaker count (<= 64); the reference's own call sites (apvast.py:380-382) are real symmetric
+        raise NotImplementedError("GPU jdiag: complex Hermitian pairs up to n = 64; real symmetric pairs up to n = 2048")
     mode = _capi.REG_ABS if EXPERIMENTAL_REGULARIZATION else _capi.REG_REL
     key = (device, mode)
     if _jdiag_engine is None or _jdiag_engine[0] != key:
@@ -99,7 +101,8 @@ class apvast:
                  device: int = 0,
                  dtype: str = "f64",
                  seed=None,
-                 fullscale_db_spl: float = 94.0):
+                 fullscale_db_spl: float = 94.0,
+                 max_sweeps: int = 0):
         self.block_size = block_size
         self.rir_A = rir_A
         self.rir_B = rir_B
@@ -121,6 +124,7 @@ class apvast:
         if rir_A.shape != rir_B.shape:
             raise RuntimeError("rirs of unequal size")                        # apvast.py:89-90
         self._fullscale_db_spl = fullscale_db_spl
+        self._max_sweeps = int(max_sweeps)       # Jacobi sweep cap (0 = default); a hop that reaches it raises LinAlgError
         if mode not in ("subband", "broadband"):
             raise ValueError("mode must be 'subband' or 'broadband'")
         if dialect not in ("python", "matlab"):
@@ -152,7 +156,8 @@ class apvast:
         zones = (1 if run_A else 0) | (2 if run_B else 0)
         self._eng = _capi.Engine(self._K, L, M, ranks=self._ranks, mu=mu, compute_dtype="f32" if dtype == "f32" else "f64",
                                  reg_mode=reg_mode, reg_dark=reg_dark, reg_bright=reg_bright, device=device,
-                                 block_size=N, hop_size=H, n_zones=zones, frontend="f32" if dtype == "mixed" else None)
+                                 block_size=N, hop_size=H, n_zones=zones, frontend="f32" if dtype == "mixed" else None,
+                                 max_sweeps=self._max_sweeps)
         self._eng.stream_init(rir_A, rir_B, reference_index_A, reference_index_B, modeling_delay)
         if perceptual:
             # the masking model carried by the MATLAB twin (perceptualModel.m); per-block curves are formed on the
@@ -162,6 +167,11 @@ class apvast:
             self.model = PerceptualTables(N, sampling_rate, fullscale_db_spl)
             self._eng.stream_set_perceptual(self.model, dialect)
         self._n_out = (int(run_A) + int(run_B)) * V * L + 2 * L
+        tgt = np.zeros((N, L))
+        tgt[modeling_delay, reference_index_A] = 1.0                           # apvast.py:389-390: one filter for A_t and B_t
+        tspec = np.fft.rfft(tgt, axis=0)
+        self.filter_spectra_A_t = [tspec.copy() for _ in range(V)]             # apvast.py:418, 422
+        self.filter_spectra_B_t = [tspec.copy() for _ in range(V)]
         if dialect == "python":
             # apvast.py:124-129: response buffers start as 1e-3 * randn, drawn from the global NumPy RNG in this
             # order; pass seed=... for a private, reproducible generator instead
@@ -171,6 +181,7 @@ class apvast:
             self.set_state({"response": np.stack(resp), "target_response": np.stack(tresp)})
         self.w_A = self.w_B = None
         self.lambda_A = self.lambda_B = None
+        self._sb_cache = {}
 
     # ---- broadband mode: the reference's own time-domain algorithm, float64 on the device ----------
     def _init_broadband(self, device, seed):
@@ -186,15 +197,16 @@ class apvast:
                 raise ValueError("MATLAB dialect: the hop is half a block (apVast.m:138)")
             reg = dict(reg_mode=_capi.REG_REL, reg_dark=5e-3, reg_bright=1e-8)
         else:
-            if not EXPERIMENTAL_REGULARIZATION:
-                raise NotImplementedError("broadband mode, Python dialect: the absolute dark loading only (apvast.py:22-24)")
             self._ranks = list(range(1, int(self.number_of_eigenvectors) + 1))
-            reg = dict(reg_mode=_capi.REG_ABS, reg_dark=1e-7)
+            if EXPERIMENTAL_REGULARIZATION:
+                reg = dict(reg_mode=_capi.REG_ABS, reg_dark=1e-7)                 # apvast.py:22-24
+            else:
+                reg = dict(reg_mode=_capi.REG_REL, reg_dark=1e-8)                 # apvast.py:26-27: B + 1e-8 ||B||_2 I
         V = len(self._ranks)
         self._K = N // 2 + 1
         zones = (1 if self.run_A else 0) | (2 if self.run_B else 0)
         self._eng = _capi.Engine(self._K, L, M, ranks=(1,), mu=self.mu, compute_dtype="f64", device=device, block_size=N,
-                                 hop_size=H, n_zones=zones, dialect=self.dialect, **reg)
+                                 hop_size=H, n_zones=zones, dialect=self.dialect, max_sweeps=self._max_sweeps, **reg)
         self._eng.bb_set_rank_list(self._ranks if matlab else [])
         self._eng.bb_init(self.rir_A, self.rir_B, self.reference_index_A, self.reference_index_B, self.modeling_delay,
                           J, S, max(self._ranks))
@@ -210,6 +222,7 @@ class apvast:
             self.set_state({"response": np.stack(resp), "target_response": np.stack(tresp)})
         self.w_A = self.w_B = None
         self.lambda_A = self.lambda_B = None
+        self._bb_cache = None
 
     def _refresh_broadband(self):
         e, V, n = self._eng, len(self._ranks), self.filter_length * self.number_of_srcs
@@ -228,6 +241,9 @@ class apvast:
             setattr(self, "r_" + z, r[zi][:, None].copy())
             setattr(self, names[z][0], e.bb_get_state(f"R{names[z][2]}", (n, n)))
             setattr(self, names[z][1], e.bb_get_state(f"R{names[z][3]}", (n, n)))
+        # the large arrays are fetched when they are read (properties below): U_A / U_B (apvast.py:380-382) and the
+        # filter spectra (apvast.py:394-403, 417-422)
+        self._bb_cache = {}
 
     # ---- per-hop call (apvast.py:153-165) -------------------------------------------------
     def process_input_buffers(self, input_A, input_B):
@@ -264,6 +280,7 @@ class apvast:
 
     def _refresh_attributes(self):
         e, K, L, V = self._eng, self._K, self.number_of_srcs, len(self._ranks)
+        self._sb_cache = {}                 # U_*, R_*, r_* of this hop are recomputed on demand (Engine.stream_statistics)
         spec = e.get_state("input_spectrum", (2, K), e.sc_dtype)
         self.input_spectrum_A = spec[0].astype(np.complex128).reshape(-1, 1)   # apvast.py:430-431
         self.input_spectrum_B = spec[1].astype(np.complex128).reshape(-1, 1)
@@ -276,16 +293,91 @@ class apvast:
             setattr(self, "lambda_" + z, lam)
             setattr(self, "filter_spectra_" + z, [getattr(self, "w_" + z)[i] for i in range(V)])   # V x (K, L)
 
+    # ---- attributes the reference sets every hop, fetched from the device when read ------------------------
+    def _bb_filter_spectra(self):
+        if "fs" not in self._bb_cache:
+            K, L, V = self._K, self.number_of_srcs, len(self._ranks)
+            fs = self._eng.bb_get_state("filter_spectra", (self._n_out, K, 2))
+            fs = fs[..., 0] + 1j * fs[..., 1]                                     # [n_out][K], channel (v, l)
+            out, pos = {}, 0
+            for z, run in (("A", self.run_A), ("B", self.run_B)):
+                if run:
+                    out[z] = [np.ascontiguousarray(fs[pos + v * L: pos + (v + 1) * L].T) for v in range(V)]    # V x (K, L)
+                    pos += V * L
+            for z in ("A_t", "B_t"):
+                t = np.ascontiguousarray(fs[pos: pos + L].T)
+                out[z] = [t.copy() for _ in range(V)]                             # the same target filter at every rank
+                pos += L
+            self._bb_cache["fs"] = out
+        return self._bb_cache["fs"]
+
+    def _subband_stats(self, zone):
+        key = ("stats", zone)
+        if key not in self._sb_cache:
+            self._sb_cache[key] = self._eng.stream_statistics(zone)
+        return self._sb_cache[key]
+
+    def _zone_attr(self, z, what):
+        """U / R_bright / R_dark / r of zone program z ('A' | 'B'); None for a zone that does not run."""
+        zi = "AB".index(z)
+        if not (self.run_A, self.run_B)[zi] or self.lambda_A is None and self.lambda_B is None:
+            return None
+        if self.mode == "broadband":
+            n = self.filter_length * self.number_of_srcs
+            if what == "U":
+                key = ("U", zi)
+                if key not in self._bb_cache:
+                    self._bb_cache[key] = self._eng.bb_get_state(f"U{zi}", (n, n))
+                return self._bb_cache[key]
+            raise AttributeError(what)
+        RB, RD, r, U, _ = self._subband_stats(zi)
+        return {"U": U, "RB": RB, "RD": RD, "r": r}[what]
+
+    # per-bin (subband mode: (K, L, L) complex128, recomputed in float64 from the hop's control-point spectra) or
+    # (J L) x (J L) real (broadband mode) eigenvectors of the last hop, columns in descending order   apvast.py:380-382
+    U_A = property(lambda self: self._zone_attr("A", "U"))
+    U_B = property(lambda self: self._zone_attr("B", "U"))
+
+    def __getattr__(self, name):
+        # attributes that exist only after the first hop and only in one of the modes; plain attribute access otherwise
+        d = self.__dict__
+        if name.startswith("filter_spectra_") and d.get("mode") == "broadband" and d.get("_bb_cache") is not None:
+            z = name[len("filter_spectra_"):]
+            fs = self._bb_filter_spectra()
+            if z in fs:
+                return fs[z]
+            if z in ("A", "B"):
+                raise AttributeError(name)                                        # that zone does not run (apvast.py:391-400)
+        sub = {"R_A_to_A": ("A", "RB"), "R_A_to_B": ("A", "RD"), "R_B_to_B": ("B", "RB"), "R_B_to_A": ("B", "RD"),
+               "r_A": ("A", "r"), "r_B": ("B", "r")}
+        if name in sub and d.get("mode") == "subband" and d.get("_sb_cache") is not None:
+            v = self._zone_attr(*sub[name])
+            if v is not None:
+                return v
+        raise AttributeError(f"{type(self).__name__!r} object has no attribute {name!r}")
+
     # ---- checkpoint / fixtures (SURVEY.md section 5) -----------------------------------------
+    _BB_STATE = ("response", "target_response", "stats", "target_stats", "overlap", "target_overlap", "input_block",
+                 "input_history", "out_overlap")
+    _SB_STATE = ("response", "target_response", "input_block", "input_history", "out_overlap")
+
     def get_state(self):
+        """Everything the next hop depends on (the reference's instance attributes of apvast.py:115-151), as float64 arrays
+        in the reference's own axis order; ``b.set_state(a.get_state())`` makes b continue exactly as a would."""
         e, N, L, M = self._eng, self.block_size, self.number_of_srcs, self.number_of_mics
         if self.mode == "broadband":
-            S = self.statistics_buffer_length
+            S, P, H = self.statistics_buffer_length, self.rir_length, self.hop_size
+            g = e.bb_get_state
             return {
-                "response": np.stack([e.bb_get_state(f"response{p}", (M, L, N)) for p in range(4)]).transpose(0, 3, 2, 1),
-                "target_response": np.stack([e.bb_get_state(f"target_response{z}", (M, N)) for z in range(2)]).transpose(0, 2, 1),
-                "stats": np.stack([e.bb_get_state(f"stats{p}", (M, L, S)) for p in range(4)]).transpose(0, 3, 2, 1),
-                "target_stats": np.stack([e.bb_get_state(f"target_stats{z}", (M, S)) for z in range(2)]).transpose(0, 2, 1),
+                "response": np.stack([g(f"response{p}", (M, L, N)) for p in range(4)]).transpose(0, 3, 2, 1),
+                "target_response": np.stack([g(f"target_response{z}", (M, N)) for z in range(2)]).transpose(0, 2, 1),
+                "stats": np.stack([g(f"stats{p}", (M, L, S)) for p in range(4)]).transpose(0, 3, 2, 1),
+                "target_stats": np.stack([g(f"target_stats{z}", (M, S)) for z in range(2)]).transpose(0, 2, 1),
+                "overlap": np.stack([g(f"overlap{p}", (M, L, N)) for p in range(4)]).transpose(0, 3, 2, 1),
+                "target_overlap": np.stack([g(f"target_overlap{z}", (M, N)) for z in range(2)]).transpose(0, 2, 1),
+                "input_block": g("input_block", (2, N)),
+                "input_history": np.stack([g(f"input_history{k}", (P - 1 + H,)) for k in range(2)]),
+                "out_overlap": g("out_overlap", (self._n_out, N)),
             }
         sd = e.s_dtype                      # float32, or float64 with the float64 front-end (dtype="f64")
         resp = np.stack([e.get_state(f"response{p}", (M, L, N), sd) for p in range(4)])
@@ -301,15 +393,31 @@ class apvast:
 
     def set_state(self, state):
         e = self._eng
+        known = self._BB_STATE if self.mode == "broadband" else self._SB_STATE
+        unknown = sorted(set(state) - set(known))
+        if unknown:
+            raise KeyError(f"set_state: no such state array(s) in {self.mode} mode: {unknown}; known: {list(known)}")
         if self.mode == "broadband":
-            if "response" in state:
-                r = np.asarray(state["response"], dtype=np.float64)
-                for p in range(4):
-                    e.bb_set_state(f"response{p}", np.ascontiguousarray(r[p].transpose(2, 1, 0)))
-            if "target_response" in state:
-                t = np.asarray(state["target_response"], dtype=np.float64)
-                for z in range(2):
-                    e.bb_set_state(f"target_response{z}", np.ascontiguousarray(t[z].T))
+            f = lambda a: np.asarray(a, dtype=np.float64)
+            per_path = {"response": "response", "stats": "stats", "overlap": "overlap"}
+            per_zone = {"target_response": "target_response", "target_stats": "target_stats", "target_overlap": "target_overlap"}
+            for key, name in per_path.items():
+                if key in state:
+                    r = f(state[key])                                             # (4, len, L, M) -> [M][L][len]
+                    for p in range(4):
+                        e.bb_set_state(f"{name}{p}", np.ascontiguousarray(r[p].transpose(2, 1, 0)))
+            for key, name in per_zone.items():
+                if key in state:
+                    t = f(state[key])                                             # (2, len, M) -> [M][len]
+                    for z in range(2):
+                        e.bb_set_state(f"{name}{z}", np.ascontiguousarray(t[z].T))
+            if "input_block" in state:
+                e.bb_set_state("input_block", f(state["input_block"]))
+            if "input_history" in state:
+                for g in range(2):
+                    e.bb_set_state(f"input_history{g}", f(state["input_history"])[g])
+            if "out_overlap" in state:
+                e.bb_set_state("out_overlap", f(state["out_overlap"]))
             return
         sd = e.s_dtype
         if "response" in state:

@@ -93,12 +93,18 @@ size_t apv_gevd_spill_bytes(int n, int K, int compute_dtype);
 hipError_t apv_launch_gevd16m(const GevdParams& p, int compute_dtype, bool fused, hipStream_t s);
 
 // kernels_gevd_large.hip: real symmetric pairs of broadband order, f64, device pointers (see the file header)
-int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const double* d_B, double reg, double* d_U,
-                   double* d_lam, const double* d_r, double mu, int V, const int* d_ranks, double* d_w, int32_t* h_status);
+int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const double* d_B, double reg,
+                   const double* d_reg_scale, double* d_U, double* d_lam, const double* d_r, double mu, int V, const int* d_ranks, double* d_w, int32_t* h_status);
+
+// stream_bb.hip: d_out[i] = ||mats[i]||_2 (largest eigenvalue of a symmetric PSD n x n matrix, Lanczos), i < count <= 4
+hipError_t apv_launch_norm2(int n, int count, const double* const* d_mats, double* d_out, hipStream_t s);
 
 // kernels_corr.hip
 hipError_t apv_launch_corr(int compute_dtype, int K, int M, int L, const float2* XB, const float2* XD,
                            const float2* d, void* RB, void* RD, void* r, hipStream_t s);
+
+hipError_t apv_launch_corr_c128(int K, int M, int L, const double2* XB, const double2* XD, const double2* d, double2* RB,
+                                double2* RD, double2* r, hipStream_t s);
 
 // bf16 inputs ((re, im) bf16 pairs, 4 B per element), f32 accumulation on v_mfma_f32_32x32x16_bf16; L in {32, 64}
 hipError_t apv_launch_corr_bf16(int K, int M, int L, const uint32_t* XB, const uint32_t* XD, const uint32_t* d,

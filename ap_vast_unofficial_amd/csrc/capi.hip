@@ -398,15 +398,19 @@ int apv_jdiag_batched(apv_handle* h, int32_t n, int32_t batch, const double* h_A
     HIPCHK(h, hipSetDevice(h->device));
     // always runs in f64 / c128, whatever the handle's streaming dtype
     const size_t mat = (size_t)batch * n * n * 16;
-    void *dA = nullptr, *dB = nullptr, *dU = nullptr, *dw = nullptr, *dl = nullptr;
-    int32_t* ds = nullptr;
+    struct Tmp {
+        void* p[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        ~Tmp() { for (void* q : p) if (q) (void)hipFree(q); }
+    } t;                                                    // freed on every way out
+    void*& dA = t.p[0]; void*& dB = t.p[1]; void*& dU = t.p[2]; void*& dw = t.p[3]; void*& dl = t.p[4];
+    void*& dsv = t.p[5]; void*& spill = t.p[6];
     HIPCHK(h, hipMalloc(&dA, mat));
     HIPCHK(h, hipMalloc(&dB, mat));
     HIPCHK(h, hipMalloc(&dU, mat));
     HIPCHK(h, hipMalloc(&dw, (size_t)batch * n * 16));
     HIPCHK(h, hipMalloc(&dl, (size_t)batch * n * 8));
-    HIPCHK(h, hipMalloc((void**)&ds, (size_t)batch * sizeof(int32_t)));
-    void* spill = nullptr;
+    HIPCHK(h, hipMalloc(&dsv, (size_t)batch * sizeof(int32_t)));
+    int32_t* ds = (int32_t*)dsv;
     const size_t sb = apv_gevd_spill_bytes(n, batch, APV_F64);   // jdiag always runs in f64
     if (sb) HIPCHK(h, hipMalloc(&spill, sb));
     HIPCHK(h, hipMemcpyAsync(dA, h_A, mat, hipMemcpyHostToDevice, h->stream));
@@ -444,9 +448,6 @@ int apv_jdiag_batched(apv_handle* h, int32_t n, int32_t batch, const double* h_A
         hipError_t se = hipStreamSynchronize(h->stream);
         if (se != hipSuccess) rc = hipfail(h, se, "jdiag sync");
     }
-    void* tofree[] = {dA, dB, dU, dw, dl, ds, spill};
-    for (void* b : tofree)
-        if (b) (void)hipFree(b);
     if (rc != APV_OK) return rc;
     return scan_status(h, st, batch);
 }
@@ -458,7 +459,11 @@ int apv_jdiag_large(apv_handle* h, int32_t n, int32_t batch, const double* h_A, 
     if (batch == 0) return APV_OK;
     HIPCHK(h, hipSetDevice(h->device));
     const size_t mat = (size_t)batch * n * n * sizeof(double);
-    double *dA = nullptr, *dB = nullptr, *dU = nullptr, *dl = nullptr;
+    struct Tmp {
+        double* p[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        ~Tmp() { for (double* q : p) if (q) (void)hipFree(q); }
+    } t;                                                    // freed on every way out
+    double*& dA = t.p[0]; double*& dB = t.p[1]; double*& dU = t.p[2]; double*& dl = t.p[3]; double*& dn = t.p[4];
     HIPCHK(h, hipMalloc((void**)&dA, mat));
     HIPCHK(h, hipMalloc((void**)&dB, mat));
     HIPCHK(h, hipMalloc((void**)&dU, mat));
@@ -471,20 +476,22 @@ int apv_jdiag_large(apv_handle* h, int32_t n, int32_t batch, const double* h_A, 
         tmp.reset(new int32_t[batch]);
         st = tmp.get();
     }
-    double reg = h->cfg.reg_dark;
     if (h->cfg.reg_mode == APV_REG_REL) {
-        void* tofree[] = {dA, dB, dU, dl};
-        for (void* b : tofree) (void)hipFree(b);
-        return fail(h, APV_ERR_ARG, "apv_jdiag_large supports absolute loading only (EXPERIMENTAL_REGULARIZATION=True)");
+        // B + reg_dark ||B||_2 I (apvast.py:26-27): the spectral norms first, four matrices per launch
+        HIPCHK(h, hipMalloc((void**)&dn, (size_t)batch * sizeof(double)));
+        for (int z0 = 0; z0 < batch; z0 += 4) {
+            const double* mats[4];
+            const int cnt = batch - z0 < 4 ? batch - z0 : 4;
+            for (int q = 0; q < cnt; ++q) mats[q] = dB + (size_t)(z0 + q) * n * n;
+            HIPCHK(h, apv_launch_norm2(n, cnt, mats, dn + z0, h->stream));
+        }
     }
-    int rc = apv_gevd_large(h, n, batch, dA, dB, reg, dU, dl, nullptr, 0.0, 0, nullptr, nullptr, st);
+    int rc = apv_gevd_large(h, n, batch, dA, dB, h->cfg.reg_dark, dn, dU, dl, nullptr, 0.0, 0, nullptr, nullptr, st);
     if (rc == APV_OK || rc == APV_ERR_NOT_PD) {
         (void)hipMemcpyAsync(h_U, dU, mat, hipMemcpyDeviceToHost, h->stream);
         (void)hipMemcpyAsync(h_lam, dl, (size_t)batch * n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
         (void)hipStreamSynchronize(h->stream);
     }
-    void* tofree[] = {dA, dB, dU, dl};
-    for (void* b : tofree) (void)hipFree(b);
     if (rc != APV_OK) return rc;
     for (int z = 0; z < batch; ++z)
         if (st[z] == 2) return fail(h, APV_ERR_NO_CONVERGE, "eigen-iteration did not converge");

@@ -16,19 +16,20 @@
 
 namespace {
 
-template <typename T>
-__global__ void __launch_bounds__(256) corr_kernel(int M, int L, const float2* __restrict__ XB,
-                                                   const float2* __restrict__ XD, const float2* __restrict__ d,
+// XT: element type of the slabs (float2 = c64; double2 = c128, the float64 streaming front-end)
+template <typename T, typename XT = float2>
+__global__ void __launch_bounds__(256) corr_kernel(int M, int L, const XT* __restrict__ XB,
+                                                   const XT* __restrict__ XD, const XT* __restrict__ d,
                                                    T* __restrict__ RB, T* __restrict__ RD, T* __restrict__ r) {
     constexpr int TPB = 256;
     constexpr int MT = 8;
     constexpr int NACC = (APV_MAX_N * APV_MAX_N) / TPB;     // 16
-    __shared__ float2 sX[MT * APV_MAX_N];
-    __shared__ float2 sd[MT];
+    __shared__ XT sX[MT * APV_MAX_N];
+    __shared__ XT sd[MT];
     const int tid = threadIdx.x;
     const int k = blockIdx.x;
     for (int which = 0; which < 2; ++which) {
-        const float2* X = (which ? XD : XB) + (size_t)k * M * L;
+        const XT* X = (which ? XD : XB) + (size_t)k * M * L;
         T ax[NACC], ay[NACC];
 #pragma unroll
         for (int a = 0; a < NACC; ++a) ax[a] = ay[a] = 0;
@@ -44,7 +45,7 @@ __global__ void __launch_bounds__(256) corr_kernel(int M, int L, const float2* _
                 if (idx < L * L) {
                     const int i = idx / L, j = idx - i * L;
                     for (int m = 0; m < rows; ++m) {
-                        const float2 xi = sX[m * L + i], xj = sX[m * L + j];
+                        const XT xi = sX[m * L + i], xj = sX[m * L + j];
                         ax[a] += (T)xi.x * (T)xj.x + (T)xi.y * (T)xj.y;
                         ay[a] += (T)xi.x * (T)xj.y - (T)xi.y * (T)xj.x;
                     }
@@ -52,7 +53,7 @@ __global__ void __launch_bounds__(256) corr_kernel(int M, int L, const float2* _
             }
             if (which == 0 && tid < L) {
                 for (int m = 0; m < rows; ++m) {
-                    const float2 xi = sX[m * L + tid], dm = sd[m];
+                    const XT xi = sX[m * L + tid], dm = sd[m];
                     rx += (T)xi.x * (T)dm.x + (T)xi.y * (T)dm.y;
                     ry += (T)xi.x * (T)dm.y - (T)xi.y * (T)dm.x;
                 }
@@ -317,6 +318,15 @@ hipError_t apv_launch_corr(int compute_dtype, int K, int M, int L, const float2*
         hipLaunchKernelGGL(corr_kernel<float>, dim3(K), dim3(256), 0, s, M, L, XB, XD, d, (float*)RB,
                            (float*)RD, (float*)r);
     }
+    return hipGetLastError();
+}
+
+// float64 statistics from c128 slabs (on-demand attributes of the float64 streaming front-end)
+hipError_t apv_launch_corr_c128(int K, int M, int L, const double2* XB, const double2* XD, const double2* d, double2* RB,
+                                double2* RD, double2* r, hipStream_t s) {
+    if (K <= 0) return hipSuccess;
+    if (L < 1 || L > APV_MAX_N || M < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((corr_kernel<double, double2>), dim3(K), dim3(256), 0, s, M, L, XB, XD, d, (double*)RB, (double*)RD, (double*)r);
     return hipGetLastError();
 }
 

@@ -78,8 +78,12 @@ __global__ void __launch_bounds__(256) chol_panel_kernel(int ld, int k, int nbk,
                                                          double* __restrict__ LiBuf, int* __restrict__ flag,
                                                          size_t mat_stride) {
     __shared__ double La[BT * LS], Lb[BT * LS], Dm[BT * LS], Wp[BT * LS], rs[BT];
+    __shared__ int sflag;
     const int z = blockIdx.z;
-    if (flag[z]) return;
+    // workgroup 0 of this very launch may raise the flag: read it once per workgroup, so that all waves take the same way
+    if (threadIdx.x == 0) sflag = flag[z];
+    __syncthreads();
+    if (sflag) return;
     B += z * mat_stride;
     LiBuf += (size_t)z * nbk * BT * BT;
     const int I = k + blockIdx.x;
@@ -196,9 +200,11 @@ __global__ void __launch_bounds__(256) tri_inverse_kernel(int ld, int nbk, const
 // Working copies with leading dimension ld >= n: Bw = B + reg I with a unit diagonal on the ghost rows of the padding
 // (so that the factorisation runs through), C0 = A with zero ghosts.                                   apvast.py:24
 __global__ void __launch_bounds__(TPB) load_pair_kernel(int n, int ne, int ld, const double* __restrict__ A,
-                                                        const double* __restrict__ B, double reg, double* __restrict__ C0,
+                                                        const double* __restrict__ B, double reg,
+                                                        const double* __restrict__ reg_scale, double* __restrict__ C0,
                                                         double* __restrict__ Bw, size_t mat_stride) {
     const int z = blockIdx.z, i = blockIdx.y;
+    if (reg_scale != nullptr) reg *= reg_scale[z];           // relative loading: reg ||B||_2 (apvast.py:26-27)
     A += (size_t)z * n * n;
     B += (size_t)z * n * n;
     C0 += z * mat_stride;
@@ -574,10 +580,10 @@ void apv_gevd_large_free(apv_handle* h) {
 }
 
 // Everything above, for `batch` independent pairs.  d_A, d_B: [batch][n][n] f64 (row-major, device, B is loaded
-// with +reg on its diagonal here); outputs d_U [batch][n][n] (sorted columns), d_lam [batch][n]; optional
+// with +reg on its diagonal here, reg x d_reg_scale[z] when that device array is given); outputs d_U [batch][n][n] (sorted columns), d_lam [batch][n]; optional
 // d_r [batch][n] -> d_w [batch][V][n] for the ranks d_ranks[0..V) (device; nullptr = 1..V).  h_status[batch]: 0 ok, 1 not positive definite, 2 sweep cap.
-int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const double* d_B, double reg, double* d_U,
-                   double* d_lam, const double* d_r, double mu, int V, const int* d_ranks, double* d_w, int32_t* h_status) {
+int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const double* d_B, double reg,
+                   const double* d_reg_scale, double* d_U, double* d_lam, const double* d_r, double mu, int V, const int* d_ranks, double* d_w, int32_t* h_status) {
     hipStream_t st = h->stream;
     const auto t_begin = std::chrono::steady_clock::now();
     const int ne = (n + BT - 1) / BT * BT, ld = ne;          // padded with ghost rows/columns: zero in A and C, unit in B
@@ -620,14 +626,21 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
     if (!ws.exec && !no_graph) {
         LCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
         two_sweeps();
-        LCHK(hipStreamEndCapture(st, &ws.graph));
+        // the capture is always closed, whatever was recorded: a stream left in capture mode fails every later call
+        const hipError_t ce = hipStreamEndCapture(st, &ws.graph);
+        const hipError_t le = hipGetLastError();
+        if (ce != hipSuccess || le != hipSuccess || !ws.graph) {
+            if (ws.graph) (void)hipGraphDestroy(ws.graph);
+            ws.graph = nullptr;
+            return apv_fail(h, APV_ERR_HIP, std::string("capturing the Jacobi sweeps: ") + hipGetErrorString(ce != hipSuccess ? ce : le));
+        }
         LCHK(hipGraphInstantiate(&ws.exec, ws.graph, nullptr, nullptr, 0));
     }
     LCHK(hipMemsetAsync(ws.W, 0, mb, st));
     LCHK(hipMemsetAsync(ws.X, 0, mb, st));
     LCHK(hipMemsetAsync(ws.flag, 0, sizeof(int) * batch, st));
     LCHK(hipMemsetAsync(ws.acc, 0, sizeof(double) * 3 * batch, st));
-    hipLaunchKernelGGL(load_pair_kernel, dim3(gx, ne, batch), dim3(TPB), 0, st, n, ne, ld, d_A, d_B, reg, ws.C0, ws.Bw, ms);   // C0 holds A for now
+    hipLaunchKernelGGL(load_pair_kernel, dim3(gx, ne, batch), dim3(TPB), 0, st, n, ne, ld, d_A, d_B, reg, d_reg_scale, ws.C0, ws.Bw, ms);   // C0 holds A for now
     for (int k = 0; k < nbk; ++k)
         hipLaunchKernelGGL(chol_panel_kernel, dim3(nbk - k, 1, batch), dim3(256), 0, st, ld, k, nbk, ws.Bw, ws.Li, ws.flag, ms);
     hipLaunchKernelGGL(tri_inverse_kernel, dim3(nbk, BT / 8, batch), dim3(256), 0, st, ld, nbk, ws.Bw, ws.Li, ws.W, ws.flag, ms);

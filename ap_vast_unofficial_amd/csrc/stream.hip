@@ -470,6 +470,55 @@ int apv_process_block_f64(apv_handle* h, const double* h_in_A, const double* h_i
 
 int apv_stream_is_f64(apv_handle* h) { return (h && h->st) ? h->st->f64 : -1; }
 
+long apv_stream_not_converged(apv_handle* h) { return (h && h->st) ? h->st->not_converged : -1; }
+
+// Per-bin statistics and eigenvectors of the CURRENT hop, recomputed in float64 on demand from the hop's control-point
+// spectra (nothing on the per-hop path pays for them).  zone 0: bright A->A, dark A->B, target A; zone 1: B->B, B->A, B.
+int apv_stream_get_statistics(apv_handle* h, int32_t zone, double* h_RB, double* h_RD, double* h_r, double* h_U,
+                              double* h_lam) {
+    if (!h || !h->st) return apv_fail(h, APV_ERR_ARG, "apv_stream_init has not been called");
+    if (zone != 0 && zone != 1) return apv_fail(h, APV_ERR_ARG, "zone must be 0 (A) or 1 (B)");
+    apv_stream* s = h->st;
+    if (!(s->zones & (1 << zone))) return apv_fail(h, APV_ERR_STATE, "this zone program does not run (run_A / run_B)");
+    SCHK(h, hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    const int K = s->K, L = s->L, M = s->M;
+    const size_t mat = (size_t)K * L * L * 16, vec = (size_t)K * L * 16;
+    struct Tmp {
+        void* p[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        ~Tmp() { for (void* q : p) if (q) (void)hipFree(q); }
+    } t;                                                    // freed on every way out
+    void*& dRB = t.p[0]; void*& dRD = t.p[1]; void*& dr = t.p[2]; void*& dU = t.p[3]; void*& dw = t.p[4]; void*& dl = t.p[5];
+    void*& dspill = t.p[6]; void*& dst = t.p[7];
+    SCHK(h, hipMalloc(&dRB, mat)); SCHK(h, hipMalloc(&dRD, mat)); SCHK(h, hipMalloc(&dr, vec));
+    const void* XB = zone ? s->X[3] : s->X[0];
+    const void* XD = zone ? s->X[2] : s->X[1];
+    hipError_t e = s->f64 ? apv_launch_corr_c128(K, M, L, (const double2*)XB, (const double2*)XD, (const double2*)s->tspec[zone],
+                                                 (double2*)dRB, (double2*)dRD, (double2*)dr, st)
+                          : apv_launch_corr(APV_F64, K, M, L, (const float2*)XB, (const float2*)XD, (const float2*)s->tspec[zone], dRB, dRD,
+                                            dr, st);
+    if (e != hipSuccess) return apv_fail(h, APV_ERR_HIP, std::string("statistics: ") + hipGetErrorString(e));
+    if (h_U || h_lam) {
+        SCHK(h, hipMalloc(&dU, mat)); SCHK(h, hipMalloc(&dw, vec)); SCHK(h, hipMalloc(&dl, (size_t)K * L * 8));
+        SCHK(h, hipMalloc(&dst, (size_t)K * 4));
+        const size_t sb = apv_gevd_spill_bytes(L, K, APV_F64);
+        if (sb) SCHK(h, hipMalloc(&dspill, sb));
+        GevdParams p = apv_base_params(h);
+        p.nV = 1; p.ranks[0] = 1; p.out_c128 = 1; p.n_zones = 1;
+        p.RB = dRB; p.RD = dRD; p.r = dr; p.w = dw; p.lam = dl; p.status = (int32_t*)dst; p.U = dU; p.Lspill = dspill;
+        std::string why;
+        e = apv_launch_gevd(p, APV_F64, false, st, &why);
+        if (e != hipSuccess) return apv_fail(h, APV_ERR_HIP, why.empty() ? hipGetErrorString(e) : why);
+    }
+    if (h_RB) SCHK(h, hipMemcpyAsync(h_RB, dRB, mat, hipMemcpyDeviceToHost, st));
+    if (h_RD) SCHK(h, hipMemcpyAsync(h_RD, dRD, mat, hipMemcpyDeviceToHost, st));
+    if (h_r) SCHK(h, hipMemcpyAsync(h_r, dr, vec, hipMemcpyDeviceToHost, st));
+    if (h_U) SCHK(h, hipMemcpyAsync(h_U, dU, mat, hipMemcpyDeviceToHost, st));
+    if (h_lam) SCHK(h, hipMemcpyAsync(h_lam, dl, (size_t)K * L * 8, hipMemcpyDeviceToHost, st));
+    SCHK(h, hipStreamSynchronize(st));
+    return APV_OK;
+}
+
 // Enable (n_channels > 0) or disable (0) the perceptual weighting.  h_G2 [K][n_channels]: squared
 // outer/middle-ear x gammatone responses (perceptualModel.m:52-54); Cs, Ca, Leff: perceptualModel.m:57, 114-115;
 // normalisation 0: unit vector over the K bins (apvast.py:322-324), 1: over the full symmetric curve

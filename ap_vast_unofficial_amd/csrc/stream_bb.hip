@@ -26,7 +26,8 @@
 
 struct apv_bb {
     int N, H, K, L, M, C, P, J, S, V, n, zones, pad;      // V = number of solutions (ranks kept)
-    int dialect, skip, ncols, toff, rel_loading;          // statistics conventions of the dialect
+    int dialect, skip, ncols, toff, rel_loading, rel_dark_py;          // statistics conventions of the dialect
+    long not_converged;    // hops whose joint diagonalisation hit the sweep cap
     int* d_ranks;          // [V] ascending
     double* nrm;           // [4] ||R_q||_2 for the relative loading
     int ring_off, stat_off, cur;
@@ -419,6 +420,14 @@ inline int path_zone(int p) { return p & 1; }
 
 }  // namespace
 
+hipError_t apv_launch_norm2(int n, int count, const double* const* d_mats, double* d_out, hipStream_t s) {
+    if (count < 1 || count > 4) return hipErrorInvalidValue;
+    NormJobs nj{};
+    for (int q = 0; q < count; ++q) nj.m[q] = d_mats[q];
+    hipLaunchKernelGGL(norm2_lanczos_kernel, dim3(count), dim3(1024), sizeof(double) * (3 * (size_t)n + 2 * KL + 33 + 520), s, n, nj, d_out);
+    return hipGetLastError();
+}
+
 void apv_bb_free(apv_handle* h) {
     apv_bb* s = h->bb;
     if (!s) return;
@@ -487,7 +496,8 @@ int apv_bb_init(apv_handle* h, int32_t rir_len, const double* h_rir_A, const dou
     s->skip = dialect == APV_DIALECT_PYTHON;                 // scipy's toeplitz drops sample J (apvast.py:336-338)
     s->ncols = S - J + (s->skip ? 0 : 1);                    // apvast.py:334 / apVast.m:420
     s->toff = s->skip ? J : J - 1;                           // apvast.py:340 d[J:] / apVast.m:425 d(J:end)
-    s->rel_loading = c.reg_mode == APV_REG_REL;              // apVast.m:552-569
+    s->rel_loading = c.reg_mode == APV_REG_REL && dialect == APV_DIALECT_MATLAB;      // apVast.m:552-569, in place
+    s->rel_dark_py = c.reg_mode == APV_REG_REL && dialect == APV_DIALECT_PYTHON;      // apvast.py:26-27, inside jdiag
     const int nz = ((s->zones & 1) ? 1 : 0) + ((s->zones & 2) ? 1 : 0);
     s->n_out = nz * nsol * L + 2 * L;
     BCHK(h, hipMalloc((void**)&s->d_ranks, sizeof(int) * nsol));
@@ -661,12 +671,13 @@ int apv_bb_process_block(apv_handle* h, const double* h_in_A, const double* h_in
         }
         hipLaunchKernelGGL(scale_kernel, dim3((2 * n + 255) / 256), dim3(256), 0, st, (size_t)2 * n, s->r, f);
     }
+    if (s->rel_loading || s->rel_dark_py) {
+        const double* mats[4];
+        for (int q = 0; q < 4; ++q) mats[q] = s->R + q * nn;
+        BCHK(h, apv_launch_norm2(n, 4, mats, s->nrm, st));
+    }
     if (s->rel_loading) {
         // apVast.m:552-569: bright += reg_bright ||R||_2, dark += reg_dark ||R||_2, in place like the reference
-        NormJobs nj{};
-        for (int q = 0; q < 4; ++q) nj.m[q] = s->R + q * nn;
-        hipLaunchKernelGGL(norm2_lanczos_kernel, dim3(4), dim3(1024), sizeof(double) * (3 * (size_t)n + 2 * KL + 33 + 520), st, n, nj,
-                           s->nrm);
         for (int q = 0; q < 4; ++q) {
             const bool live = (q == 0 || q == 2) ? runA : runB;
             if (!live) continue;
@@ -676,11 +687,13 @@ int apv_bb_process_block(apv_handle* h, const double* h_in_A, const double* h_in
     }
     stage_done();
     // 4: jdiag + filters; both zone programs in one batch when both run
+    int32_t status[2] = {0, 0};
     {
-        int32_t status[2] = {0, 0};
         const int first = runA ? 0 : 1, batch = (runA && runB) ? 2 : 1;
+        // Python dialect, EXPERIMENTAL_REGULARIZATION = False: jdiag loads a copy of the dark matrix with reg_dark ||B||_2
+        // (apvast.py:26-27); the R_* attributes stay as accumulated
         int rc = apv_gevd_large(h, n, batch, s->R + first * nn, s->R + (2 + first) * nn, s->rel_loading ? 0.0 : h->cfg.reg_dark,
-                                s->U + first * nn, s->lam + (size_t)first * n, s->r + (size_t)first * n, h->cfg.mu, V, s->d_ranks,
+                                s->rel_dark_py ? s->nrm + 2 + first : nullptr, s->U + first * nn, s->lam + (size_t)first * n, s->r + (size_t)first * n, h->cfg.mu, V, s->d_ranks,
                                 s->w + (size_t)first * V * n, status);
         if (rc != APV_OK) return rc;
     }
@@ -716,6 +729,10 @@ int apv_bb_process_block(apv_handle* h, const double* h_in_A, const double* h_in
     if (timing)
         fprintf(stderr, "[apv bb] fir %.3f  wola %.3f  stats %.3f  gevd %.3f  out %.3f ms\n", t_stage[0], t_stage[1],
                 t_stage[2], t_stage[3], t_stage[4]);
+    if (status[0] == 2 || status[1] == 2) {
+        s->not_converged++;
+        return apv_fail(h, APV_ERR_NO_CONVERGE, "eigen-iteration did not converge (Jacobi sweep cap reached); the outputs of this hop were written");
+    }
     return APV_OK;
 }
 
@@ -759,7 +776,11 @@ int apv_predict_pressure(apv_handle* h, int32_t T, int32_t L, int32_t M, int32_t
     if (T < 0 || L < 1 || M < 1 || M > 256 || P < 1) return apv_fail(h, APV_ERR_ARG, "predict_pressure: bad sizes (M <= 256)");
     if (T == 0) return APV_OK;
     BCHK(h, hipSetDevice(h->device));
-    double *dx = nullptr, *dr = nullptr, *dout = nullptr;
+    struct Tmp {
+        double* p[3] = {nullptr, nullptr, nullptr};
+        ~Tmp() { for (double* q : p) if (q) (void)hipFree(q); }
+    } tmpbufs;                                              // freed on every way out
+    double*& dx = tmpbufs.p[0]; double*& dr = tmpbufs.p[1]; double*& dout = tmpbufs.p[2];
     BCHK(h, hipMalloc((void**)&dx, sizeof(double) * (size_t)T * L));
     BCHK(h, hipMalloc((void**)&dr, sizeof(double) * (size_t)P * L * M));
     BCHK(h, hipMalloc((void**)&dout, sizeof(double) * (size_t)T * M));
@@ -769,7 +790,6 @@ int apv_predict_pressure(apv_handle* h, int32_t T, int32_t L, int32_t M, int32_t
     hipLaunchKernelGGL(predict_pressure_kernel, dim3((T + tpb - 1) / tpb), dim3(256), 0, h->stream, T, L, M, P, dx, dr, dout);
     BCHK(h, hipMemcpyAsync(h_out, dout, sizeof(double) * (size_t)T * M, hipMemcpyDeviceToHost, h->stream));
     BCHK(h, hipStreamSynchronize(h->stream));
-    (void)hipFree(dx); (void)hipFree(dr); (void)hipFree(dout);
     return APV_OK;
 }
 
@@ -799,7 +819,12 @@ int apv_vast_static(apv_handle* h, int32_t Nb, int32_t Nd, int32_t P, int32_t L,
     for (int m = 0; m < Nb; ++m)                                                   // target: delayed reference RIR (vast.m:59)
         for (int q = modeling_delay; q < P && J + q < S; ++q)
             td[(size_t)m * S + J + q] = h_gB[((size_t)m * P + (q - modeling_delay)) * L + reference_index];
-    double *dsb = nullptr, *dsd = nullptr, *dtd = nullptr, *dR = nullptr, *dr = nullptr, *dU = nullptr, *dl = nullptr, *dw = nullptr;
+    struct Tmp {
+        double* p[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        ~Tmp() { for (double* q : p) if (q) (void)hipFree(q); }
+    } tmpbufs;                                              // freed on every way out
+    double*& dsb = tmpbufs.p[0]; double*& dsd = tmpbufs.p[1]; double*& dtd = tmpbufs.p[2]; double*& dR = tmpbufs.p[3];
+    double*& dr = tmpbufs.p[4]; double*& dU = tmpbufs.p[5]; double*& dl = tmpbufs.p[6]; double*& dw = tmpbufs.p[7];
     BCHK(h, hipMalloc((void**)&dsb, sizeof(double) * sb.size()));
     BCHK(h, hipMalloc((void**)&dsd, sizeof(double) * sd.size()));
     BCHK(h, hipMalloc((void**)&dtd, sizeof(double) * td.size()));
@@ -826,18 +851,22 @@ int apv_vast_static(apv_handle* h, int32_t Nb, int32_t Nd, int32_t P, int32_t L,
     hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((2 * nn + 255) / 256)), dim3(256), 0, st, 2 * nn, dR, f);
     hipLaunchKernelGGL(scale_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (size_t)n, dr, f);
     int32_t status = 0;
-    int rc = apv_gevd_large(h, n, 1, dR, dR + nn, 0.0, dU, dl, dr, mu, V, nullptr, dw, &status);     // jdiag(RB, RD, 'vector', true): no loading
+    int rc = apv_gevd_large(h, n, 1, dR, dR + nn, 0.0, nullptr, dU, dl, dr, mu, V, nullptr, dw, &status);     // jdiag(RB, RD, 'vector', true): no loading
     if (rc == APV_OK) {
         (void)hipMemcpyAsync(h_w, dw + (size_t)(V - 1) * n, sizeof(double) * n, hipMemcpyDeviceToHost, st);
         (void)hipStreamSynchronize(st);
     }
-    double* tofree[] = {dsb, dsd, dtd, dR, dr, dU, dl, dw};
-    for (double* b : tofree) (void)hipFree(b);
+    if (rc == APV_OK && status == 2)
+        return apv_fail(h, APV_ERR_NO_CONVERGE, "vast_static: eigen-iteration did not converge (Jacobi sweep cap reached); w was written");
     return rc;
 }
 
-// state: "response<p>" [C][N], "target_response<z>" [M][N] (rings, logical order); "R<q>" [n][n] (AA, BB, AB, BA),
-// "r" [2][n], "lambda" [2][n], "w" [2][V][n], "stats<p>" [C][S], "target_stats<z>" [M][S] (rings, logical order)
+// state: "response<p>" [C][N], "target_response<z>" [M][N], "input_block" [2][N] (rings, logical order); "R<q>" [n][n]
+// (AA, BB, AB, BA), "r" [2][n], "lambda" [2][n], "w" [2][V][n], "U<z>" [n][n] (columns = eigenvectors, descending),
+// "stats<p>" [C][S], "target_stats<z>" [M][S] (rings, logical order); and what a bit-for-bit resume also needs:
+// "input_history<g>" [P-1+H] (the reference's lfilter states, apvast.py:115-120, as the inputs they came from),
+// "overlap<p>" [C][N], "target_overlap<z>" [M][N] (WOLA overlap buffers, apvast.py:132-137), "out_overlap" [n_out][N]
+// (apvast.py:148-151), "filter_spectra" [n_out][K] c128 (apvast.py:394-403, 417-422)
 static int bb_lookup(apv_handle* h, const char* name, double** d, size_t* count, int* rows, int* len, int* off) {
     apv_bb* s = h->bb;
     const std::string nm(name);
@@ -852,6 +881,13 @@ static int bb_lookup(apv_handle* h, const char* name, double** d, size_t* count,
     if ((q = idx("target_response", 2)) >= 0) { *d = s->tresp[q]; *count = (size_t)s->M * s->N; *rows = s->M; *len = s->N; *off = s->ring_off; return APV_OK; }
     if ((q = idx("stats", 4)) >= 0) { *d = s->stats[q]; *count = (size_t)s->C * s->S; *rows = s->C; *len = s->S; *off = s->stat_off; return APV_OK; }
     if ((q = idx("target_stats", 2)) >= 0) { *d = s->tstats[q]; *count = (size_t)s->M * s->S; *rows = s->M; *len = s->S; *off = s->stat_off; return APV_OK; }
+    if (nm == "input_block") { *d = s->inblk; *count = (size_t)2 * s->N; *rows = 2; *len = s->N; *off = s->ring_off; return APV_OK; }
+    if ((q = idx("input_history", 2)) >= 0) { *d = s->xhist[s->cur][q]; *count = (size_t)s->P - 1 + s->H; return APV_OK; }
+    if ((q = idx("overlap", 4)) >= 0) { *d = s->ov[q]; *count = (size_t)s->C * s->N; return APV_OK; }
+    if ((q = idx("target_overlap", 2)) >= 0) { *d = s->tov[q]; *count = (size_t)s->M * s->N; return APV_OK; }
+    if (nm == "out_overlap") { *d = s->outov; *count = (size_t)s->n_out * s->N; return APV_OK; }
+    if (nm == "filter_spectra") { *d = s->fspec; *count = (size_t)s->n_out * s->K * 2; return APV_OK; }
+    if ((q = idx("U", 2)) >= 0) { *d = s->U + (size_t)q * s->n * s->n; *count = (size_t)s->n * s->n; return APV_OK; }
     if ((q = idx("R", 4)) >= 0) { *d = s->R + (size_t)q * s->n * s->n; *count = (size_t)s->n * s->n; return APV_OK; }
     if (nm == "r") { *d = s->r; *count = (size_t)2 * s->n; return APV_OK; }
     if (nm == "lambda") { *d = s->lam; *count = (size_t)2 * s->n; return APV_OK; }

@@ -181,6 +181,14 @@ int  apv_process_block(apv_handle* h, const float* h_in_A, const float* h_in_B, 
 int  apv_process_block_f64(apv_handle* h, const double* h_in_A, const double* h_in_B, double* h_out);
 /* 1 if the stream's front-end (and therefore its named state arrays) is float64, 0 if float32, -1 without a stream */
 int  apv_stream_is_f64(apv_handle* h);
+/* Per-bin statistics and eigenvectors of the CURRENT hop of a streaming handle, recomputed in float64 on demand from
+ * the hop's control-point spectra (the per-hop path never writes R or U to HBM).  zone 0 = A (bright A->A, dark A->B),
+ * 1 = B.  h_RB, h_RD, h_U [K][L][L] c128 (U: columns = eigenvectors, descending), h_r [K][L] c128, h_lam [K][L] f64; any
+ * of them may be NULL.       replaces the attributes R_*, r_*, U_*, lambda_* of apvast.py:368-387, per bin */
+int  apv_stream_get_statistics(apv_handle* h, int32_t zone, double* h_RB, double* h_RD, double* h_r, double* h_U,
+                               double* h_lam);
+/* hops so far in which some bin reached the Jacobi sweep cap (each such hop also returned APV_ERR_NO_CONVERGE) */
+long apv_stream_not_converged(apv_handle* h);
 /* Perceptual ("AP") weighting of the control-point and target spectra, evaluated per block on the device from the
  * target spectra (van de Par 2005 model as carried by the reference's MATLAB twin).  h_G2 [K][n_channels] float64
  * = squared outer/middle-ear x gammatone responses; n_channels = 0 switches it off (all-ones, apvast.py:326-327).

@@ -59,7 +59,9 @@ class BroadbandOracle:
     def __init__(self, block_size, rir_A, rir_B, filter_length, modeling_delay,
                  reference_index_A, reference_index_B, number_of_eigenvectors, mu,
                  statistics_buffer_length, hop_size=None, sampling_rate=48000,
-                 run_A=True, run_B=True, perceptual=False, model=None):
+                 run_A=True, run_B=True, perceptual=False, model=None, reg_mode=gevd.REG_MODE_ABS):
+        # reg_mode: which branch of jdiag's loading runs (apvast.py:22-27; module flag EXPERIMENTAL_REGULARIZATION)
+        self.reg_mode = reg_mode
         # perceptual=True: `model` is an oracle.perceptual.Model (the MATLAB twin's masking model; the reference's
         # Python class would call the absent libdetectability here -- unpinned)
         if perceptual and model is None:
@@ -186,12 +188,14 @@ class BroadbandOracle:
         tspec = self._filter_spectrum(target)
         self.filter_spectra = [None, None, np.stack([tspec] * self.V), np.stack([tspec] * self.V)]
         if self.run_A:
-            U, lam = gevd.jdiag(self.R_AA, self.R_AB)
+            U, lam = gevd.jdiag(self.R_AA, self.R_AB, self.reg_mode)
+            self.U_A = U
             self.lambda_A = lam
             self.w_A = gevd.vast_filter(U, lam, self.r_A, self.mu, ranks)
             self.filter_spectra[0] = np.stack([self._filter_spectrum(w) for w in self.w_A])
         if self.run_B:
-            U, lam = gevd.jdiag(self.R_BB, self.R_BA)
+            U, lam = gevd.jdiag(self.R_BB, self.R_BA, self.reg_mode)
+            self.U_B = U
             self.lambda_B = lam
             self.w_B = gevd.vast_filter(U, lam, self.r_B, self.mu, ranks)
             self.filter_spectra[1] = np.stack([self._filter_spectrum(w) for w in self.w_B])

@@ -252,11 +252,49 @@ def g6_errors(ref):
     np.savez(os.path.join(OUT, "g6_errors.npz"), **{k: np.array(v) for k, v in msgs.items()})
 
 
+def g7_relative_loading(ref):
+    """G7: the else-branch of jdiag, B + 1e-8 ||B||_2 I (apvast.py:26-27, EXPERIMENTAL_REGULARIZATION = False): three
+    hops at cfg1 from the G1 start buffers and inputs -> outputs (ranks 1, 4, 8), lambda, w, r per hop; plus jdiag on
+    one real pair of order 96 (a leading block of the hop-3 statistics) and on complex per-bin pairs."""
+    rirA, rirB = cfg1_rirs()
+    keep = ref.EXPERIMENTAL_REGULARIZATION
+    ref.EXPERIMENTAL_REGULARIZATION = False
+    try:
+        ap = make_ref_obj(ref, rirA, rirB, seed=0)
+        H, hops = CFG1["hop_size"], 3
+        x = np.random.default_rng(7).standard_normal((2, G1_HOPS * H))[:, : hops * H]      # the first hops of G1's input
+        outs = np.zeros((hops, 4, len(G1_RANKS), H, 8))
+        lam = np.zeros((hops, 2, 256))
+        w = np.zeros((hops, 2, 8, 256))
+        for h in range(hops):
+            o = ap.process_input_buffers(x[0, h * H:(h + 1) * H], x[1, h * H:(h + 1) * H])
+            for q in range(4):
+                for i, v in enumerate(G1_RANKS):
+                    outs[h, q, i] = o[q][v]
+            lam[h, 0], lam[h, 1] = ap.lambda_A, ap.lambda_B
+            w[h, 0], w[h, 1] = ap.w_A[:, :, 0], ap.w_B[:, :, 0]
+        A, B = ap.R_A_to_A[:96, :96].copy(), ap.R_A_to_B[:96, :96].copy()
+        U, D = ref.jdiag(A, B)
+        rng = np.random.default_rng(3)
+        X = (rng.standard_normal((6, 2, 24, 12)) + 1j * rng.standard_normal((6, 2, 24, 12))) * np.sqrt(0.5)
+        Ac = np.einsum("kmi,kmj->kij", X[:, 0].conj(), X[:, 0])
+        Bc = np.einsum("kmi,kmj->kij", X[:, 1].conj(), X[:, 1])
+        lamc = np.stack([np.diag(ref.jdiag(Ac[k], Bc[k])[1]).real for k in range(6)])
+    finally:
+        ref.EXPERIMENTAL_REGULARIZATION = keep
+    np.savez_compressed(os.path.join(OUT, "g7_relative_loading.npz"), x=x, ranks=np.array(G1_RANKS), outputs=outs, lam=lam,
+                        w=w, jd_A=A, jd_B=B, jd_lam=np.diag(D), jd_UtBU_err=np.abs(U.T @ (B + 1e-8 * np.linalg.norm(B, 2) * np.eye(96)) @ U - np.eye(96)).max(),
+                        c_A=Ac, c_B=Bc, c_lam=lamc)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     ref = load_reference()
     if len(sys.argv) > 1 and sys.argv[1] == "g4":        # add the fixture without regenerating the others
         g4_stft_stage(ref)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "g7":
+        g7_relative_loading(ref)
         sys.exit(0)
     g1_broadband(ref)
     g4_stft_stage(ref)
@@ -265,5 +303,6 @@ if __name__ == "__main__":
     g3_jdiag_complex(ref)
     g5_known_answers(ref)
     g6_errors(ref)
+    g7_relative_loading(ref)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

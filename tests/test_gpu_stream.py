@@ -286,3 +286,28 @@ def test_g4_control_point_spectra_vs_reference(golden):
                 ref = g4["target_spectra"][i, z]
                 assert np.abs(T - ref).max() <= 1e-12 * np.abs(ref).max(), (h, z)
     ap.close()
+
+
+def test_stream_per_bin_attributes():
+    """U_A, R_A_to_A, R_A_to_B, r_A (apvast.py:368-387) per bin in subband mode, recomputed on demand from the hop's
+    control-point spectra: statistics against the oracle's, U through jdiag's contract, and w from U."""
+    rirA, rirB = synth_rirs(200, 8, 16, 1)
+    ap, orc, got, exp = run_pair(256, 128, rirA, rirB, 12, 2, 5, 4, 1.0, hops=3)
+    from oracle import subband
+    for z, (names, bright, dark) in enumerate(((("R_A_to_A", "R_A_to_B", "r_A", "U_A", "lambda_A", "w_A"), 0, 1),
+                                               (("R_B_to_B", "R_B_to_A", "r_B", "U_B", "lambda_B", "w_B"), 3, 2))):
+        RB, RD, r = subband.correlate(orc.spectra[bright].transpose(0, 2, 1), orc.spectra[dark].transpose(0, 2, 1),
+                                      orc.target_spectra[z])
+        gRB, gRD, gr, U, lam, w = (getattr(ap, n) for n in names)
+        assert gRB.shape == (129, 8, 8) and U.shape == (129, 8, 8)
+        for got_, ref in ((gRB, RB), (gRD, RD), (gr, r)):
+            assert np.abs(got_ - ref).max() < 1e-12 * np.abs(ref).max()
+        UH = U.conj().transpose(0, 2, 1)
+        assert np.abs(UH @ (RD + 1e-7 * np.eye(8)) @ U - np.eye(8)).max() < 1e-8
+        D = UH @ RB @ U
+        assert np.abs(D - lam[:, :, None] * np.eye(8)).max() < 1e-8 * lam.max()
+        coef = np.einsum("kli,kl->ki", U.conj(), r) / (lam + 1.0)
+        w4 = np.einsum("kli,ki->kl", U[:, :, :4], coef[:, :4])
+        assert np.abs(w4 - w[3]).max() < 1e-9 * np.abs(w4).max()
+    assert len(ap.filter_spectra_A_t) == 4 and np.abs(ap.filter_spectra_A_t[0] - orc.target_filter).max() < 1e-14
+    ap.close()

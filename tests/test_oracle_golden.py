@@ -210,3 +210,26 @@ def test_g4_stft_stage_of_the_oracle(golden):
             tspec = np.fft.rfft(w[None, :, None] * orc.target_response, axis=1)
             assert np.abs(spec - g4["spectra"][i]).max() < 2e-7 * np.abs(g4["spectra"][i]).max()      # fixture is c64
             assert np.abs(tspec - g4["target_spectra"][i]).max() < 2e-7 * np.abs(g4["target_spectra"][i]).max()
+
+
+def test_g7_relative_loading(golden, rirs):
+    """G7: the reference run with EXPERIMENTAL_REGULARIZATION = False (jdiag loads B + 1e-8 ||B||_2 I, apvast.py:26-27):
+    three hops at cfg1, jdiag on a real pair of order 96 and on complex per-bin pairs."""
+    g, g1 = golden("g7_relative_loading"), golden("g1_broadband_cfg1")
+    o = broadband.BroadbandOracle(256, rirs[0], rirs[1], 32, 16, 0, 0, 8, 1.0, 512, hop_size=128, reg_mode=gevd.REG_MODE_REL)
+    o.response[:] = g1["init_response"]
+    o.target_response[:] = g1["init_target_response"]
+    x, H, ranks = g["x"], 128, g["ranks"]
+    for h in range(3):
+        out = o.process_input_buffers(x[0, h * H:(h + 1) * H], x[1, h * H:(h + 1) * H])
+        for q in range(4):
+            assert np.abs(out[q][ranks] - g["outputs"][h, q]).max() <= 1e-9 * np.abs(g["outputs"][h, q]).max(), (h, q)
+        for z, (lam, w) in enumerate(((o.lambda_A, o.w_A), (o.lambda_B, o.w_B))):
+            assert np.abs(lam[:8] / g["lam"][h, z, :8] - 1).max() < 1e-9
+            for i in range(8):
+                assert np.linalg.norm(w[i] - g["w"][h, z, i]) <= 1e-8 * np.linalg.norm(g["w"][h, z, i]), (h, z, i)
+    U, lam = gevd.jdiag(g["jd_A"], g["jd_B"], gevd.REG_MODE_REL)
+    assert np.abs(lam / g["jd_lam"] - 1).max() < 1e-9
+    for k in range(g["c_A"].shape[0]):
+        _, lk = gevd.jdiag(g["c_A"][k], g["c_B"][k], gevd.REG_MODE_REL)
+        assert np.abs(lk / g["c_lam"][k] - 1).max() < 1e-9
