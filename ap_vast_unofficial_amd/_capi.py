@@ -7,7 +7,7 @@ import os
 
 import numpy as np
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_RANKS = 64
 MAX_N = 64
 
@@ -46,6 +46,7 @@ class Config(C.Structure):
         ("dialect", C.c_int32),
         ("frontend", C.c_int32),
         ("reserved", C.c_int32 * 5),
+        ("sweep_tol2", C.c_double),
     ]
 
 
@@ -169,7 +170,7 @@ class Engine:
 
     def __init__(self, n_bins, n_srcs, n_mics, ranks=(1,), mu=1.0, compute_dtype="f64", out_c128=None,
                  reg_mode=REG_ABS, reg_dark=1e-7, reg_bright=0.0, device=0, max_sweeps=0,
-                 block_size=0, hop_size=0, n_zones=1, debug_stop=0, dialect="python", frontend=None):
+                 block_size=0, hop_size=0, n_zones=1, debug_stop=0, dialect="python", frontend=None, sweep_tol2=0.0):
         self.lib = load()
         self.h = None
         ranks = [int(v) for v in ranks]
@@ -191,6 +192,7 @@ class Engine:
         cfg.block_size, cfg.hop_size, cfg.n_zones = block_size, hop_size, n_zones
         cfg.debug_stop = debug_stop           # profiling aid (kernels_gevd16m.hip), 0 in normal use
         cfg.dialect = 1 if dialect == "matlab" else 0
+        cfg.sweep_tol2 = float(sweep_tol2)    # Jacobi stop threshold (0 = default)
         # streaming front-end precision: None follows compute_dtype; "f32" / "f64" force it
         cfg.frontend = {None: 0, "f32": 1, "f64": 2}[frontend]
         self.frontend_f64 = self.f64 if frontend is None else frontend == "f64"

@@ -102,7 +102,8 @@ class apvast:
                  dtype: str = "f64",
                  seed=None,
                  fullscale_db_spl: float = 94.0,
-                 max_sweeps: int = 0):
+                 max_sweeps: int = 0,
+                 sweep_tol2: float = 0.0):
         self.block_size = block_size
         self.rir_A = rir_A
         self.rir_B = rir_B
@@ -157,7 +158,7 @@ class apvast:
         self._eng = _capi.Engine(self._K, L, M, ranks=self._ranks, mu=mu, compute_dtype="f32" if dtype == "f32" else "f64",
                                  reg_mode=reg_mode, reg_dark=reg_dark, reg_bright=reg_bright, device=device,
                                  block_size=N, hop_size=H, n_zones=zones, frontend="f32" if dtype == "mixed" else None,
-                                 max_sweeps=self._max_sweeps)
+                                 max_sweeps=self._max_sweeps, sweep_tol2=sweep_tol2)
         self._eng.stream_init(rir_A, rir_B, reference_index_A, reference_index_B, modeling_delay)
         if perceptual:
             # the masking model carried by the MATLAB twin (perceptualModel.m); per-block curves are formed on the

@@ -58,6 +58,7 @@ GevdParams apv_base_params(const apv_handle* h) {
     p.reg_mode = c.reg_mode;
     p.max_sweeps = c.max_sweeps;
     p.debug_stop = c.debug_stop;
+    p.sweep_tol2 = c.sweep_tol2;
     p.out_c128 = c.out_c128;
     p.Lspill = h->d_Lspill;
     return p;

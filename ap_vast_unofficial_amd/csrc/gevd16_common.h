@@ -12,8 +12,10 @@ template <typename T> __device__ __forceinline__ Cx<T> mk(T a, T b) { Cx<T> r; r
 
 template <typename T> struct Prec;
 template <> struct Prec<double> {
-    // a sweep that met off^2/||C||^2 <= tol2 leaves ~tol2^2 behind (quadratic convergence): it is the last one
-    static constexpr double sweep_tol2 = 1e-10;
+    // a sweep that met off^2/||C||^2 <= tol2 leaves ~tol2^2 behind (quadratic convergence): it is the last one.  1e-10 is
+    // enough for spectra within a few decades; on the reference's own room responses (cfg1, cond(R_D) ~ 1e5) it left the
+    // filters at 6e-4 of the oracle's, 1e-14 at 5e-8, 1e-18 at 4e-11 (tools/probes/cfg1_square_probe.py)
+    static constexpr double sweep_tol2 = 1e-16;
     static constexpr int max_sweeps = 14;
 };
 template <> struct Prec<float> {
@@ -303,6 +305,101 @@ __device__ __forceinline__ void rotation(T alpha, T gamma, T bx, T by, T& c, T& 
     c = rsq_full((T)1 + dx * dx + dy * dy);
     sx = dx * c;
     sy = dy * c;
+}
+
+// The register-resident cyclic Jacobi of stage 3 on the 2 x 2 blocks (tt, tb; bt, bb) of this lane and its two rows
+// of V, in precision TT.  Runs sweeps until one of them meets sum |pivot|^2 <= tol2 normS2 (that sweep is the last) or
+// max_sweeps is reached; returns the number of sweeps done (its parity says which slot layout the blocks are left in).
+template <typename TT>
+__device__ __forceinline__ int jacobi16_sweeps(Cx<TT>& tt_, Cx<TT>& tb_, Cx<TT>& bt_, Cx<TT>& bb_, Cx<TT>& v0t_, Cx<TT>& v0b_,
+                                               Cx<TT>& v1t_, Cx<TT>& v1b_, TT (*srot)[4], int lane, TT tol2, TT normS2,
+                                               int max_sweeps, bool& converged_) {
+    using CC = Cx<TT>;
+    const int a = lane >> 3, b = lane & 7;
+    const bool diag = (a == b);
+    int sweeps_done = 0;
+    bool converged = false;
+    // work on local copies: the blocks must stay in registers (by-reference structs end up in scratch otherwise)
+    CC tt = tt_, tb = tb_, bt = bt_, bb = bb_, v0t = v0t_, v0b = v0b_, v1t = v1t_, v1b = v1b_;
+    for (int sweep = 0; sweep < max_sweeps && !converged; ++sweep) {
+        TT off = 0;
+        // the schedule as two nibble strings in scalar registers (a table in memory costs a load per round)
+        const unsigned long long dseq = (sweep & 1) ? XS_DELTA1 : XS_DELTA0;
+        const unsigned long long tseq = (sweep & 1) ? XS_TBIT1 : XS_TBIT0;
+        for (int r = 0; r < 15; ++r) {
+            const int delta = (int)((dseq >> (4 * r)) & 15), tbit = (int)((tseq >> (4 * r)) & 15) - 1;
+            if (tbit >= 0) {
+                // columns first, then rows; the row exchanges and the bit-2 column exchange are masked lane swaps
+                if (tbit == 2) {
+                    cxswap_col4(tt, tb);
+                    cxswap_col4(bt, bb);
+                    cxswap_col4(v0t, v0b);
+                    cxswap_col4(v1t, v1b);
+                    cxswap_row<2>(tt, bt);
+                    cxswap_row<2>(tb, bb);
+                } else {
+                    const bool cb_ = (b >> tbit) & 1;
+                    const int pc = lane ^ (1 << tbit);
+                    xchg(tt, tb, cb_, pc);
+                    xchg(bt, bb, cb_, pc);
+                    xchg(v0t, v0b, cb_, pc);
+                    xchg(v1t, v1b, cb_, pc);
+                    if (tbit == 1) {
+                        cxswap_row<1>(tt, bt);
+                        cxswap_row<1>(tb, bb);
+                    } else {
+                        cxswap_row<0>(tt, bt);
+                        cxswap_row<0>(tb, bb);
+                    }
+                }
+            }
+            switch (delta) {
+                case 1: move_bottoms<1>(tb, bt, bb, v0b, v1b, lane); break;
+                case 2: move_bottoms<2>(tb, bt, bb, v0b, v1b, lane); break;
+                case 4: move_bottoms<4>(tb, bt, bb, v0b, v1b, lane); break;
+                default: break;
+            }
+            if (diag) off += tb.x * tb.x + tb.y * tb.y;
+            TT c, sx, sy;
+            rotation<TT>(tt.x, bb.x, tb.x, tb.y, c, sx, sy);
+            TT ca, sax, say, cb, sbx, sby;
+            if constexpr (sizeof(TT) == 8) {
+                // double: the eight rotations go through LDS (two wide reads per lane instead of twelve ds_bpermute)
+                if (diag) {
+                    srot[a][0] = c;
+                    srot[a][1] = sx;
+                    srot[a][2] = sy;
+                }
+                wsync();
+                ca = srot[a][0]; sax = srot[a][1]; say = srot[a][2];
+                cb = srot[b][0]; sbx = srot[b][1]; sby = srot[b][2];
+            } else {
+                const int da = 9 * a, db = 9 * b;
+                ca = __shfl(c, da, 64); sax = __shfl(sx, da, 64); say = __shfl(sy, da, 64);
+                cb = __shfl(c, db, 64); sbx = __shfl(sx, db, 64); sby = __shfl(sy, db, 64);
+            }
+            const CC sa = mk<TT>(sax, say), sb = mk<TT>(sbx, sby);
+            CC ypp, ypq, yqp, yqq;
+            rot_cols<TT>(cb, sb, tt, tb, ypp, ypq);
+            rot_cols<TT>(cb, sb, bt, bb, yqp, yqq);
+            rot_rows<TT>(ca, sa, ypp, yqp, tt, bt);
+            rot_rows<TT>(ca, sa, ypq, yqq, tb, bb);
+            if (diag) {         // the angle is float-accurate: the residual beta' ~ 1e-7 beta is real data, keep it
+                tt.y = 0;
+                bb.y = 0;
+            }
+            CC w0p, w0q, w1p, w1q;
+            rot_cols<TT>(cb, sb, v0t, v0b, w0p, w0q);
+            rot_cols<TT>(cb, sb, v1t, v1b, w1p, w1q);
+            v0t = w0p; v0b = w0q; v1t = w1p; v1b = w1q;
+        }
+        ++sweeps_done;
+        const TT tot = wave_sum(off);
+        if (tot <= tol2 * normS2) converged = true;
+    }
+    tt_ = tt; tb_ = tb; bt_ = bt; bb_ = bb; v0t_ = v0t; v0b_ = v0b; v1t_ = v1t; v1b_ = v1b;
+    converged_ = converged;
+    return sweeps_done;
 }
 
 }  // namespace

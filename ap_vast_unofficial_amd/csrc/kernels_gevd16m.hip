@@ -6,8 +6,9 @@
 //            live in registers, one column / one row is broadcast through LDS per step      apvast.py:22-27
 //   stage 2  C = W R_B W^H                         two complex MFMA products                 apvast.py:28-29
 //   stage 3  cyclic Jacobi, register resident, XOR pairing schedule (gevd16_common.h)        apvast.py:30
-//            float64: a float32 pre-solve on packed math, its eigenvector matrix re-orthonormalised to first order
-//            and C re-formed on the f64 MFMA, then the double sweeps (one, at the default tolerance)
+//            float64: a float32 pre-solve on packed math, then ONE refinement step of its eigenvector matrix on the
+//            f64 MFMA (four complex products, Ogita & Aishima 2018); a wave whose spectrum has a gap too narrow for
+//            that step re-orthonormalises to first order, re-forms C on the MFMA and runs double sweeps instead
 //   stage 4  sort                                                                            apvast.py:32-35
 //   stage 5  X = W^H Q                             one complex MFMA product                  apvast.py:31
 //   stage 6  w_V = sum_{i<V} (x_i^H r)/(lam_i+mu) x_i                                        apvast.py:406-414
@@ -57,101 +58,6 @@ __device__ __forceinline__ void cmm16(FA fa, FB fb, int lane, Cx<float> out[4]) 
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) out[t] = mk<float>(re[t], im[t]);
-}
-
-// The register-resident cyclic Jacobi of stage 3 on the 2 x 2 blocks (tt, tb; bt, bb) of this lane and its two rows
-// of V, in precision TT.  Runs sweeps until one of them meets sum |pivot|^2 <= tol2 normS2 (that sweep is the last) or
-// max_sweeps is reached; returns the number of sweeps done (its parity says which slot layout the blocks are left in).
-template <typename TT>
-__device__ __forceinline__ int jacobi16_sweeps(Cx<TT>& tt_, Cx<TT>& tb_, Cx<TT>& bt_, Cx<TT>& bb_, Cx<TT>& v0t_, Cx<TT>& v0b_,
-                                               Cx<TT>& v1t_, Cx<TT>& v1b_, TT (*srot)[4], int lane, TT tol2, TT normS2,
-                                               int max_sweeps, bool& converged_) {
-    using CC = Cx<TT>;
-    const int a = lane >> 3, b = lane & 7;
-    const bool diag = (a == b);
-    int sweeps_done = 0;
-    bool converged = false;
-    // work on local copies: the blocks must stay in registers (by-reference structs end up in scratch otherwise)
-    CC tt = tt_, tb = tb_, bt = bt_, bb = bb_, v0t = v0t_, v0b = v0b_, v1t = v1t_, v1b = v1b_;
-    for (int sweep = 0; sweep < max_sweeps && !converged; ++sweep) {
-        TT off = 0;
-        // the schedule as two nibble strings in scalar registers (a table in memory costs a load per round)
-        const unsigned long long dseq = (sweep & 1) ? XS_DELTA1 : XS_DELTA0;
-        const unsigned long long tseq = (sweep & 1) ? XS_TBIT1 : XS_TBIT0;
-        for (int r = 0; r < 15; ++r) {
-            const int delta = (int)((dseq >> (4 * r)) & 15), tbit = (int)((tseq >> (4 * r)) & 15) - 1;
-            if (tbit >= 0) {
-                // columns first, then rows; the row exchanges and the bit-2 column exchange are masked lane swaps
-                if (tbit == 2) {
-                    cxswap_col4(tt, tb);
-                    cxswap_col4(bt, bb);
-                    cxswap_col4(v0t, v0b);
-                    cxswap_col4(v1t, v1b);
-                    cxswap_row<2>(tt, bt);
-                    cxswap_row<2>(tb, bb);
-                } else {
-                    const bool cb_ = (b >> tbit) & 1;
-                    const int pc = lane ^ (1 << tbit);
-                    xchg(tt, tb, cb_, pc);
-                    xchg(bt, bb, cb_, pc);
-                    xchg(v0t, v0b, cb_, pc);
-                    xchg(v1t, v1b, cb_, pc);
-                    if (tbit == 1) {
-                        cxswap_row<1>(tt, bt);
-                        cxswap_row<1>(tb, bb);
-                    } else {
-                        cxswap_row<0>(tt, bt);
-                        cxswap_row<0>(tb, bb);
-                    }
-                }
-            }
-            switch (delta) {
-                case 1: move_bottoms<1>(tb, bt, bb, v0b, v1b, lane); break;
-                case 2: move_bottoms<2>(tb, bt, bb, v0b, v1b, lane); break;
-                case 4: move_bottoms<4>(tb, bt, bb, v0b, v1b, lane); break;
-                default: break;
-            }
-            if (diag) off += tb.x * tb.x + tb.y * tb.y;
-            TT c, sx, sy;
-            rotation<TT>(tt.x, bb.x, tb.x, tb.y, c, sx, sy);
-            TT ca, sax, say, cb, sbx, sby;
-            if constexpr (sizeof(TT) == 8) {
-                // double: the eight rotations go through LDS (two wide reads per lane instead of twelve ds_bpermute)
-                if (diag) {
-                    srot[a][0] = c;
-                    srot[a][1] = sx;
-                    srot[a][2] = sy;
-                }
-                wsync();
-                ca = srot[a][0]; sax = srot[a][1]; say = srot[a][2];
-                cb = srot[b][0]; sbx = srot[b][1]; sby = srot[b][2];
-            } else {
-                const int da = 9 * a, db = 9 * b;
-                ca = __shfl(c, da, 64); sax = __shfl(sx, da, 64); say = __shfl(sy, da, 64);
-                cb = __shfl(c, db, 64); sbx = __shfl(sx, db, 64); sby = __shfl(sy, db, 64);
-            }
-            const CC sa = mk<TT>(sax, say), sb = mk<TT>(sbx, sby);
-            CC ypp, ypq, yqp, yqq;
-            rot_cols<TT>(cb, sb, tt, tb, ypp, ypq);
-            rot_cols<TT>(cb, sb, bt, bb, yqp, yqq);
-            rot_rows<TT>(ca, sa, ypp, yqp, tt, bt);
-            rot_rows<TT>(ca, sa, ypq, yqq, tb, bb);
-            if (diag) {         // the angle is float-accurate: the residual beta' ~ 1e-7 beta is real data, keep it
-                tt.y = 0;
-                bb.y = 0;
-            }
-            CC w0p, w0q, w1p, w1q;
-            rot_cols<TT>(cb, sb, v0t, v0b, w0p, w0q);
-            rot_cols<TT>(cb, sb, v1t, v1b, w1p, w1q);
-            v0t = w0p; v0b = w0q; v1t = w1p; v1b = w1q;
-        }
-        ++sweeps_done;
-        const TT tot = wave_sum(off);
-        if (tot <= tol2 * normS2) converged = true;
-    }
-    tt_ = tt; tb_ = tb; bt_ = bt; bb_ = bb; v0t_ = v0t; v0b_ = v0b; v1t_ = v1t; v1b_ = v1b;
-    converged_ = converged;
-    return sweeps_done;
 }
 
 // XT: element type of the fused input slabs (float2 = c64, double2 = c128: the float64 streaming front-end)
@@ -284,7 +190,7 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
         const int sexp = (normF2 > (T)0) ? -(ilogb((double)normF2) / 2) : 0;
         const T scl = (T)ldexp(1.0, sexp), iscl = (T)ldexp(1.0, -sexp);
         const T normS2 = normF2 * scl * scl;
-        bool v_in_lds = false;
+        bool v_in_lds = false, refined = false;
         if constexpr (sizeof(T) == 8) {
             // ---- float32 pre-solve (debug_stop == 4 skips it: double sweeps only, for A/B timing) -------------------
             // The sweeps are the cost of the kernel and the packed-float ones are less than half as expensive, so C is
@@ -322,6 +228,76 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
                 for (int t = 0; t < 4; ++t) sA[mfma_row<T>(lane, t) * LD + mcol] = accT[t];
                 wsync();
                 cmm16([&](int r, int kx) { return cj(sB[kx * LD + r]); }, [&](int kx, int c) { return sA[kx * LD + c]; }, lane, accC);   // C1 = V^H C V
+                // ---- one refinement step on the matrix cores in place of the double sweep (Ogita & Aishima 2018) ---------
+                // With S = V^H C V, Gram = V^H V = I + E and the Rayleigh quotients d_i = S_ii / Gram_ii, the update
+                //   V'' = V (I + Z),  Z_ij = (S_ij - d_j E_ij) / (d_j - d_i)  (i != j),  Z_ii = -E_ii / 2
+                // removes the float solve's error to second order: what is left is |Z|^2, the same order a double Jacobi sweep
+                // from (C', V') leaves.  |Z_ij| <= kRefineGuard on every pair keeps that below 1e-9; a wave that meets a
+                // narrower spectral gap (or a pair the float sweeps did not finish) takes the double sweeps instead.
+                constexpr double kRefineGuard2 = 9e-10;        // |Z_ij|^2 <= (3e-5)^2
+                // debug_stop == 5: always the double sweeps (A/B timing); a caller-set sweep tolerance (jdiag: 1e-17) asks for more
+                // than the refinement's 1e-9 and gets the sweeps too
+                bool refine_ok = (p.debug_stop != 5) && !(p.sweep_tol2 > 0.0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (mfma_row<T>(lane, t) == mcol) sLam[mcol] = accC[t].x / accG[t].x;
+                wsync();
+                C accZ[4];
+                T lam2[4];                                      // eigenvalue of this lane's row t, to second order
+                bool bad = false;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int row = mfma_row<T>(lane, t);
+                    const T di = sLam[row], dj = sLam[mcol];
+                    lam2[t] = (T)0;
+                    if (row == mcol) {
+                        accZ[t] = mk<T>((T)0.5 * ((T)1 - accG[t].x), (T)0);
+                    } else {
+                        const T den = dj - di;
+                        T inv = __builtin_amdgcn_rcp(den);
+                        inv = inv * __builtin_fma(-den, inv, (T)2);                  // one Newton step: full precision
+                        const T zx = __builtin_fma(-dj, accG[t].x, accC[t].x) * inv, zy = __builtin_fma(-dj, accG[t].y, accC[t].y) * inv;
+                        bad = bad || !(zx * zx + zy * zy <= (T)kRefineGuard2);      // NaN / inf (equal quotients) count as bad
+                        accZ[t] = mk<T>(zx, zy);
+                        // the rotation part of Z is G = Z + E/2; the Rayleigh quotient d_i misses -sum_j |G_ij|^2 (d_j - d_i)
+                        const T gx = __builtin_fma((T)0.5, accG[t].x, zx), gy = __builtin_fma((T)0.5, accG[t].y, zy);
+                        lam2[t] = -(gx * gx + gy * gy) * den;
+                    }
+                }
+                // sum over the 16 lanes that share this lane's rows (lane ^ 1, 2, 4, 8), then add the quotient itself
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    T v = lam2[t];
+                    v += xcol<1>(v);
+                    v += xcol<2>(v);
+                    v += xcol<4>(v);
+                    v += xrow<1>(v, lane);
+                    lam2[t] = v + sLam[mfma_row<T>(lane, t)];
+                }
+                refine_ok = refine_ok && !__any(bad);
+                if (refine_ok) {
+                    wsync();
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        sA[mfma_row<T>(lane, t) * LD + mcol] = accZ[t];
+                        if (mcol == 0) sLam[mfma_row<T>(lane, t)] = lam2[t];
+                    }
+                    wsync();
+                    cmm16([&](int r, int kx) { return sB[r * LD + kx]; }, [&](int kx, int c) { return sA[kx * LD + c]; }, lane, accV);   // V Z
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const C v = sB[mfma_row<T>(lane, t) * LD + mcol];
+                        accV[t] = mk<T>(v.x + accV[t].x, v.y + accV[t].y);                                                               // V''
+                    }
+                    wsync();
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        sA[mfma_row<T>(lane, t) * LD + mcol] = accV[t];             // Q for stage 5; sLam already holds the eigenvalues
+                        sB[i * LD + jq + 4 * t] = wrow[t];                          // W back in place for stage 5
+                    }
+                    wsync();
+                    refined = true;
+                } else {
                 wsync();
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
@@ -359,36 +335,39 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
                 }
                 wsync();
                 v_in_lds = true;
+                }
             }
         }
-        C tt = sA[a * LD + b], tb = sA[a * LD + 8 + b], bt = sA[(8 + a) * LD + b], bb = sA[(8 + a) * LD + 8 + b];
-        tt = mk<T>(tt.x * scl, tt.y * scl); tb = mk<T>(tb.x * scl, tb.y * scl);
-        bt = mk<T>(bt.x * scl, bt.y * scl); bb = mk<T>(bb.x * scl, bb.y * scl);
-        C v0t = mk<T>((2 * a == b) ? (T)1 : (T)0, 0), v0b = mk<T>((2 * a == 8 + b) ? (T)1 : (T)0, 0);
-        C v1t = mk<T>((2 * a + 1 == b) ? (T)1 : (T)0, 0), v1b = mk<T>((2 * a + 1 == 8 + b) ? (T)1 : (T)0, 0);
-        if (v_in_lds) {
-            v0t = sB[(2 * a) * LD + b]; v0b = sB[(2 * a) * LD + 8 + b];
-            v1t = sB[(2 * a + 1) * LD + b]; v1b = sB[(2 * a + 1) * LD + 8 + b];
+        if (!refined) {
+            C tt = sA[a * LD + b], tb = sA[a * LD + 8 + b], bt = sA[(8 + a) * LD + b], bb = sA[(8 + a) * LD + 8 + b];
+            tt = mk<T>(tt.x * scl, tt.y * scl); tb = mk<T>(tb.x * scl, tb.y * scl);
+            bt = mk<T>(bt.x * scl, bt.y * scl); bb = mk<T>(bb.x * scl, bb.y * scl);
+            C v0t = mk<T>((2 * a == b) ? (T)1 : (T)0, 0), v0b = mk<T>((2 * a == 8 + b) ? (T)1 : (T)0, 0);
+            C v1t = mk<T>((2 * a + 1 == b) ? (T)1 : (T)0, 0), v1b = mk<T>((2 * a + 1 == 8 + b) ? (T)1 : (T)0, 0);
+            if (v_in_lds) {
+                v0t = sB[(2 * a) * LD + b]; v0b = sB[(2 * a) * LD + 8 + b];
+                v1t = sB[(2 * a + 1) * LD + b]; v1b = sB[(2 * a + 1) * LD + 8 + b];
+                wsync();
+    #pragma unroll
+                for (int t = 0; t < 4; ++t) sB[i * LD + jq + 4 * t] = wrow[t];          // W back in place for stage 5
+            }
+            const bool diag = (a == b);
+            const int sweeps_done = jacobi16_sweeps<T>(tt, tb, bt, bb, v0t, v0b, v1t, v1b, srot, lane, tol2, normS2, max_sweeps, converged);
+            if (!converged) status = 2;
+            // after an odd number of sweeps slot s holds (2s, 2s+1), after an even number (s, 8+s)
+            const bool nat = sweeps_done & 1;
+            const int it_b = nat ? 2 * b : b, ib_b = nat ? 2 * b + 1 : 8 + b;
             wsync();
-#pragma unroll
-            for (int t = 0; t < 4; ++t) sB[i * LD + jq + 4 * t] = wrow[t];          // W back in place for stage 5
+            sA[(2 * a) * LD + it_b] = v0t;
+            sA[(2 * a) * LD + ib_b] = v0b;
+            sA[(2 * a + 1) * LD + it_b] = v1t;
+            sA[(2 * a + 1) * LD + ib_b] = v1b;
+            if (diag) {
+                sLam[it_b] = tt.x * iscl;
+                sLam[ib_b] = bb.x * iscl;
+            }
+            wsync();
         }
-        const bool diag = (a == b);
-        const int sweeps_done = jacobi16_sweeps<T>(tt, tb, bt, bb, v0t, v0b, v1t, v1b, srot, lane, tol2, normS2, max_sweeps, converged);
-        if (!converged) status = 2;
-        // after an odd number of sweeps slot s holds (2s, 2s+1), after an even number (s, 8+s)
-        const bool nat = sweeps_done & 1;
-        const int it_b = nat ? 2 * b : b, ib_b = nat ? 2 * b + 1 : 8 + b;
-        wsync();
-        sA[(2 * a) * LD + it_b] = v0t;
-        sA[(2 * a) * LD + ib_b] = v0b;
-        sA[(2 * a + 1) * LD + it_b] = v1t;
-        sA[(2 * a + 1) * LD + ib_b] = v1b;
-        if (diag) {
-            sLam[it_b] = tt.x * iscl;
-            sLam[ib_b] = bb.x * iscl;
-        }
-        wsync();
 
         // ---------------- stage 4: descending order ----------------
         if (lane < N) {

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define APV_ABI_VERSION 1
+#define APV_ABI_VERSION 2
 #define APV_MAX_RANKS 64     /* number of simultaneously produced ranks V (nV) */
 #define APV_MAX_N 64         /* largest GEVD order n = L handled on-chip */
 
@@ -93,6 +93,9 @@ typedef struct apv_config {
                                  0 = follow compute_dtype (APV_F64: everything float64, as the reference's lfilter / rfft /
                                  irfft are, apvast.py:171-192, 202-203, 461-496), 1 = float32, 2 = float64 */
     int32_t reserved[5];
+    double  sweep_tol2;       /* Jacobi stop threshold: a sweep whose pivots satisfy sum |c_pq|^2 <= sweep_tol2 ||C||_F^2 is the
+                                 last one (quadratic convergence leaves ~sweep_tol2^2 behind).  0 = default (1e-10 in float64,
+                                 1e-8 in float32); apv_jdiag_* always iterate to 1e-17 */
 } apv_config;
 
 /* ---- lifetime ---------------------------------------------------------- */
