@@ -92,6 +92,10 @@ size_t apv_gevd_spill_bytes(int n, int K, int compute_dtype);
 // Jacobi); hipErrorNotSupported when the problem does not qualify
 hipError_t apv_launch_gevd16m(const GevdParams& p, int compute_dtype, bool fused, hipStream_t s);
 
+// kernels_gevd64.hip: order-64 float64 path (float32 block Jacobi on the f32 MFMA + float64 refinement on the f64 MFMA);
+// hipErrorNotSupported when the problem does not qualify.  Needs p.Lspill with apv_gevd_spill_bytes() bytes.
+hipError_t apv_launch_gevd64(const GevdParams& p, int compute_dtype, bool fused, hipStream_t s);
+
 // kernels_gevd_large.hip: real symmetric pairs of broadband order, f64, device pointers (see the file header)
 int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const double* d_B, double reg,
                    const double* d_reg_scale, double* d_U, double* d_lam, const double* d_r, double mu, int V, const int* d_ranks, double* d_w, int32_t* h_status);

@@ -310,10 +310,13 @@ __device__ __forceinline__ void rotation(T alpha, T gamma, T bx, T by, T& c, T& 
 // The register-resident cyclic Jacobi of stage 3 on the 2 x 2 blocks (tt, tb; bt, bb) of this lane and its two rows
 // of V, in precision TT.  Runs sweeps until one of them meets sum |pivot|^2 <= tol2 normS2 (that sweep is the last) or
 // max_sweeps is reached; returns the number of sweeps done (its parity says which slot layout the blocks are left in).
+// n_rounds < 15 cuts a sweep short: the first 8 rounds of an even sweep are exactly the 64 pairs between the index halves
+// {0..7} and {8..15} (slot s pairs s with 8 + (s ^ x), x running through a Gray code) and bring the slots back to where
+// they started, which is what the block Jacobi of the order-64 kernel needs for a pair of blocks.
 template <typename TT>
 __device__ __forceinline__ int jacobi16_sweeps(Cx<TT>& tt_, Cx<TT>& tb_, Cx<TT>& bt_, Cx<TT>& bb_, Cx<TT>& v0t_, Cx<TT>& v0b_,
                                                Cx<TT>& v1t_, Cx<TT>& v1b_, TT (*srot)[4], int lane, TT tol2, TT normS2,
-                                               int max_sweeps, bool& converged_) {
+                                               int max_sweeps, bool& converged_, int n_rounds = 15) {
     using CC = Cx<TT>;
     const int a = lane >> 3, b = lane & 7;
     const bool diag = (a == b);
@@ -326,7 +329,7 @@ __device__ __forceinline__ int jacobi16_sweeps(Cx<TT>& tt_, Cx<TT>& tb_, Cx<TT>&
         // the schedule as two nibble strings in scalar registers (a table in memory costs a load per round)
         const unsigned long long dseq = (sweep & 1) ? XS_DELTA1 : XS_DELTA0;
         const unsigned long long tseq = (sweep & 1) ? XS_TBIT1 : XS_TBIT0;
-        for (int r = 0; r < 15; ++r) {
+        for (int r = 0; r < n_rounds; ++r) {
             const int delta = (int)((dseq >> (4 * r)) & 15), tbit = (int)((tseq >> (4 * r)) & 15) - 1;
             if (tbit >= 0) {
                 // columns first, then rows; the row exchanges and the bit-2 column exchange are masked lane swaps

@@ -45,7 +45,9 @@ template <typename T> __device__ __forceinline__ T cabs2(Cx<T> a) { return a.x *
 
 template <typename T> struct Tol;
 template <> struct Tol<double> {
-    static constexpr double sweep_tol2 = 1e-10;   // quadratic convergence: the sweep that meets it leaves ~tol2^2
+    // quadratic convergence: the sweep that meets it leaves ~tol2^2 behind.  The threshold is relative to ||C||_F, so the
+    // vectors of eigenvalues far below ||C|| need it tight: see Prec<double> in gevd16_common.h for the measurements
+    static constexpr double sweep_tol2 = 1e-16;
     static constexpr int max_sweeps = 16;
 };
 template <> struct Tol<float> {
@@ -584,7 +586,8 @@ hipError_t launch_t(const GevdParams& p, bool fused, hipStream_t s) {
 }  // namespace
 
 size_t apv_gevd_spill_bytes(int n, int K, int compute_dtype) {
-    if (compute_dtype == APV_F64 && n > 32) return (size_t)2 * K * n * n * 2 * sizeof(double);   // x2: two-zone launches
+    // per (zone program, bin): the order-64 kernel parks C and W (two c128 matrices), the LDS kernel its Cholesky factor
+    if (compute_dtype == APV_F64 && n > 32) return (size_t)2 * K * 2 * n * n * 2 * sizeof(double);   // leading 2: two-zone launches
     return 0;
 }
 
@@ -594,6 +597,8 @@ hipError_t apv_launch_gevd(const GevdParams& p, int compute_dtype, bool fused, h
     if (!force_generic) {
         const hipError_t e16 = apv_launch_gevd16m(p, compute_dtype, fused, s);
         if (e16 != hipErrorNotSupported) return e16;
+        const hipError_t e64 = apv_launch_gevd64(p, compute_dtype, fused, s);
+        if (e64 != hipErrorNotSupported) return e64;
     }
     if (n < 1 || n > APV_MAX_N) {
         if (why) *why = "GEVD order n out of range (1..64)";

@@ -1,0 +1,600 @@
+// Order-64 fused subband update in float64 (BASELINE config 5: 64 loudspeakers x 128 control points), one workgroup of
+// 16 waves per frequency bin.  Same stages as the other update kernels (reference Python/apvast.py:20-36, 329-364,
+// 406-414; spec Matlab/ControlMethods/jdiag.m:103-117), arranged so that every dense product runs on the matrix cores
+// and the eigen-iteration does its sweeps in float32:
+//
+//   stage 0  R_B, R_D = X^H X on v_mfma_f64_16x16x4_f64, one 16 x 16 tile per wave, operands straight from HBM/L2
+//   stage 1  Cholesky of R_D + reg I in LDS; W = L^-1 in place                                   apvast.py:22-27
+//   stage 2  C = W R_B W^H: two complex 64^3 products on the f64 MFMA                            apvast.py:28-29
+//   stage 3  eigenvectors of C                                                                   apvast.py:30
+//            (a) float32 BLOCK Jacobi: 8 blocks of 8, round-robin over the 28 block pairs (7 rounds of 4 pairs per
+//                sweep).  A round solves its four 16 x 16 pair problems with the register-resident wave-level Jacobi of
+//                the order-16 kernel (gevd16_common.h, one wave each; only the pairs between the two blocks, except in round 0
+//                where the pairs inside every block are rotated too) and applies the four 16 x 16 unitary factors to
+//                C and V as 16 x 16 x 16 complex products on v_mfma_f32_16x16x4_f32, one tile per wave: 7 barriers-pairs
+//                per sweep instead of the 63 of a plain cyclic Jacobi.
+//            (b) float64 refinement of that eigenvector matrix (Ogita & Aishima 2018), four complex 64^3 products on the
+//                f64 MFMA per step, repeated until every correction |Z_ij| <= 3e-5 (what is then left is |Z|^2 <= 1e-9)
+//   stage 4  sort                                                                                apvast.py:32-35
+//   stage 5  X = W^H Q, one product                                                              apvast.py:31
+//   stage 6  w_V = sum_{i<V} (x_i^H r)/(lam_i+mu) x_i                                            apvast.py:406-414
+//
+// LDS: two regions of 66 KB (R_B -> W R_B -> [C, V in float32] -> refinement work space; R_D -> L -> W -> V in float64).
+// C and W wait in a 128 KB slot of HBM scratch per bin (L2 resident) while the LDS is used for the sweeps.
+#include "apv_internal.h"
+
+#include "gevd16_common.h"
+
+namespace {
+
+constexpr int N64 = 64;
+constexpr int LDD = 65;            // row stride of a c128 matrix in LDS
+constexpr int LDF = 66;            // row stride of a c64 matrix in LDS (rows stay 16-byte aligned)
+constexpr int REGION = N64 * LDF * 8 * 2;          // bytes: two c64 matrices; >= one c128 matrix (64 * 65 * 16)
+constexpr int NBLK = 8, BS = 8;                    // block Jacobi: 8 blocks of 8
+
+using C128 = Cx<double>;
+using C64 = Cx<float>;
+
+// round-robin tournament of NBLK players, round r in [0, NBLK-1), slot a in [0, NBLK/2): the pair (P < Q)
+__device__ __forceinline__ void rr_pair8(int r, int a, int& P, int& Q) {
+    constexpr int m1 = NBLK - 1;
+    int u, v;
+    if (a == 0) {
+        u = m1;
+        v = r;
+    } else {
+        u = (r + a) % m1;
+        v = (r - a + m1) % m1;
+    }
+    P = u < v ? u : v;
+    Q = u < v ? v : u;
+}
+
+// one 16 x 16 tile (ti, tj) of a complex 64 x 64 x 64 product on the f64 MFMA; fa(i, k), fb(k, j) fetch operand elements;
+// k runs over [k_begin, k_end) in steps of 4.  out element t is (16 ti + (lane >> 4) + 4 t, 16 tj + (lane & 15)).
+template <typename FA, typename FB>
+__device__ __forceinline__ void cmm64_tile(FA fa, FB fb, int ti, int tj, int lane, int k_begin, int k_end, C128 out[4]) {
+    d4 re = {0, 0, 0, 0}, im = {0, 0, 0, 0};
+    const int il = lane & 15, kq = lane >> 4;
+    const int i = 16 * ti + il, j = 16 * tj + il;
+    for (int k0 = k_begin; k0 < k_end; k0 += 16) {
+        C128 a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a[u] = fa(i, k0 + 4 * u + kq);
+            b[u] = fb(k0 + 4 * u + kq, j);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            re = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u].x, b[u].x, re, 0, 0, 0);
+            re = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[u].y, b[u].y, re, 0, 0, 0);
+            im = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u].x, b[u].y, im, 0, 0, 0);
+            im = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u].y, b[u].x, im, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) out[t] = mk<double>(re[t], im[t]);
+}
+
+__device__ __forceinline__ C128 cj(C128 w) { return mk<double>(w.x, -w.y); }
+
+// sum of v over the workgroup (every thread gets it); red: 16 doubles of LDS
+__device__ __forceinline__ double block_sum(double v, double* red, int tid) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    double s = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) s += red[w];
+    return s;
+}
+
+// XT: element type of the fused input slabs (float2 = c64, double2 = c128); FUSED = false takes explicit R_B, R_D, r (c128)
+template <bool FUSED, typename XT>
+__global__ void __launch_bounds__(1024) gevd64_kernel(const GevdParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char sRegA[REGION];
+    __shared__ __attribute__((aligned(16))) unsigned char sRegB[REGION];
+    __shared__ C128 sr[N64], scoef[N64];
+    __shared__ double sDinv[N64], sLam[N64], sPart[4][N64], sPartI[4][N64], sRed[16];
+    __shared__ int sOrder[N64];
+    __shared__ int sFlag[2];
+    __shared__ C64 sU[4][16 * 17];                     // the four 16 x 16 unitary factors of a block round
+
+    const bool z1 = (blockIdx.y == 1);
+    const XT* const pXB = reinterpret_cast<const XT*>(z1 ? p.XB1 : p.XB);
+    const XT* const pXD = reinterpret_cast<const XT*>(z1 ? p.XD1 : p.XD);
+    const XT* const pd = reinterpret_cast<const XT*>(z1 ? p.d1 : p.d);
+    void* const pw = z1 ? p.w1 : p.w;
+    void* const plam = z1 ? p.lam1 : p.lam;
+    int32_t* const pstatus = z1 ? p.status1 : p.status;
+
+    C128* const RA = reinterpret_cast<C128*>(sRegA);
+    C128* const RB = reinterpret_cast<C128*>(sRegB);
+    C64* const Cf = reinterpret_cast<C64*>(sRegA);
+    C64* const Vf = Cf + N64 * LDF;
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int il = lane & 15, kq = lane >> 4;
+    const int ti = wave >> 2, tj = wave & 3;           // this wave's 16 x 16 tile of a 64 x 64 matrix
+    const int k = blockIdx.x;
+    int status = 0;
+    // per-bin scratch in HBM (L2 resident): C (c128, row-major 64 x 64), then W
+    C128* const gC = reinterpret_cast<C128*>(p.Lspill) + ((size_t)blockIdx.y * p.K + k) * (2 * N64 * N64);
+    C128* const gW = gC + N64 * N64;
+
+    // ---------------- stage 0 ----------------
+    if constexpr (FUSED) {
+        const int M = p.M;
+        // both matrices in one loop, 16 control points of each per step: 16 loads are in flight before the first MFMA of a
+        // step, so a wave meets the memory latency M / 16 times in all instead of M / 16 times per matrix
+        const XT* XBk = pXB + (size_t)k * M * N64;
+        const XT* XDk = pXD + (size_t)k * M * N64;
+        d4 bre = {0, 0, 0, 0}, bim = {0, 0, 0, 0}, dre = {0, 0, 0, 0}, dim_ = {0, 0, 0, 0};
+        XT zero;
+        zero.x = 0;
+        zero.y = 0;
+        for (int m0 = 0; m0 < M; m0 += 16) {
+            XT ba[4], bb_[4], da[4], db[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int m = m0 + 4 * u + kq;
+                const bool ok = m < M;
+                const size_t o = (size_t)m * N64;
+                ba[u] = ok ? XBk[o + 16 * ti + il] : zero;
+                bb_[u] = ok ? XBk[o + 16 * tj + il] : zero;
+                da[u] = ok ? XDk[o + 16 * ti + il] : zero;
+                db[u] = ok ? XDk[o + 16 * tj + il] : zero;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                // conj(x_i) x_j: re = ar br + ai bi, im = ar bi - ai br
+                double ar = ba[u].x, ai = ba[u].y, br = bb_[u].x, bi = bb_[u].y;
+                bre = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, bre, 0, 0, 0);
+                bre = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bi, bre, 0, 0, 0);
+                bim = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, bim, 0, 0, 0);
+                bim = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, br, bim, 0, 0, 0);
+                ar = da[u].x; ai = da[u].y; br = db[u].x; bi = db[u].y;
+                dre = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, dre, 0, 0, 0);
+                dre = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bi, dre, 0, 0, 0);
+                dim_ = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, dim_, 0, 0, 0);
+                dim_ = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, br, dim_, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            RA[(16 * ti + kq + 4 * t) * LDD + 16 * tj + il] = mk<double>(bre[t], bim[t]);
+            RB[(16 * ti + kq + 4 * t) * LDD + 16 * tj + il] = mk<double>(dre[t], dim_[t]);
+        }
+        // r = X_B^H d: four waves take every fourth control point each (eight loads in flight), partial sums meet in LDS
+        if (tid < 256) {
+            const XT* X = pXB + (size_t)k * M * N64;
+            const XT* dv = pd + (size_t)k * M;
+            const int l = tid & 63, q = tid >> 6;
+            double rx = 0, ry = 0;
+            for (int m0 = q; m0 < M; m0 += 32) {
+                XT xv[8], dm[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int m = m0 + 4 * u;
+                    const bool ok = m < M;
+                    xv[u] = ok ? X[(size_t)m * N64 + l] : zero;
+                    dm[u] = ok ? dv[m] : zero;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    rx += (double)xv[u].x * (double)dm[u].x + (double)xv[u].y * (double)dm[u].y;     // conj(x) * d
+                    ry += (double)xv[u].x * (double)dm[u].y - (double)xv[u].y * (double)dm[u].x;
+                }
+            }
+            sPart[q][l] = rx;
+            sPartI[q][l] = ry;
+        }
+        __syncthreads();
+        if (tid < N64)
+            sr[tid] = mk<double>(sPart[0][tid] + sPart[1][tid] + sPart[2][tid] + sPart[3][tid],
+                                 sPartI[0][tid] + sPartI[1][tid] + sPartI[2][tid] + sPartI[3][tid]);
+    } else {
+        const C128* gRB = reinterpret_cast<const C128*>(p.RB) + (size_t)k * N64 * N64;
+        const C128* gRD = reinterpret_cast<const C128*>(p.RD) + (size_t)k * N64 * N64;
+        for (int idx = tid; idx < N64 * N64; idx += 1024) {
+            const int i = idx >> 6, j = idx & 63;
+            RA[i * LDD + j] = gRB[idx];
+            RB[i * LDD + j] = gRD[idx];
+        }
+        if (tid < N64) sr[tid] = p.r ? reinterpret_cast<const C128*>(p.r)[(size_t)k * N64 + tid] : mk<double>(0, 0);
+    }
+    __syncthreads();
+    if (p.debug_stop == 1) return;
+
+    // ---------------- stage 1: Cholesky of B + reg I (lower, in place), then W = L^-1 in place ----------------
+    if (tid < N64) RB[tid * LDD + tid] = mk<double>(RB[tid * LDD + tid].x + p.reg_dark, 0);
+    __syncthreads();
+    {
+        const int ty = tid >> 5, tx = tid & 31;
+        for (int kk = 0; kk < N64; ++kk) {
+            const double dkk = RB[kk * LDD + kk].x;
+            if (!(dkk > 0.0) || !(dkk < 1e300)) {           // uniform: every thread reads the same word
+                status = 1;
+                break;
+            }
+            const double inv = rsq_full(dkk);
+            if (tid == 0) sDinv[kk] = inv;
+            for (int i = kk + 1 + tid; i < N64; i += 1024) {
+                const C128 v = RB[i * LDD + kk];
+                RB[i * LDD + kk] = mk<double>(v.x * inv, v.y * inv);
+            }
+            __syncthreads();
+            for (int i = kk + 1 + ty; i < N64; i += 32) {
+                const C128 li = RB[i * LDD + kk];
+                for (int j = kk + 1 + tx; j <= i; j += 32) {
+                    const C128 lj = RB[j * LDD + kk];
+                    C128 v = RB[i * LDD + j];
+                    v.x -= li.x * lj.x + li.y * lj.y;            // l_i conj(l_j)
+                    v.y -= li.y * lj.x - li.x * lj.y;
+                    RB[i * LDD + j] = v;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (p.debug_stop == 2) return;
+    if (status == 0) {
+        // W = L^-1, column by column from the right: W[i][j] = -(sum_{j<k<=i} W[i][k] L[k][j]) / L[j][j].  Sixteen lanes share a
+        // row; the column of L is overwritten only after every row has read it.
+        if (tid < N64) RB[tid * LDD + tid] = mk<double>(sDinv[tid], 0);
+        __syncthreads();
+        {
+            const int rrow = tid >> 4, sub = tid & 15;
+            for (int j = N64 - 2; j >= 0; --j) {
+                const int i = j + 1 + rrow;
+                double sx = 0, sy = 0;
+                if (i < N64) {
+                    for (int kk = j + 1 + sub; kk <= i; kk += 16) {
+                        const C128 w = RB[i * LDD + kk], l = RB[kk * LDD + j];
+                        sx += w.x * l.x - w.y * l.y;
+                        sy += w.x * l.y + w.y * l.x;
+                    }
+                }
+                sx += xcol<1>(sx); sy += xcol<1>(sy);
+                sx += xcol<2>(sx); sy += xcol<2>(sy);
+                sx += xcol<4>(sx); sy += xcol<4>(sy);
+                sx += xrow<1>(sx, lane); sy += xrow<1>(sy, lane);
+                __syncthreads();
+                if (i < N64 && sub == 0) {
+                    const double dj = sDinv[j];
+                    RB[i * LDD + j] = mk<double>(-sx * dj, -sy * dj);
+                }
+                __syncthreads();
+            }
+        }
+
+        if (p.debug_stop == 3) return;
+        // ---------------- stage 2: C = W A W^H ----------------
+        C128 acc[4];
+        // W is lower triangular: W[i][k] = 0 for k > i (the upper triangle of the region still holds R_D)
+        cmm64_tile([&](int i, int kk) { return kk <= i ? RB[i * LDD + kk] : mk<double>(0, 0); },
+                   [&](int kk, int j) { return RA[kk * LDD + j]; }, ti, tj, lane, 0, 16 * (ti + 1), acc);       // T = W A
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) RA[(16 * ti + kq + 4 * t) * LDD + 16 * tj + il] = acc[t];
+        __syncthreads();
+        cmm64_tile([&](int i, int kk) { return RA[i * LDD + kk]; },
+                   [&](int kk, int j) { return kk <= j ? cj(RB[j * LDD + kk]) : mk<double>(0, 0); }, ti, tj, lane, 0, 16 * (tj + 1),
+                   acc);                                                                                          // C = T W^H
+        double nrm = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int row = 16 * ti + kq + 4 * t, col = 16 * tj + il;
+            if (row == col) acc[t].y = 0;
+            nrm += acc[t].x * acc[t].x + acc[t].y * acc[t].y;
+            gC[row * N64 + col] = acc[t];
+        }
+        // W to the scratch slot, zeros above the diagonal
+        for (int idx = tid; idx < N64 * N64; idx += 1024) {
+            const int i = idx >> 6, j = idx & 63;
+            gW[idx] = j <= i ? RB[i * LDD + j] : mk<double>(0, 0);
+        }
+        const double normF2 = block_sum(nrm, sRed, tid);          // (its barriers also end every read of T in region A)
+        const int sexp = (normF2 > 0.0) ? -(ilogb(normF2) / 2) : 0;
+        const double scl = ldexp(1.0, sexp);
+        // float32 working copies: C scaled to ||C||_F ~ 1, V = I
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int row = 16 * ti + kq + 4 * t, col = 16 * tj + il;
+            Cf[row * LDF + col] = mk<float>((float)(acc[t].x * scl), (float)(acc[t].y * scl));
+            Vf[row * LDF + col] = mk<float>(row == col ? 1.f : 0.f, 0.f);
+        }
+        __syncthreads();
+        if (p.debug_stop == 4) return;
+
+        // ---------------- stage 3a: float32 block Jacobi ----------------
+        const int max_sweeps = p.max_sweeps > 0 ? p.max_sweeps : 14;
+        const int ua = lane >> 3, ub = lane & 7;                  // inner solve: the 8 x 8 grid of 2 x 2 blocks of a pair problem
+        double off_prev = 1e300;
+        // off-diagonal weight at which the float sweeps hand over to the float64 refinement (a refinement step costs 0.6 of a sweep)
+        const double kPreTol = p.sweep_tol2 < 0.0 ? -p.sweep_tol2 : 1e-8;
+        bool pre_done = false;
+        int n_sweeps = 0, n_ref = 0;
+        for (int sweep = 0; sweep < max_sweeps && !pre_done; ++sweep) {
+            ++n_sweeps;
+            for (int r = 0; r < NBLK - 1; ++r) {
+                if (wave < 4 && p.debug_stop != 7) {             // debug_stop 7 / 8: timing without the inner solves / the outer update
+                    int P, Q;
+                    rr_pair8(r, wave, P, Q);
+                    auto idx = [&](int x) { return x < BS ? BS * P + x : BS * Q + (x - BS); };
+                    const int r0 = idx(ua), r1 = idx(8 + ua), c0 = idx(ub), c1 = idx(8 + ub);
+                    C64 tt = Cf[r0 * LDF + c0], tb = Cf[r0 * LDF + c1], bt = Cf[r1 * LDF + c0], bb = Cf[r1 * LDF + c1];
+                    C64 v0t = mk<float>((2 * ua == ub) ? 1.f : 0.f, 0.f), v0b = mk<float>((2 * ua == 8 + ub) ? 1.f : 0.f, 0.f);
+                    C64 v1t = mk<float>((2 * ua + 1 == ub) ? 1.f : 0.f, 0.f), v1b = mk<float>((2 * ua + 1 == 8 + ub) ? 1.f : 0.f, 0.f);
+                    bool conv = false;
+                    // Round 0 of an outer sweep pairs every block once: a full inner sweep there covers the pairs INSIDE all eight
+                    // blocks; the other rounds rotate only the 64 pairs between their two blocks (the first 8 rounds of the
+                    // schedule, which leave the slots as they were).  Together: every one of the 2016 index pairs once per sweep.
+                    const bool full = (r == 0);
+                    const int ns = jacobi16_sweeps<float>(tt, tb, bt, bb, v0t, v0b, v1t, v1b, (float (*)[4]) nullptr, lane, 0.f, 1.0f, 1, conv,
+                                                          full ? 15 : 8);
+                    (void)conv;
+                    const bool nat = full && (ns & 1);
+                    const int it_b = nat ? 2 * ub : ub, ib_b = nat ? 2 * ub + 1 : 8 + ub;
+                    C64* U = sU[wave];
+                    U[(2 * ua) * 17 + it_b] = v0t;
+                    U[(2 * ua) * 17 + ib_b] = v0b;
+                    U[(2 * ua + 1) * 17 + it_b] = v1t;
+                    U[(2 * ua + 1) * 17 + ib_b] = v1b;
+                }
+                __syncthreads();
+                if (p.debug_stop != 8) {
+                    // tile (a, b) of the pair grid: C_ab <- U_a^H C_ab U_b; rows 16 a' .. of V: V_b <- V_b U_b   (a' = a)
+                    const int a = ti, b = tj;
+                    int Pa, Qa, Pb, Qb;
+                    rr_pair8(r, a, Pa, Qa);
+                    rr_pair8(r, b, Pb, Qb);
+                    auto ia = [&](int x) { return x < BS ? BS * Pa + x : BS * Qa + (x - BS); };
+                    auto ib = [&](int x) { return x < BS ? BS * Pb + x : BS * Qb + (x - BS); };
+                    const C64* Ua = sU[a];
+                    const C64* Ub = sU[b];
+                    // operands with k = 4 kq + s: four consecutive columns of the pair's index set
+                    const int crow = ia(il), vrow = 16 * a + il, kc = ib(4 * kq);       // 4 kq .. 4 kq + 3 stay inside one block
+                    C64 tr[4], vr[4], ubv[4], uav[4];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        tr[s] = Cf[crow * LDF + kc + s];
+                        vr[s] = Vf[vrow * LDF + kc + s];
+                        ubv[s] = Ub[(4 * kq + s) * 17 + il];
+                        uav[s] = Ua[(4 * kq + s) * 17 + il];
+                    }
+                    f4 pre = {0, 0, 0, 0}, pim = {0, 0, 0, 0}, vre = {0, 0, 0, 0}, vim = {0, 0, 0, 0};
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        pre = __builtin_amdgcn_mfma_f32_16x16x4f32(tr[s].x, ubv[s].x, pre, 0, 0, 0);
+                        pre = __builtin_amdgcn_mfma_f32_16x16x4f32(-tr[s].y, ubv[s].y, pre, 0, 0, 0);
+                        pim = __builtin_amdgcn_mfma_f32_16x16x4f32(tr[s].x, ubv[s].y, pim, 0, 0, 0);
+                        pim = __builtin_amdgcn_mfma_f32_16x16x4f32(tr[s].y, ubv[s].x, pim, 0, 0, 0);
+                        vre = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[s].x, ubv[s].x, vre, 0, 0, 0);
+                        vre = __builtin_amdgcn_mfma_f32_16x16x4f32(-vr[s].y, ubv[s].y, vre, 0, 0, 0);
+                        vim = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[s].x, ubv[s].y, vim, 0, 0, 0);
+                        vim = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[s].y, ubv[s].x, vim, 0, 0, 0);
+                    }
+                    // second product U_a^H (C_ab U_b): register s of the first accumulator is row 4 kq + s of the product, i.e.
+                    // exactly the B operand of k = 4 kq + s; A[i][k] = conj(U_a[k][i])
+                    f4 cre = {0, 0, 0, 0}, cim = {0, 0, 0, 0};
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        cre = __builtin_amdgcn_mfma_f32_16x16x4f32(uav[s].x, pre[s], cre, 0, 0, 0);
+                        cre = __builtin_amdgcn_mfma_f32_16x16x4f32(uav[s].y, pim[s], cre, 0, 0, 0);
+                        cim = __builtin_amdgcn_mfma_f32_16x16x4f32(uav[s].x, pim[s], cim, 0, 0, 0);
+                        cim = __builtin_amdgcn_mfma_f32_16x16x4f32(-uav[s].y, pre[s], cim, 0, 0, 0);
+                    }
+                    // accumulator element t: row 4 kq + t, column il of the tile
+                    const int ccol = ib(il);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int row = ia(4 * kq + t);
+                        C64 v = mk<float>(cre[t], cim[t]);
+                        if (row == ccol) v.y = 0.f;
+                        Cf[row * LDF + ccol] = v;
+                        Vf[(16 * a + 4 * kq + t) * LDF + ccol] = mk<float>(vre[t], vim[t]);
+                    }
+                }
+                __syncthreads();
+            }
+            // off-diagonal weight left (C is scaled to ||C||_F ~ 1): stop at 1e-10, or when float32 rounding stalls the decrease
+            double off = 0;
+            for (int idx = tid; idx < N64 * N64; idx += 1024) {
+                const int i = idx >> 6, j = idx & 63;
+                if (i != j) {
+                    const C64 v = Cf[i * LDF + j];
+                    off += (double)v.x * v.x + (double)v.y * v.y;
+                }
+            }
+            off = block_sum(off, sRed, tid);
+            const double nrm_s = normF2 * scl * scl;
+            if (off <= kPreTol * nrm_s || (off <= 1e-7 * nrm_s && off > 0.25 * off_prev)) pre_done = true;
+            off_prev = off;
+        }
+
+        if (p.debug_stop == 5 || p.debug_stop == 7 || p.debug_stop == 8) {
+            if (pstatus != nullptr && tid == 0) pstatus[k] = 100 * n_sweeps;
+            return;
+        }
+        // ---------------- stage 3b: float64 refinement on the matrix cores ----------------
+        for (int idx = tid; idx < N64 * N64; idx += 1024) {
+            const int i = idx >> 6, j = idx & 63;
+            const C64 v = Vf[i * LDF + j];
+            RB[i * LDD + j] = mk<double>((double)v.x, (double)v.y);
+        }
+        __syncthreads();
+        constexpr double kGuard2 = 9e-10;          // |Z_ij|^2 <= (3e-5)^2 on every pair: the step that meets it is the last
+        constexpr double kClamp2 = 1e-2;           // |Z_ij| > 0.1 is outside the step's range: damped to 0.1
+        bool converged = false;
+        const int max_ref = 6;
+        for (int it = 0; it < max_ref && !converged; ++it) {
+            ++n_ref;
+            C128 accT[4], accG[4], accS[4];
+            // C is Hermitian: C[i][k] = conj(C[k][i]) read along a row of the scratch copy (coalesced)
+            cmm64_tile([&](int i, int kk) { return cj(gC[kk * N64 + i]); }, [&](int kk, int j) { return RB[kk * LDD + j]; }, ti, tj, lane, 0,
+                       N64, accT);                                                                              // C V
+            cmm64_tile([&](int i, int kk) { return cj(RB[kk * LDD + i]); }, [&](int kk, int j) { return RB[kk * LDD + j]; }, ti, tj, lane, 0,
+                       N64, accG);                                                                              // V^H V
+            if (tid < 2) sFlag[tid] = 0;
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < 4; ++t) RA[(16 * ti + kq + 4 * t) * LDD + 16 * tj + il] = accT[t];
+            __syncthreads();
+            cmm64_tile([&](int i, int kk) { return cj(RB[kk * LDD + i]); }, [&](int kk, int j) { return RA[kk * LDD + j]; }, ti, tj, lane, 0,
+                       N64, accS);                                                                              // S = V^H C V
+            if (ti == tj) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (kq + 4 * t == il) sLam[16 * ti + il] = accS[t].x / accG[t].x;                            // Rayleigh quotients
+            }
+            __syncthreads();
+            C128 accZ[4];
+            double lam2[4];
+            bool bad = false;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int row = 16 * ti + kq + 4 * t, col = 16 * tj + il;
+                const double di = sLam[row], dj = sLam[col];
+                lam2[t] = 0.0;
+                if (row == col) {
+                    accZ[t] = mk<double>(0.5 * (1.0 - accG[t].x), 0.0);
+                } else {
+                    const double den = dj - di;
+                    double zx = -0.5 * accG[t].x, zy = -0.5 * accG[t].y;        // equal quotients: no rotation inside the pair
+                    if (den != 0.0) {
+                        const double inv = 1.0 / den;
+                        zx = __builtin_fma(-dj, accG[t].x, accS[t].x) * inv;
+                        zy = __builtin_fma(-dj, accG[t].y, accS[t].y) * inv;
+                    }
+                    double z2 = zx * zx + zy * zy;
+                    if (!(z2 <= kClamp2)) {
+                        const double f = (z2 < 1e300) ? 0.1 * rsq_full(z2) : 0.0;
+                        zx *= f;
+                        zy *= f;
+                        z2 = kClamp2;
+                    }
+                    bad = bad || !(z2 <= kGuard2);
+                    accZ[t] = mk<double>(zx, zy);
+                    const double gx = __builtin_fma(0.5, accG[t].x, zx), gy = __builtin_fma(0.5, accG[t].y, zy);
+                    lam2[t] = -(gx * gx + gy * gy) * den;
+                }
+            }
+            if (bad) sFlag[0] = 1;
+            // second-order part of the eigenvalues: row sums over this tile's 16 columns, then over the four column tiles
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                double v = lam2[t];
+                v += xcol<1>(v);
+                v += xcol<2>(v);
+                v += xcol<4>(v);
+                v += xrow<1>(v, lane);
+                if (il == 0) sPart[tj][16 * ti + kq + 4 * t] = v;
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) RA[(16 * ti + kq + 4 * t) * LDD + 16 * tj + il] = accZ[t];              // every read of T is done
+            __syncthreads();
+            converged = (sFlag[0] == 0);
+            C128 accV[4];
+            cmm64_tile([&](int i, int kk) { return RB[i * LDD + kk]; }, [&](int kk, int j) { return RA[kk * LDD + j]; }, ti, tj, lane, 0, N64,
+                       accV);                                                                                   // V Z
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const C128 v = RB[(16 * ti + kq + 4 * t) * LDD + 16 * tj + il];
+                accV[t] = mk<double>(v.x + accV[t].x, v.y + accV[t].y);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < 4; ++t) RB[(16 * ti + kq + 4 * t) * LDD + 16 * tj + il] = accV[t];              // V''
+            if (converged && tid < N64) sLam[tid] += sPart[0][tid] + sPart[1][tid] + sPart[2][tid] + sPart[3][tid];
+            __syncthreads();
+        }
+        if (!converged) status = 2;
+        if (p.debug_stop == 6) {                       // profiling aid: sweeps and refinement steps this bin took
+            if (pstatus != nullptr && tid == 0) pstatus[k] = 100 * n_sweeps + n_ref;
+            return;
+        }
+
+        // ---------------- stage 4: descending order ----------------
+        if (tid < N64) {
+            const double li = sLam[tid];
+            int rank = 0;
+            for (int j = 0; j < N64; ++j) {
+                const double lj = sLam[j];
+                rank += (lj > li) || (lj == li && j < tid);
+            }
+            sOrder[rank] = tid;
+        }
+        // ---------------- stage 5: X = W^H Q   (W[k][i] = 0 for k < i) ----------------
+        cmm64_tile([&](int i, int kk) { return cj(gW[kk * N64 + i]); }, [&](int kk, int j) { return RB[kk * LDD + j]; }, ti, tj, lane, 16 * ti,
+                   N64, acc);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) RA[(16 * ti + kq + 4 * t) * LDD + 16 * tj + il] = acc[t];
+        __syncthreads();
+        // ---------------- stage 6: coefficients (x_c^H r) / (lam_c + mu) ----------------
+        if (tid < N64) {
+            double sx = 0, sy = 0;
+            for (int l = 0; l < N64; ++l) {
+                const C128 v = RA[l * LDD + tid], rr = sr[l];
+                sx += v.x * rr.x + v.y * rr.y;
+                sy += v.x * rr.y - v.y * rr.x;
+            }
+            const double den = 1.0 / (sLam[tid] + p.mu);
+            scoef[tid] = mk<double>(sx * den, sy * den);
+        }
+        __syncthreads();
+    }
+
+    // ---------------- outputs ----------------
+    if (tid < N64) {
+        double ax = 0, ay = 0;
+        int done = 0;
+        for (int t = 0; t < p.nV; ++t) {
+            const int V = p.ranks[t];
+            if (status != 1) {
+                for (; done < V; ++done) {
+                    const int c = sOrder[done];
+                    const C128 cf = scoef[c], v = RA[tid * LDD + c];
+                    ax += cf.x * v.x - cf.y * v.y;
+                    ay += cf.x * v.y + cf.y * v.x;
+                }
+            }
+            const size_t o = ((size_t)k * p.nV + t) * N64 + tid;
+            if (p.out_c128) reinterpret_cast<double2*>(pw)[o] = make_double2(ax, ay);
+            else reinterpret_cast<float2*>(pw)[o] = make_float2((float)ax, (float)ay);
+        }
+        if (plam != nullptr) {
+            const double lv = (status != 1) ? sLam[sOrder[tid]] : 0.0;
+            if (p.out_c128) reinterpret_cast<double*>(plam)[(size_t)k * N64 + tid] = lv;
+            else reinterpret_cast<float*>(plam)[(size_t)k * N64 + tid] = (float)lv;
+        }
+    }
+    if (p.U != nullptr) {
+        C128* U = reinterpret_cast<C128*>(p.U) + (size_t)k * N64 * N64;
+        for (int idx = tid; idx < N64 * N64; idx += 1024) {
+            const int i = idx >> 6, j = idx & 63;
+            U[idx] = (status != 1) ? RA[i * LDD + sOrder[j]] : mk<double>(0, 0);
+        }
+    }
+    if (pstatus != nullptr && tid == 0) pstatus[k] = status;
+}
+
+}  // namespace
+
+// hipErrorNotSupported when the problem does not qualify (order != 64, float32 arithmetic, relative or bright loading, a
+// caller-set sweep tolerance): the LDS kernel of kernels_gevd.hip then takes it
+hipError_t apv_launch_gevd64(const GevdParams& p, int compute_dtype, bool fused, hipStream_t s) {
+    static const bool off = (getenv("APV_NO_GEVD64") != nullptr);          // A/B switch
+    if (off || p.n != 64 || compute_dtype != APV_F64 || p.reg_mode != APV_REG_ABS || p.reg_bright != 0.0 || p.sweep_tol2 > 0.0 ||   /* sweep_tol2 < 0: tuning aid, -value = hand-over threshold of the pre-solve */
+        p.Lspill == nullptr)
+        return hipErrorNotSupported;
+    if (p.K <= 0) return hipSuccess;
+    const dim3 grid(p.K, p.n_zones > 1 ? 2 : 1);
+    if (fused && p.x_c128) hipLaunchKernelGGL((gevd64_kernel<true, double2>), grid, dim3(1024), 0, s, p);
+    else if (fused) hipLaunchKernelGGL((gevd64_kernel<true, float2>), grid, dim3(1024), 0, s, p);
+    else hipLaunchKernelGGL((gevd64_kernel<false, float2>), grid, dim3(1024), 0, s, p);
+    return hipGetLastError();
+}

@@ -25,7 +25,7 @@ def pressure_matching(XB, XD, d, mu, reg):
 
 
 @pytest.mark.parametrize("K,L,M,dtype", [(32 * 1024, 16, 32, "f64"), (32 * 1024, 16, 32, "f32"), (512, 16, 32, "f64"),
-                                         (2048, 64, 128, "f32")])
+                                         (2048, 64, 128, "f32"), (2048, 64, 128, "f64")])
 def test_full_size_properties(K, L, M, dtype):
     from ap_vast_unofficial_amd import Engine
     rng = np.random.default_rng(K + L)
@@ -45,7 +45,7 @@ def test_full_size_properties(K, L, M, dtype):
     # vectorised oracle on every bin (all three ranks)
     w_ref, lam_ref = subband.update_vectorised(XB, XD, d, mu, [1, L // 2, L], reg=reg)
     lt = 1e-9 if dtype == "f64" else 1e-5
-    assert (np.abs(lam - lam_ref) / lam_ref[:, :1]).max() < lt * (10 if L == 64 else 1)
+    assert (np.abs(lam - lam_ref) / lam_ref[:, :1]).max() < lt * (10 if (L == 64 and dtype == "f32") else 1)
     errw = np.linalg.norm(w - w_ref, axis=-1) / np.linalg.norm(w_ref, axis=-1)
     if dtype == "f64":
         assert errw.max() < tol, errw.max()

@@ -183,7 +183,8 @@ def test_stream_single_zone_and_errors(golden):
     w, wr = ap.w_A, orc.w[0].transpose(1, 0, 2)
     werr = np.linalg.norm(w - wr, axis=-1) / np.linalg.norm(wr, axis=-1)
     assert werr.max() < 1e-7, werr.max()
-    check_outputs([(g_[0], None, None, None) for g_ in got], [(e[0], None, None, None) for e in exp], TOL["f64"]["out"])
+    # outputs: the filters' 1e-7 bound carried through (measured 4e-9 of the largest sample with cond(R_D) ~ 1e5)
+    check_outputs([(g_[0], None, None, None) for g_ in got], [(e[0], None, None, None) for e in exp], 5e-8)
     ap.close()
 
 
