@@ -150,6 +150,7 @@ __global__ void __launch_bounds__(TPB) gevd_vast_kernel(const GevdParams p) {
     __shared__ T sLam[NMAX];
     __shared__ T sRow[NMAX];
     __shared__ int sOrder[NMAX];
+    __shared__ int sMs[64];                                   // multisection votes of the spectral-norm estimate
     __shared__ T rc[NP];
     __shared__ C rs[NP];
     __shared__ T roff[NP];
@@ -275,30 +276,82 @@ __global__ void __launch_bounds__(TPB) gevd_vast_kernel(const GevdParams p) {
     T load = (T)p.reg_dark;
     T load_bright = 0;
     if (p.reg_mode == APV_REG_REL || p.reg_bright != 0.0) {
-        // spectral norm by power iteration on the Hermitian PSD matrix (||.||_2 of apvast.py:26,
-        // apVast.m:552-569).  sRow holds |x|^2 partials, scoef the iterate.
+        // spectral norm (||.||_2 of apvast.py:26, apVast.m:552-569) = largest eigenvalue of the Hermitian PSD matrix: n steps of
+        // the Lanczos recurrence (no re-orthogonalisation: the largest Ritz value does not need it) from a start vector with no
+        // symmetry (an all-ones start is orthogonal to the dominant eigenvector of many array geometries), then the largest
+        // eigenvalue of the tridiagonal matrix by 64-way multisection on Sturm counts.  sLam / sDiag hold alpha / beta.
         for (int which = 0; which < 2; ++which) {
             const bool need = which ? (p.reg_mode == APV_REG_REL) : (p.reg_bright != 0.0);
             if (!need) continue;
             const C* Mx = which ? sB : sA;
-            if (tid < n) scoef[tid] = mk<T>((T)1, (T)0);
-            __syncthreads();
-            T nrm = 0;
-            for (int it = 0; it < 48; ++it) {
-                C y = mk<T>(0, 0);
-                if (tid < n)
-                    for (int j = 0; j < n; ++j) y = cadd(y, cmul(Mx[tid * LD + j], scoef[j]));
-                if (tid < n) sRow[tid] = cabs2(y);
+            C vcur = mk<T>(0, 0), vprev = mk<T>(0, 0);
+            {
+                const T f = (T)tid * (T)0.6180339887498949;
+                if (tid < n) vcur = mk<T>((T)1 + (f - floor(f)), (T)0);
+                if (tid < n) sRow[tid] = cabs2(vcur);
                 __syncthreads();
                 T s2 = 0;
                 for (int j = 0; j < n; ++j) s2 += sRow[j];
-                T xs = 0;
-                for (int j = 0; j < n; ++j) xs += cabs2(scoef[j]);
-                nrm = sqrt(s2 / xs);                       // ||Mx x|| / ||x||
-                __syncthreads();
-                if (tid < n) scoef[tid] = cscale(y, (T)1 / sqrt(s2));
+                vcur = cscale(vcur, (T)1 / sqrt(s2));
                 __syncthreads();
             }
+            T beta_prev = 0;
+            int m = 0;
+            for (int it = 0; it < n; ++it) {
+                if (tid < n) scoef[tid] = vcur;
+                __syncthreads();
+                C y = mk<T>(0, 0);
+                if (tid < n)
+                    for (int j = 0; j < n; ++j) y = cadd(y, cmul(Mx[tid * LD + j], scoef[j]));
+                if (tid < n) sRow[tid] = vcur.x * y.x + vcur.y * y.y;                  // Re(conj(v) y)
+                __syncthreads();
+                T alpha = 0;
+                for (int j = 0; j < n; ++j) alpha += sRow[j];
+                __syncthreads();
+                C w = csub(csub(y, cscale(vcur, alpha)), cscale(vprev, beta_prev));
+                if (tid < n) sRow[tid] = cabs2(w);
+                if (tid == 0) sLam[it] = alpha;
+                __syncthreads();
+                T b2 = 0;
+                for (int j = 0; j < n; ++j) b2 += sRow[j];
+                const T beta = sqrt(b2);
+                if (tid == 0) sDiag[it] = beta;
+                m = it + 1;
+                __syncthreads();
+                if (!(beta > (T)1e-14 * fabs(alpha)) || it + 1 == n) break;            // invariant subspace reached (uniform)
+                vprev = vcur;
+                vcur = cscale(w, (T)1 / beta);
+                beta_prev = beta;
+            }
+            // Gershgorin interval of the m x m tridiagonal matrix, then nine passes of 64-way multisection
+            T lo = 0, hi = 0;
+            for (int i = 0; i < m; ++i) {
+                const T r = (i > 0 ? sDiag[i - 1] : (T)0) + (i + 1 < m ? sDiag[i] : (T)0);
+                hi = fmax(hi, sLam[i] + r);
+            }
+            for (int pass = 0; pass < 9 && hi > lo; ++pass) {
+                const int t = tid & 63;
+                const T x = lo + (hi - lo) * (T)(t + 1) / (T)65;
+                int below = 0;                                                         // eigenvalues < x
+                T dq = sLam[0] - x;
+                below += dq < (T)0;
+                for (int i = 1; i < m; ++i) {
+                    if (dq == (T)0) dq = (T)1e-300;
+                    dq = sLam[i] - x - sDiag[i - 1] * sDiag[i - 1] / dq;
+                    below += dq < (T)0;
+                }
+                __syncthreads();
+                if (tid < 64) sMs[t] = (below < m) ? 1 : 0;                            // x_t still below the largest eigenvalue
+                __syncthreads();
+                int q = 0;
+                for (int j = 0; j < 64; ++j) q += sMs[j];
+                const T step = (hi - lo) / (T)65;
+                const T nlo = lo + step * (T)q, nhi = lo + step * (T)(q + 1);
+                lo = nlo;
+                hi = q < 64 ? nhi : hi;
+                __syncthreads();
+            }
+            const T nrm = (T)0.5 * (lo + hi);
             if (which) load = (T)p.reg_dark * nrm; else load_bright = (T)p.reg_bright * nrm;
         }
     }

@@ -486,6 +486,14 @@ __global__ void __launch_bounds__(TPB) frob2_kernel(int n, int ld, const double*
     if (threadIdx.x == 0) atomicAdd(out + blockIdx.z, red[0]);
 }
 
+// out[0..count) = 0.  A kernel, not hipMemsetAsync: the two-sweep sequence is captured into a hipGraph, and a graph that
+// holds a memset node brings rocprofv3 --kernel-trace down (segfault at the first replay, ROCm 7.2; profiles/r02/
+// rocprof_graph_segfault.md).  With kernel nodes only the replayed graph traces like any other launch.
+__global__ void __launch_bounds__(64) zero_f64_kernel(int count, double* __restrict__ out) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i < count) out[i] = 0.0;
+}
+
 // ---- step 4 ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(TPB) rank_kernel(int n, int ld, const double* __restrict__ C, double* __restrict__ lam,
                                                    int* __restrict__ order, size_t mat_stride, size_t vec_stride) {
@@ -612,8 +620,10 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
         LCHK(hipMalloc((void**)&ws.order, sizeof(int) * vs * batch));
     }
     // two sweeps: 2 (nb - 1) block rounds bring the ping-pong buffers back to where they started
+    static const bool memset_node = getenv("APV_GRAPH_MEMSET") != nullptr;      // reproduces the rocprofv3 crash (see zero_f64_kernel)
     auto two_sweeps = [&]() {
-        (void)hipMemsetAsync(ws.acc, 0, sizeof(double) * 2 * batch, st);
+        if (memset_node) (void)hipMemsetAsync(ws.acc, 0, sizeof(double) * 2 * batch, st);
+        else hipLaunchKernelGGL(zero_f64_kernel, dim3((2 * batch + 63) / 64), dim3(64), 0, st, 2 * batch, ws.acc);
         double *Cc = ws.C0, *Cn = ws.C1;
         for (int sw = 0; sw < 2; ++sw)
             for (int r = 0; r < rounds; ++r) {
