@@ -95,6 +95,7 @@ hipError_t apv_launch_gevd16m(const GevdParams& p, int compute_dtype, bool fused
 // kernels_gevd64.hip: order-64 float64 path (float32 block Jacobi on the f32 MFMA + float64 refinement on the f64 MFMA);
 // hipErrorNotSupported when the problem does not qualify.  Needs p.Lspill with apv_gevd_spill_bytes() bytes.
 hipError_t apv_launch_gevd64(const GevdParams& p, int compute_dtype, bool fused, hipStream_t s);
+size_t apv_gevd64_slot_bytes();          // scratch per (zone program, bin)
 
 // kernels_gevd_large.hip: real symmetric pairs of broadband order, f64, device pointers (see the file header)
 int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const double* d_B, double reg,

@@ -639,8 +639,8 @@ hipError_t launch_t(const GevdParams& p, bool fused, hipStream_t s) {
 }  // namespace
 
 size_t apv_gevd_spill_bytes(int n, int K, int compute_dtype) {
-    // per (zone program, bin): the order-64 kernel parks C and W (two c128 matrices), the LDS kernel its Cholesky factor
-    if (compute_dtype == APV_F64 && n > 32) return (size_t)2 * K * 2 * n * n * 2 * sizeof(double);   // leading 2: two-zone launches
+    // per (zone program, bin): the order-64 kernel parks C, W (c128) and a float32 matrix; the LDS kernel its Cholesky factor
+    if (compute_dtype == APV_F64 && n > 32) return (size_t)2 * K * apv_gevd64_slot_bytes();   // leading 2: two-zone launches
     return 0;
 }
 

@@ -242,47 +242,41 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
                 for (int t = 0; t < 4; ++t)
                     if (mfma_row<T>(lane, t) == mcol) sLam[mcol] = accC[t].x / accG[t].x;
                 wsync();
-                C accZ[4];
-                T lam2[4];                                      // eigenvalue of this lane's row t, to second order
+                // Z goes straight into sA (T = C V is spent: every lane is past the third product) and the second-order
+                // eigenvalue terms into the idle coefficient array: nothing of this step stays in registers
+                T* const sLam2 = reinterpret_cast<T*>(&scoef[0]);
                 bool bad = false;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const int row = mfma_row<T>(lane, t);
                     const T di = sLam[row], dj = sLam[mcol];
-                    lam2[t] = (T)0;
+                    T l2 = (T)0;
+                    C z;
                     if (row == mcol) {
-                        accZ[t] = mk<T>((T)0.5 * ((T)1 - accG[t].x), (T)0);
+                        z = mk<T>((T)0.5 * ((T)1 - accG[t].x), (T)0);
                     } else {
                         const T den = dj - di;
                         T inv = __builtin_amdgcn_rcp(den);
                         inv = inv * __builtin_fma(-den, inv, (T)2);                  // one Newton step: full precision
                         const T zx = __builtin_fma(-dj, accG[t].x, accC[t].x) * inv, zy = __builtin_fma(-dj, accG[t].y, accC[t].y) * inv;
                         bad = bad || !(zx * zx + zy * zy <= (T)kRefineGuard2);      // NaN / inf (equal quotients) count as bad
-                        accZ[t] = mk<T>(zx, zy);
+                        z = mk<T>(zx, zy);
                         // the rotation part of Z is G = Z + E/2; the Rayleigh quotient d_i misses -sum_j |G_ij|^2 (d_j - d_i)
                         const T gx = __builtin_fma((T)0.5, accG[t].x, zx), gy = __builtin_fma((T)0.5, accG[t].y, zy);
-                        lam2[t] = -(gx * gx + gy * gy) * den;
+                        l2 = -(gx * gx + gy * gy) * den;
                     }
-                }
-                // sum over the 16 lanes that share this lane's rows (lane ^ 1, 2, 4, 8), then add the quotient itself
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    T v = lam2[t];
-                    v += xcol<1>(v);
-                    v += xcol<2>(v);
-                    v += xcol<4>(v);
-                    v += xrow<1>(v, lane);
-                    lam2[t] = v + sLam[mfma_row<T>(lane, t)];
+                    sA[row * LD + mcol] = z;
+                    // sum over the 16 lanes that share this row (lane ^ 1, 2, 4, 8), then add the quotient itself
+                    l2 += xcol<1>(l2);
+                    l2 += xcol<2>(l2);
+                    l2 += xcol<4>(l2);
+                    l2 += xrow<1>(l2, lane);
+                    if (mcol == 0) sLam2[row] = l2 + di;
                 }
                 refine_ok = refine_ok && !__any(bad);
                 if (refine_ok) {
                     wsync();
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        sA[mfma_row<T>(lane, t) * LD + mcol] = accZ[t];
-                        if (mcol == 0) sLam[mfma_row<T>(lane, t)] = lam2[t];
-                    }
-                    wsync();
+                    if (lane < N) sLam[lane] = sLam2[lane];
                     cmm16([&](int r, int kx) { return sB[r * LD + kx]; }, [&](int kx, int c) { return sA[kx * LD + c]; }, lane, accV);   // V Z
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {

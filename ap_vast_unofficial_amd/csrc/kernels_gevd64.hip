@@ -20,7 +20,12 @@
 //   stage 6  w_V = sum_{i<V} (x_i^H r)/(lam_i+mu) x_i                                            apvast.py:406-414
 //
 // LDS: two regions of 66 KB (R_B -> W R_B -> [C, V in float32] -> refinement work space; R_D -> L -> W -> V in float64).
-// C and W wait in a 128 KB slot of HBM scratch per bin (L2 resident) while the LDS is used for the sweeps.
+// C and W wait in a slot of HBM scratch per bin (L2 resident) while the LDS is used for the sweeps.
+//
+// Two kernels share the stages.  gevd64_kernel: one bin per workgroup.  gevd64x2_kernel: TWO bins per workgroup; the
+// float64 stages run for one bin after the other, but the float32 sweeps of the two bins (66 KB each: both fit) are
+// interleaved: while four waves solve the pair problems of one bin (latency bound, one wave per SIMD), the other twelve
+// apply the previous round's factors of the other bin on the matrix cores (the Hermitian half of C only, mirrored).
 #include "apv_internal.h"
 
 #include "gevd16_common.h"
@@ -91,38 +96,45 @@ __device__ __forceinline__ double block_sum(double v, double* red, int tid) {
     return s;
 }
 
-// XT: element type of the fused input slabs (float2 = c64, double2 = c128); FUSED = false takes explicit R_B, R_D, r (c128)
-template <bool FUSED, typename XT>
-__global__ void __launch_bounds__(1024) gevd64_kernel(const GevdParams p) {
-    __shared__ __attribute__((aligned(16))) unsigned char sRegA[REGION];
-    __shared__ __attribute__((aligned(16))) unsigned char sRegB[REGION];
-    __shared__ C128 sr[N64], scoef[N64];
-    __shared__ double sDinv[N64], sLam[N64], sPart[4][N64], sPartI[4][N64], sRed[16];
-    __shared__ int sOrder[N64];
-    __shared__ int sFlag[2];
-    __shared__ C64 sU[4][16 * 17];                     // the four 16 x 16 unitary factors of a block round
 
-    const bool z1 = (blockIdx.y == 1);
+// ---- shared memory of a workgroup, handed to the stage functions ------------------------------------------------------
+struct Sh {
+    unsigned char* regA;
+    unsigned char* regB;
+    C128* sr;
+    C128* scoef;
+    double* sDinv;
+    double* sLam;
+    double (*sPart)[N64];
+    double (*sPartI)[N64];
+    double* sRed;
+    int* sOrder;
+    int* sFlag;
+};
+
+constexpr size_t SLOT_BYTES = (size_t)2 * N64 * N64 * 16 + (size_t)N64 * N64 * 8 + (size_t)N64 * 16;   // C, W (c128), one c64 matrix, r
+
+// stages 0-2 for bin k: leaves C and W in the scratch slot, the scaled float32 copy of C at cf_dst (row stride cf_ld; LDS or
+// scratch) and, if vf_dst is given, V = I beside it.  Returns the status (1: not positive definite), or -1 on a debug stop.
+template <bool FUSED, typename XT>
+__device__ __forceinline__ int front64(const GevdParams& p, const Sh& sh, bool z1, int k, C128* gC, C128* gW, C64* cf_dst, int cf_ld,
+                                       C64* vf_dst, double& normF2, double& scl) {
     const XT* const pXB = reinterpret_cast<const XT*>(z1 ? p.XB1 : p.XB);
     const XT* const pXD = reinterpret_cast<const XT*>(z1 ? p.XD1 : p.XD);
     const XT* const pd = reinterpret_cast<const XT*>(z1 ? p.d1 : p.d);
-    void* const pw = z1 ? p.w1 : p.w;
-    void* const plam = z1 ? p.lam1 : p.lam;
-    int32_t* const pstatus = z1 ? p.status1 : p.status;
-
-    C128* const RA = reinterpret_cast<C128*>(sRegA);
-    C128* const RB = reinterpret_cast<C128*>(sRegB);
-    C64* const Cf = reinterpret_cast<C64*>(sRegA);
-    C64* const Vf = Cf + N64 * LDF;
-
+    C128* const RA = reinterpret_cast<C128*>(sh.regA);
+    C128* const RB = reinterpret_cast<C128*>(sh.regB);
+    C128* const sr = sh.sr;
+    double* const sDinv = sh.sDinv;
+    double (*const sPart)[N64] = sh.sPart;
+    double (*const sPartI)[N64] = sh.sPartI;
+    double* const sRed = sh.sRed;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int il = lane & 15, kq = lane >> 4;
     const int ti = wave >> 2, tj = wave & 3;           // this wave's 16 x 16 tile of a 64 x 64 matrix
-    const int k = blockIdx.x;
     int status = 0;
-    // per-bin scratch in HBM (L2 resident): C (c128, row-major 64 x 64), then W
-    C128* const gC = reinterpret_cast<C128*>(p.Lspill) + ((size_t)blockIdx.y * p.K + k) * (2 * N64 * N64);
-    C128* const gW = gC + N64 * N64;
+    normF2 = 0.0;
+    scl = 1.0;
 
     // ---------------- stage 0 ----------------
     if constexpr (FUSED) {
@@ -206,7 +218,8 @@ __global__ void __launch_bounds__(1024) gevd64_kernel(const GevdParams p) {
         if (tid < N64) sr[tid] = p.r ? reinterpret_cast<const C128*>(p.r)[(size_t)k * N64 + tid] : mk<double>(0, 0);
     }
     __syncthreads();
-    if (p.debug_stop == 1) return;
+
+    if (p.debug_stop == 1) return -1;
 
     // ---------------- stage 1: Cholesky of B + reg I (lower, in place), then W = L^-1 in place ----------------
     if (tid < N64) RB[tid * LDD + tid] = mk<double>(RB[tid * LDD + tid].x + p.reg_dark, 0);
@@ -239,7 +252,7 @@ __global__ void __launch_bounds__(1024) gevd64_kernel(const GevdParams p) {
             __syncthreads();
         }
     }
-    if (p.debug_stop == 2) return;
+    if (p.debug_stop == 2) return -1;
     if (status == 0) {
         // W = L^-1, column by column from the right: W[i][j] = -(sum_{j<k<=i} W[i][k] L[k][j]) / L[j][j].  Sixteen lanes share a
         // row; the column of L is overwritten only after every row has read it.
@@ -270,7 +283,7 @@ __global__ void __launch_bounds__(1024) gevd64_kernel(const GevdParams p) {
             }
         }
 
-        if (p.debug_stop == 3) return;
+        if (p.debug_stop == 3) return -1;
         // ---------------- stage 2: C = W A W^H ----------------
         C128 acc[4];
         // W is lower triangular: W[i][k] = 0 for k > i (the upper triangle of the region still holds R_D)
@@ -296,133 +309,158 @@ __global__ void __launch_bounds__(1024) gevd64_kernel(const GevdParams p) {
             const int i = idx >> 6, j = idx & 63;
             gW[idx] = j <= i ? RB[i * LDD + j] : mk<double>(0, 0);
         }
-        const double normF2 = block_sum(nrm, sRed, tid);          // (its barriers also end every read of T in region A)
+        normF2 = block_sum(nrm, sRed, tid);          // (its barriers also end every read of T in region A)
         const int sexp = (normF2 > 0.0) ? -(ilogb(normF2) / 2) : 0;
-        const double scl = ldexp(1.0, sexp);
-        // float32 working copies: C scaled to ||C||_F ~ 1, V = I
+        scl = ldexp(1.0, sexp);
+        // float32 working copy: C scaled to ||C||_F ~ 1 (and V = I beside it)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int row = 16 * ti + kq + 4 * t, col = 16 * tj + il;
-            Cf[row * LDF + col] = mk<float>((float)(acc[t].x * scl), (float)(acc[t].y * scl));
-            Vf[row * LDF + col] = mk<float>(row == col ? 1.f : 0.f, 0.f);
+            cf_dst[row * cf_ld + col] = mk<float>((float)(acc[t].x * scl), (float)(acc[t].y * scl));
+            if (vf_dst != nullptr) vf_dst[row * cf_ld + col] = mk<float>(row == col ? 1.f : 0.f, 0.f);
         }
-        __syncthreads();
-        if (p.debug_stop == 4) return;
+    }
+    __syncthreads();
+    return status;
+}
 
-        // ---------------- stage 3a: float32 block Jacobi ----------------
-        const int max_sweeps = p.max_sweeps > 0 ? p.max_sweeps : 14;
-        const int ua = lane >> 3, ub = lane & 7;                  // inner solve: the 8 x 8 grid of 2 x 2 blocks of a pair problem
-        double off_prev = 1e300;
-        // off-diagonal weight at which the float sweeps hand over to the float64 refinement (a refinement step costs 0.6 of a sweep)
-        const double kPreTol = p.sweep_tol2 < 0.0 ? -p.sweep_tol2 : 1e-8;
-        bool pre_done = false;
-        int n_sweeps = 0, n_ref = 0;
-        for (int sweep = 0; sweep < max_sweeps && !pre_done; ++sweep) {
-            ++n_sweeps;
-            for (int r = 0; r < NBLK - 1; ++r) {
-                if (wave < 4 && p.debug_stop != 7) {             // debug_stop 7 / 8: timing without the inner solves / the outer update
-                    int P, Q;
-                    rr_pair8(r, wave, P, Q);
-                    auto idx = [&](int x) { return x < BS ? BS * P + x : BS * Q + (x - BS); };
-                    const int r0 = idx(ua), r1 = idx(8 + ua), c0 = idx(ub), c1 = idx(8 + ub);
-                    C64 tt = Cf[r0 * LDF + c0], tb = Cf[r0 * LDF + c1], bt = Cf[r1 * LDF + c0], bb = Cf[r1 * LDF + c1];
-                    C64 v0t = mk<float>((2 * ua == ub) ? 1.f : 0.f, 0.f), v0b = mk<float>((2 * ua == 8 + ub) ? 1.f : 0.f, 0.f);
-                    C64 v1t = mk<float>((2 * ua + 1 == ub) ? 1.f : 0.f, 0.f), v1b = mk<float>((2 * ua + 1 == 8 + ub) ? 1.f : 0.f, 0.f);
-                    bool conv = false;
-                    // Round 0 of an outer sweep pairs every block once: a full inner sweep there covers the pairs INSIDE all eight
-                    // blocks; the other rounds rotate only the 64 pairs between their two blocks (the first 8 rounds of the
-                    // schedule, which leave the slots as they were).  Together: every one of the 2016 index pairs once per sweep.
-                    const bool full = (r == 0);
-                    const int ns = jacobi16_sweeps<float>(tt, tb, bt, bb, v0t, v0b, v1t, v1b, (float (*)[4]) nullptr, lane, 0.f, 1.0f, 1, conv,
-                                                          full ? 15 : 8);
-                    (void)conv;
-                    const bool nat = full && (ns & 1);
-                    const int it_b = nat ? 2 * ub : ub, ib_b = nat ? 2 * ub + 1 : 8 + ub;
-                    C64* U = sU[wave];
-                    U[(2 * ua) * 17 + it_b] = v0t;
-                    U[(2 * ua) * 17 + ib_b] = v0b;
-                    U[(2 * ua + 1) * 17 + it_b] = v1t;
-                    U[(2 * ua + 1) * 17 + ib_b] = v1b;
-                }
-                __syncthreads();
-                if (p.debug_stop != 8) {
-                    // tile (a, b) of the pair grid: C_ab <- U_a^H C_ab U_b; rows 16 a' .. of V: V_b <- V_b U_b   (a' = a)
-                    const int a = ti, b = tj;
-                    int Pa, Qa, Pb, Qb;
-                    rr_pair8(r, a, Pa, Qa);
-                    rr_pair8(r, b, Pb, Qb);
-                    auto ia = [&](int x) { return x < BS ? BS * Pa + x : BS * Qa + (x - BS); };
-                    auto ib = [&](int x) { return x < BS ? BS * Pb + x : BS * Qb + (x - BS); };
-                    const C64* Ua = sU[a];
-                    const C64* Ub = sU[b];
-                    // operands with k = 4 kq + s: four consecutive columns of the pair's index set
-                    const int crow = ia(il), vrow = 16 * a + il, kc = ib(4 * kq);       // 4 kq .. 4 kq + 3 stay inside one block
-                    C64 tr[4], vr[4], ubv[4], uav[4];
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        tr[s] = Cf[crow * LDF + kc + s];
-                        vr[s] = Vf[vrow * LDF + kc + s];
-                        ubv[s] = Ub[(4 * kq + s) * 17 + il];
-                        uav[s] = Ua[(4 * kq + s) * 17 + il];
-                    }
-                    f4 pre = {0, 0, 0, 0}, pim = {0, 0, 0, 0}, vre = {0, 0, 0, 0}, vim = {0, 0, 0, 0};
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        pre = __builtin_amdgcn_mfma_f32_16x16x4f32(tr[s].x, ubv[s].x, pre, 0, 0, 0);
-                        pre = __builtin_amdgcn_mfma_f32_16x16x4f32(-tr[s].y, ubv[s].y, pre, 0, 0, 0);
-                        pim = __builtin_amdgcn_mfma_f32_16x16x4f32(tr[s].x, ubv[s].y, pim, 0, 0, 0);
-                        pim = __builtin_amdgcn_mfma_f32_16x16x4f32(tr[s].y, ubv[s].x, pim, 0, 0, 0);
-                        vre = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[s].x, ubv[s].x, vre, 0, 0, 0);
-                        vre = __builtin_amdgcn_mfma_f32_16x16x4f32(-vr[s].y, ubv[s].y, vre, 0, 0, 0);
-                        vim = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[s].x, ubv[s].y, vim, 0, 0, 0);
-                        vim = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[s].y, ubv[s].x, vim, 0, 0, 0);
-                    }
-                    // second product U_a^H (C_ab U_b): register s of the first accumulator is row 4 kq + s of the product, i.e.
-                    // exactly the B operand of k = 4 kq + s; A[i][k] = conj(U_a[k][i])
-                    f4 cre = {0, 0, 0, 0}, cim = {0, 0, 0, 0};
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        cre = __builtin_amdgcn_mfma_f32_16x16x4f32(uav[s].x, pre[s], cre, 0, 0, 0);
-                        cre = __builtin_amdgcn_mfma_f32_16x16x4f32(uav[s].y, pim[s], cre, 0, 0, 0);
-                        cim = __builtin_amdgcn_mfma_f32_16x16x4f32(uav[s].x, pim[s], cim, 0, 0, 0);
-                        cim = __builtin_amdgcn_mfma_f32_16x16x4f32(-uav[s].y, pre[s], cim, 0, 0, 0);
-                    }
-                    // accumulator element t: row 4 kq + t, column il of the tile
-                    const int ccol = ib(il);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const int row = ia(4 * kq + t);
-                        C64 v = mk<float>(cre[t], cim[t]);
-                        if (row == ccol) v.y = 0.f;
-                        Cf[row * LDF + ccol] = v;
-                        Vf[(16 * a + 4 * kq + t) * LDF + ccol] = mk<float>(vre[t], vim[t]);
-                    }
-                }
-                __syncthreads();
-            }
-            // off-diagonal weight left (C is scaled to ||C||_F ~ 1): stop at 1e-10, or when float32 rounding stalls the decrease
-            double off = 0;
-            for (int idx = tid; idx < N64 * N64; idx += 1024) {
-                const int i = idx >> 6, j = idx & 63;
-                if (i != j) {
-                    const C64 v = Cf[i * LDF + j];
-                    off += (double)v.x * v.x + (double)v.y * v.y;
-                }
-            }
-            off = block_sum(off, sRed, tid);
-            const double nrm_s = normF2 * scl * scl;
-            if (off <= kPreTol * nrm_s || (off <= 1e-7 * nrm_s && off > 0.25 * off_prev)) pre_done = true;
-            off_prev = off;
-        }
+// ---- float32 block Jacobi: the tasks of a round ------------------------------------------------------------------------
+// pair problem w of round r, solved by one wave: reads its 16 x 16 sub-matrix of Cf, leaves the unitary factor in U
+__device__ __forceinline__ void inner_solve(const C64* Cf, C64* U, int r, int w, int lane) {
+    const int ua = lane >> 3, ub = lane & 7;                      // the 8 x 8 grid of 2 x 2 blocks of a pair problem
+    int P, Q;
+    rr_pair8(r, w, P, Q);
+    auto idx = [&](int x) { return x < BS ? BS * P + x : BS * Q + (x - BS); };
+    const int r0 = idx(ua), r1 = idx(8 + ua), c0 = idx(ub), c1 = idx(8 + ub);
+    C64 tt = Cf[r0 * LDF + c0], tb = Cf[r0 * LDF + c1], bt = Cf[r1 * LDF + c0], bb = Cf[r1 * LDF + c1];
+    C64 v0t = mk<float>((2 * ua == ub) ? 1.f : 0.f, 0.f), v0b = mk<float>((2 * ua == 8 + ub) ? 1.f : 0.f, 0.f);
+    C64 v1t = mk<float>((2 * ua + 1 == ub) ? 1.f : 0.f, 0.f), v1b = mk<float>((2 * ua + 1 == 8 + ub) ? 1.f : 0.f, 0.f);
+    bool conv = false;
+    // Round 0 of an outer sweep pairs every block once: a full inner sweep there covers the pairs INSIDE all eight
+    // blocks; the other rounds rotate only the 64 pairs between their two blocks (the first 8 rounds of the
+    // schedule, which leave the slots as they were).  Together: every one of the 2016 index pairs once per sweep.
+    const bool full = (r == 0);
+    const int ns = jacobi16_sweeps<float>(tt, tb, bt, bb, v0t, v0b, v1t, v1b, (float (*)[4]) nullptr, lane, 0.f, 1.0f, 1, conv, full ? 15 : 8);
+    (void)conv;
+    const bool nat = full && (ns & 1);
+    const int it_b = nat ? 2 * ub : ub, ib_b = nat ? 2 * ub + 1 : 8 + ub;
+    U[(2 * ua) * 17 + it_b] = v0t;
+    U[(2 * ua) * 17 + ib_b] = v0b;
+    U[(2 * ua + 1) * 17 + it_b] = v1t;
+    U[(2 * ua + 1) * 17 + ib_b] = v1b;
+}
 
-        if (p.debug_stop == 5 || p.debug_stop == 7 || p.debug_stop == 8) {
-            if (pstatus != nullptr && tid == 0) pstatus[k] = 100 * n_sweeps;
-            return;
-        }
+// tile (a, b) of the pair grid of round r: C_ab <- U_a^H C_ab U_b on v_mfma_f32_16x16x4_f32; with `mirror` the Hermitian
+// counterpart C_ba is written too.  Returns this lane's share of the off-diagonal weight of what it wrote.
+__device__ __forceinline__ float outer_ctile(C64* Cf, const C64 (*sUr)[16 * 17], int r, int a, int b, int lane, bool mirror) {
+    const int il = lane & 15, kq = lane >> 4;
+    int Pa, Qa, Pb, Qb;
+    rr_pair8(r, a, Pa, Qa);
+    rr_pair8(r, b, Pb, Qb);
+    auto ia = [&](int x) { return x < BS ? BS * Pa + x : BS * Qa + (x - BS); };
+    auto ib = [&](int x) { return x < BS ? BS * Pb + x : BS * Qb + (x - BS); };
+    const C64* Ua = sUr[a];
+    const C64* Ub = sUr[b];
+    // operands with k = 4 kq + s: four consecutive columns of the pair's index set (they stay inside one block)
+    const int crow = ia(il), kc = ib(4 * kq);
+    C64 tr[4], ubv[4], uav[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        tr[s] = Cf[crow * LDF + kc + s];
+        ubv[s] = Ub[(4 * kq + s) * 17 + il];
+        uav[s] = Ua[(4 * kq + s) * 17 + il];
+    }
+    f4 pre = {0, 0, 0, 0}, pim = {0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        pre = __builtin_amdgcn_mfma_f32_16x16x4f32(tr[s].x, ubv[s].x, pre, 0, 0, 0);
+        pre = __builtin_amdgcn_mfma_f32_16x16x4f32(-tr[s].y, ubv[s].y, pre, 0, 0, 0);
+        pim = __builtin_amdgcn_mfma_f32_16x16x4f32(tr[s].x, ubv[s].y, pim, 0, 0, 0);
+        pim = __builtin_amdgcn_mfma_f32_16x16x4f32(tr[s].y, ubv[s].x, pim, 0, 0, 0);
+    }
+    // second product U_a^H (C_ab U_b): register s of the first accumulator is row 4 kq + s of the product, i.e. exactly the
+    // B operand of k = 4 kq + s; A[i][k] = conj(U_a[k][i])
+    f4 cre = {0, 0, 0, 0}, cim = {0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        cre = __builtin_amdgcn_mfma_f32_16x16x4f32(uav[s].x, pre[s], cre, 0, 0, 0);
+        cre = __builtin_amdgcn_mfma_f32_16x16x4f32(uav[s].y, pim[s], cre, 0, 0, 0);
+        cim = __builtin_amdgcn_mfma_f32_16x16x4f32(uav[s].x, pim[s], cim, 0, 0, 0);
+        cim = __builtin_amdgcn_mfma_f32_16x16x4f32(-uav[s].y, pre[s], cim, 0, 0, 0);
+    }
+    // accumulator element t: row 4 kq + t, column il of the tile
+    const int ccol = ib(il);
+    float off = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int row = ia(4 * kq + t);
+        C64 v = mk<float>(cre[t], cim[t]);
+        if (row == ccol) v.y = 0.f;
+        else off += v.x * v.x + v.y * v.y;
+        Cf[row * LDF + ccol] = v;
+        if (mirror) Cf[ccol * LDF + row] = mk<float>(v.x, -v.y);
+    }
+    return mirror ? 2.f * off : off;
+}
+
+// rows 16 rb .. 16 rb + 15 of V, columns of pair b of round r: V_b <- V_b U_b
+__device__ __forceinline__ void outer_vtile(C64* Vf, const C64 (*sUr)[16 * 17], int r, int rb, int b, int lane) {
+    const int il = lane & 15, kq = lane >> 4;
+    int Pb, Qb;
+    rr_pair8(r, b, Pb, Qb);
+    auto ib = [&](int x) { return x < BS ? BS * Pb + x : BS * Qb + (x - BS); };
+    const C64* Ub = sUr[b];
+    const int vrow = 16 * rb + il, kc = ib(4 * kq);
+    C64 vr[4], ubv[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        vr[s] = Vf[vrow * LDF + kc + s];
+        ubv[s] = Ub[(4 * kq + s) * 17 + il];
+    }
+    f4 vre = {0, 0, 0, 0}, vim = {0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        vre = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[s].x, ubv[s].x, vre, 0, 0, 0);
+        vre = __builtin_amdgcn_mfma_f32_16x16x4f32(-vr[s].y, ubv[s].y, vre, 0, 0, 0);
+        vim = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[s].x, ubv[s].y, vim, 0, 0, 0);
+        vim = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[s].y, ubv[s].x, vim, 0, 0, 0);
+    }
+    const int ccol = ib(il);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) Vf[(16 * rb + 4 * kq + t) * LDF + ccol] = mk<float>(vre[t], vim[t]);
+}
+
+// hand-over rule of the float sweeps: off-diagonal weight `off` (C scaled to ||C||_F^2 = nrm_s) small enough for the float64
+// refinement, or no longer falling (float32 rounding)
+__device__ __forceinline__ bool presolve_done(double off, double off_prev, double nrm_s, double tol) {
+    return off <= tol * nrm_s || (off <= 1e-7 * nrm_s && off > 0.25 * off_prev);
+}
+
+// stage 3b .. 6 and the outputs of bin k; vf_src: the float32 eigenvector matrix of the sweeps (row stride vf_ld; LDS or scratch)
+template <typename XT>
+__device__ __forceinline__ void back64(const GevdParams& p, const Sh& sh, bool z1, int k, const C128* gC, const C128* gW,
+                                       const C64* vf_src, int vf_ld, int status, int n_sweeps) {
+    void* const pw = z1 ? p.w1 : p.w;
+    void* const plam = z1 ? p.lam1 : p.lam;
+    int32_t* const pstatus = z1 ? p.status1 : p.status;
+    C128* const RA = reinterpret_cast<C128*>(sh.regA);
+    C128* const RB = reinterpret_cast<C128*>(sh.regB);
+    C128* const sr = sh.sr;
+    C128* const scoef = sh.scoef;
+    double* const sLam = sh.sLam;
+    double (*const sPart)[N64] = sh.sPart;
+    int* const sOrder = sh.sOrder;
+    int* const sFlag = sh.sFlag;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int il = lane & 15, kq = lane >> 4;
+    const int ti = wave >> 2, tj = wave & 3;
+    int n_ref = 0;
+    if (status == 0) {
+        C128 acc[4];
         // ---------------- stage 3b: float64 refinement on the matrix cores ----------------
         for (int idx = tid; idx < N64 * N64; idx += 1024) {
             const int i = idx >> 6, j = idx & 63;
-            const C64 v = Vf[i * LDF + j];
+            const C64 v = vf_src[i * vf_ld + j];
             RB[i * LDD + j] = mk<double>((double)v.x, (double)v.y);
         }
         __syncthreads();
@@ -548,6 +586,7 @@ __global__ void __launch_bounds__(1024) gevd64_kernel(const GevdParams p) {
         __syncthreads();
     }
 
+
     // ---------------- outputs ----------------
     if (tid < N64) {
         double ax = 0, ay = 0;
@@ -582,19 +621,226 @@ __global__ void __launch_bounds__(1024) gevd64_kernel(const GevdParams p) {
     if (pstatus != nullptr && tid == 0) pstatus[k] = status;
 }
 
+
+// ---- one bin per workgroup ---------------------------------------------------------------------------------------------
+// XT: element type of the fused input slabs (float2 = c64, double2 = c128); FUSED = false takes explicit R_B, R_D, r (c128)
+template <bool FUSED, typename XT>
+__global__ void __launch_bounds__(1024) gevd64_kernel(const GevdParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char sRegA[REGION];
+    __shared__ __attribute__((aligned(16))) unsigned char sRegB[REGION];
+    __shared__ C128 sr[N64], scoef[N64];
+    __shared__ double sDinv[N64], sLam[N64], sPart[4][N64], sPartI[4][N64], sRed[16];
+    __shared__ int sOrder[N64];
+    __shared__ int sFlag[2];
+    __shared__ C64 sU[4][16 * 17];                     // the four 16 x 16 unitary factors of a block round
+    const Sh sh{sRegA, sRegB, sr, scoef, sDinv, sLam, sPart, sPartI, sRed, sOrder, sFlag};
+    const bool z1 = (blockIdx.y == 1);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int ti = wave >> 2, tj = wave & 3;
+    const int k = blockIdx.x;
+    unsigned char* const slot = reinterpret_cast<unsigned char*>(p.Lspill) + ((size_t)blockIdx.y * p.K + k) * SLOT_BYTES;
+    C128* const gC = reinterpret_cast<C128*>(slot);
+    C128* const gW = gC + N64 * N64;
+    C64* const Cf = reinterpret_cast<C64*>(sRegA);
+    C64* const Vf = Cf + N64 * LDF;
+    double normF2, scl;
+    const int status = front64<FUSED, XT>(p, sh, z1, k, gC, gW, Cf, LDF, Vf, normF2, scl);
+    if (status < 0 || p.debug_stop == 4) return;
+    int n_sweeps = 0;
+    if (status == 0) {
+        // ---------------- stage 3a: float32 block Jacobi, all sixteen waves on the one bin ----------------
+        const int max_sweeps = p.max_sweeps > 0 ? p.max_sweeps : 14;
+        // off-diagonal weight at which the float sweeps hand over to the float64 refinement (a refinement step costs 0.6 of a sweep)
+        const double kPreTol = p.sweep_tol2 < 0.0 ? -p.sweep_tol2 : 1e-8;
+        double off_prev = 1e300;
+        bool pre_done = false;
+        for (int sweep = 0; sweep < max_sweeps && !pre_done; ++sweep) {
+            ++n_sweeps;
+            float offw = 0.f;
+            for (int r = 0; r < NBLK - 1; ++r) {
+                if (wave < 4 && p.debug_stop != 7) inner_solve(Cf, sU[wave], r, wave, lane);   // debug_stop 7 / 8: timing aids
+                __syncthreads();
+                if (p.debug_stop != 8) {
+                    const float o = outer_ctile(Cf, sU, r, ti, tj, lane, false);
+                    outer_vtile(Vf, sU, r, ti, tj, lane);
+                    if (r == NBLK - 2) offw = o;           // the last round of the sweep rewrites all of C: its off-diagonal weight
+                }
+                __syncthreads();
+            }
+            const double off = block_sum((double)offw, sRed, tid);
+            pre_done = presolve_done(off, off_prev, normF2 * scl * scl, kPreTol);
+            off_prev = off;
+        }
+    }
+    if (p.debug_stop == 5 || p.debug_stop == 7 || p.debug_stop == 8) {
+        int32_t* const pstatus = z1 ? p.status1 : p.status;
+        if (pstatus != nullptr && tid == 0) pstatus[k] = 100 * n_sweeps;
+        return;
+    }
+    back64<XT>(p, sh, z1, k, gC, gW, Vf, LDF, status, n_sweeps);
+}
+
+// ---- two bins per workgroup: float32 sweeps of the two bins interleaved ----------------------------------------------
+__constant__ signed char kUpperA[10] = {0, 0, 0, 0, 1, 1, 1, 2, 2, 3};
+__constant__ signed char kUpperB[10] = {0, 1, 2, 3, 1, 2, 3, 2, 3, 3};
+
+template <bool FUSED, typename XT>
+__global__ void __launch_bounds__(1024) gevd64x2_kernel(const GevdParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char sRegA[REGION];
+    __shared__ __attribute__((aligned(16))) unsigned char sRegB[REGION];
+    __shared__ C128 sr[N64], scoef[N64];
+    __shared__ double sDinv[N64], sLam[N64], sPart[4][N64], sPartI[4][N64], sRed[16];
+    __shared__ int sOrder[N64];
+    __shared__ int sFlag[2];
+    __shared__ C64 sU[2][4][16 * 17];                  // per bin: the four unitary factors of its round in flight
+    __shared__ float sOffW[2][16];
+    const Sh sh{sRegA, sRegB, sr, scoef, sDinv, sLam, sPart, sPartI, sRed, sOrder, sFlag};
+    const bool z1 = (blockIdx.y == 1);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int k0 = 2 * blockIdx.x;
+    const int nb = (k0 + 1 < p.K) ? 2 : 1;
+    // per-bin state lives in scalars selected by a uniform index (indexed local arrays would go to scratch memory)
+    unsigned char* const slot0 = reinterpret_cast<unsigned char*>(p.Lspill) + ((size_t)blockIdx.y * p.K + k0) * SLOT_BYTES;
+    unsigned char* const slot1 = slot0 + (nb == 2 ? SLOT_BYTES : 0);
+    auto gCb = [&](int b) { return reinterpret_cast<C128*>(b ? slot1 : slot0); };
+    auto gWb = [&](int b) { return gCb(b) + N64 * N64; };
+    auto gFb = [&](int b) { return reinterpret_cast<C64*>(gCb(b) + 2 * N64 * N64); };
+    auto gRb = [&](int b) { return reinterpret_cast<C128*>(gFb(b) + N64 * N64); };          // r = X_B^H d of the bin
+    auto Cfb = [&](int b) { return reinterpret_cast<C64*>(b ? sRegB : sRegA); };
+    auto Vfb = [&](int b) { return Cfb(b) + N64 * LDF; };
+    int status0 = 0, status1 = 1;
+    double normF2_0 = 0, normF2_1 = 0, scl0 = 1, scl1 = 1;
+    // float64 front stages, one bin after the other; the scaled float32 copy of C goes to the scratch slot
+    status0 = front64<FUSED, XT>(p, sh, z1, k0, gCb(0), gWb(0), gFb(0), N64, nullptr, normF2_0, scl0);
+    if (status0 < 0) return;
+    if (tid < N64) gRb(0)[tid] = sr[tid];
+    __syncthreads();
+    if (nb == 2) {
+        status1 = front64<FUSED, XT>(p, sh, z1, k0 + 1, gCb(1), gWb(1), gFb(1), N64, nullptr, normF2_1, scl1);
+        if (tid < N64) gRb(1)[tid] = sr[tid];
+        __syncthreads();
+    }
+    for (int b = 0; b < nb; ++b) {
+        if ((b ? status1 : status0) != 0) continue;
+        C64* const Cf = Cfb(b);
+        C64* const Vf = Vfb(b);
+        const C64* const src = gFb(b);
+        for (int idx = tid; idx < N64 * N64; idx += 1024) {
+            const int i = idx >> 6, j = idx & 63;
+            Cf[i * LDF + j] = src[idx];
+            Vf[i * LDF + j] = mk<float>(i == j ? 1.f : 0.f, 0.f);
+        }
+    }
+    __syncthreads();
+    // ---------------- stage 3a for both bins: in every step four waves solve the pair problems of one bin's next round
+    // while the other twelve apply the factors of the other bin's current round (10 Hermitian tiles of C with their mirrors
+    // + 16 tiles of V = 36 products of 16^3, three per wave); the bins swap roles from step to step
+    enum { INNER = 0, OUTER = 1, DONE = 2 };
+    int st0 = status0 == 0 ? INNER : DONE, st1 = (nb == 2 && status1 == 0) ? INNER : DONE;
+    int rnd0 = 0, rnd1 = 0, swp0 = 0, swp1 = 0;
+    double offp0 = 1e300, offp1 = 1e300;
+    const int max_sweeps = p.max_sweeps > 0 ? p.max_sweeps : 14;
+    const double kPreTol = p.sweep_tol2 < 0.0 ? -p.sweep_tol2 : 1e-8;
+    for (int step = 0; step < 2 * (NBLK - 1) * max_sweeps + 4 && !(st0 == DONE && st1 == DONE); ++step) {
+        const int bS = step & 1, bU = bS ^ 1;
+        const int stS = bS ? st1 : st0, stU = bU ? st1 : st0;
+        const int rS = bS ? rnd1 : rnd0, rU = bU ? rnd1 : rnd0;
+        const bool do_inner = (stS == INNER), do_outer = (stU == OUTER);
+        const bool sweep_end = do_outer && rU == NBLK - 2;
+        float offw = 0.f;
+        if (wave < 4) {
+            if (do_inner) inner_solve(Cfb(bS), sU[bS][wave], rS, wave, lane);
+        } else if (do_outer) {
+            const int u = wave - 4;
+            C64* const Cf = Cfb(bU);
+            C64* const Vf = Vfb(bU);
+            if (u < 10) {
+                const int a = kUpperA[u], b = kUpperB[u];
+                offw = outer_ctile(Cf, sU[bU], rU, a, b, lane, a != b);
+                outer_vtile(Vf, sU[bU], rU, u >> 2, u & 3, lane);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int vt = 10 + 3 * (u - 10) + q;
+                    outer_vtile(Vf, sU[bU], rU, vt >> 2, vt & 3, lane);
+                }
+            }
+        }
+        if (sweep_end) {
+            const float w = wave_sum(offw);
+            if (lane == 0) sOffW[step & 1][wave] = w;
+        }
+        __syncthreads();
+        if (do_inner) {
+            if (bS) st1 = OUTER; else st0 = OUTER;
+        }
+        if (do_outer) {
+            int nst = INNER, nr = rU + 1;
+            if (sweep_end) {
+                double off = 0;
+#pragma unroll
+                for (int w = 4; w < 14; ++w) off += (double)sOffW[step & 1][w];
+                const int sw = (bU ? swp1 : swp0) + 1;
+                const double nrm_s = bU ? normF2_1 * scl1 * scl1 : normF2_0 * scl0 * scl0;
+                nst = (presolve_done(off, bU ? offp1 : offp0, nrm_s, kPreTol) || sw >= max_sweeps) ? DONE : INNER;
+                nr = 0;
+                if (bU) { swp1 = sw; offp1 = off; } else { swp0 = sw; offp0 = off; }
+            }
+            if (bU) { st1 = nst; rnd1 = nr; } else { st0 = nst; rnd0 = nr; }
+        }
+    }
+    __syncthreads();
+    // the float32 eigenvector matrices wait in the scratch slots while the float64 back stages use all of the LDS
+    for (int b = 0; b < nb; ++b) {
+        if ((b ? status1 : status0) != 0) continue;
+        const C64* const Vf = Vfb(b);
+        C64* const dst = gFb(b);
+        for (int idx = tid; idx < N64 * N64; idx += 1024) dst[idx] = Vf[(idx >> 6) * LDF + (idx & 63)];
+    }
+    __syncthreads();
+    if (p.debug_stop == 5) {
+        int32_t* const pstatus = z1 ? p.status1 : p.status;
+        if (pstatus != nullptr && tid < nb) pstatus[k0 + tid] = 100 * (tid ? swp1 : swp0);
+        return;
+    }
+    if (tid < N64) sr[tid] = gRb(0)[tid];
+    __syncthreads();
+    back64<XT>(p, sh, z1, k0, gCb(0), gWb(0), gFb(0), N64, status0, swp0);
+    if (nb == 2) {
+        __syncthreads();
+        if (tid < N64) sr[tid] = gRb(1)[tid];
+        __syncthreads();
+        back64<XT>(p, sh, z1, k0 + 1, gCb(1), gWb(1), gFb(1), N64, status1, swp1);
+    }
+}
+
 }  // namespace
+
+size_t apv_gevd64_slot_bytes() { return SLOT_BYTES; }
 
 // hipErrorNotSupported when the problem does not qualify (order != 64, float32 arithmetic, relative or bright loading, a
 // caller-set sweep tolerance): the LDS kernel of kernels_gevd.hip then takes it
 hipError_t apv_launch_gevd64(const GevdParams& p, int compute_dtype, bool fused, hipStream_t s) {
-    static const bool off = (getenv("APV_NO_GEVD64") != nullptr);          // A/B switch
-    if (off || p.n != 64 || compute_dtype != APV_F64 || p.reg_mode != APV_REG_ABS || p.reg_bright != 0.0 || p.sweep_tol2 > 0.0 ||   /* sweep_tol2 < 0: tuning aid, -value = hand-over threshold of the pre-solve */
+    static const bool off = (getenv("APV_NO_GEVD64") != nullptr);          // A/B switch: the LDS kernel
+    static const bool single = (getenv("APV_GEVD64_SINGLE") != nullptr);   // A/B switch: one bin per workgroup
+    if (off || p.n != 64 || compute_dtype != APV_F64 || p.reg_mode != APV_REG_ABS || p.reg_bright != 0.0 ||
+        p.sweep_tol2 > 0.0 ||   /* sweep_tol2 < 0: tuning aid, -value = hand-over threshold of the pre-solve */
         p.Lspill == nullptr)
         return hipErrorNotSupported;
     if (p.K <= 0) return hipSuccess;
-    const dim3 grid(p.K, p.n_zones > 1 ? 2 : 1);
-    if (fused && p.x_c128) hipLaunchKernelGGL((gevd64_kernel<true, double2>), grid, dim3(1024), 0, s, p);
-    else if (fused) hipLaunchKernelGGL((gevd64_kernel<true, float2>), grid, dim3(1024), 0, s, p);
-    else hipLaunchKernelGGL((gevd64_kernel<false, float2>), grid, dim3(1024), 0, s, p);
+    const bool xd = fused && p.x_c128;
+    // one bin per workgroup while that still gives every CU its own workgroup (the two-bin kernel halves the grid), and for the
+    // timing aids of the single-bin kernel (debug_stop 6, 7, 8)
+    if (single || p.K * (p.n_zones > 1 ? 2 : 1) < 512 || p.debug_stop >= 6) {
+        const dim3 grid(p.K, p.n_zones > 1 ? 2 : 1);
+        if (xd) hipLaunchKernelGGL((gevd64_kernel<true, double2>), grid, dim3(1024), 0, s, p);
+        else if (fused) hipLaunchKernelGGL((gevd64_kernel<true, float2>), grid, dim3(1024), 0, s, p);
+        else hipLaunchKernelGGL((gevd64_kernel<false, float2>), grid, dim3(1024), 0, s, p);
+    } else {
+        const dim3 grid((p.K + 1) / 2, p.n_zones > 1 ? 2 : 1);
+        if (xd) hipLaunchKernelGGL((gevd64x2_kernel<true, double2>), grid, dim3(1024), 0, s, p);
+        else if (fused) hipLaunchKernelGGL((gevd64x2_kernel<true, float2>), grid, dim3(1024), 0, s, p);
+        else hipLaunchKernelGGL((gevd64x2_kernel<false, float2>), grid, dim3(1024), 0, s, p);
+    }
     return hipGetLastError();
 }
