@@ -383,7 +383,7 @@ class apvast:
         sd = e.s_dtype                      # float32, or float64 with the float64 front-end (dtype="f64")
         resp = np.stack([e.get_state(f"response{p}", (M, L, N), sd) for p in range(4)])
         tresp = np.stack([e.get_state(f"target_response{z}", (M, N), sd) for z in range(2)])
-        return {
+        st = {
             "response": resp.transpose(0, 3, 2, 1).astype(np.float64),           # (4, N, L, M)
             "target_response": tresp.transpose(0, 2, 1).astype(np.float64),      # (2, N, M)
             "input_block": e.get_state("input_block", (2, N), sd).astype(np.float64),
@@ -391,6 +391,7 @@ class apvast:
                                                    sd) for g in range(2)]).astype(np.float64),
             "out_overlap": e.get_state("out_overlap", (self._n_out, N), sd).astype(np.float64),
         }
+        return st
 
     def set_state(self, state):
         e = self._eng

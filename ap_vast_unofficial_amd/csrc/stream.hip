@@ -81,10 +81,13 @@ int frontend_f64(const apv_config& c) {
     return c.compute_dtype == APV_F64;
 }
 
+// Uploads go on the handle's stream, like the zero-fill of dalloc before them: that stream does not synchronise with the
+// null stream, so a plain hipMemcpy could overtake the pending fill and be wiped by it.
 template <typename T>
 int upload_as(apv_handle* h, void* dst, const std::vector<double>& src) {
     std::vector<T> tmp(src.begin(), src.end());
-    SCHK(h, hipMemcpy(dst, tmp.data(), sizeof(T) * tmp.size(), hipMemcpyHostToDevice));
+    SCHK(h, hipMemcpyAsync(dst, tmp.data(), sizeof(T) * tmp.size(), hipMemcpyHostToDevice, h->stream));
+    SCHK(h, hipStreamSynchronize(h->stream));               // tmp goes out of scope
     return APV_OK;
 }
 int upload(apv_handle* h, int f64, void* dst, const std::vector<double>& src) {

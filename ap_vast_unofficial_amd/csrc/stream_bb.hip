@@ -516,8 +516,10 @@ int apv_bb_init(apv_handle* h, int32_t rir_len, const double* h_rir_A, const dou
             for (int m = 0; m < M; ++m) ttmp[(size_t)p * M + m] = src[((size_t)(p - modeling_delay) * L + ref) * M + m];
         if ((rc = dalloc(h, &s->rir[z], (size_t)P * C))) return rc;
         if ((rc = dalloc(h, &s->trir[z], (size_t)P * M))) return rc;
-        BCHK(h, hipMemcpy(s->rir[z], tmp.data(), sizeof(double) * tmp.size(), hipMemcpyHostToDevice));
-        BCHK(h, hipMemcpy(s->trir[z], ttmp.data(), sizeof(double) * ttmp.size(), hipMemcpyHostToDevice));
+        // on the handle's stream, behind the zero-fill of dalloc (a null-stream hipMemcpy is not ordered with it)
+        BCHK(h, hipMemcpyAsync(s->rir[z], tmp.data(), sizeof(double) * tmp.size(), hipMemcpyHostToDevice, h->stream));
+        BCHK(h, hipMemcpyAsync(s->trir[z], ttmp.data(), sizeof(double) * ttmp.size(), hipMemcpyHostToDevice, h->stream));
+        BCHK(h, hipStreamSynchronize(h->stream));           // tmp / ttmp are rewritten for the next zone
     }
     const size_t hist = (size_t)P - 1 + H + s->pad;
     for (int b = 0; b < 2; ++b)
@@ -561,7 +563,8 @@ int apv_bb_init(apv_handle* h, int32_t rir_len, const double* h_rir_A, const dou
             tg[o] = std::cos(ph);
             tg[o + 1] = std::sin(ph);
         }
-    BCHK(h, hipMemcpy(s->fspec + (size_t)nz * nsol * L * K * 2, tg.data(), sizeof(double) * tg.size(), hipMemcpyHostToDevice));
+    BCHK(h, hipMemcpyAsync(s->fspec + (size_t)nz * nsol * L * K * 2, tg.data(), sizeof(double) * tg.size(), hipMemcpyHostToDevice,
+                           h->stream));
     BCHK(h, apv_stft_prepare(N, 1));
     BCHK(h, hipStreamSynchronize(h->stream));
     return APV_OK;
@@ -762,6 +765,7 @@ int apv_bb_set_perceptual(apv_handle* h, int32_t n_channels, const double* h_G2,
     if ((rc = dalloc(h, &s->G2T, (size_t)K * n_channels))) return rc;
     for (int z = 0; z < 2; ++z)
         if ((rc = dalloc(h, &s->Wgt[z], (size_t)K * s->M))) return rc;
+    BCHK(h, hipStreamSynchronize(h->stream));               // the zero-fills of dalloc are on the handle's stream
     BCHK(h, hipMemcpy(s->G2, h_G2, sizeof(double) * (size_t)K * n_channels, hipMemcpyHostToDevice));
     BCHK(h, hipMemcpy(s->G2T, gt.data(), sizeof(double) * gt.size(), hipMemcpyHostToDevice));
     s->nch = n_channels; s->Cs = Cs; s->Ca = Ca; s->Leff = Leff; s->norm_mode = normalisation;

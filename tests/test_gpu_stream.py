@@ -1,4 +1,6 @@
 """GPU parity of the streaming path (class apvast, mode='subband') against the CPU oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -311,3 +313,4 @@ def test_stream_per_bin_attributes():
         assert np.abs(w4 - w[3]).max() < 1e-9 * np.abs(w4).max()
     assert len(ap.filter_spectra_A_t) == 4 and np.abs(ap.filter_spectra_A_t[0] - orc.target_filter).max() < 1e-14
     ap.close()
+
