@@ -151,7 +151,7 @@ def main():
                     help="audio blocks resident per step: per rank x 1024 bins at 1 GPU (default 32), GLOBAL x 4096 bins "
                          "sharded over the ranks at N GPUs (default 8 N, the same 32768 bin-updates per GPU)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
-    ap.add_argument("--prespin", type=float, default=0.4, help="seconds of untimed launches before the counted warm-up (clock ramp)")
+    ap.add_argument("--prespin", type=float, default=0.3, help="seconds of untimed launches before the counted warm-up (clock ramp)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -222,8 +222,10 @@ def main():
         if multi:
             eng.comm_barrier()     # every rank (one-word ncclAllReduce)
 
-    # untimed pre-spin: a cold GPU needs a few tenths of a second of work to reach its steady clock, which a short
-    # --steps run would otherwise measure
+    # untimed pre-spin: a GPU that has idled for a few milliseconds runs its next ~25 launches up to 17 % slower (clock ramp,
+    # profiles/r02/clock_ramp.md), which a short --steps run would otherwise measure.  The one host-side pause of this
+    # program (the download of the per-bin status words) therefore comes AFTER the timed region, and nothing but the fence
+    # stands between the pre-spin, the counted warm-up and the timed region.
     t_spin = time.perf_counter()
     n_spin = 0
     while time.perf_counter() - t_spin < args.prespin:
@@ -233,10 +235,6 @@ def main():
         n_spin += 8
     for _ in range(args.warmup):
         step()
-    fence()
-    status = dstatus.download((K,), np.int32)
-    if status.any():
-        raise RuntimeError(f"GEVD status != 0 in {int((status != 0).sum())} bins")
 
     # timed region: K steps between fences; HIP events on the launch stream bracket the same K launches, so
     # the per-launch kernel time (roofline) and the wall time (value) come from the same executions
@@ -248,6 +246,9 @@ def main():
     kern_ms = eng.timer_stop() / args.steps       # waits for the last update kernel only
     fence()
     elapsed = time.perf_counter() - t0
+    status = dstatus.download((K,), np.int32)      # every launch rewrote it: this is the last step's
+    if status.any():
+        raise RuntimeError(f"GEVD status != 0 in {int((status != 0).sum())} bins")
     gather_ms = gather_bytes = None
     if multi:
         gather_ms, gather_bytes = eng.comm_last_gather()
