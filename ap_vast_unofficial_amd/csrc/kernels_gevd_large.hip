@@ -680,6 +680,8 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
     int n_graphs = 0;
     std::vector<double> norm2(hacc.begin() + 2 * batch, hacc.end());
     const int max_pairs = (h->cfg.max_sweeps > 0 ? h->cfg.max_sweeps : 30) / 2 + 1;
+    // a sweep whose pivots weigh <= tol ||C||^2 leaves ~tol^2 behind (quadratic convergence); APV_LARGE_TOL2 is a tuning aid
+    static const double kLargeTol2 = getenv("APV_LARGE_TOL2") ? atof(getenv("APV_LARGE_TOL2")) : 1e-16;   // 1e-20 (round 1) cost two more sweeps for the same G1 errors
     bool converged = false;
     for (int it = 0; it < max_pairs && !converged; ++it) {
         if (ws.exec) LCHK(hipGraphLaunch(ws.exec, st));
@@ -689,7 +691,7 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
         LCHK(hipStreamSynchronize(st));
         converged = true;                     // judged on the second sweep of the pair
         for (int z = 0; z < batch; ++z)
-            if (!(hacc[batch + z] <= 1e-20 * norm2[z])) converged = false;
+            if (!(hacc[batch + z] <= kLargeTol2 * norm2[z])) converged = false;
     }
     const auto t_sweeps = std::chrono::steady_clock::now();
     if (!converged)
