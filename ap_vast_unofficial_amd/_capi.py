@@ -27,7 +27,7 @@ EXPORTS = (
     "apv_timer_start", "apv_timer_stop",
     "apv_update_dev", "apv_update", "apv_corr_dev", "apv_corr_bf16_dev", "apv_to_bf16_dev", "apv_gevd_vast_dev", "apv_jdiag_batched", "apv_jdiag_large",
     "apv_stft_analysis_dev", "apv_istft_ola_dev",
-    "apv_stream_init", "apv_stream_set_perceptual", "apv_process_block", "apv_process_block_f64", "apv_stream_is_f64", "apv_stream_get_statistics", "apv_stream_not_converged", "apv_state_bytes", "apv_get_state", "apv_set_state",
+    "apv_stream_init", "apv_stream_set_perceptual", "apv_process_block", "apv_process_block_f64", "apv_process_signal", "apv_process_signal_f64", "apv_stream_is_f64", "apv_stream_get_statistics", "apv_stream_not_converged", "apv_state_bytes", "apv_get_state", "apv_set_state",
     "apv_bb_set_rank_list", "apv_bb_init", "apv_bb_set_perceptual", "apv_bb_process_block", "apv_bb_get_state", "apv_bb_set_state",
     "apv_predict_pressure", "apv_vast_static",
     "apv_comm_unique_id", "apv_comm_init", "apv_allgather_filters_dev", "apv_comm_last_gather", "apv_comm_barrier",
@@ -96,6 +96,8 @@ def load():
     lib.apv_stream_set_perceptual.argtypes = [vp, i32, vp, C.c_double, C.c_double, C.c_double, i32]
     lib.apv_process_block.argtypes = [vp, vp, vp, vp]
     lib.apv_process_block_f64.argtypes = [vp, vp, vp, vp]
+    lib.apv_process_signal.argtypes = [vp, C.c_int32, vp, vp, vp]
+    lib.apv_process_signal_f64.argtypes = [vp, C.c_int32, vp, vp, vp]
     lib.apv_stream_is_f64.argtypes = [vp]
     lib.apv_stream_get_statistics.argtypes = [vp, i32, vp, vp, vp, vp, vp]
     lib.apv_stream_not_converged.argtypes = [vp]
@@ -407,6 +409,25 @@ class Engine:
         out = np.empty((n_out, self.cfg.hop_size), dtype=dt)
         fn = self.lib.apv_process_block_f64 if self.frontend_f64 else self.lib.apv_process_block
         self._chk(fn(self.h, _ptr(in_A), _ptr(in_B), _ptr(out)))
+        return out
+
+    def process_signal(self, in_A, in_B, n_out, out=None):
+        """Whole signals (a multiple of hop_size samples each) in one call, hops pipelined on the device; returns
+        (n_hops, n_out, hop_size).  Sample for sample what n_hops calls of process_block return.  `out`: a C-contiguous
+        array of that shape and the front-end's dtype to write into (saves the page faults of a fresh one)."""
+        dt = np.float64 if self.frontend_f64 else np.float32
+        in_A = np.ascontiguousarray(in_A, dtype=dt).ravel()
+        in_B = np.ascontiguousarray(in_B, dtype=dt).ravel()
+        H = self.cfg.hop_size
+        if in_A.size != in_B.size or in_A.size % H:
+            raise RuntimeError("invalid input size")
+        n_hops = in_A.size // H
+        if out is None:
+            out = np.empty((n_hops, n_out, H), dtype=dt)
+        elif out.shape != (n_hops, n_out, H) or out.dtype != dt or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous %s array of shape %r" % (np.dtype(dt).name, (n_hops, n_out, H)))
+        fn = self.lib.apv_process_signal_f64 if self.frontend_f64 else self.lib.apv_process_signal
+        self._chk(fn(self.h, n_hops, _ptr(in_A), _ptr(in_B), _ptr(out)))
         return out
 
     def stream_statistics(self, zone, want_U=True):

@@ -262,6 +262,38 @@ class apvast:
         self._refresh_attributes()
         return res
 
+    def process_signal(self, input_A, input_B):
+        """Every hop of two whole signals in one call (subband mode): the hop loop of main.m:52-62 /
+        make_python_test.m:44-51 around process_input_buffers, with consecutive hops pipelined on the device.  Returns
+        (output_A, output_B, target_A, target_B): per zone a list over the ranks of (n_samples, L) arrays, None for a
+        zone that does not run; sample for sample what the per-hop calls return, concatenated.  The attributes
+        afterwards are those of the last hop."""
+        input_A = np.asarray(input_A).ravel()
+        input_B = np.asarray(input_B).ravel()
+        if input_A.size != input_B.size or input_A.size % self.hop_size:
+            raise RuntimeError("invalid input size")
+        if self.mode == "broadband":
+            raise NotImplementedError("process_signal: subband mode only (the broadband hop is one serial chain)")
+        if input_A.size == 0:
+            raise RuntimeError("invalid input size")
+        out = self._eng.process_signal(input_A, input_B, self._n_out).astype(np.float64)      # (n_hops, n_out, H)
+        L, V, H = self.number_of_srcs, len(self._ranks), self.hop_size
+        n = out.shape[0] * H
+        pos, res = 0, []
+        for run in (self.run_A, self.run_B):
+            if run:
+                blk = out[:, pos:pos + V * L].reshape(-1, V, L, H)
+                res.append([np.ascontiguousarray(blk[:, i].transpose(0, 2, 1).reshape(n, L)) for i in range(V)])
+                pos += V * L
+            else:
+                res.append(None)
+        for _ in range(2):
+            t = np.ascontiguousarray(out[:, pos:pos + L].transpose(0, 2, 1).reshape(n, L))
+            res.append([t.copy() for _ in range(V)])
+            pos += L
+        self._refresh_attributes()
+        return tuple(res)
+
     def _split_outputs(self, out):
         L, V, H = self.number_of_srcs, len(self._ranks), self.hop_size
         pos = 0

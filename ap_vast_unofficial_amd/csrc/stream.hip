@@ -12,6 +12,7 @@
 // matrix X[k] = [M][L] is one contiguous slab of the bin-major spectra [K][M*L].
 #include "apv_internal.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -52,6 +53,19 @@ struct apv_stream {
     void* pin_out;                // [n_out][H]
     int32_t* pin_status;          // [2][K]
     int period;                   // hops after which (ring_off, cur) repeat; 0 = graphs off
+    // whole-signal path (apv_process_signal): a second set of the hop's spectra, a second stream and four events, so
+    // that the front half (FIR + analysis) of hop h+1 runs beside the back half (GEVD + synthesis) of hop h
+    void* X1[4];                  // like X, tspec, inspec: hops alternate between the two sets
+    void* tspec1[2];
+    void* inspec1;
+    hipStream_t front;            // front-half stream; the back half stays on the handle's stream
+    hipEvent_t ev_front[2];       // set p filled by the front half
+    hipEvent_t ev_back[2];        // set p released by the back half
+    hipEvent_t ev_chunk[2];       // chunk c & 1 of the pinned staging complete
+    void* sig_in;                 // pinned [2][chunk][2][H]
+    void* sig_out;                // pinned [2][chunk][n_out][H]
+    int32_t* sig_status;          // pinned [2][chunk][2][K]
+    int sig_chunk;                // hops per half of the pinned staging
     long hop;                     // hops processed
     long not_converged;           // hops in which some bin hit the sweep cap (status 2)
     std::vector<hipGraphExec_t> execs;
@@ -118,20 +132,48 @@ void apv_stream_free(apv_handle* h) {
     if (s->pin_in) (void)hipHostFree(s->pin_in);
     if (s->pin_out) (void)hipHostFree(s->pin_out);
     if (s->pin_status) (void)hipHostFree(s->pin_status);
+    void* second[] = {s->X1[0], s->X1[1], s->X1[2], s->X1[3], s->tspec1[0], s->tspec1[1], s->inspec1};
+    for (void* b : second)
+        if (b) (void)hipFree(b);
+    for (int p = 0; p < 2; ++p) {
+        if (s->ev_front[p]) (void)hipEventDestroy(s->ev_front[p]);
+        if (s->ev_back[p]) (void)hipEventDestroy(s->ev_back[p]);
+        if (s->ev_chunk[p]) (void)hipEventDestroy(s->ev_chunk[p]);
+    }
+    if (s->front) (void)hipStreamDestroy(s->front);
+    if (s->sig_in) (void)hipHostFree(s->sig_in);
+    if (s->sig_out) (void)hipHostFree(s->sig_out);
+    if (s->sig_status) (void)hipHostFree(s->sig_status);
     delete s;
     h->st = nullptr;
 }
 
-// everything one hop puts on the stream, from the pinned input staging to the pinned output staging; advances
-// (ring_off, cur) on the host.  Pure enqueue: also used under stream capture.
-static int enqueue_hop(apv_handle* h) {
+// the spectra of one hop: set 0 is the handle's own (state arrays, apv_stream_get_statistics), set 1 exists once
+// apv_process_signal has been called
+struct HopSpectra {
+    void* X[4];
+    void* tspec[2];
+    void* inspec;
+};
+static HopSpectra hop_spectra(const apv_stream* s, int set) {
+    HopSpectra q;
+    for (int p = 0; p < 4; ++p) q.X[p] = set ? s->X1[p] : s->X[p];
+    for (int z = 0; z < 2; ++z) q.tspec[z] = set ? s->tspec1[z] : s->tspec[z];
+    q.inspec = set ? s->inspec1 : s->inspec;
+    return q;
+}
+
+// Front half of a hop on stream `st`: pinned hop `pin_src` [2][H] -> input histories, response rings (K1), analysis
+// spectra of set `set` (K2, perceptual weighting).  Advances (ring_off, cur) on the host.  Pure enqueue: also used
+// under stream capture.
+static int enqueue_front(apv_handle* h, hipStream_t st, int set, const void* pin_src) {
     apv_stream* s = h->st;
-    hipStream_t st = h->stream;
+    const HopSpectra q = hop_spectra(s, set);
     const int N = s->N, H = s->H, K = s->K, L = s->L, M = s->M, C = s->C, P = s->P, f64 = s->f64;
-    const size_t e1 = s->esz, e2 = 2 * s->esz;
+    const size_t e1 = s->esz;
     std::string why;
     // hop -> device, input history and input-block rings
-    SCHK(h, hipMemcpyAsync(s->xin, s->pin_in, e1 * 2 * H, hipMemcpyHostToDevice, st));     // [A | B], contiguous on both sides
+    SCHK(h, hipMemcpyAsync(s->xin, pin_src, e1 * 2 * H, hipMemcpyHostToDevice, st));     // [A | B], contiguous on both sides
     const int nxt = s->cur ^ 1;
     // all rings advance by one hop: logical sample n now lives H further on
     s->ring_off = (s->ring_off + H) % N;
@@ -183,10 +225,10 @@ static int enqueue_hop(apv_handle* h) {
         for (int p = 0; p < 4; ++p) {
             const bool need = (p < 2) ? runA : runB;       // A->A, A->B feed zone program A; B->A, B->B feed B
             if (!need) continue;
-            jx[nj] = s->resp[p]; jspec[nj] = s->X[p]; jch[nj] = C; jsc[nj] = 1; jsk[nj] = C; ++nj;
+            jx[nj] = s->resp[p]; jspec[nj] = q.X[p]; jch[nj] = C; jsc[nj] = 1; jsk[nj] = C; ++nj;
         }
-        for (int z = 0; z < 2; ++z) { jx[nj] = s->tresp[z]; jspec[nj] = s->tspec[z]; jch[nj] = M; jsc[nj] = 1; jsk[nj] = M; ++nj; }
-        jx[nj] = s->inblk; jspec[nj] = s->inspec; jch[nj] = 2; jsc[nj] = K; jsk[nj] = 1; ++nj;
+        for (int z = 0; z < 2; ++z) { jx[nj] = s->tresp[z]; jspec[nj] = q.tspec[z]; jch[nj] = M; jsc[nj] = 1; jsk[nj] = M; ++nj; }
+        jx[nj] = s->inblk; jspec[nj] = q.inspec; jch[nj] = 2; jsc[nj] = K; jsk[nj] = 1; ++nj;
         hipError_t e = apv_launch_stft_analysis_jobs(f64, N, nj, jx, jch, jspec, jsc, jsk, s->ring_off, st, &why);
         if (e != hipSuccess) return apv_fail(h, APV_ERR_HIP, why.empty() ? hipGetErrorString(e) : why);
     }
@@ -194,14 +236,26 @@ static int enqueue_hop(apv_handle* h) {
         // weights from the UNWEIGHTED target spectra (apvast.py:205), then spectra x weights (apvast.py:208-209,
         // 258-262): A->A and B->A take zone A's curve, A->B and B->B zone B's
         for (int z = 0; z < 2; ++z)
-            SCHK(h, apv_launch_perceptual_weights(f64, K, M, s->nch, s->tspec[z], s->G2, s->G2T, s->Cs, s->Ca, s->Leff, N,
+            SCHK(h, apv_launch_perceptual_weights(f64, K, M, s->nch, q.tspec[z], s->G2, s->G2T, s->Cs, s->Ca, s->Leff, N,
                                                   s->norm_mode, s->Wgt[z], st));
         for (int p = 0; p < 4; ++p) {
             const bool need = (p < 2) ? runA : runB;
-            if (need) SCHK(h, apv_launch_scale_spectra(f64, K, C, L, s->X[p], s->Wgt[path_zone(p)], st));
+            if (need) SCHK(h, apv_launch_scale_spectra(f64, K, C, L, q.X[p], s->Wgt[path_zone(p)], st));
         }
-        for (int z = 0; z < 2; ++z) SCHK(h, apv_launch_scale_spectra(f64, K, M, 1, s->tspec[z], s->Wgt[z], st));
+        for (int z = 0; z < 2; ++z) SCHK(h, apv_launch_scale_spectra(f64, K, M, 1, q.tspec[z], s->Wgt[z], st));
     }
+    return APV_OK;
+}
+
+// Back half of a hop on stream `st`: spectra of set `set` -> per-bin filters (K5'-K10), output spectra (K3), synthesis
+// and overlap-add (K4); the emitted samples land in pinned `pin_dst` [n_out][H], the status words in `pin_stat` [2][K].
+static int enqueue_back(apv_handle* h, hipStream_t st, int set, void* pin_dst, int32_t* pin_stat) {
+    apv_stream* s = h->st;
+    const HopSpectra q = hop_spectra(s, set);
+    const int N = s->N, H = s->H, K = s->K, L = s->L, f64 = s->f64;
+    const size_t e1 = s->esz, e2 = 2 * s->esz;
+    const bool runA = s->zones & 1, runB = s->zones & 2;
+    std::string why;
     // per-bin update per zone program: A: bright A->A, dark A->B, target A;  B: bright B->B, dark B->A, target B
     int oc = 0;     // output channel cursor
     {
@@ -209,15 +263,15 @@ static int enqueue_hop(apv_handle* h) {
         GevdParams p = apv_base_params(h);
         const int first = runA ? 0 : 1;
         p.x_c128 = f64;
-        p.XB = first ? s->X[3] : s->X[0];
-        p.XD = first ? s->X[2] : s->X[1];
-        p.d = s->tspec[first];
+        p.XB = first ? q.X[3] : q.X[0];
+        p.XD = first ? q.X[2] : q.X[1];
+        p.d = q.tspec[first];
         p.w = s->w[first];
         p.lam = s->lam[first];
         p.status = s->status[first];
         p.n_zones = (runA && runB) ? 2 : 1;
         if (p.n_zones == 2) {
-            p.XB1 = s->X[3]; p.XD1 = s->X[2]; p.d1 = s->tspec[1];
+            p.XB1 = q.X[3]; p.XD1 = q.X[2]; p.d1 = q.tspec[1];
             p.w1 = s->w[1]; p.lam1 = s->lam[1]; p.status1 = s->status[1];
         }
         hipError_t e = apv_launch_gevd(p, h->cfg.compute_dtype, true, st, &why);
@@ -232,28 +286,36 @@ static int enqueue_hop(apv_handle* h) {
         int jf[4], jtg[4], nj = 0;
         for (int z = 0; z < 2; ++z) {
             if (!(z ? runB : runA)) continue;
-            jin[nj] = (const char*)s->inspec + (size_t)z * K * e2; jw[nj] = s->w[z]; jt[nj] = nullptr;
+            jin[nj] = (const char*)q.inspec + (size_t)z * K * e2; jw[nj] = s->w[z]; jt[nj] = nullptr;
             jout[nj] = (char*)s->outspec + (size_t)oc * K * e2;
             jf[nj] = s->nV * L; jtg[nj] = 0; ++nj;
             oc += s->nV * L;
         }
         for (int z = 0; z < 2; ++z) {
-            jin[nj] = (const char*)s->inspec + (size_t)z * K * e2; jw[nj] = nullptr; jt[nj] = s->tgt;
+            jin[nj] = (const char*)q.inspec + (size_t)z * K * e2; jw[nj] = nullptr; jt[nj] = s->tgt;
             jout[nj] = (char*)s->outspec + (size_t)oc * K * e2;
             jf[nj] = 0; jtg[nj] = L; ++nj;
             oc += L;
         }
         SCHK(h, apv_launch_apply_jobs(K, nj, jin, jw, jt, jout, jf, jtg, h->cfg.out_c128, f64, st));
         const int zf = runA ? 0 : 1, zn = (runA && runB) ? 2 : 1;
-        SCHK(h, hipMemcpyAsync(s->pin_status + (size_t)zf * K, s->status[zf], sizeof(int32_t) * K * zn, hipMemcpyDeviceToHost, st));
+        SCHK(h, hipMemcpyAsync(pin_stat + (size_t)zf * K, s->status[zf], sizeof(int32_t) * K * zn, hipMemcpyDeviceToHost, st));
     }
     // K4: synthesis + overlap-add + emit
     {
         hipError_t e = apv_launch_synthesis(f64, N, H, s->n_out, s->outspec, K, 1, s->outov, s->out, st, &why);
         if (e != hipSuccess) return apv_fail(h, APV_ERR_HIP, why.empty() ? hipGetErrorString(e) : why);
     }
-    SCHK(h, hipMemcpyAsync(s->pin_out, s->out, e1 * (size_t)s->n_out * H, hipMemcpyDeviceToHost, st));
+    SCHK(h, hipMemcpyAsync(pin_dst, s->out, e1 * (size_t)s->n_out * H, hipMemcpyDeviceToHost, st));
     return APV_OK;
+}
+
+// everything one hop puts on the handle's stream, from the pinned input staging to the pinned output staging
+static int enqueue_hop(apv_handle* h) {
+    apv_stream* s = h->st;
+    int rc = enqueue_front(h, h->stream, 0, s->pin_in);
+    if (rc != APV_OK) return rc;
+    return enqueue_back(h, h->stream, 0, s->pin_out, s->pin_status);
 }
 
 // run one hop whose input is already in the pinned staging; the output is left in the pinned staging
@@ -298,7 +360,7 @@ static int run_hop(apv_handle* h) {
 }
 
 // scan the per-bin status words of the hop: 1 = not positive definite (error, apvast.py:21-24), 2 = sweep cap reached
-static int scan_hop_status(apv_handle* h) {
+static int scan_hop_status(apv_handle* h, const int32_t* stat, long hop) {
     apv_stream* s = h->st;
     const int K = s->K;
     const bool runA = s->zones & 1, runB = s->zones & 2;
@@ -306,10 +368,10 @@ static int scan_hop_status(apv_handle* h) {
     for (int z = 0; z < 2; ++z) {
         if (!(z ? runB : runA)) continue;
         for (int k = 0; k < K; ++k) {
-            const int v = s->pin_status[(size_t)z * K + k];
+            const int v = stat[(size_t)z * K + k];
             if (v == 1) {
-                char buf[96];
-                std::snprintf(buf, sizeof(buf), "Matrix is not positive definite (zone %c, bin %d)", z ? 'B' : 'A', k);
+                char buf[112];
+                std::snprintf(buf, sizeof(buf), "Matrix is not positive definite (zone %c, bin %d, hop %ld)", z ? 'B' : 'A', k, hop);
                 return apv_fail(h, APV_ERR_NOT_PD, buf);
             }
             if (v == 2 && slow_zone < 0) { slow_zone = z; slow_bin = k; }
@@ -317,9 +379,9 @@ static int scan_hop_status(apv_handle* h) {
     }
     if (slow_zone >= 0) {
         s->not_converged++;
-        char buf[112];
-        std::snprintf(buf, sizeof(buf), "eigen-iteration did not converge (zone %c, bin %d); the outputs of this hop were written",
-                      slow_zone ? 'B' : 'A', slow_bin);
+        char buf[128];
+        std::snprintf(buf, sizeof(buf), "eigen-iteration did not converge (zone %c, bin %d, hop %ld); the outputs of this hop were written",
+                      slow_zone ? 'B' : 'A', slow_bin, hop);
         return apv_fail(h, APV_ERR_NO_CONVERGE, buf);
     }
     return APV_OK;
@@ -349,7 +411,145 @@ static int process_block_t(apv_handle* h, const TI* h_in_A, const TI* h_in_B, TI
         const float* po = (const float*)s->pin_out;
         for (size_t i = 0; i < nout; ++i) h_out[i] = (TI)po[i];
     }
-    return scan_hop_status(h);
+    return scan_hop_status(h, s->pin_status, s->hop - 1);
+}
+
+// what the whole-signal path needs beyond the per-hop path; allocated at its first call
+static int signal_prepare(apv_handle* h) {
+    apv_stream* s = h->st;
+    if (s->sig_chunk > 0) return APV_OK;
+    const size_t K = s->K, C = s->C, M = s->M, H = s->H, e1 = s->esz, e2 = 2 * s->esz;
+    const int chunk = 16;
+    int rc;
+    for (int p = 0; p < 4; ++p)
+        if (!s->X1[p] && (rc = dalloc(h, &s->X1[p], K * C, e2))) return rc;
+    for (int z = 0; z < 2; ++z)
+        if (!s->tspec1[z] && (rc = dalloc(h, &s->tspec1[z], K * M, e2))) return rc;
+    if (!s->inspec1 && (rc = dalloc(h, &s->inspec1, 2 * K, e2))) return rc;
+    if (!s->front) SCHK(h, hipStreamCreateWithFlags(&s->front, hipStreamNonBlocking));
+    for (int p = 0; p < 2; ++p) {
+        if (!s->ev_front[p]) SCHK(h, hipEventCreateWithFlags(&s->ev_front[p], hipEventDisableTiming));
+        if (!s->ev_back[p]) SCHK(h, hipEventCreateWithFlags(&s->ev_back[p], hipEventDisableTiming));
+        if (!s->ev_chunk[p]) SCHK(h, hipEventCreateWithFlags(&s->ev_chunk[p], hipEventDisableTiming));
+    }
+    // two chunks of pinned staging: the host converts chunk c-1 while the device runs chunk c
+    if (!s->sig_in) SCHK(h, hipHostMalloc(&s->sig_in, e1 * 2 * chunk * 2 * H, hipHostMallocDefault));
+    if (!s->sig_out) SCHK(h, hipHostMalloc(&s->sig_out, e1 * 2 * chunk * (size_t)s->n_out * H, hipHostMallocDefault));
+    if (!s->sig_status) SCHK(h, hipHostMalloc((void**)&s->sig_status, sizeof(int32_t) * 2 * chunk * 2 * K, hipHostMallocDefault));
+    std::memset(s->sig_status, 0, sizeof(int32_t) * 2 * chunk * 2 * K);
+    SCHK(h, hipStreamSynchronize(h->stream));               // the zero-fills above
+    s->sig_chunk = chunk;
+    return APV_OK;
+}
+
+// n_hops consecutive hops in one call.  Per hop the kernels, their order and their operands are those of
+// apv_process_block, so the samples returned are the same bit for bit; what changes is the schedule: the front half of
+// hop h+1 (nothing in it depends on hop h's filters) runs on a second stream beside the back half of hop h, the spectra
+// alternating between two sets, and the host never waits for a hop: it stages and converts one chunk of hops while the
+// device works on the next.
+template <typename TI>
+static int process_signal_t(apv_handle* h, int n_hops, const TI* h_in_A, const TI* h_in_B, TI* h_out) {
+    if (!h || !h_in_A || !h_in_B || !h_out) return apv_fail(h, APV_ERR_ARG, "null argument");
+    apv_stream* s = h->st;
+    if (!s) return apv_fail(h, APV_ERR_ARG, "apv_stream_init has not been called");
+    if (n_hops < 0) return apv_fail(h, APV_ERR_ARG, "n_hops must be >= 0");
+    if (n_hops == 0) return APV_OK;
+    SCHK(h, hipSetDevice(h->device));
+    int rc = signal_prepare(h);
+    if (rc != APV_OK) return rc;
+    const int H = s->H, K = s->K, chunk = s->sig_chunk;
+    const size_t e1 = s->esz, nout = (size_t)s->n_out * H;
+    hipStream_t back = h->stream;
+    auto drain = [&]() { (void)hipStreamSynchronize(s->front); (void)hipStreamSynchronize(back); };
+    int set = 0, last_set = 0;
+    bool released[2] = {true, true};                         // nothing reads either set yet
+    int worst = APV_OK;                                      // first APV_ERR_NO_CONVERGE, overridden by APV_ERR_NOT_PD
+    std::string worst_msg;
+    const int n_chunks = (n_hops + chunk - 1) / chunk;
+    const long hop_first = s->hop;
+    // chunk c of the signal lives in half c & 1 of the pinned staging
+    auto stage_in = [&](int c) {
+        const int base = c * chunk, nc = std::min(chunk, n_hops - base);
+        for (int i = 0; i < nc; ++i) {
+            const TI* a = h_in_A + (size_t)(base + i) * H;
+            const TI* b = h_in_B + (size_t)(base + i) * H;
+            const size_t slot = ((size_t)(c & 1) * chunk + i) * 2 * H;
+            if (s->f64) {
+                double* pi = (double*)s->sig_in + slot;
+                for (int t = 0; t < H; ++t) { pi[t] = (double)a[t]; pi[H + t] = (double)b[t]; }
+            } else {
+                float* pi = (float*)s->sig_in + slot;
+                for (int t = 0; t < H; ++t) { pi[t] = (float)a[t]; pi[H + t] = (float)b[t]; }
+            }
+        }
+    };
+    auto collect = [&](int c) -> int {
+        const int base = c * chunk, nc = std::min(chunk, n_hops - base);
+        hipError_t e = hipEventSynchronize(s->ev_chunk[c & 1]);
+        if (e != hipSuccess) return apv_fail(h, APV_ERR_HIP, std::string("apv_process_signal: ") + hipGetErrorString(e));
+        TI* dst = h_out + (size_t)base * nout;
+        const size_t slot = (size_t)(c & 1) * chunk * nout;
+        if (s->f64) {
+            const double* po = (const double*)s->sig_out + slot;
+            for (size_t i = 0; i < nout * nc; ++i) dst[i] = (TI)po[i];
+        } else {
+            const float* po = (const float*)s->sig_out + slot;
+            for (size_t i = 0; i < nout * nc; ++i) dst[i] = (TI)po[i];
+        }
+        for (int i = 0; i < nc; ++i) {
+            const int r = scan_hop_status(h, s->sig_status + ((size_t)(c & 1) * chunk + i) * 2 * K, hop_first + base + i);
+            if (r == APV_ERR_NOT_PD && worst != APV_ERR_NOT_PD) { worst = r; worst_msg = h->err; }
+            if (r == APV_ERR_NO_CONVERGE && worst == APV_OK) { worst = r; worst_msg = h->err; }
+        }
+        return APV_OK;
+    };
+    int c_done = 0;                                          // chunks collected
+    for (int c = 0; c < n_chunks && worst != APV_ERR_NOT_PD; ++c) {
+        const int base = c * chunk, nc = std::min(chunk, n_hops - base);
+        stage_in(c);                                         // this half was collected when chunk c-2's event came in
+        for (int i = 0; i < nc; ++i) {
+            const size_t slot = (size_t)(c & 1) * chunk + i;
+            hipError_t e = hipSuccess;
+            if (!released[set]) e = hipStreamWaitEvent(s->front, s->ev_back[set], 0);      // hop h-2 is done with this set
+            if (e == hipSuccess) {
+                rc = enqueue_front(h, s->front, set, (const char*)s->sig_in + slot * 2 * H * e1);
+                if (rc != APV_OK) { drain(); return rc; }
+                e = hipEventRecord(s->ev_front[set], s->front);
+            }
+            if (e == hipSuccess) e = hipStreamWaitEvent(back, s->ev_front[set], 0);
+            if (e == hipSuccess) {
+                rc = enqueue_back(h, back, set, (char*)s->sig_out + slot * nout * e1, s->sig_status + slot * 2 * K);
+                if (rc != APV_OK) { drain(); return rc; }
+                e = hipEventRecord(s->ev_back[set], back);
+            }
+            if (e != hipSuccess) {
+                drain();
+                return apv_fail(h, APV_ERR_HIP, std::string("apv_process_signal: ") + hipGetErrorString(e));
+            }
+            released[set] = false;
+            last_set = set;
+            set ^= 1;
+            s->hop++;
+        }
+        SCHK(h, hipEventRecord(s->ev_chunk[c & 1], back));   // every front half is upstream of some back half
+        if (c > 0) {
+            if ((rc = collect(c - 1)) != APV_OK) { drain(); return rc; }
+            c_done = c;
+        }
+    }
+    // the chunks still in flight (one, or none if a hop was not positive definite in the last one collected)
+    for (int c = c_done; c < n_chunks && (size_t)c * chunk < (size_t)(s->hop - hop_first); ++c)
+        if ((rc = collect(c)) != APV_OK) { drain(); return rc; }
+    if (last_set == 1) {
+        // the state arrays and apv_process_block live in set 0: bring the last hop's spectra there
+        const size_t C = s->C, M = s->M, e2 = 2 * e1;
+        for (int p = 0; p < 4; ++p) SCHK(h, hipMemcpyAsync(s->X[p], s->X1[p], (size_t)K * C * e2, hipMemcpyDeviceToDevice, back));
+        for (int z = 0; z < 2; ++z) SCHK(h, hipMemcpyAsync(s->tspec[z], s->tspec1[z], (size_t)K * M * e2, hipMemcpyDeviceToDevice, back));
+        SCHK(h, hipMemcpyAsync(s->inspec, s->inspec1, (size_t)2 * K * e2, hipMemcpyDeviceToDevice, back));
+    }
+    SCHK(h, hipStreamSynchronize(back));
+    if (worst != APV_OK) return apv_fail(h, worst, worst_msg);
+    return APV_OK;
 }
 
 extern "C" {
@@ -469,6 +669,14 @@ int apv_process_block(apv_handle* h, const float* h_in_A, const float* h_in_B, f
 
 int apv_process_block_f64(apv_handle* h, const double* h_in_A, const double* h_in_B, double* h_out) {
     return process_block_t<double>(h, h_in_A, h_in_B, h_out);
+}
+
+int apv_process_signal(apv_handle* h, int32_t n_hops, const float* h_in_A, const float* h_in_B, float* h_out) {
+    return process_signal_t<float>(h, n_hops, h_in_A, h_in_B, h_out);
+}
+
+int apv_process_signal_f64(apv_handle* h, int32_t n_hops, const double* h_in_A, const double* h_in_B, double* h_out) {
+    return process_signal_t<double>(h, n_hops, h_in_A, h_in_B, h_out);
 }
 
 int apv_stream_is_f64(apv_handle* h) { return (h && h->st) ? h->st->f64 : -1; }

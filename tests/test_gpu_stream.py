@@ -314,3 +314,84 @@ def test_stream_per_bin_attributes():
     assert len(ap.filter_spectra_A_t) == 4 and np.abs(ap.filter_spectra_A_t[0] - orc.target_filter).max() < 1e-14
     ap.close()
 
+
+
+def _hop_loop(ap, x, h0, h1):
+    H = ap.hop_size
+    outs = [ap.process_input_buffers(x[0, h * H:(h + 1) * H], x[1, h * H:(h + 1) * H]) for h in range(h0, h1)]
+    # concatenate like main.m:58-61: per zone a list over the ranks of (n_samples, L)
+    return [None if outs[0][q] is None else [np.concatenate([o[q][v] for o in outs]) for v in range(len(outs[0][q]))]
+            for q in range(4)]
+
+
+@pytest.mark.parametrize("dtype,run_A,run_B,perceptual", [("f64", True, True, False), ("mixed", True, True, False),
+                                                          ("f32", True, False, False), ("f64", False, True, True)])
+def test_process_signal_equals_hop_loop(dtype, run_A, run_B, perceptual):
+    """process_signal pipelines consecutive hops on two streams over two sets of spectra; per hop the kernels and
+    their operands are those of process_input_buffers, so every sample, filter and state array must come out bit
+    for bit: across chunk boundaries (16 hops per half of the pinned staging), ending on either set, and mixed with per-hop
+    calls before and after."""
+    from ap_vast_unofficial_amd.apvast import apvast
+    rirA, rirB = synth_rirs(70, 4, 8, 11)
+    N, H = 128, 64
+    mk = lambda: apvast(N, rirA, rirB, 16, 5, 1, 2, 2, 1.0, 4 * N, hop_size=H, run_A=run_A, run_B=run_B, seed=3,
+                        dtype=dtype, perceptual=perceptual, sampling_rate=16000)
+    a, b = mk(), mk()
+    n_hops = 2 + 41 + 2 + 4 + 1
+    x = np.random.default_rng(8).standard_normal((2, n_hops * H))
+    ref = _hop_loop(a, x, 0, n_hops)
+    parts = [_hop_loop(b, x, 0, 2)]
+    pos = 2
+    for n in (41, 0, 4):                    # 41: three chunks, ends on set 0;  4: ends on set 1 -> copied to set 0
+        if n == 0:
+            parts.append(_hop_loop(b, x, pos, pos + 2))
+            pos += 2
+            continue
+        parts.append(list(b.process_signal(x[0, pos * H:(pos + n) * H], x[1, pos * H:(pos + n) * H])))
+        pos += n
+        # attributes and state arrays are those of the last hop of the signal
+        c = mk()
+        _hop_loop(c, x, 0, pos)
+        sb, sc = b.get_state(), c.get_state()
+        assert sb.keys() == sc.keys()
+        for k in sb:
+            assert np.array_equal(sb[k], sc[k]), k
+        for z, run in (("A", run_A), ("B", run_B)):
+            if run:
+                assert np.array_equal(getattr(b, "w_" + z), getattr(c, "w_" + z))
+                assert np.array_equal(getattr(b, "R_%s_to_%s" % (z, z)), getattr(c, "R_%s_to_%s" % (z, z)))
+        c.close()
+    parts.append(_hop_loop(b, x, pos, pos + 1))
+    for q in range(4):
+        if ref[q] is None:
+            assert all(p[q] is None for p in parts)
+            continue
+        for v in range(len(ref[q])):
+            got = np.concatenate([p[q][v] for p in parts])
+            assert got.shape == ref[q][v].shape == (n_hops * H, 4)
+            assert np.array_equal(got, ref[q][v]), (q, v)
+    with pytest.raises(RuntimeError):
+        b.process_signal(x[0, :H + 1], x[1, :H + 1])
+    a.close()
+    b.close()
+
+
+def test_process_signal_vs_oracle_cfg3_shape():
+    """The pipelined path against the oracle at BASELINE configs[2]'s shape (16 loudspeakers, 32 control points,
+    block 2048, 800-tap RIRs), float64 end to end."""
+    from ap_vast_unofficial_amd.apvast import apvast
+    rirA, rirB = cfg3_rirs()
+    N, H, L, M, V, hops = 2048, 1024, 16, 32, 2, 5
+    ap = apvast(N, rirA, rirB, 16, 100, 0, 0, V, 1.0, 4 * N, hop_size=H, perceptual=False, seed=0, dtype="f64")
+    rs = np.random.RandomState(0)
+    init_r = np.stack([1e-3 * rs.randn(N, L, M) for _ in range(4)])
+    init_t = np.stack([1e-3 * rs.randn(N, M) for _ in range(2)])
+    orc = SubbandStreamOracle(N, rirA, rirB, 100, 0, 0, [1, 2], 1.0, hop_size=H, init_response=init_r,
+                              init_target_response=init_t)
+    x = pink(hops * H, 77)
+    sig = ap.process_signal(x[0], x[1])
+    exp = [orc.process(x[0, h * H:(h + 1) * H], x[1, h * H:(h + 1) * H]) for h in range(hops)]
+    got = [tuple([sig[q][v][h * H:(h + 1) * H] for v in range(V)] for q in range(4)) for h in range(hops)]
+    check_outputs(got, exp, TOL["f64"]["out"], TOL["f64"]["tgt"])
+    check_last_hop_state(ap, orc, TOL["f64"], N // 2 + 1, L, M)
+    ap.close()

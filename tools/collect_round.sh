@@ -9,6 +9,7 @@ python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_f64_20steps
 python bench.py --dtype f32 --no-cpu-baseline > $OUT/bench_f32.json 2>/dev/null
 APV_BENCH_FORCE_DIST=1 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29671 python bench.py --no-cpu-baseline > $OUT/bench_dist_rehearsal.json 2> $OUT/bench_dist.err
 for dt in f64 mixed f32; do python tools/bench_stream.py --hops 468 --dtype $dt $([ $dt = f64 ] && echo --cpu-hops 2) > $OUT/stream_cfg3_$dt.json 2>/dev/null; cat $OUT/stream_cfg3_$dt.json; done
+for dt in f64 mixed f32; do python tools/bench_stream.py --hops 468 --dtype $dt --signal > $OUT/stream_cfg3_signal_$dt.json 2>/dev/null; cat $OUT/stream_cfg3_signal_$dt.json; done
 python tools/bench_broadband.py 20 > $OUT/broadband_cfg1.json 2>/dev/null; cat $OUT/broadband_cfg1.json
 python tools/bench_broadband.py 5 reftest > $OUT/broadband_reftest.json 2>/dev/null; cat $OUT/broadband_reftest.json
 python tools/bench_cfg5.py > $OUT/cfg5.json 2>/dev/null; cat $OUT/cfg5.json
