@@ -60,6 +60,25 @@ __device__ __forceinline__ void cmm16(FA fa, FB fb, int lane, Cx<float> out[4]) 
     for (int t = 0; t < 4; ++t) out[t] = mk<float>(re[t], im[t]);
 }
 
+// The same product with operand lambdas that also receive the k-step s: the accumulator layout of a product X,
+// out[t] = X[(lane >> 4) + 4 t][lane & 15], is at once the B operand X of the next product (fb = out[s]) and the A operand
+// X^T (fa = out[s]), so a result can feed a product without a round trip through LDS.
+template <typename FA, typename FB>
+__device__ __forceinline__ void cmm16x(FA fa, FB fb, int lane, Cx<double> out[4]) {
+    d4 re = {0, 0, 0, 0}, im = {0, 0, 0, 0};
+    const int rc = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const Cx<double> a = fa(s, rc, 4 * s + kq), b = fb(s, 4 * s + kq, rc);
+        re = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.x, re, 0, 0, 0);
+        re = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.y, b.y, re, 0, 0, 0);
+        im = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.y, im, 0, 0, 0);
+        im = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b.x, im, 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) out[t] = mk<double>(re[t], im[t]);
+}
+
 // XT: element type of the fused input slabs (float2 = c64, double2 = c128: the float64 streaming front-end)
 template <typename T, bool FUSED, typename XT>
 __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
@@ -187,9 +206,9 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
         const int max_sweeps = p.max_sweeps > 0 ? p.max_sweeps : Prec<T>::max_sweeps;
         const T tol2 = p.sweep_tol2 > 0.0 ? (T)p.sweep_tol2 : Prec<T>::sweep_tol2;
         bool converged = false;
-        const int sexp = (normF2 > (T)0) ? -(ilogb((double)normF2) / 2) : 0;
-        const T scl = (T)ldexp(1.0, sexp), iscl = (T)ldexp(1.0, -sexp);
-        const T normS2 = normF2 * scl * scl;
+        // the scale exponent is wave-uniform: kept in a scalar register, the factors are re-formed where they are used
+        const int sexp = __builtin_amdgcn_readfirstlane((normF2 > (T)0) ? -(ilogb((double)normF2) / 2) : 0);
+        const T normS2 = (T)ldexp((double)normF2, 2 * sexp);
         bool v_in_lds = false, refined = false;
         if constexpr (sizeof(T) == 8) {
             // ---- float32 pre-solve (debug_stop == 4 skips it: double sweeps only, for A/B timing) -------------------
@@ -203,7 +222,10 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
                 // looser than the float kernel's own 1e-8: a double sweep follows anyway, so the float sweep that would only
                 // confirm convergence is not run (1e-6 measured best; 1e-5 leaves more bins needing a second double sweep)
                 constexpr float kPresolveTol2 = 1e-6f;
-                auto ldf = [&](int r, int c) { const C v = sA[r * LD + c]; return mk<float>((float)(v.x * scl), (float)(v.y * scl)); };
+                auto ldf = [&](int r, int c) {
+                    const C v = sA[r * LD + c];
+                    return mk<float>((float)ldexp((double)v.x, sexp), (float)ldexp((double)v.y, sexp));
+                };
                 CF ftt = ldf(a, b), ftb = ldf(a, 8 + b), fbt = ldf(8 + a, b), fbb = ldf(8 + a, 8 + b);
                 CF f0t = mk<float>((2 * a == b) ? 1.f : 0.f, 0.f), f0b = mk<float>((2 * a == 8 + b) ? 1.f : 0.f, 0.f);
                 CF f1t = mk<float>((2 * a + 1 == b) ? 1.f : 0.f, 0.f), f1b = mk<float>((2 * a + 1 == 8 + b) ? 1.f : 0.f, 0.f);
@@ -235,63 +257,96 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
                 // from (C', V') leaves.  |Z_ij| <= kRefineGuard on every pair keeps that below 1e-9; a wave that meets a
                 // narrower spectral gap (or a pair the float sweeps did not finish) takes the double sweeps instead.
                 constexpr double kRefineGuard2 = 9e-10;        // |Z_ij|^2 <= (3e-5)^2
+                // A step that misses the guard by less than |Z_ij| <= 1e-2 is applied all the same and followed by a second one
+                // in the rotated basis: S'' = (I+Z)^H S (I+Z) needs no C (the accumulator of S is itself an MFMA operand),
+                // Gram'' = V''^H V''.  On the bench workload 24 % of the bins miss the guard at the first step (two eigenvalues
+                // closer than ~3e-3 ||C||) and all but 0.1 % pass it at the second; the double sweeps are left for true clusters.
+                constexpr double kSecondStep2 = 1e-4;
                 // debug_stop == 5: always the double sweeps (A/B timing); a caller-set sweep tolerance (jdiag: 1e-17) asks for more
                 // than the refinement's 1e-9 and gets the sweeps too
-                bool refine_ok = (p.debug_stop != 5) && !(p.sweep_tol2 > 0.0);
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    if (mfma_row<T>(lane, t) == mcol) sLam[mcol] = accC[t].x / accG[t].x;
-                wsync();
+                const bool refine_ok = (p.debug_stop != 5) && !(p.sweep_tol2 > 0.0);
                 // Z goes straight into sA (T = C V is spent: every lane is past the third product) and the second-order
                 // eigenvalue terms into the idle coefficient array: nothing of this step stays in registers
                 T* const sLam2 = reinterpret_cast<T*>(&scoef[0]);
-                bool bad = false;
+                for (int step = 0; step < 2; ++step) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int row = mfma_row<T>(lane, t);
-                    const T di = sLam[row], dj = sLam[mcol];
-                    T l2 = (T)0;
-                    C z;
-                    if (row == mcol) {
-                        z = mk<T>((T)0.5 * ((T)1 - accG[t].x), (T)0);
-                    } else {
-                        const T den = dj - di;
-                        T inv = __builtin_amdgcn_rcp(den);
-                        inv = inv * __builtin_fma(-den, inv, (T)2);                  // one Newton step: full precision
-                        const T zx = __builtin_fma(-dj, accG[t].x, accC[t].x) * inv, zy = __builtin_fma(-dj, accG[t].y, accC[t].y) * inv;
-                        bad = bad || !(zx * zx + zy * zy <= (T)kRefineGuard2);      // NaN / inf (equal quotients) count as bad
-                        z = mk<T>(zx, zy);
-                        // the rotation part of Z is G = Z + E/2; the Rayleigh quotient d_i misses -sum_j |G_ij|^2 (d_j - d_i)
-                        const T gx = __builtin_fma((T)0.5, accG[t].x, zx), gy = __builtin_fma((T)0.5, accG[t].y, zy);
-                        l2 = -(gx * gx + gy * gy) * den;
+                    for (int t = 0; t < 4; ++t)
+                        if (mfma_row<T>(lane, t) == mcol) sLam[mcol] = accC[t].x / accG[t].x;
+                    wsync();
+                    bool bad = false, hopeless = false;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int row = mfma_row<T>(lane, t);
+                        const T di = sLam[row], dj = sLam[mcol];
+                        T l2 = (T)0;
+                        C z;
+                        if (row == mcol) {
+                            z = mk<T>((T)0.5 * ((T)1 - accG[t].x), (T)0);
+                        } else {
+                            const T den = dj - di;
+                            T inv = __builtin_amdgcn_rcp(den);
+                            inv = inv * __builtin_fma(-den, inv, (T)2);                  // one Newton step: full precision
+                            const T zx = __builtin_fma(-dj, accG[t].x, accC[t].x) * inv, zy = __builtin_fma(-dj, accG[t].y, accC[t].y) * inv;
+                            const T zz = zx * zx + zy * zy;
+                            bad = bad || !(zz <= (T)kRefineGuard2);                      // NaN / inf (equal quotients) count as bad
+                            hopeless = hopeless || !(zz <= (T)kSecondStep2);
+                            z = mk<T>(zx, zy);
+                            // the rotation part of Z is G = Z + E/2; the Rayleigh quotient d_i misses -sum_j |G_ij|^2 (d_j - d_i)
+                            const T gx = __builtin_fma((T)0.5, accG[t].x, zx), gy = __builtin_fma((T)0.5, accG[t].y, zy);
+                            l2 = -(gx * gx + gy * gy) * den;
+                        }
+                        sA[row * LD + mcol] = z;
+                        // sum over the 16 lanes that share this row (lane ^ 1, 2, 4, 8), then add the quotient itself
+                        l2 += xcol<1>(l2);
+                        l2 += xcol<2>(l2);
+                        l2 += xcol<4>(l2);
+                        l2 += xrow<1>(l2, lane);
+                        if (mcol == 0) sLam2[row] = l2 + di;
                     }
-                    sA[row * LD + mcol] = z;
-                    // sum over the 16 lanes that share this row (lane ^ 1, 2, 4, 8), then add the quotient itself
-                    l2 += xcol<1>(l2);
-                    l2 += xcol<2>(l2);
-                    l2 += xcol<4>(l2);
-                    l2 += xrow<1>(l2, lane);
-                    if (mcol == 0) sLam2[row] = l2 + di;
+                    const bool pass = !__any(bad) || p.debug_stop == 10;                 // 10: guard off (timing aid, results invalid)
+                    if (p.debug_stop == 9 && !pass) status = 8 << step;                  // 9: mark the bins by the step they miss
+                    // the double sweeps start from the triple (V, S, Gram) as it is: leave before anything of it is touched
+                    if (!refine_ok || (!pass && (step == 1 || __any(hopeless)))) break;
+                    wsync();
+                    auto v_step = [&]() {
+                        cmm16([&](int r, int kx) { return sB[r * LD + kx]; }, [&](int kx, int c) { return sA[kx * LD + c]; }, lane, accV);   // V Z
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const C v = sB[mfma_row<T>(lane, t) * LD + mcol];
+                            accV[t] = mk<T>(v.x + accV[t].x, v.y + accV[t].y);                                                               // V'' = V (I + Z)
+                        }
+                    };
+                    if (pass) {
+                        v_step();
+                        if (lane < N) sLam[lane] = sLam2[lane];
+                        wsync();
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            sA[mfma_row<T>(lane, t) * LD + mcol] = accV[t];             // Q for stage 5; sLam already holds the eigenvalues
+                            sB[i * LD + jq + 4 * t] = wrow[t];                          // W back in place for stage 5
+                        }
+                        wsync();
+                        refined = true;
+                        break;
+                    }
+                    if constexpr (sizeof(T) == 8) {
+                        // the triple after the step.  P = S (I + Z) takes S^T = conj(S) from its accumulator as the A operand,
+                        // S'' = (I + Z)^H P takes P's accumulator as the B operand; then V'' and its Gram matrix
+                        auto ipz = [&](int r, int c) { const C zv = sA[r * LD + c]; return mk<T>(zv.x + (r == c ? (T)1 : (T)0), zv.y); };
+                        cmm16x([&](int s_, int, int) { return cj(accC[s_]); }, [&](int, int kx, int c) { return ipz(kx, c); }, lane, accT);           // P
+                        cmm16x([&](int, int r, int kx) { return cj(ipz(kx, r)); }, [&](int s_, int, int) { return accT[s_]; }, lane, accC);          // S''
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            if (mfma_row<T>(lane, t) == mcol) accC[t].y = 0;
+                        v_step();
+                        wsync();
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) sB[mfma_row<T>(lane, t) * LD + mcol] = accV[t];                                      // V''
+                        wsync();
+                        cmm16([&](int r, int kx) { return cj(sB[kx * LD + r]); }, [&](int kx, int c) { return sB[kx * LD + c]; }, lane, accG);   // Gram''
+                    }
                 }
-                refine_ok = refine_ok && !__any(bad);
-                if (refine_ok) {
-                    wsync();
-                    if (lane < N) sLam[lane] = sLam2[lane];
-                    cmm16([&](int r, int kx) { return sB[r * LD + kx]; }, [&](int kx, int c) { return sA[kx * LD + c]; }, lane, accV);   // V Z
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const C v = sB[mfma_row<T>(lane, t) * LD + mcol];
-                        accV[t] = mk<T>(v.x + accV[t].x, v.y + accV[t].y);                                                               // V''
-                    }
-                    wsync();
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        sA[mfma_row<T>(lane, t) * LD + mcol] = accV[t];             // Q for stage 5; sLam already holds the eigenvalues
-                        sB[i * LD + jq + 4 * t] = wrow[t];                          // W back in place for stage 5
-                    }
-                    wsync();
-                    refined = true;
-                } else {
+                if (!refined) {
                 wsync();
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
@@ -334,6 +389,7 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
         }
         if (!refined) {
             C tt = sA[a * LD + b], tb = sA[a * LD + 8 + b], bt = sA[(8 + a) * LD + b], bb = sA[(8 + a) * LD + 8 + b];
+            const T scl = (T)ldexp(1.0, sexp);
             tt = mk<T>(tt.x * scl, tt.y * scl); tb = mk<T>(tb.x * scl, tb.y * scl);
             bt = mk<T>(bt.x * scl, bt.y * scl); bb = mk<T>(bb.x * scl, bb.y * scl);
             C v0t = mk<T>((2 * a == b) ? (T)1 : (T)0, 0), v0b = mk<T>((2 * a == 8 + b) ? (T)1 : (T)0, 0);
@@ -357,6 +413,7 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
             sA[(2 * a + 1) * LD + it_b] = v1t;
             sA[(2 * a + 1) * LD + ib_b] = v1b;
             if (diag) {
+                const T iscl = (T)ldexp(1.0, -sexp);
                 sLam[it_b] = tt.x * iscl;
                 sLam[ib_b] = bb.x * iscl;
             }
