@@ -405,4 +405,148 @@ __device__ __forceinline__ int jacobi16_sweeps(Cx<TT>& tt_, Cx<TT>& tb_, Cx<TT>&
     return sweeps_done;
 }
 
+
+// ---- float32 ONE-SIDED Jacobi (Hestenes) for the pre-solve of the float64 order-16 kernel -------------------------------
+// With G G^H = C, column rotations G <- G J leave G G^H alone and end with orthogonal columns G J = U Sigma, so the
+// normalised columns ARE the eigenvectors of C: no accumulation of V, no two-sided update of C.  A round rotates one
+// 16 x 16 array once (12 packed operations per lane) where the two-sided form rotates three (36), the pivots
+// g_p^H g_q come from an all-reduce over the eight lanes that share a column slot (so every lane forms its rotation itself:
+// no broadcast), and only the columns move between lanes.  The schedule, the slot layout and the moves are those of
+// jacobi16_sweeps: lane (a, b) holds rows 2a, 2a+1 of the columns in slot b (top, bottom).
+
+// sum over the eight lanes a = 0..7 that share b (lane bits 3, 4, 5), result in every lane: the row_ror:8 step is fused
+// into the add, lane ^ 16 is a ds_swizzle and lane ^ 32 a ds_bpermute (both on the LDS crossbar, not on the VALU)
+__device__ __forceinline__ float colsum8(float v, int lane) {
+    v += __int_as_float(dpp_xor8(__float_as_int(v)));
+    v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));
+    v += __int_as_float(__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __float_as_int(v)));
+    return v;
+}
+__device__ __forceinline__ void xchg_f(float& top, float& bot, bool bit, int peer) {
+    const float send = bit ? top : bot;
+    const float recv = __shfl(send, peer, 64);
+    if (bit) top = recv; else bot = recv;
+}
+
+// float32 Cholesky factor of (2^sexp C + delta I) from the float64 matrix in sA, left in fG [16][LDF] (lower triangle,
+// zeros above).  Lane (i = lane >> 2, jq = lane & 3) owns row i, columns jq + 4t; one column goes through LDS per step.
+// A pivot that is not positive is clamped: the factor only seeds the pre-solve, whose result the float64 refinement
+// certifies against the exact C.
+template <int LDA, int LDF>
+__device__ __forceinline__ void chol16_f32(const Cx<double>* sA, int sexp, float delta, Cx<float>* fG, Cx<float> (*fcol)[16],
+                                           int lane) {
+    const int i = lane >> 2, jq = lane & 3;
+    f2v brow[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int j = jq + 4 * t;
+        const Cx<double> v = sA[i * LDA + j];
+        brow[t] = (f2v){(float)ldexp(v.x, sexp), (float)ldexp(v.y, sexp)};
+        if (j == i) brow[t] = (f2v){brow[t].x + delta, 0.f};
+    }
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+        const int buf = kk & 1;
+        if (jq == (kk & 3)) fcol[buf][i] = mk<float>(brow[kk >> 2].x, brow[kk >> 2].y);
+        wsync();
+        const float dkk = fmaxf(fcol[buf][kk].x, 1e-12f);
+        const float inv = __builtin_amdgcn_rsqf(dkk), inv2 = inv * inv;
+        const Cx<float> lic = fcol[buf][i];
+        const f2v li = {lic.x, lic.y};
+        if (jq == (kk & 3)) {
+            Cx<float> g = mk<float>(li.x * inv, li.y * inv);
+            if (i == kk) g = mk<float>(dkk * inv, 0.f);
+            if (i < kk) g = mk<float>(0.f, 0.f);
+            fG[i * LDF + kk] = g;
+        }
+        if (i > kk) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int j = jq + 4 * t;
+                if (j > kk && j <= i) {                      // B[i][j] -= B[i][kk] conj(B[j][kk]) / d
+                    const Cx<float> ljc = fcol[buf][j];
+                    const f2v lj = {ljc.x * inv2, ljc.y * inv2};
+                    brow[t] -= pk_cmulc(lj, li);
+                }
+            }
+        }
+    }
+    wsync();
+}
+
+// Sweeps until one of them meets sum |g_p^H g_q|^2 <= tol2 normS2 (that sweep is the last) or max_sweeps is reached; the
+// columns come back normalised.  Returns the number of sweeps (its parity says which slot layout the columns are left in).
+__device__ __forceinline__ int jacobi16_onesided(Cx<float>& g0t_, Cx<float>& g0b_, Cx<float>& g1t_, Cx<float>& g1b_, int lane,
+                                                 float tol2, float normS2, int max_sweeps, bool& converged_) {
+    using CC = Cx<float>;
+    const int b = lane & 7, lane4 = lane << 2;
+    int sweeps_done = 0;
+    bool converged = false;
+    CC g0t = g0t_, g0b = g0b_, g1t = g1t_, g1b = g1b_;
+    auto norm2 = [&](CC x, CC y) { return colsum8(x.x * x.x + x.y * x.y + y.x * y.x + y.y * y.y, lane); };
+    for (int sweep = 0; sweep < max_sweeps && !converged; ++sweep) {
+        float off = 0.f;
+        // squared column norms: formed afresh every sweep, carried through the rotations inside it
+        float nt = norm2(g0t, g1t), nb = norm2(g0b, g1b);
+        const unsigned long long dseq = (sweep & 1) ? XS_DELTA1 : XS_DELTA0;
+        const unsigned long long tseq = (sweep & 1) ? XS_TBIT1 : XS_TBIT0;
+        for (int r = 0; r < 15; ++r) {
+            const int delta = (int)((dseq >> (4 * r)) & 15), tbit = (int)((tseq >> (4 * r)) & 15) - 1;
+            if (tbit >= 0) {
+                if (tbit == 2) {
+                    cxswap_col4(g0t, g0b);
+                    cxswap_col4(g1t, g1b);
+                    xswap_col4(nt, nb);
+                } else {
+                    const bool cb_ = (b >> tbit) & 1;
+                    const int pc = lane ^ (1 << tbit);
+                    xchg(g0t, g0b, cb_, pc);
+                    xchg(g1t, g1b, cb_, pc);
+                    xchg_f(nt, nb, cb_, pc);
+                }
+            }
+            if (delta != 0) {
+                // the bottoms move by slot-XOR delta: five crossbar permutes under one per-round address (the VALU, the bound
+                // unit, spends one instruction on the move instead of five DPP moves and the copies around a three-way branch)
+                const int addr = lane4 ^ (delta << 2);
+                auto mv = [&](float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v))); };
+                g0b = mk<float>(mv(g0b.x), mv(g0b.y));
+                g1b = mk<float>(mv(g1b.x), mv(g1b.y));
+                nb = mv(nb);
+            }
+            // pivot beta = g_top^H g_bottom over the 16 rows
+            const f2v part = pk_cmulc((f2v){g0t.x, g0t.y}, (f2v){g0b.x, g0b.y}) + pk_cmulc((f2v){g1t.x, g1t.y}, (f2v){g1b.x, g1b.y});
+            const float bx = colsum8(part.x, lane), by = colsum8(part.y, lane);
+            const float b2 = bx * bx + by * by;
+            off += b2;
+            // rotation for [[nt, beta], [conj(beta), nb]]: with zeta = (nb - nt)/2 and D = |zeta| + sqrt(zeta^2 + |beta|^2),
+            // t = sign(zeta) beta / D (|t| <= 1; no division by |beta|), c = 1/sqrt(1 + |t|^2), s = t c; the diagonal moves by
+            // Re(conj(t) beta) = sign(zeta) |beta|^2 / D.  Three transcendental instructions, no branch: zeta = beta = 0 gives t = 0.
+            const float zeta = 0.5f * (nb - nt);
+            const float x = fmaxf(__builtin_fmaf(zeta, zeta, b2), 1e-36f);
+            const float D = fabsf(zeta) + x * __builtin_amdgcn_rsqf(x);
+            const float tsgn = copysignf(__builtin_amdgcn_rcpf(D), zeta);
+            const float tx = bx * tsgn, ty = by * tsgn;
+            const float c = __builtin_amdgcn_rsqf(__builtin_fmaf(tx, tx, __builtin_fmaf(ty, ty, 1.0f)));
+            const CC s = mk<float>(tx * c, ty * c);
+            const float shift = b2 * tsgn;
+            nt -= shift;
+            nb += shift;
+            CC w0p, w0q, w1p, w1q;
+            rot_cols<float>(c, s, g0t, g0b, w0p, w0q);
+            rot_cols<float>(c, s, g1t, g1b, w1p, w1q);
+            g0t = w0p; g0b = w0q; g1t = w1p; g1b = w1q;
+        }
+        ++sweeps_done;
+        // every pair was counted by the eight lanes of its slot
+        const float tot = wave_sum(off) * 0.125f;
+        if (tot <= tol2 * normS2) converged = true;
+    }
+    const float it = __builtin_amdgcn_rsqf(fmaxf(norm2(g0t, g1t), 1e-30f)), ib = __builtin_amdgcn_rsqf(fmaxf(norm2(g0b, g1b), 1e-30f));
+    g0t_ = mk<float>(g0t.x * it, g0t.y * it); g1t_ = mk<float>(g1t.x * it, g1t.y * it);
+    g0b_ = mk<float>(g0b.x * ib, g0b.y * ib); g1b_ = mk<float>(g1b.x * ib, g1b.y * ib);
+    converged_ = converged;
+    return sweeps_done;
+}
+
 }  // namespace

@@ -222,16 +222,33 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
                 // looser than the float kernel's own 1e-8: a double sweep follows anyway, so the float sweep that would only
                 // confirm convergence is not run (1e-6 measured best; 1e-5 leaves more bins needing a second double sweep)
                 constexpr float kPresolveTol2 = 1e-6f;
-                auto ldf = [&](int r, int c) {
-                    const C v = sA[r * LD + c];
-                    return mk<float>((float)ldexp((double)v.x, sexp), (float)ldexp((double)v.y, sexp));
-                };
-                CF ftt = ldf(a, b), ftb = ldf(a, 8 + b), fbt = ldf(8 + a, b), fbb = ldf(8 + a, 8 + b);
-                CF f0t = mk<float>((2 * a == b) ? 1.f : 0.f, 0.f), f0b = mk<float>((2 * a == 8 + b) ? 1.f : 0.f, 0.f);
-                CF f1t = mk<float>((2 * a + 1 == b) ? 1.f : 0.f, 0.f), f1b = mk<float>((2 * a + 1 == 8 + b) ? 1.f : 0.f, 0.f);
+                CF f0t, f0b, f1t, f1b;
                 bool fconv = false;
-                const int fs = jacobi16_sweeps<float>(ftt, ftb, fbt, fbb, f0t, f0b, f1t, f1b, (float (*)[4]) nullptr, lane,
-                                                      kPresolveTol2, (float)normS2, Prec<float>::max_sweeps, fconv);
+                int fs;
+                if (p.debug_stop != 11) {
+                    // one-sided form on the float Cholesky factor of 2^sexp C + delta I (same eigenvectors; the shift keeps the
+                    // float pivots positive when C is singular to float precision).  The factor goes through sB, which is free
+                    // until V32 lands there (W waits in registers), its column staging through the spent Cholesky staging.
+                    constexpr int LDF = 17;
+                    constexpr float kShift = 8e-6f;                                   // x ||C||_F (scaled to ~1)
+                    CF* const fG = reinterpret_cast<CF*>(&sB[0]);
+                    CF (*const fcol)[16] = reinterpret_cast<CF(*)[16]>(&scol[0][0]);
+                    chol16_f32<LD, LDF>(sA, sexp, kShift * sqrtf((float)normS2), fG, fcol, lane);
+                    f0t = fG[(2 * a) * LDF + b]; f0b = fG[(2 * a) * LDF + 8 + b];
+                    f1t = fG[(2 * a + 1) * LDF + b]; f1b = fG[(2 * a + 1) * LDF + 8 + b];
+                    fs = jacobi16_onesided(f0t, f0b, f1t, f1b, lane, kPresolveTol2, (float)normS2, Prec<float>::max_sweeps, fconv);
+                } else {
+                    // debug_stop == 11: round 2a's two-sided pre-solve (A/B timing)
+                    auto ldf = [&](int r, int c) {
+                        const C v = sA[r * LD + c];
+                        return mk<float>((float)ldexp((double)v.x, sexp), (float)ldexp((double)v.y, sexp));
+                    };
+                    CF ftt = ldf(a, b), ftb = ldf(a, 8 + b), fbt = ldf(8 + a, b), fbb = ldf(8 + a, 8 + b);
+                    f0t = mk<float>((2 * a == b) ? 1.f : 0.f, 0.f); f0b = mk<float>((2 * a == 8 + b) ? 1.f : 0.f, 0.f);
+                    f1t = mk<float>((2 * a + 1 == b) ? 1.f : 0.f, 0.f); f1b = mk<float>((2 * a + 1 == 8 + b) ? 1.f : 0.f, 0.f);
+                    fs = jacobi16_sweeps<float>(ftt, ftb, fbt, fbb, f0t, f0b, f1t, f1b, (float (*)[4]) nullptr, lane,
+                                                kPresolveTol2, (float)normS2, Prec<float>::max_sweeps, fconv);
+                }
                 const bool fnat = fs & 1;
                 const int fit = fnat ? 2 * b : b, fib = fnat ? 2 * b + 1 : 8 + b;
                 const int mcol = lane & 15;
@@ -242,7 +259,7 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
                 sB[(2 * a + 1) * LD + fit] = mk<T>((T)f1t.x, (T)f1t.y);
                 sB[(2 * a + 1) * LD + fib] = mk<T>((T)f1b.x, (T)f1b.y);
                 wsync();
-                C accT[4], accG[4], accC[4], accV[4], accE[4];
+                C accT[4], accG[4], accC[4], accV[4];
                 cmm16([&](int r, int kx) { return sA[r * LD + kx]; }, [&](int kx, int c) { return sB[kx * LD + c]; }, lane, accT);       // C V
                 cmm16([&](int r, int kx) { return cj(sB[kx * LD + r]); }, [&](int kx, int c) { return sB[kx * LD + c]; }, lane, accG);   // V^H V
                 wsync();
@@ -291,9 +308,11 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
                             bad = bad || !(zz <= (T)kRefineGuard2);                      // NaN / inf (equal quotients) count as bad
                             hopeless = hopeless || !(zz <= (T)kSecondStep2);
                             z = mk<T>(zx, zy);
-                            // the rotation part of Z is G = Z + E/2; the Rayleigh quotient d_i misses -sum_j |G_ij|^2 (d_j - d_i)
-                            const T gx = __builtin_fma((T)0.5, accG[t].x, zx), gy = __builtin_fma((T)0.5, accG[t].y, zy);
-                            l2 = -(gx * gx + gy * gy) * den;
+                            // second-order term of the eigenvalue of the pencil (S, Gram) next to d_i: -|S_ij - d_i E_ij|^2 / (d_j - d_i).
+                            // (Exact to third order in Z AND E: the one-sided pre-solve leaves E ~ 1e-5 between the columns of small
+                            // eigenvalues, where a formula that orthonormalises to first order only is off by E^2.)
+                            const T nx = __builtin_fma(-di, accG[t].x, accC[t].x), ny = __builtin_fma(-di, accG[t].y, accC[t].y);
+                            l2 = -(nx * nx + ny * ny) * inv;
                         }
                         sA[row * LD + mcol] = z;
                         // sum over the 16 lanes that share this row (lane ^ 1, 2, 4, 8), then add the quotient itself
@@ -347,42 +366,34 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
                     }
                 }
                 if (!refined) {
-                wsync();
+                    // ---- double sweeps instead: they start from an orthonormal V' and C' = V'^H C V' -----------------------------
+                    // V' = V Y with Y = I - E/2 = (3 I - Gram)/2 is orthonormal to E^2, C' = Y S Y exactly (Y is Hermitian; S and
+                    // the intermediate product feed the MFMA from their accumulators).  The one-sided pre-solve leaves E ~ 1e-4
+                    // between the columns of small eigenvalues, so the step is taken twice: E -> E^2 -> E^4.
+                    for (int it = 0; it < 2; ++it) {
+                        wsync();
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int row = mfma_row<T>(lane, t);
-                    sA[row * LD + mcol] = mk<T>(accG[t].x - (row == mcol ? (T)1 : (T)0), accG[t].y);                                     // E
-                }
-                wsync();
-                cmm16([&](int r, int kx) { return sB[r * LD + kx]; }, [&](int kx, int c) { return sA[kx * LD + c]; }, lane, accV);       // V E
+                        for (int t = 0; t < 4; ++t) {
+                            const int row = mfma_row<T>(lane, t);
+                            sA[row * LD + mcol] = mk<T>((row == mcol ? (T)1.5 : (T)0) - (T)0.5 * accG[t].x, (T)-0.5 * accG[t].y);      // Y
+                        }
+                        wsync();
+                        cmm16([&](int r, int kx) { return sB[r * LD + kx]; }, [&](int kx, int c) { return sA[kx * LD + c]; }, lane, accV);   // V Y
+                        cmm16x([&](int s_, int, int) { return cj(accC[s_]); }, [&](int, int kx, int c) { return sA[kx * LD + c]; }, lane, accT);   // S Y
+                        cmm16x([&](int, int r, int kx) { return sA[r * LD + kx]; }, [&](int s_, int, int) { return accT[s_]; }, lane, accC);       // Y (S Y)
+                        wsync();
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const C v = sB[mfma_row<T>(lane, t) * LD + mcol];
-                    accV[t] = mk<T>(v.x - (T)0.5 * accV[t].x, v.y - (T)0.5 * accV[t].y);                                                 // V'
-                }
-                wsync();
+                        for (int t = 0; t < 4; ++t) {
+                            sB[mfma_row<T>(lane, t) * LD + mcol] = accV[t];                                                              // V'
+                            if (mfma_row<T>(lane, t) == mcol) accC[t].y = 0;
+                        }
+                        wsync();
+                        if (it == 0)
+                            cmm16([&](int r, int kx) { return cj(sB[kx * LD + r]); }, [&](int kx, int c) { return sB[kx * LD + c]; }, lane, accG);   // Gram'
+                    }
 #pragma unroll
-                for (int t = 0; t < 4; ++t) sB[mfma_row<T>(lane, t) * LD + mcol] = accC[t];
-                wsync();
-                cmm16([&](int r, int kx) { return sA[r * LD + kx]; }, [&](int kx, int c) { return sB[kx * LD + c]; }, lane, accE);       // E C1
-                wsync();
-#pragma unroll
-                for (int t = 0; t < 4; ++t) sA[mfma_row<T>(lane, t) * LD + mcol] = accE[t];
-                wsync();
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int row = mfma_row<T>(lane, t);
-                    const C h = cj(sA[mcol * LD + row]);                                                                                // (E C1)^H = C1 E
-                    accC[t] = mk<T>(accC[t].x - (T)0.5 * (accE[t].x + h.x), accC[t].y - (T)0.5 * (accE[t].y + h.y));
-                    if (row == mcol) accC[t].y = 0;
-                }
-                wsync();
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    sA[mfma_row<T>(lane, t) * LD + mcol] = accC[t];                                                                     // C'
-                    sB[mfma_row<T>(lane, t) * LD + mcol] = accV[t];                                                                     // V'
-                }
-                wsync();
+                    for (int t = 0; t < 4; ++t) sA[mfma_row<T>(lane, t) * LD + mcol] = accC[t];                                          // C'
+                    wsync();
                 v_in_lds = true;
                 }
             }

@@ -8,7 +8,7 @@ from ap_vast_unofficial_amd import Engine
 import bench
 K = 32 * 1024
 XB, XD, d = bench.synth(K, 1234)
-for name, stop in (("normal", 0), ("mark", 9), ("guard off", 10)):
+for name, stop in (("normal", 0), ("mark", 9), ("guard off", 10), ("two-sided pre-solve", 11)):
     eng = Engine(K, 16, 32, ranks=(1,), compute_dtype="f64", out_c128=True, debug_stop=stop)
     dXB, dXD, dd = eng.to_device(XB), eng.to_device(XD), eng.to_device(d)
     dw, ds = eng.alloc(K * 16 * 16), eng.alloc(K * 4)
