@@ -234,9 +234,14 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
                     CF* const fG = reinterpret_cast<CF*>(&sB[0]);
                     CF (*const fcol)[16] = reinterpret_cast<CF(*)[16]>(&scol[0][0]);
                     chol16_f32<LD, LDF>(sA, sexp, kShift * sqrtf((float)normS2), fG, fcol, lane);
+                    if (p.debug_stop == 12) return;                                   // timing aids: 12 after the float factor, 13 after the sweeps
                     f0t = fG[(2 * a) * LDF + b]; f0b = fG[(2 * a) * LDF + 8 + b];
                     f1t = fG[(2 * a + 1) * LDF + b]; f1b = fG[(2 * a + 1) * LDF + 8 + b];
                     fs = jacobi16_onesided(f0t, f0b, f1t, f1b, lane, kPresolveTol2, (float)normS2, Prec<float>::max_sweeps, fconv);
+                    if (p.debug_stop == 13) {
+                        if (lane == 0 && pstatus != nullptr) pstatus[k] = fs;        // sweeps of the pre-solve
+                        return;
+                    }
                 } else {
                     // debug_stop == 11: round 2a's two-sided pre-solve (A/B timing)
                     auto ldf = [&](int r, int c) {
