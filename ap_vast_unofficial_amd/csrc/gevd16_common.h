@@ -432,16 +432,18 @@ __device__ __forceinline__ void xchg_f(float& top, float& bot, bool bit, int pee
 // zeros above).  Lane (i = lane >> 2, jq = lane & 3) owns row i, columns jq + 4t; one column goes through LDS per step.
 // A pivot that is not positive is clamped: the factor only seeds the pre-solve, whose result the float64 refinement
 // certifies against the exact C.
-template <int LDA, int LDF>
-__device__ __forceinline__ void chol16_f32(const Cx<double>* sA, int sexp, float delta, Cx<float>* fG, Cx<float> (*fcol)[16],
+__device__ __forceinline__ float scale_to_f32(double v, int e) { return (float)ldexp(v, e); }
+__device__ __forceinline__ float scale_to_f32(float v, int e) { return ldexpf(v, e); }
+template <typename TS, int LDA, int LDF>
+__device__ __forceinline__ void chol16_f32(const Cx<TS>* sA, int sexp, float delta, Cx<float>* fG, Cx<float> (*fcol)[16],
                                            int lane) {
     const int i = lane >> 2, jq = lane & 3;
     f2v brow[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int j = jq + 4 * t;
-        const Cx<double> v = sA[i * LDA + j];
-        brow[t] = (f2v){(float)ldexp(v.x, sexp), (float)ldexp(v.y, sexp)};
+        const Cx<TS> v = sA[i * LDA + j];
+        brow[t] = (f2v){scale_to_f32(v.x, sexp), scale_to_f32(v.y, sexp)};
         if (j == i) brow[t] = (f2v){brow[t].x + delta, 0.f};
     }
 #pragma unroll
@@ -477,7 +479,7 @@ __device__ __forceinline__ void chol16_f32(const Cx<double>* sA, int sexp, float
 // Sweeps until one of them meets sum |g_p^H g_q|^2 <= tol2 normS2 (that sweep is the last) or max_sweeps is reached; the
 // columns come back normalised.  Returns the number of sweeps (its parity says which slot layout the columns are left in).
 __device__ __forceinline__ int jacobi16_onesided(Cx<float>& g0t_, Cx<float>& g0b_, Cx<float>& g1t_, Cx<float>& g1b_, int lane,
-                                                 float tol2, float normS2, int max_sweeps, bool& converged_) {
+                                                 float tol2, float normS2, int max_sweeps, bool& converged_, float& n2t_, float& n2b_) {
     using CC = Cx<float>;
     const int b = lane & 7, lane4 = lane << 2;
     int sweeps_done = 0;
@@ -542,7 +544,10 @@ __device__ __forceinline__ int jacobi16_onesided(Cx<float>& g0t_, Cx<float>& g0b
         const float tot = wave_sum(off) * 0.125f;
         if (tot <= tol2 * normS2) converged = true;
     }
-    const float it = __builtin_amdgcn_rsqf(fmaxf(norm2(g0t, g1t), 1e-30f)), ib = __builtin_amdgcn_rsqf(fmaxf(norm2(g0b, g1b), 1e-30f));
+    // squared column norms = eigenvalues of G G^H
+    n2t_ = norm2(g0t, g1t);
+    n2b_ = norm2(g0b, g1b);
+    const float it = __builtin_amdgcn_rsqf(fmaxf(n2t_, 1e-30f)), ib = __builtin_amdgcn_rsqf(fmaxf(n2b_, 1e-30f));
     g0t_ = mk<float>(g0t.x * it, g0t.y * it); g1t_ = mk<float>(g1t.x * it, g1t.y * it);
     g0b_ = mk<float>(g0b.x * ib, g0b.y * ib); g1b_ = mk<float>(g1b.x * ib, g1b.y * ib);
     converged_ = converged;

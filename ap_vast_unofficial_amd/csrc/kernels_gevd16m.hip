@@ -207,8 +207,10 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
         const T tol2 = p.sweep_tol2 > 0.0 ? (T)p.sweep_tol2 : Prec<T>::sweep_tol2;
         bool converged = false;
         // the scale exponent is wave-uniform: kept in a scalar register, the factors are re-formed where they are used
-        const int sexp = __builtin_amdgcn_readfirstlane((normF2 > (T)0) ? -(ilogb((double)normF2) / 2) : 0);
-        const T normS2 = (T)ldexp((double)normF2, 2 * sexp);
+        const int sexp = __builtin_amdgcn_readfirstlane((normF2 > (T)0) ? -((sizeof(T) == 8 ? ilogb((double)normF2) : ilogbf((float)normF2)) / 2) : 0);
+        T normS2;
+        if constexpr (sizeof(T) == 8) normS2 = (T)ldexp((double)normF2, 2 * sexp);
+        else normS2 = (T)ldexpf((float)normF2, 2 * sexp);
         bool v_in_lds = false, refined = false;
         if constexpr (sizeof(T) == 8) {
             // ---- float32 pre-solve (debug_stop == 4 skips it: double sweeps only, for A/B timing) -------------------
@@ -233,11 +235,12 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
                     constexpr float kShift = 8e-6f;                                   // x ||C||_F (scaled to ~1)
                     CF* const fG = reinterpret_cast<CF*>(&sB[0]);
                     CF (*const fcol)[16] = reinterpret_cast<CF(*)[16]>(&scol[0][0]);
-                    chol16_f32<LD, LDF>(sA, sexp, kShift * sqrtf((float)normS2), fG, fcol, lane);
+                    chol16_f32<T, LD, LDF>(sA, sexp, kShift * sqrtf((float)normS2), fG, fcol, lane);
                     if (p.debug_stop == 12) return;                                   // timing aids: 12 after the float factor, 13 after the sweeps
                     f0t = fG[(2 * a) * LDF + b]; f0b = fG[(2 * a) * LDF + 8 + b];
                     f1t = fG[(2 * a + 1) * LDF + b]; f1b = fG[(2 * a + 1) * LDF + 8 + b];
-                    fs = jacobi16_onesided(f0t, f0b, f1t, f1b, lane, kPresolveTol2, (float)normS2, Prec<float>::max_sweeps, fconv);
+                    float n2t, n2b;
+                    fs = jacobi16_onesided(f0t, f0b, f1t, f1b, lane, kPresolveTol2, (float)normS2, Prec<float>::max_sweeps, fconv, n2t, n2b);
                     if (p.debug_stop == 13) {
                         if (lane == 0 && pstatus != nullptr) pstatus[k] = fs;        // sweeps of the pre-solve
                         return;
@@ -403,9 +406,41 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
                 }
             }
         }
+        if constexpr (sizeof(T) == 4) {
+            // float kernel: the one-sided form IS the solve (debug_stop == 11: the two-sided sweeps below, for A/B timing).
+            // Eigenvalues are the squared column norms less the shift, eigenvectors the normalised columns.
+            if (p.debug_stop != 11) {
+                constexpr int LDF = 17;
+                constexpr float kShift = 8e-6f;
+                const float delta = kShift * sqrtf((float)normS2);
+                Cx<float>* const fG = reinterpret_cast<Cx<float>*>(&sB[0]);
+                Cx<float> (*const fcol)[16] = reinterpret_cast<Cx<float>(*)[16]>(&scol[0][0]);
+                chol16_f32<T, LD, LDF>(sA, sexp, delta, fG, fcol, lane);
+                Cx<float> g0t = fG[(2 * a) * LDF + b], g0b = fG[(2 * a) * LDF + 8 + b];
+                Cx<float> g1t = fG[(2 * a + 1) * LDF + b], g1b = fG[(2 * a + 1) * LDF + 8 + b];
+                float n2t, n2b;
+                const int fs = jacobi16_onesided(g0t, g0b, g1t, g1b, lane, (float)tol2, (float)normS2, max_sweeps, converged, n2t, n2b);
+                if (!converged) status = 2;
+                const bool fnat = fs & 1;
+                const int it_b = fnat ? 2 * b : b, ib_b = fnat ? 2 * b + 1 : 8 + b;
+                wsync();
+                sA[(2 * a) * LD + it_b] = mk<T>(g0t.x, g0t.y);
+                sA[(2 * a) * LD + ib_b] = mk<T>(g0b.x, g0b.y);
+                sA[(2 * a + 1) * LD + it_b] = mk<T>(g1t.x, g1t.y);
+                sA[(2 * a + 1) * LD + ib_b] = mk<T>(g1b.x, g1b.y);
+                if (a == 0) {
+                    sLam[it_b] = (T)ldexpf(n2t - delta, -sexp);
+                    sLam[ib_b] = (T)ldexpf(n2b - delta, -sexp);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) sB[i * LD + jq + 4 * t] = wrow[t];          // W back in place for stage 5
+                wsync();
+                refined = true;
+            }
+        }
         if (!refined) {
             C tt = sA[a * LD + b], tb = sA[a * LD + 8 + b], bt = sA[(8 + a) * LD + b], bb = sA[(8 + a) * LD + 8 + b];
-            const T scl = (T)ldexp(1.0, sexp);
+            const T scl = (sizeof(T) == 8) ? (T)ldexp(1.0, sexp) : (T)ldexpf(1.0f, sexp);
             tt = mk<T>(tt.x * scl, tt.y * scl); tb = mk<T>(tb.x * scl, tb.y * scl);
             bt = mk<T>(bt.x * scl, bt.y * scl); bb = mk<T>(bb.x * scl, bb.y * scl);
             C v0t = mk<T>((2 * a == b) ? (T)1 : (T)0, 0), v0b = mk<T>((2 * a == 8 + b) ? (T)1 : (T)0, 0);
@@ -429,7 +464,7 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
             sA[(2 * a + 1) * LD + it_b] = v1t;
             sA[(2 * a + 1) * LD + ib_b] = v1b;
             if (diag) {
-                const T iscl = (T)ldexp(1.0, -sexp);
+                const T iscl = (sizeof(T) == 8) ? (T)ldexp(1.0, -sexp) : (T)ldexpf(1.0f, -sexp);
                 sLam[it_b] = tt.x * iscl;
                 sLam[ib_b] = bb.x * iscl;
             }
