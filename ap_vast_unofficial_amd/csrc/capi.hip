@@ -1,6 +1,8 @@
 // C ABI of libapvast_hip.so (see include/apvast_hip.h for the contract).
 #include "apv_internal.h"
 
+#include <cstdlib>
+
 #include <rccl/rccl.h>
 
 #include <cstdio>
@@ -261,7 +263,10 @@ int apv_update_dev(apv_handle* h, const void* d_XB, const void* d_XD, const void
     std::string why;
     const apv_config& c = h->cfg;
     hipError_t e;
-    if (c.compute_dtype == APV_F32 && (c.n_srcs == 32 || c.n_srcs == 64) && (c.n_mics % 2) == 0 && c.n_mics >= 8) {
+    // order 64 takes the fused order-64 kernel in either arithmetic (kernels_gevd64.hip) unless that kernel is switched off
+    static const bool no_gevd64 = (getenv("APV_NO_GEVD64") != nullptr);
+    const bool split64 = c.n_srcs == 64 && (no_gevd64 || c.reg_mode != APV_REG_ABS || c.reg_bright != 0.0 || c.sweep_tol2 > 0.0);
+    if (c.compute_dtype == APV_F32 && (c.n_srcs == 32 || split64) && (c.n_mics % 2) == 0 && c.n_mics >= 8) {
         // large orders in f32: correlation on the f32 matrix cores into a scratch R (HBM round trip of
         // 2 L^2 c64 per bin, small against the eigen-iteration), then the LDS-resident GEVD from explicit R
         const size_t K = c.n_bins, L = c.n_srcs;

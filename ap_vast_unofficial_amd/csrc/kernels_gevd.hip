@@ -640,7 +640,9 @@ hipError_t launch_t(const GevdParams& p, bool fused, hipStream_t s) {
 
 size_t apv_gevd_spill_bytes(int n, int K, int compute_dtype) {
     // per (zone program, bin): the order-64 kernel parks C, W (c128) and a float32 matrix; the LDS kernel its Cholesky factor
-    if (compute_dtype == APV_F64 && n > 32) return (size_t)2 * K * apv_gevd64_slot_bytes();   // leading 2: two-zone launches
+    // (either arithmetic: the fused order-64 update runs the float64 kernel for both)
+    (void)compute_dtype;
+    if (n > 32) return (size_t)2 * K * apv_gevd64_slot_bytes();   // leading 2: two-zone launches
     return 0;
 }
 
