@@ -5,10 +5,12 @@
 //   stage 1  Cholesky of R_D + reg I TOGETHER WITH W = L^-1 (elimination applied to [B | I]); rows of B and W
 //            live in registers, one column / one row is broadcast through LDS per step      apvast.py:22-27
 //   stage 2  C = W R_B W^H                         two complex MFMA products                 apvast.py:28-29
-//   stage 3  cyclic Jacobi, register resident, XOR pairing schedule (gevd16_common.h)        apvast.py:30
-//            float64: a float32 pre-solve on packed math, then ONE refinement step of its eigenvector matrix on the
-//            f64 MFMA (four complex products, Ogita & Aishima 2018); a wave whose spectrum has a gap too narrow for
-//            that step re-orthonormalises to first order, re-forms C on the MFMA and runs double sweeps instead
+//   stage 3  eigenvectors of C                                                                apvast.py:30
+//            float64: a float32 pre-solve on packed math -- ONE-SIDED Jacobi on the float Cholesky factor of C (column
+//            rotations only, gevd16_common.h) -- then one or two refinement steps of its eigenvector matrix on the f64 MFMA
+//            (four complex products each, Ogita & Aishima 2018); a wave whose spectrum has a gap too narrow for that
+//            orthonormalises exactly, re-forms C on the MFMA and runs register-resident double sweeps (XOR pairing schedule)
+//            float32: the one-sided Jacobi is the solve
 //   stage 4  sort                                                                            apvast.py:32-35
 //   stage 5  X = W^H Q                             one complex MFMA product                  apvast.py:31
 //   stage 6  w_V = sum_{i<V} (x_i^H r)/(lam_i+mu) x_i                                        apvast.py:406-414
