@@ -260,6 +260,7 @@ __device__ __forceinline__ void rot_rows(T c, Cx<T> s, Cx<T> p, Cx<T> q, Cx<T>& 
     qo.y = c * q.y + (s.x * p.y - s.y * p.x);
 }
 using f2v = __attribute__((ext_vector_type(2))) float;
+using f4v = __attribute__((ext_vector_type(4))) float;
 __device__ __forceinline__ f2v pk_cmul(f2v s, f2v z) {          // s z
     const f2v t = {-s.y, s.y};
     return __builtin_elementwise_fma((f2v){s.x, s.x}, z, t * (f2v){z.y, z.x});
@@ -446,38 +447,42 @@ __device__ __forceinline__ void chol16_f32(const Cx<TS>* sA, int sexp, float del
         brow[t] = (f2v){scale_to_f32(v.x, sexp), scale_to_f32(v.y, sexp)};
         if (j == i) brow[t] = (f2v){brow[t].x + delta, 0.f};
     }
+    // The outer-product update runs on the WHOLE Hermitian matrix, without the triangle tests: rows and columns already
+    // eliminated only cancel to rounding level and are never read again, and a wave-wide unconditional update is cheaper than
+    // its predicates.  The column goes through LDS permuted (element j = jq + 4t at jq*4 + t) so that the four partners of a
+    // lane are two 16-byte reads.
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) {
         const int buf = kk & 1;
-        if (jq == (kk & 3)) fcol[buf][i] = mk<float>(brow[kk >> 2].x, brow[kk >> 2].y);
+        if (jq == (kk & 3)) fcol[buf][(i & 3) * 4 + (i >> 2)] = mk<float>(brow[kk >> 2].x, brow[kk >> 2].y);
         wsync();
-        const float dkk = fmaxf(fcol[buf][kk].x, 1e-12f);
+        const float dkk = fmaxf(fcol[buf][(kk & 3) * 4 + (kk >> 2)].x, 1e-12f);
         const float inv = __builtin_amdgcn_rsqf(dkk), inv2 = inv * inv;
-        const Cx<float> lic = fcol[buf][i];
-        const f2v li = {lic.x, lic.y};
+        const Cx<float> lic = fcol[buf][(i & 3) * 4 + (i >> 2)];
         if (jq == (kk & 3)) {
-            Cx<float> g = mk<float>(li.x * inv, li.y * inv);
+            Cx<float> g = mk<float>(lic.x * inv, lic.y * inv);
             if (i == kk) g = mk<float>(dkk * inv, 0.f);
             if (i < kk) g = mk<float>(0.f, 0.f);
             fG[i * LDF + kk] = g;
         }
-        if (i > kk) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int j = jq + 4 * t;
-                if (j > kk && j <= i) {                      // B[i][j] -= B[i][kk] conj(B[j][kk]) / d
-                    const Cx<float> ljc = fcol[buf][j];
-                    const f2v lj = {ljc.x * inv2, ljc.y * inv2};
-                    brow[t] -= pk_cmulc(lj, li);
-                }
-            }
-        }
+        const f2v li2 = {lic.x * inv2, lic.y * inv2};
+        const f4v* const part = reinterpret_cast<const f4v*>(&fcol[buf][jq * 4]);
+        const f4v l01 = part[0], l23 = part[1];
+        brow[0] -= pk_cmulc((f2v){l01.x, l01.y}, li2);       // B[i][j] -= B[i][kk] conj(B[j][kk]) / d
+        brow[1] -= pk_cmulc((f2v){l01.z, l01.w}, li2);
+        brow[2] -= pk_cmulc((f2v){l23.x, l23.y}, li2);
+        brow[3] -= pk_cmulc((f2v){l23.z, l23.w}, li2);
     }
     wsync();
 }
 
 // Sweeps until one of them meets sum |g_p^H g_q|^2 <= tol2 normS2 (that sweep is the last) or max_sweeps is reached; the
 // columns come back normalised.  Returns the number of sweeps (its parity says which slot layout the columns are left in).
+// REL: columns of small norm (small eigenvalues; the null space of a rank-deficient C sits at the shift) weigh nothing in the
+// absolute sum, so their mutual orthogonality is not covered by it.  With REL a pair whose cosine exceeds 1e-2 keeps the
+// sweeps going (three instructions per round: the float kernel, whose result is final, pays them; the float64 kernel's
+// pre-solve does not, because its refinement measures V^H V anyway and discards a pre-solve that left columns askew).
+template <bool REL>
 __device__ __forceinline__ int jacobi16_onesided(Cx<float>& g0t_, Cx<float>& g0b_, Cx<float>& g1t_, Cx<float>& g1b_, int lane,
                                                  float tol2, float normS2, int max_sweeps, bool& converged_, float& n2t_, float& n2b_) {
     using CC = Cx<float>;
@@ -488,6 +493,7 @@ __device__ __forceinline__ int jacobi16_onesided(Cx<float>& g0t_, Cx<float>& g0b
     auto norm2 = [&](CC x, CC y) { return colsum8(x.x * x.x + x.y * x.y + y.x * y.x + y.y * y.y, lane); };
     for (int sweep = 0; sweep < max_sweeps && !converged; ++sweep) {
         float off = 0.f;
+        bool loose = false;
         // squared column norms: formed afresh every sweep, carried through the rotations inside it
         float nt = norm2(g0t, g1t), nb = norm2(g0b, g1b);
         const unsigned long long dseq = (sweep & 1) ? XS_DELTA1 : XS_DELTA0;
@@ -521,6 +527,7 @@ __device__ __forceinline__ int jacobi16_onesided(Cx<float>& g0t_, Cx<float>& g0b
             const float bx = colsum8(part.x, lane), by = colsum8(part.y, lane);
             const float b2 = bx * bx + by * by;
             off += b2;
+            if constexpr (REL) loose = loose || (b2 > 1e-4f * nt * nb);
             // rotation for [[nt, beta], [conj(beta), nb]]: with zeta = (nb - nt)/2 and D = |zeta| + sqrt(zeta^2 + |beta|^2),
             // t = sign(zeta) beta / D (|t| <= 1; no division by |beta|), c = 1/sqrt(1 + |t|^2), s = t c; the diagonal moves by
             // Re(conj(t) beta) = sign(zeta) |beta|^2 / D.  Three transcendental instructions, no branch: zeta = beta = 0 gives t = 0.
@@ -542,7 +549,7 @@ __device__ __forceinline__ int jacobi16_onesided(Cx<float>& g0t_, Cx<float>& g0b
         ++sweeps_done;
         // every pair was counted by the eight lanes of its slot
         const float tot = wave_sum(off) * 0.125f;
-        if (tot <= tol2 * normS2) converged = true;
+        if (tot <= tol2 * normS2 && !(REL && __any(loose))) converged = true;
     }
     // squared column norms = eigenvalues of G G^H
     n2t_ = norm2(g0t, g1t);

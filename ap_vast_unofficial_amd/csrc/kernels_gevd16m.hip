@@ -152,20 +152,22 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
         if (!(dkk > (T)0) || !(dkk < (T)3.0e38)) { status = 1; break; }         // uniform: same LDS word for all lanes
         const T inv = rsq_full(dkk), inv2 = inv * inv;
         const C li = scol[buf][i];
+        const C li2 = mk<T>(li.x * inv2, li.y * inv2);
+        // The outer-product update of B runs on the whole Hermitian matrix, without the triangle tests: rows and columns
+        // already eliminated only cancel to rounding level and are never read again, and the unconditional update costs less
+        // than its predicates.  W: rows past the pivot take the pivot row (zero beyond column kk), the pivot row is scaled.
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const C lj = scol[buf][jq + 4 * t];                  // B[i][j] -= B[i][kk] conj(B[j][kk]) / d
+            brow[t].x -= li2.x * lj.x + li2.y * lj.y;
+            brow[t].y -= li2.y * lj.x - li2.x * lj.y;
+        }
         if (i > kk) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const int j = jq + 4 * t;
-                if (j > kk && j <= i) {                  // B[i][j] -= B[i][kk] conj(B[j][kk]) / d
-                    const C lj = scol[buf][j];
-                    brow[t].x -= (li.x * lj.x + li.y * lj.y) * inv2;
-                    brow[t].y -= (li.y * lj.x - li.x * lj.y) * inv2;
-                }
-                if (j <= kk) {                           // W[i][j] -= (B[i][kk]/sqrt d) (W[kk][j]/sqrt d)
-                    const C wk = swr[buf][j];
-                    wrow[t].x -= (li.x * wk.x - li.y * wk.y) * inv2;
-                    wrow[t].y -= (li.x * wk.y + li.y * wk.x) * inv2;
-                }
+                const C wk = swr[buf][jq + 4 * t];               // W[i][j] -= (B[i][kk]/sqrt d) (W[kk][j]/sqrt d)
+                wrow[t].x -= li2.x * wk.x - li2.y * wk.y;
+                wrow[t].y -= li2.x * wk.y + li2.y * wk.x;
             }
         } else if (i == kk) {
 #pragma unroll
@@ -182,23 +184,27 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
         wsync();
         // ---------------- stage 2: C = W A W^H ----------------
         C acc[4];
-        cmm16([&](int r, int kx) { return sB[r * LD + kx]; }, [&](int kx, int c) { return sA[kx * LD + c]; }, lane, acc);
-        wsync();
         const int col = lane & 15;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) sA[mfma_row<T>(lane, t) * LD + col] = acc[t];          // T1 = W A
-        wsync();
-        cmm16([&](int r, int kx) { return sA[r * LD + kx]; },
-              [&](int kx, int c) { const C w = sB[c * LD + kx]; return mk<T>(w.x, -w.y); }, lane, acc);
-        wsync();
         T nrm = 0;
+        auto whiten = [&]() {                              // sA: A -> C, sB: W
+            cmm16([&](int r, int kx) { return sB[r * LD + kx]; }, [&](int kx, int c) { return sA[kx * LD + c]; }, lane, acc);
+            wsync();
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int row = mfma_row<T>(lane, t);
-            if (row == col) acc[t].y = 0;
-            sA[row * LD + col] = acc[t];                                                    // C
-            nrm += acc[t].x * acc[t].x + acc[t].y * acc[t].y;
-        }
+            for (int t = 0; t < 4; ++t) sA[mfma_row<T>(lane, t) * LD + col] = acc[t];          // T1 = W A
+            wsync();
+            cmm16([&](int r, int kx) { return sA[r * LD + kx]; },
+                  [&](int kx, int c) { const C w = sB[c * LD + kx]; return mk<T>(w.x, -w.y); }, lane, acc);
+            wsync();
+            nrm = 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int row = mfma_row<T>(lane, t);
+                if (row == col) acc[t].y = 0;
+                sA[row * LD + col] = acc[t];                                                    // C
+                nrm += acc[t].x * acc[t].x + acc[t].y * acc[t].y;
+            }
+        };
+        whiten();
         const T normF2 = wave_sum(nrm);
         wsync();
         if (p.debug_stop == 3) return;
@@ -242,7 +248,7 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
                     f0t = fG[(2 * a) * LDF + b]; f0b = fG[(2 * a) * LDF + 8 + b];
                     f1t = fG[(2 * a + 1) * LDF + b]; f1b = fG[(2 * a + 1) * LDF + 8 + b];
                     float n2t, n2b;
-                    fs = jacobi16_onesided(f0t, f0b, f1t, f1b, lane, kPresolveTol2, (float)normS2, Prec<float>::max_sweeps, fconv, n2t, n2b);
+                    fs = jacobi16_onesided<false>(f0t, f0b, f1t, f1b, lane, kPresolveTol2, (float)normS2, Prec<float>::max_sweeps, fconv, n2t, n2b);
                     if (p.debug_stop == 13) {
                         if (lane == 0 && pstatus != nullptr) pstatus[k] = fs;        // sweeps of the pre-solve
                         return;
@@ -376,11 +382,40 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
                     }
                 }
                 if (!refined) {
-                    // ---- double sweeps instead: they start from an orthonormal V' and C' = V'^H C V' -----------------------------
-                    // V' = V Y with Y = I - E/2 = (3 I - Gram)/2 is orthonormal to E^2, C' = Y S Y exactly (Y is Hermitian; S and
-                    // the intermediate product feed the MFMA from their accumulators).  The one-sided pre-solve leaves E ~ 1e-4
-                    // between the columns of small eigenvalues, so the step is taken twice: E -> E^2 -> E^4.
-                    for (int it = 0; it < 2; ++it) {
+                    // ---- double sweeps instead ----------------------------------------------------------------------------------
+                    // They start from an orthonormal V' and C' = V'^H C V'.  V' = V Y with Y = I - E/2 = (3 I - Gram)/2 is
+                    // orthonormal to E^2 and C' = Y S Y exactly (Y is Hermitian; S and the intermediate product feed the MFMA
+                    // from their accumulators); the step is repeated, E -> E^2 -> E^4, as often as the measured max |E| asks for.
+                    // The one-sided pre-solve leaves E ~ 1e-4 between the columns of small eigenvalues -- but columns at the
+                    // shift (the null space of a rank-deficient C) it does not orthogonalise at all: there |E| ~ 1 and the pre-solve
+                    // is thrown away, C rebuilt from the inputs, the sweeps started from the identity.
+                    T e2 = 0;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const T ex = accG[t].x - (mfma_row<T>(lane, t) == mcol ? (T)1 : (T)0);
+                        e2 = fmax(e2, ex * ex + accG[t].y * accG[t].y);
+                    }
+                    const bool askew = __any(!(e2 <= (T)4e-4));                       // |E_ij| > 2e-2 somewhere (NaN counts)
+                    const int n_it = __any(e2 > (T)1e-7) ? 3 : 2;                     // three steps from 2e-2: 3e-4, 7e-8, 4e-15
+                    if (askew) {
+                        wsync();
+                        if constexpr (FUSED) {
+                            correlate16<T, XT>(pXB + (size_t)k * p.M * N, (const XT*)nullptr, p.M, sA, sr, lane);
+                        } else {
+                            const C* RB = reinterpret_cast<const C*>(p.RB) + (size_t)k * N * N;
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                const int idx = lane + 64 * t;
+                                sA[(idx >> 4) * LD + (idx & 15)] = RB[idx];
+                            }
+                        }
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) sB[i * LD + jq + 4 * t] = wrow[t];
+                        wsync();
+                        whiten();
+                        wsync();
+                    } else {
+                    for (int it = 0; it < n_it; ++it) {
                         wsync();
 #pragma unroll
                         for (int t = 0; t < 4; ++t) {
@@ -398,13 +433,14 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
                             if (mfma_row<T>(lane, t) == mcol) accC[t].y = 0;
                         }
                         wsync();
-                        if (it == 0)
+                        if (it + 1 < n_it)
                             cmm16([&](int r, int kx) { return cj(sB[kx * LD + r]); }, [&](int kx, int c) { return sB[kx * LD + c]; }, lane, accG);   // Gram'
                     }
 #pragma unroll
                     for (int t = 0; t < 4; ++t) sA[mfma_row<T>(lane, t) * LD + mcol] = accC[t];                                          // C'
                     wsync();
-                v_in_lds = true;
+                    }
+                    v_in_lds = !askew;
                 }
             }
         }
@@ -421,7 +457,7 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
                 Cx<float> g0t = fG[(2 * a) * LDF + b], g0b = fG[(2 * a) * LDF + 8 + b];
                 Cx<float> g1t = fG[(2 * a + 1) * LDF + b], g1b = fG[(2 * a + 1) * LDF + 8 + b];
                 float n2t, n2b;
-                const int fs = jacobi16_onesided(g0t, g0b, g1t, g1b, lane, (float)tol2, (float)normS2, max_sweeps, converged, n2t, n2b);
+                const int fs = jacobi16_onesided<true>(g0t, g0b, g1t, g1b, lane, (float)tol2, (float)normS2, max_sweeps, converged, n2t, n2b);
                 if (!converged) status = 2;
                 const bool fnat = fs & 1;
                 const int it_b = fnat ? 2 * b : b, ib_b = fnat ? 2 * b + 1 : 8 + b;

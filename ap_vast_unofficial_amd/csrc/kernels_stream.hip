@@ -168,13 +168,19 @@ __global__ void __launch_bounds__(256) fir_f64_mfma_kernel(int P, int H, int N, 
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = (d4){0, 0, 0, 0};
     constexpr int G = NT > 1 ? 8 : 32;           // k-steps whose taps are in flight together
-    for (int s0 = s_begin; s0 < s_end; s0 += G) {
-        double bv[G];
+    // taps of the NEXT group are requested before the MFMAs of the current one are issued: a tap comes from L2 or the
+    // Infinity Cache (the six filter banks are 7 MB) and its latency is longer than one group's 8 NT MFMAs
+    auto load_taps = [&](double (&dst)[G], int s0) {
 #pragma unroll
         for (int q = 0; q < G; ++q) {
             const int pt = 4 * (s0 + q) + kq;
-            bv[q] = (s0 + q < s_end && pt < P && c_ok) ? rir[(size_t)pt * C + c] : 0.0;
+            dst[q] = (s0 + q < s_end && pt < P && c_ok) ? rir[(size_t)pt * C + c] : 0.0;
         }
+    };
+    double bv[G], bn[G];
+    load_taps(bv, s_begin);
+    for (int s0 = s_begin; s0 < s_end; s0 += G) {
+        load_taps(bn, s0 + G);                               // past s_end: all zeros, never used
 #pragma unroll
         for (int q = 0; q < G; ++q) {
             const int pt = 4 * (s0 + q) + kq;
@@ -185,6 +191,8 @@ __global__ void __launch_bounds__(256) fir_f64_mfma_kernel(int P, int H, int N, 
                 acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(xw[wj > 0 ? wj : 0], bv[q], acc[t], 0, 0, 0);
             }
         }
+#pragma unroll
+        for (int q = 0; q < G; ++q) bv[q] = bn[q];
     }
     // partial tiles -> LDS (row stride RS keeps the transposed read below off a single bank), then each thread sums the four
     // waves for NT consecutive samples of one channel: the ring is written in runs of 16 NT samples per channel
