@@ -478,11 +478,9 @@ __device__ __forceinline__ void chol16_f32(const Cx<TS>* sA, int sexp, float del
 
 // Sweeps until one of them meets sum |g_p^H g_q|^2 <= tol2 normS2 (that sweep is the last) or max_sweeps is reached; the
 // columns come back normalised.  Returns the number of sweeps (its parity says which slot layout the columns are left in).
-// REL: columns of small norm (small eigenvalues; the null space of a rank-deficient C sits at the shift) weigh nothing in the
-// absolute sum, so their mutual orthogonality is not covered by it.  With REL a pair whose cosine exceeds 1e-2 keeps the
-// sweeps going (three instructions per round: the float kernel, whose result is final, pays them; the float64 kernel's
-// pre-solve does not, because its refinement measures V^H V anyway and discards a pre-solve that left columns askew).
-template <bool REL>
+// The stop criterion is absolute: columns of small norm (eigenvalues below ~1e-3 of the largest; the null space of a
+// rank-deficient C sits at the shift) weigh nothing in it and may be left askew.  The squared column norms -- the eigenvalues
+// of G G^H -- come back with the columns; the caller looks at them and does not use such a result (gevd16m: `trust`).
 __device__ __forceinline__ int jacobi16_onesided(Cx<float>& g0t_, Cx<float>& g0b_, Cx<float>& g1t_, Cx<float>& g1b_, int lane,
                                                  float tol2, float normS2, int max_sweeps, bool& converged_, float& n2t_, float& n2b_) {
     using CC = Cx<float>;
@@ -493,7 +491,6 @@ __device__ __forceinline__ int jacobi16_onesided(Cx<float>& g0t_, Cx<float>& g0b
     auto norm2 = [&](CC x, CC y) { return colsum8(x.x * x.x + x.y * x.y + y.x * y.x + y.y * y.y, lane); };
     for (int sweep = 0; sweep < max_sweeps && !converged; ++sweep) {
         float off = 0.f;
-        bool loose = false;
         // squared column norms: formed afresh every sweep, carried through the rotations inside it
         float nt = norm2(g0t, g1t), nb = norm2(g0b, g1b);
         const unsigned long long dseq = (sweep & 1) ? XS_DELTA1 : XS_DELTA0;
@@ -527,7 +524,6 @@ __device__ __forceinline__ int jacobi16_onesided(Cx<float>& g0t_, Cx<float>& g0b
             const float bx = colsum8(part.x, lane), by = colsum8(part.y, lane);
             const float b2 = bx * bx + by * by;
             off += b2;
-            if constexpr (REL) loose = loose || (b2 > 1e-4f * nt * nb);
             // rotation for [[nt, beta], [conj(beta), nb]]: with zeta = (nb - nt)/2 and D = |zeta| + sqrt(zeta^2 + |beta|^2),
             // t = sign(zeta) beta / D (|t| <= 1; no division by |beta|), c = 1/sqrt(1 + |t|^2), s = t c; the diagonal moves by
             // Re(conj(t) beta) = sign(zeta) |beta|^2 / D.  Three transcendental instructions, no branch: zeta = beta = 0 gives t = 0.
@@ -549,7 +545,7 @@ __device__ __forceinline__ int jacobi16_onesided(Cx<float>& g0t_, Cx<float>& g0b
         ++sweeps_done;
         // every pair was counted by the eight lanes of its slot
         const float tot = wave_sum(off) * 0.125f;
-        if (tot <= tol2 * normS2 && !(REL && __any(loose))) converged = true;
+        if (tot <= tol2 * normS2) converged = true;
     }
     // squared column norms = eigenvalues of G G^H
     n2t_ = norm2(g0t, g1t);

@@ -185,26 +185,22 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
         // ---------------- stage 2: C = W A W^H ----------------
         C acc[4];
         const int col = lane & 15;
+        cmm16([&](int r, int kx) { return sB[r * LD + kx]; }, [&](int kx, int c) { return sA[kx * LD + c]; }, lane, acc);
+        wsync();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) sA[mfma_row<T>(lane, t) * LD + col] = acc[t];          // T1 = W A
+        wsync();
+        cmm16([&](int r, int kx) { return sA[r * LD + kx]; },
+              [&](int kx, int c) { const C w = sB[c * LD + kx]; return mk<T>(w.x, -w.y); }, lane, acc);
+        wsync();
         T nrm = 0;
-        auto whiten = [&]() {                              // sA: A -> C, sB: W
-            cmm16([&](int r, int kx) { return sB[r * LD + kx]; }, [&](int kx, int c) { return sA[kx * LD + c]; }, lane, acc);
-            wsync();
 #pragma unroll
-            for (int t = 0; t < 4; ++t) sA[mfma_row<T>(lane, t) * LD + col] = acc[t];          // T1 = W A
-            wsync();
-            cmm16([&](int r, int kx) { return sA[r * LD + kx]; },
-                  [&](int kx, int c) { const C w = sB[c * LD + kx]; return mk<T>(w.x, -w.y); }, lane, acc);
-            wsync();
-            nrm = 0;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int row = mfma_row<T>(lane, t);
-                if (row == col) acc[t].y = 0;
-                sA[row * LD + col] = acc[t];                                                    // C
-                nrm += acc[t].x * acc[t].x + acc[t].y * acc[t].y;
-            }
-        };
-        whiten();
+        for (int t = 0; t < 4; ++t) {
+            const int row = mfma_row<T>(lane, t);
+            if (row == col) acc[t].y = 0;
+            sA[row * LD + col] = acc[t];                                                    // C
+            nrm += acc[t].x * acc[t].x + acc[t].y * acc[t].y;
+        }
         const T normF2 = wave_sum(nrm);
         wsync();
         if (p.debug_stop == 3) return;
@@ -220,6 +216,16 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
         if constexpr (sizeof(T) == 8) normS2 = (T)ldexp((double)normF2, 2 * sexp);
         else normS2 = (T)ldexpf((float)normF2, 2 * sexp);
         bool v_in_lds = false, refined = false;
+        // A one-sided solve is used only if it converged and its eigenvalues (the squared column norms) span less than 1e3: its
+        // stop criterion is absolute, so columns of smaller norm (the null space of a rank-deficient C sits at the shift) may be
+        // left askew.  Such a bin takes the two-sided sweeps on C, which is still intact in sA at that point.
+        auto spectrum_ok = [&](float nt, float nb) {
+            float mn = fminf(nt, nb), mx = fmaxf(nt, nb);                       // over the eight slots (lane bits 0-2)
+            mn = fminf(mn, xcol<1>(mn)); mx = fmaxf(mx, xcol<1>(mx));
+            mn = fminf(mn, xcol<2>(mn)); mx = fmaxf(mx, xcol<2>(mx));
+            mn = fminf(mn, xcol<4>(mn)); mx = fmaxf(mx, xcol<4>(mx));
+            return !__any(!(mn >= 1e-3f * mx));                                   // NaN counts as not ok
+        };
         if constexpr (sizeof(T) == 8) {
             // ---- float32 pre-solve (debug_stop == 4 skips it: double sweeps only, for A/B timing) -------------------
             // The sweeps are the cost of the kernel and the packed-float ones are less than half as expensive, so C is
@@ -233,7 +239,7 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
                 // confirm convergence is not run (1e-6 measured best; 1e-5 leaves more bins needing a second double sweep)
                 constexpr float kPresolveTol2 = 1e-6f;
                 CF f0t, f0b, f1t, f1b;
-                bool fconv = false;
+                bool fconv = false, trust = true;
                 int fs;
                 if (p.debug_stop != 11) {
                     // one-sided form on the float Cholesky factor of 2^sexp C + delta I (same eigenvectors; the shift keeps the
@@ -248,7 +254,8 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
                     f0t = fG[(2 * a) * LDF + b]; f0b = fG[(2 * a) * LDF + 8 + b];
                     f1t = fG[(2 * a + 1) * LDF + b]; f1b = fG[(2 * a + 1) * LDF + 8 + b];
                     float n2t, n2b;
-                    fs = jacobi16_onesided<false>(f0t, f0b, f1t, f1b, lane, kPresolveTol2, (float)normS2, Prec<float>::max_sweeps, fconv, n2t, n2b);
+                    fs = jacobi16_onesided(f0t, f0b, f1t, f1b, lane, kPresolveTol2, (float)normS2, Prec<float>::max_sweeps, fconv, n2t, n2b);
+                    trust = fconv && spectrum_ok(n2t, n2b);
                     if (p.debug_stop == 13) {
                         if (lane == 0 && pstatus != nullptr) pstatus[k] = fs;        // sweeps of the pre-solve
                         return;
@@ -265,6 +272,12 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
                     fs = jacobi16_sweeps<float>(ftt, ftb, fbt, fbb, f0t, f0b, f1t, f1b, (float (*)[4]) nullptr, lane,
                                                 kPresolveTol2, (float)normS2, Prec<float>::max_sweeps, fconv);
                 }
+                if (!trust) {
+                    wsync();
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) sB[i * LD + jq + 4 * t] = wrow[t];      // the float factor went through sB: W back in place
+                    wsync();
+                } else {
                 const bool fnat = fs & 1;
                 const int fit = fnat ? 2 * b : b, fib = fnat ? 2 * b + 1 : 8 + b;
                 const int mcol = lane & 15;
@@ -385,36 +398,10 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
                     // ---- double sweeps instead ----------------------------------------------------------------------------------
                     // They start from an orthonormal V' and C' = V'^H C V'.  V' = V Y with Y = I - E/2 = (3 I - Gram)/2 is
                     // orthonormal to E^2 and C' = Y S Y exactly (Y is Hermitian; S and the intermediate product feed the MFMA
-                    // from their accumulators); the step is repeated, E -> E^2 -> E^4, as often as the measured max |E| asks for.
-                    // The one-sided pre-solve leaves E ~ 1e-4 between the columns of small eigenvalues -- but columns at the
-                    // shift (the null space of a rank-deficient C) it does not orthogonalise at all: there |E| ~ 1 and the pre-solve
-                    // is thrown away, C rebuilt from the inputs, the sweeps started from the identity.
-                    T e2 = 0;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const T ex = accG[t].x - (mfma_row<T>(lane, t) == mcol ? (T)1 : (T)0);
-                        e2 = fmax(e2, ex * ex + accG[t].y * accG[t].y);
-                    }
-                    const bool askew = __any(!(e2 <= (T)4e-4));                       // |E_ij| > 2e-2 somewhere (NaN counts)
-                    const int n_it = __any(e2 > (T)1e-7) ? 3 : 2;                     // three steps from 2e-2: 3e-4, 7e-8, 4e-15
-                    if (askew) {
-                        wsync();
-                        if constexpr (FUSED) {
-                            correlate16<T, XT>(pXB + (size_t)k * p.M * N, (const XT*)nullptr, p.M, sA, sr, lane);
-                        } else {
-                            const C* RB = reinterpret_cast<const C*>(p.RB) + (size_t)k * N * N;
-#pragma unroll
-                            for (int t = 0; t < 4; ++t) {
-                                const int idx = lane + 64 * t;
-                                sA[(idx >> 4) * LD + (idx & 15)] = RB[idx];
-                            }
-                        }
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) sB[i * LD + jq + 4 * t] = wrow[t];
-                        wsync();
-                        whiten();
-                        wsync();
-                    } else {
+                    // from their accumulators).  A trusted pre-solve leaves |E| <= 1e-2 at worst (between the columns of its smallest
+                    // eigenvalues), so three steps do: 1e-2 -> 7.5e-5 -> 4e-9 -> 1e-17.
+                    constexpr int n_it = 3;
+                    {
                     for (int it = 0; it < n_it; ++it) {
                         wsync();
 #pragma unroll
@@ -440,7 +427,8 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
                     for (int t = 0; t < 4; ++t) sA[mfma_row<T>(lane, t) * LD + mcol] = accC[t];                                          // C'
                     wsync();
                     }
-                    v_in_lds = !askew;
+                    v_in_lds = true;
+                }
                 }
             }
         }
@@ -457,8 +445,13 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
                 Cx<float> g0t = fG[(2 * a) * LDF + b], g0b = fG[(2 * a) * LDF + 8 + b];
                 Cx<float> g1t = fG[(2 * a + 1) * LDF + b], g1b = fG[(2 * a + 1) * LDF + 8 + b];
                 float n2t, n2b;
-                const int fs = jacobi16_onesided<true>(g0t, g0b, g1t, g1b, lane, (float)tol2, (float)normS2, max_sweeps, converged, n2t, n2b);
-                if (!converged) status = 2;
+                const int fs = jacobi16_onesided(g0t, g0b, g1t, g1b, lane, (float)tol2, (float)normS2, max_sweeps, converged, n2t, n2b);
+                const bool trust = converged && spectrum_ok(n2t, n2b);
+                converged = false;
+                wsync();
+#pragma unroll
+                for (int t = 0; t < 4; ++t) sB[i * LD + jq + 4 * t] = wrow[t];          // W back in place (stage 5, or the sweeps below)
+                if (trust) {
                 const bool fnat = fs & 1;
                 const int it_b = fnat ? 2 * b : b, ib_b = fnat ? 2 * b + 1 : 8 + b;
                 wsync();
@@ -470,10 +463,9 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
                     sLam[it_b] = (T)ldexpf(n2t - delta, -sexp);
                     sLam[ib_b] = (T)ldexpf(n2b - delta, -sexp);
                 }
-#pragma unroll
-                for (int t = 0; t < 4; ++t) sB[i * LD + jq + 4 * t] = wrow[t];          // W back in place for stage 5
-                wsync();
                 refined = true;
+                }
+                wsync();
             }
         }
         if (!refined) {

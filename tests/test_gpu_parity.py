@@ -328,6 +328,25 @@ def test_corr_bf16_exact_on_rounded_inputs(Engine):
     eng.close()
 
 
+def test_rank_deficient_bright_matrix_every_bin(Engine):
+    """M < L at the headline order, 64 bins, float64, filters returned in complex128: eight eigenvalues of C are zero, which
+    the float32 pre-solve sees as eight columns at its shift that it does not orthogonalise against each other.  The float64
+    stage must notice (V^H V far from I), throw the pre-solve away and rebuild C: before it did, one bin in thirty came out
+    with its LEADING eigenvector off by 4e-5 while three bins of the same shape passed (tools/probes/rankdef_f32_probe.py)."""
+    K, L, M, ranks = 64, 16, 8, (1, 4, 8)
+    for seed in (1, 2):
+        rng = np.random.default_rng(seed)
+        XB, XD, d = cn(rng, K, M, L), cn(rng, K, M, L), cn(rng, K, M)
+        eng = Engine(K, L, M, ranks=ranks, mu=0.7, compute_dtype="f64", reg_dark=1e-2, out_c128=True)
+        w, lam, status = eng.update(XB, XD, d)
+        eng.close()
+        w_ref, lam_ref, _ = subband.update(XB, XD, d, 0.7, list(ranks), reg=1e-2)
+        assert not status.any()
+        e = np.linalg.norm(w - w_ref, axis=-1) / np.linalg.norm(w_ref, axis=-1)
+        assert e.max() < 1e-9, (seed, e.max(), np.unravel_index(e.argmax(), e.shape))
+        assert (np.abs(lam[:, :M] - lam_ref[:, :M]) / lam_ref[:, :1]).max() < 1e-11
+
+
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 def test_degenerate_spectra(Engine, dtype):
     """Edge cases of the eigen-iteration at the headline shape: an all-zero bright slab (every pivot is exactly zero:
