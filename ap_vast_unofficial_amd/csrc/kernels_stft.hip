@@ -209,9 +209,16 @@ template <typename T>
 __global__ void __launch_bounds__(STFT_TPB) stft_analysis_jobs_kernel(FftPlan plan, StftJobs<T> jobs, int ring_off,
                                                                       const C2<T>* __restrict__ tw,
                                                                       const T* __restrict__ win) {
+    // Workgroups go to the eight XCDs round-robin, and a channel writes its bins 16 (8) bytes at a stride of a whole row of the
+    // bin-major spectra: channel c and its neighbours fill the same 64-byte lines.  Workgroup b therefore takes the b/8-th
+    // channel of the (b mod 8)-th eighth of the launch, so that one XCD's L2 sees neighbouring channels back to back and
+    // writes whole lines.
+    const int total = jobs.ch0[jobs.n], q8 = total >> 3, r8 = total & 7;
+    const int g8 = (int)blockIdx.x & 7, i8 = (int)blockIdx.x >> 3;
+    const int wg = g8 * q8 + min(g8, r8) + i8;
     int j = 0;
-    while (j + 1 < jobs.n && (int)blockIdx.x >= jobs.ch0[j + 1]) ++j;
-    const int c = (int)blockIdx.x - jobs.ch0[j];
+    while (j + 1 < jobs.n && wg >= jobs.ch0[j + 1]) ++j;
+    const int c = wg - jobs.ch0[j];
     stft_analysis_body<T>(plan, jobs.x[j] + (size_t)c * plan.N, plan.N, ring_off, 1, jobs.spec[j] + (size_t)c * jobs.stride_c[j],
                           jobs.stride_k[j], tw, win);
 }

@@ -148,12 +148,20 @@ using d4 = __attribute__((ext_vector_type(4))) double;
 template <int NT>
 __global__ void __launch_bounds__(256) fir_f64_mfma_kernel(int P, int H, int N, int ring_off, int njobs, FirJobsD jobs) {
     extern __shared__ double fir_lds[];          // [P - 1 + 16 NT] history window, then [4][NT][264] partial tiles
+    // Workgroups go to the eight XCDs round-robin.  All sample tiles of a channel tile read the same P x 16 taps (102 KB at
+    // P = 800; the six filter banks together are 7 MB, more than one XCD's L2): workgroup b takes the b/8-th (channel tile,
+    // sample tile) pair, sample tile fastest, of the (b mod 8)-th eighth of the launch, so the pairs that share taps run
+    // back to back on ONE XCD and the taps come from HBM once.
+    const int lin = (int)blockIdx.x + (int)gridDim.x * (int)blockIdx.y, total = (int)(gridDim.x * gridDim.y);
+    const int q8 = total >> 3, r8 = total & 7, g8 = lin & 7;
+    const int wg = g8 * q8 + min(g8, r8) + (lin >> 3);
+    const int by = wg / (int)gridDim.x, bx = wg - by * (int)gridDim.x;
     int j = 0;
-    while (j + 1 < njobs && (int)blockIdx.y >= jobs.tile0[j + 1]) ++j;
+    while (j + 1 < njobs && by >= jobs.tile0[j + 1]) ++j;
     const int C = jobs.C[j];
     const double* __restrict__ rir = jobs.rir[j];
     const double* __restrict__ xh = jobs.xh[j];
-    const int c0 = ((int)blockIdx.y - jobs.tile0[j]) * 16, n0 = blockIdx.x * 16 * NT;
+    const int c0 = (by - jobs.tile0[j]) * 16, n0 = bx * 16 * NT;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, il = lane & 15, kq = lane >> 4;
     constexpr int SPAN = 16 * NT - 1;
     double* xw = fir_lds;
@@ -183,6 +191,7 @@ __global__ void __launch_bounds__(256) fir_f64_mfma_kernel(int P, int H, int N, 
         load_taps(bn, s0 + G);                               // past s_end: all zeros, never used
 #pragma unroll
         for (int q = 0; q < G; ++q) {
+            if (s0 + q >= s_end) break;                      // wave-uniform: the last group of a wave is usually partial
             const int pt = 4 * (s0 + q) + kq;
             const int wi = P - 1 + il - pt;                  // taps past P carry a zero B operand
 #pragma unroll
