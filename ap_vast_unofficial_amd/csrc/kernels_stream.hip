@@ -3,6 +3,8 @@
 //   apply_filters_kernel K3: output spectra = input spectrum x filter spectra    apvast.py:445-452
 #include "apv_internal.h"
 
+#include <algorithm>
+
 namespace {
 
 constexpr int FIR_TN = 32;     // output samples per thread
@@ -147,7 +149,7 @@ using d4 = __attribute__((ext_vector_type(4))) double;
 
 template <int NT>
 __global__ void __launch_bounds__(256) fir_f64_mfma_kernel(int P, int H, int N, int ring_off, int njobs, FirJobsD jobs) {
-    extern __shared__ double fir_lds[];          // [P - 1 + 16 NT] history window, then [4][NT][264] partial tiles
+    extern __shared__ double fir_lds[];          // [P - 1 + 16 NT] history window; afterwards [4][NT][264] partial tiles
     // Workgroups go to the eight XCDs round-robin.  All sample tiles of a channel tile read the same P x 16 taps (102 KB at
     // P = 800; the six filter banks together are 7 MB, more than one XCD's L2): workgroup b takes the b/8-th (channel tile,
     // sample tile) pair, sample tile fastest, of the (b mod 8)-th eighth of the launch, so the pairs that share taps run
@@ -165,7 +167,7 @@ __global__ void __launch_bounds__(256) fir_f64_mfma_kernel(int P, int H, int N, 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, il = lane & 15, kq = lane >> 4;
     constexpr int SPAN = 16 * NT - 1;
     double* xw = fir_lds;
-    double* part = fir_lds + ((P + SPAN + 1) & ~1);
+    double* part = fir_lds;                      // the partial tiles take the window's place once every wave is done with it
     for (int i = tid; i < P + SPAN; i += 256) xw[i] = xh[n0 + i];
     const int steps_total = (P + 3) >> 2, spw = (steps_total + 3) >> 2;
     const int s_begin = wave * spw, s_end = min(s_begin + spw, steps_total);
@@ -206,6 +208,7 @@ __global__ void __launch_bounds__(256) fir_f64_mfma_kernel(int P, int H, int N, 
     // partial tiles -> LDS (row stride RS keeps the transposed read below off a single bank), then each thread sums the four
     // waves for NT consecutive samples of one channel: the ring is written in runs of 16 NT samples per channel
     constexpr int RS = 66, TS = 4 * RS;
+    __syncthreads();
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -457,11 +460,11 @@ hipError_t apv_launch_fir_jobs_f64(FirJobsD jobs, int njobs, int P, int H, int N
     // four sample tiles per workgroup once the hop is long enough to still fill the chip: every tap load then feeds four MFMAs
     if (H >= 256) {
         constexpr int NT = 4;
-        const size_t lds = sizeof(double) * (((size_t)P + 16 * NT) + 4 * NT * 264);
+        const size_t lds = sizeof(double) * std::max((size_t)P + 16 * NT, (size_t)4 * NT * 264);
         hipLaunchKernelGGL(fir_f64_mfma_kernel<NT>, dim3((H + 16 * NT - 1) / (16 * NT), tiles), dim3(256), lds, s, P, H, N,
                            ring_off % N, njobs, jobs);
     } else {
-        const size_t lds = sizeof(double) * (((size_t)P + 16) + 4 * 264);
+        const size_t lds = sizeof(double) * std::max((size_t)P + 16, (size_t)4 * 264);
         hipLaunchKernelGGL(fir_f64_mfma_kernel<1>, dim3((H + 15) / 16, tiles), dim3(256), lds, s, P, H, N, ring_off % N, njobs, jobs);
     }
     return hipGetLastError();
