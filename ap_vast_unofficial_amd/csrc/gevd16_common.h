@@ -413,14 +413,17 @@ __device__ __forceinline__ int jacobi16_sweeps(Cx<TT>& tt_, Cx<TT>& tb_, Cx<TT>&
 // 16 x 16 array once (12 packed operations per lane) where the two-sided form rotates three (36), the pivots
 // g_p^H g_q come from an all-reduce over the eight lanes that share a column slot (so every lane forms its rotation itself:
 // no broadcast), and only the columns move between lanes.  The schedule, the slot layout and the moves are those of
-// jacobi16_sweeps: lane (a, b) holds rows 2a, 2a+1 of the columns in slot b (top, bottom).
+// jacobi16_sweeps; lane a + 8 b holds rows 2a, 2a+1 of the columns in slot b (top, bottom).
 
-// sum over the eight lanes a = 0..7 that share b (lane bits 3, 4, 5), result in every lane: the row_ror:8 step is fused
-// into the add, lane ^ 16 is a ds_swizzle and lane ^ 32 a ds_bpermute (both on the LDS crossbar, not on the VALU)
-__device__ __forceinline__ float colsum8(float v, int lane) {
-    v += __int_as_float(dpp_xor8(__float_as_int(v)));
-    v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));
-    v += __int_as_float(__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __float_as_int(v)));
+// Lane layout of the one-sided solve: lane = a + 8 b, a = row pair (rows 2a, 2a+1), b = column slot -- the transpose of the
+// two-sided layout, chosen so that the sum over the eight lanes that share a slot (a = lane bits 0-2) is three DPP adds on
+// the VALU (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror: after the first two every lane of a quad holds the quad's
+// sum, and the mirror pairs quad 0 with quad 1) instead of a DPP add and two round trips over the LDS crossbar: a Jacobi round
+// has one such round trip left (the column moves), where the serial chain of the round used to have three.
+__device__ __forceinline__ float colsum8(float v) {
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, false));
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, false));
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xf, 0xf, false));
     return v;
 }
 __device__ __forceinline__ void xchg_f(float& top, float& bot, bool bit, int peer) {
@@ -484,11 +487,11 @@ __device__ __forceinline__ void chol16_f32(const Cx<TS>* sA, int sexp, float del
 __device__ __forceinline__ int jacobi16_onesided(Cx<float>& g0t_, Cx<float>& g0b_, Cx<float>& g1t_, Cx<float>& g1b_, int lane,
                                                  float tol2, float normS2, int max_sweeps, bool& converged_, float& n2t_, float& n2b_) {
     using CC = Cx<float>;
-    const int b = lane & 7, lane4 = lane << 2;
+    const int b = lane >> 3, lane4 = lane << 2;
     int sweeps_done = 0;
     bool converged = false;
     CC g0t = g0t_, g0b = g0b_, g1t = g1t_, g1b = g1b_;
-    auto norm2 = [&](CC x, CC y) { return colsum8(x.x * x.x + x.y * x.y + y.x * y.x + y.y * y.y, lane); };
+    auto norm2 = [&](CC x, CC y) { return colsum8(x.x * x.x + x.y * x.y + y.x * y.x + y.y * y.y); };
     for (int sweep = 0; sweep < max_sweeps && !converged; ++sweep) {
         float off = 0.f;
         // squared column norms: formed afresh every sweep, carried through the rotations inside it
@@ -498,22 +501,17 @@ __device__ __forceinline__ int jacobi16_onesided(Cx<float>& g0t_, Cx<float>& g0b
         for (int r = 0; r < 15; ++r) {
             const int delta = (int)((dseq >> (4 * r)) & 15), tbit = (int)((tseq >> (4 * r)) & 15) - 1;
             if (tbit >= 0) {
-                if (tbit == 2) {
-                    cxswap_col4(g0t, g0b);
-                    cxswap_col4(g1t, g1b);
-                    xswap_col4(nt, nb);
-                } else {
-                    const bool cb_ = (b >> tbit) & 1;
-                    const int pc = lane ^ (1 << tbit);
-                    xchg(g0t, g0b, cb_, pc);
-                    xchg(g1t, g1b, cb_, pc);
-                    xchg_f(nt, nb, cb_, pc);
-                }
+                // re-deal of tops and bottoms between slots b and b ^ (1 << tbit): three times per sweep
+                const bool cb_ = (b >> tbit) & 1;
+                const int pc = lane ^ (8 << tbit);
+                xchg(g0t, g0b, cb_, pc);
+                xchg(g1t, g1b, cb_, pc);
+                xchg_f(nt, nb, cb_, pc);
             }
             if (delta != 0) {
                 // the bottoms move by slot-XOR delta: five crossbar permutes under one per-round address (the VALU, the bound
                 // unit, spends one instruction on the move instead of five DPP moves and the copies around a three-way branch)
-                const int addr = lane4 ^ (delta << 2);
+                const int addr = lane4 ^ (delta << 5);                 // lane ^ (8 delta)
                 auto mv = [&](float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v))); };
                 g0b = mk<float>(mv(g0b.x), mv(g0b.y));
                 g1b = mk<float>(mv(g1b.x), mv(g1b.y));
@@ -521,7 +519,7 @@ __device__ __forceinline__ int jacobi16_onesided(Cx<float>& g0t_, Cx<float>& g0b
             }
             // pivot beta = g_top^H g_bottom over the 16 rows
             const f2v part = pk_cmulc((f2v){g0t.x, g0t.y}, (f2v){g0b.x, g0b.y}) + pk_cmulc((f2v){g1t.x, g1t.y}, (f2v){g1b.x, g1b.y});
-            const float bx = colsum8(part.x, lane), by = colsum8(part.y, lane);
+            const float bx = colsum8(part.x), by = colsum8(part.y);
             const float b2 = bx * bx + by * by;
             off += b2;
             // rotation for [[nt, beta], [conj(beta), nb]]: with zeta = (nb - nt)/2 and D = |zeta| + sqrt(zeta^2 + |beta|^2),

@@ -220,10 +220,12 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
         // stop criterion is absolute, so columns of smaller norm (the null space of a rank-deficient C sits at the shift) may be
         // left askew.  Such a bin takes the two-sided sweeps on C, which is still intact in sA at that point.
         auto spectrum_ok = [&](float nt, float nb) {
-            float mn = fminf(nt, nb), mx = fmaxf(nt, nb);                       // over the eight slots (lane bits 0-2)
-            mn = fminf(mn, xcol<1>(mn)); mx = fmaxf(mx, xcol<1>(mx));
-            mn = fminf(mn, xcol<2>(mn)); mx = fmaxf(mx, xcol<2>(mx));
-            mn = fminf(mn, xcol<4>(mn)); mx = fmaxf(mx, xcol<4>(mx));
+            float mn = fminf(nt, nb), mx = fmaxf(nt, nb);
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) {                                    // over the wave (any lane layout)
+                mn = fminf(mn, __shfl_xor(mn, m, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+            }
             return !__any(!(mn >= 1e-3f * mx));                                   // NaN counts as not ok
         };
         if constexpr (sizeof(T) == 8) {
@@ -241,6 +243,7 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
                 CF f0t, f0b, f1t, f1b;
                 bool fconv = false, trust = true;
                 int fs;
+                int va = a, vb = b;                                                   // (row pair, slot) of this lane's part of V32
                 if (p.debug_stop != 11) {
                     // one-sided form on the float Cholesky factor of 2^sexp C + delta I (same eigenvectors; the shift keeps the
                     // float pivots positive when C is singular to float precision).  The factor goes through sB, which is free
@@ -251,8 +254,9 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
                     CF (*const fcol)[16] = reinterpret_cast<CF(*)[16]>(&scol[0][0]);
                     chol16_f32<T, LD, LDF>(sA, sexp, kShift * sqrtf((float)normS2), fG, fcol, lane);
                     if (p.debug_stop == 12) return;                                   // timing aids: 12 after the float factor, 13 after the sweeps
-                    f0t = fG[(2 * a) * LDF + b]; f0b = fG[(2 * a) * LDF + 8 + b];
-                    f1t = fG[(2 * a + 1) * LDF + b]; f1b = fG[(2 * a + 1) * LDF + 8 + b];
+                    va = lane & 7; vb = lane >> 3;                                   // the one-sided solve's layout: lane = a + 8 b
+                    f0t = fG[(2 * va) * LDF + vb]; f0b = fG[(2 * va) * LDF + 8 + vb];
+                    f1t = fG[(2 * va + 1) * LDF + vb]; f1b = fG[(2 * va + 1) * LDF + 8 + vb];
                     float n2t, n2b;
                     fs = jacobi16_onesided(f0t, f0b, f1t, f1b, lane, kPresolveTol2, (float)normS2, Prec<float>::max_sweeps, fconv, n2t, n2b);
                     trust = fconv && spectrum_ok(n2t, n2b);
@@ -279,14 +283,14 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
                     wsync();
                 } else {
                 const bool fnat = fs & 1;
-                const int fit = fnat ? 2 * b : b, fib = fnat ? 2 * b + 1 : 8 + b;
+                const int fit = fnat ? 2 * vb : vb, fib = fnat ? 2 * vb + 1 : 8 + vb;
                 const int mcol = lane & 15;
                 auto cj = [](C w) { return mk<T>(w.x, -w.y); };
                 wsync();
-                sB[(2 * a) * LD + fit] = mk<T>((T)f0t.x, (T)f0t.y);                 // V32 takes W's place
-                sB[(2 * a) * LD + fib] = mk<T>((T)f0b.x, (T)f0b.y);
-                sB[(2 * a + 1) * LD + fit] = mk<T>((T)f1t.x, (T)f1t.y);
-                sB[(2 * a + 1) * LD + fib] = mk<T>((T)f1b.x, (T)f1b.y);
+                sB[(2 * va) * LD + fit] = mk<T>((T)f0t.x, (T)f0t.y);                // V32 takes W's place
+                sB[(2 * va) * LD + fib] = mk<T>((T)f0b.x, (T)f0b.y);
+                sB[(2 * va + 1) * LD + fit] = mk<T>((T)f1t.x, (T)f1t.y);
+                sB[(2 * va + 1) * LD + fib] = mk<T>((T)f1b.x, (T)f1b.y);
                 wsync();
                 C accT[4], accG[4], accC[4], accV[4];
                 cmm16([&](int r, int kx) { return sA[r * LD + kx]; }, [&](int kx, int c) { return sB[kx * LD + c]; }, lane, accT);       // C V
@@ -442,8 +446,9 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
                 Cx<float>* const fG = reinterpret_cast<Cx<float>*>(&sB[0]);
                 Cx<float> (*const fcol)[16] = reinterpret_cast<Cx<float>(*)[16]>(&scol[0][0]);
                 chol16_f32<T, LD, LDF>(sA, sexp, delta, fG, fcol, lane);
-                Cx<float> g0t = fG[(2 * a) * LDF + b], g0b = fG[(2 * a) * LDF + 8 + b];
-                Cx<float> g1t = fG[(2 * a + 1) * LDF + b], g1b = fG[(2 * a + 1) * LDF + 8 + b];
+                const int oa = lane & 7, ob = lane >> 3;                        // the one-sided solve's layout: lane = a + 8 b
+                Cx<float> g0t = fG[(2 * oa) * LDF + ob], g0b = fG[(2 * oa) * LDF + 8 + ob];
+                Cx<float> g1t = fG[(2 * oa + 1) * LDF + ob], g1b = fG[(2 * oa + 1) * LDF + 8 + ob];
                 float n2t, n2b;
                 const int fs = jacobi16_onesided(g0t, g0b, g1t, g1b, lane, (float)tol2, (float)normS2, max_sweeps, converged, n2t, n2b);
                 const bool trust = converged && spectrum_ok(n2t, n2b);
@@ -453,13 +458,13 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
                 for (int t = 0; t < 4; ++t) sB[i * LD + jq + 4 * t] = wrow[t];          // W back in place (stage 5, or the sweeps below)
                 if (trust) {
                 const bool fnat = fs & 1;
-                const int it_b = fnat ? 2 * b : b, ib_b = fnat ? 2 * b + 1 : 8 + b;
+                const int it_b = fnat ? 2 * ob : ob, ib_b = fnat ? 2 * ob + 1 : 8 + ob;
                 wsync();
-                sA[(2 * a) * LD + it_b] = mk<T>(g0t.x, g0t.y);
-                sA[(2 * a) * LD + ib_b] = mk<T>(g0b.x, g0b.y);
-                sA[(2 * a + 1) * LD + it_b] = mk<T>(g1t.x, g1t.y);
-                sA[(2 * a + 1) * LD + ib_b] = mk<T>(g1b.x, g1b.y);
-                if (a == 0) {
+                sA[(2 * oa) * LD + it_b] = mk<T>(g0t.x, g0t.y);
+                sA[(2 * oa) * LD + ib_b] = mk<T>(g0b.x, g0b.y);
+                sA[(2 * oa + 1) * LD + it_b] = mk<T>(g1t.x, g1t.y);
+                sA[(2 * oa + 1) * LD + ib_b] = mk<T>(g1b.x, g1b.y);
+                if (oa == 0) {
                     sLam[it_b] = (T)ldexpf(n2t - delta, -sexp);
                     sLam[ib_b] = (T)ldexpf(n2b - delta, -sexp);
                 }
