@@ -258,7 +258,7 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
                     f0t = fG[(2 * va) * LDF + vb]; f0b = fG[(2 * va) * LDF + 8 + vb];
                     f1t = fG[(2 * va + 1) * LDF + vb]; f1b = fG[(2 * va + 1) * LDF + 8 + vb];
                     float n2t, n2b;
-                    fs = jacobi16_onesided(f0t, f0b, f1t, f1b, lane, kPresolveTol2, (float)normS2, Prec<float>::max_sweeps, fconv, n2t, n2b);
+                    fs = jacobi16_onesided(f0t, f0b, f1t, f1b, lane, (p.debug_stop >= 20 && p.debug_stop <= 27) ? __builtin_powif(10.f, 20 - p.debug_stop) : kPresolveTol2, (float)normS2, Prec<float>::max_sweeps, fconv, n2t, n2b);
                     trust = fconv && spectrum_ok(n2t, n2b);
                     if (p.debug_stop == 13) {
                         if (lane == 0 && pstatus != nullptr) pstatus[k] = fs;        // sweeps of the pre-solve
