@@ -507,15 +507,20 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
         }
 
         // ---------------- stage 4: descending order ----------------
-        if (lane < N) {
-            const T li = sLam[lane];
+        // all 64 lanes: lane (i = lane & 15, q = lane >> 4) compares eigenvalue i with four others, the counts meet over q
+        {
+            const int i16 = lane & 15, q4 = lane >> 4;
+            const T li = sLam[i16];
             int rank = 0;
 #pragma unroll
-            for (int j = 0; j < N; ++j) {
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j = 4 * q4 + jj;
                 const T lj = sLam[j];
-                rank += (lj > li) || (lj == li && j < lane);
+                rank += (lj > li) || (lj == li && j < i16);
             }
-            sOrder[rank] = lane;
+            rank += __shfl_xor(rank, 16, 64);
+            rank += __shfl_xor(rank, 32, 64);
+            if (q4 == 0) sOrder[rank] = i16;
         }
 
         // ---------------- stage 5: X = W^H Q ----------------
@@ -527,16 +532,23 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
         wsync();
 
         // ---------------- stage 6: coefficients (x_i^H r) / (lam_i + mu) ----------------
-        if (lane < N) {
+        // all 64 lanes: lane (i, q) sums four of the sixteen terms of x_i^H r, the partial sums meet over q
+        {
+            const int i16 = lane & 15, q4 = lane >> 4;
             T sx = 0, sy = 0;
 #pragma unroll
-            for (int l = 0; l < N; ++l) {
-                const C v = sA[l * LD + lane], rr = sr[l];
+            for (int ll = 0; ll < 4; ++ll) {
+                const int l = 4 * q4 + ll;
+                const C v = sA[l * LD + i16], rr = sr[l];
                 sx += v.x * rr.x + v.y * rr.y;
                 sy += v.x * rr.y - v.y * rr.x;
             }
-            const T den = (T)1 / (sLam[lane] + (T)p.mu);
-            scoef[lane] = mk<T>(sx * den, sy * den);
+            sx += __shfl_xor(sx, 16, 64); sy += __shfl_xor(sy, 16, 64);
+            sx += __shfl_xor(sx, 32, 64); sy += __shfl_xor(sy, 32, 64);
+            if (q4 == 0) {
+                const T den = (T)1 / (sLam[i16] + (T)p.mu);
+                scoef[i16] = mk<T>(sx * den, sy * den);
+            }
         }
         wsync();
     }
