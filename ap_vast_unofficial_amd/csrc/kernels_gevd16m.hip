@@ -230,15 +230,14 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
         };
         if constexpr (sizeof(T) == 8) {
             // ---- float32 pre-solve (debug_stop == 4 skips it: double sweeps only, for A/B timing) -------------------
-            // The sweeps are the cost of the kernel and the packed-float ones are less than half as expensive, so C is
-            // first diagonalised in float: V32 with V32^H C V32 diagonal to ~1e-7.  V32 is unitary only to 1e-7, so it is
-            // not used as it is: with E = V32^H V32 - I,  V' = V32 (I - E/2) is unitary to E^2 ~ 1e-14 and
-            // C' = V'^H C V' = C1 - (E C1 + C1 E)/2,  C1 = V32^H C V32  (five complex 16 x 16 x 16 MFMA products).  The
-            // double sweeps then start from (C', V'): one is enough for the default tolerance.  W waits in registers.
+            // The sweeps are the cost of the kernel and packed-float ones cost a fraction of double ones, so C is first
+            // diagonalised in float32: V32 with V32^H C V32 diagonal to ~1e-7.  V32 is then refined against the exact float64 C on
+            // the matrix cores (below); W waits in registers meanwhile.
             if (p.debug_stop != 4) {
                 using CF = Cx<float>;
-                // looser than the float kernel's own 1e-8: a double sweep follows anyway, so the float sweep that would only
-                // confirm convergence is not run (1e-6 measured best; 1e-5 leaves more bins needing a second double sweep)
+                // looser than the float kernel's own 1e-8: the refinement follows anyway, so the float sweep that would only confirm
+                // convergence is not run (1e-6 measured best: at 1e-5 so many more bins need a second refinement step that the launch
+                // is 5 % slower, tools/probes/presolve_tol.py; debug_stop = 20 + e sets 1e-e)
                 constexpr float kPresolveTol2 = 1e-6f;
                 CF f0t, f0b, f1t, f1b;
                 bool fconv = false, trust = true;
