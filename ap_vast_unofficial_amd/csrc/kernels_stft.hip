@@ -91,13 +91,18 @@ __device__ __forceinline__ void stockham_stage(const C2<T>* __restrict__ src, C2
                                                const C2<T>* __restrict__ tw, int N) {
     const int m = Nh / R;
     const int tstep = 2 * (Nh / (Ns * R));            // tw index step for exp(-2 pi i k / (Ns R))
+    // j = q Ns + k: a shift and a mask while the sub-transform length is a power of two (every stage of a power-of-two block,
+    // the leading stages of a mixed-radix one); integer division is ~25 instructions on this machine, more than the butterfly
+    const bool pow2 = (Ns & (Ns - 1)) == 0;
+    const int sh = __ffs(Ns) - 1;
     for (int j = threadIdx.x; j < m; j += STFT_TPB) {
-        const int k = j % Ns;
+        const int q = pow2 ? (j >> sh) : (j / Ns);
+        const int k = j - q * Ns;
         C2<T> u[R];
 #pragma unroll
         for (int t = 0; t < R; ++t) {
             u[t] = src[j + t * m];
-            if (t > 0) u[t] = cmul(u[t], tw[(t * k * tstep) % N]);
+            if (t > 0) u[t] = cmul(u[t], tw[t * k * tstep]);       // t k tstep <= (R-1)(Ns-1) N / (Ns R) < N: no wrap
         }
         C2<T> v[R];
         if constexpr (R == 2) {
@@ -120,7 +125,7 @@ __device__ __forceinline__ void stockham_stage(const C2<T>* __restrict__ src, C2
                 v[o] = acc;
             }
         }
-        const int base = (j / Ns) * Ns * R + k;
+        const int base = q * Ns * R + k;
 #pragma unroll
         for (int t = 0; t < R; ++t) dst[base + t * Ns] = v[t];
     }
