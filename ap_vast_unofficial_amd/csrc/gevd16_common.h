@@ -483,28 +483,58 @@ __device__ __forceinline__ void chol16_f32(const Cx<TS>* sA, int sexp, float del
 }
 
 // Sweeps until one of them meets sum |g_p^H g_q|^2 <= tol2 normS2 (that sweep is the last) or max_sweeps is reached; the
-// columns come back normalised.  Returns the number of sweeps (its parity says which slot layout the columns are left in).
+// columns come back normalised.  Returns the number of sweeps.
 // The stop criterion is absolute: columns of small norm (eigenvalues below ~1e-3 of the largest; the null space of a
 // rank-deficient C sits at the shift) weigh nothing in it and may be left askew.  The squared column norms -- the eigenvalues
 // of G G^H -- come back with the columns; the caller looks at them and does not use such a result (gevd16m: `trust`).
+// The one-sided solve runs ONE schedule, the same pairs in the same order in every sweep: r = 15, 14, ..., 1 (round r pairs
+// index i with i ^ r).  Cyclic Jacobi converges faster when a sweep repeats the previous one than when the pairing is
+// re-dealt from sweep to sweep, as the two alternating schedules of jacobi16_sweeps do (NumPy model, tools/probes/
+// onesided_proto.py: 5.0 sweeps alternating, 4.8 the same slot schedule with the columns put back where they started,
+// 4.6 this order).  The moves are crossbar permutes here, so a round may shift the bottoms by any slot-XOR (not only the
+// single bits a DPP move reaches); four re-deals per sweep.  Entry r of the nibble strings: delta / (re-deal bit + 1).
+constexpr unsigned long long os_pack(const int (&v)[15]) {
+    unsigned long long x = 0;
+    for (int r = 0; r < 15; ++r) x |= (unsigned long long)v[r] << (4 * r);
+    return x;
+}
+constexpr int OS_DELTA_V[15] = {7, 1, 3, 1, 7, 1, 3, 1, 6, 4, 6, 0, 2, 4, 2};
+constexpr int OS_TBIT_V[15] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 2, 0, 3, 0, 2, 0};
+constexpr unsigned long long OS_DELTA = os_pack(OS_DELTA_V), OS_TBIT = os_pack(OS_TBIT_V);
+// where the columns are after a sweep that started with slot b holding columns (b, 8 + b): nibble b = column in slot b
+constexpr unsigned OS_TOP_END = 0xE6D5B380u, OS_BOT_END = 0xF7C4A291u;     // tops 0,8,3,11,5,13,6,14; bottoms 1,9,2,10,4,12,7,15
+__device__ __forceinline__ int os_top_end(int b) { return (OS_TOP_END >> (4 * b)) & 15; }
+__device__ __forceinline__ int os_bot_end(int b) { return (OS_BOT_END >> (4 * b)) & 15; }
+
+// `stage` [16][LDF]: LDS staging through which the columns go back to their starting slots between two sweeps.  After the
+// last sweep they are left where the schedule ends (os_top_end / os_bot_end).
+template <int LDF>
 __device__ __forceinline__ int jacobi16_onesided(Cx<float>& g0t_, Cx<float>& g0b_, Cx<float>& g1t_, Cx<float>& g1b_, int lane,
-                                                 float tol2, float normS2, int max_sweeps, bool& converged_, float& n2t_, float& n2b_) {
+                                                 float tol2, float normS2, int max_sweeps, bool& converged_, float& n2t_, float& n2b_,
+                                                 Cx<float>* stage) {
     using CC = Cx<float>;
-    const int b = lane >> 3, lane4 = lane << 2;
+    const int a = lane & 7, b = lane >> 3, lane4 = lane << 2;
     int sweeps_done = 0;
     bool converged = false;
     CC g0t = g0t_, g0b = g0b_, g1t = g1t_, g1b = g1b_;
     auto norm2 = [&](CC x, CC y) { return colsum8(x.x * x.x + x.y * x.y + y.x * y.x + y.y * y.y); };
     for (int sweep = 0; sweep < max_sweeps && !converged; ++sweep) {
+        if (sweep > 0) {
+            // columns back to their starting slots: the same pairs meet in the same order in every sweep
+            wsync();
+            stage[(2 * a) * LDF + os_top_end(b)] = g0t; stage[(2 * a) * LDF + os_bot_end(b)] = g0b;
+            stage[(2 * a + 1) * LDF + os_top_end(b)] = g1t; stage[(2 * a + 1) * LDF + os_bot_end(b)] = g1b;
+            wsync();
+            g0t = stage[(2 * a) * LDF + b]; g0b = stage[(2 * a) * LDF + 8 + b];
+            g1t = stage[(2 * a + 1) * LDF + b]; g1b = stage[(2 * a + 1) * LDF + 8 + b];
+        }
         float off = 0.f;
         // squared column norms: formed afresh every sweep, carried through the rotations inside it
         float nt = norm2(g0t, g1t), nb = norm2(g0b, g1b);
-        const unsigned long long dseq = (sweep & 1) ? XS_DELTA1 : XS_DELTA0;
-        const unsigned long long tseq = (sweep & 1) ? XS_TBIT1 : XS_TBIT0;
         for (int r = 0; r < 15; ++r) {
-            const int delta = (int)((dseq >> (4 * r)) & 15), tbit = (int)((tseq >> (4 * r)) & 15) - 1;
+            const int delta = (int)((OS_DELTA >> (4 * r)) & 15), tbit = (int)((OS_TBIT >> (4 * r)) & 15) - 1;
             if (tbit >= 0) {
-                // re-deal of tops and bottoms between slots b and b ^ (1 << tbit): three times per sweep
+                // re-deal of tops and bottoms between slots b and b ^ (1 << tbit): four times per sweep
                 const bool cb_ = (b >> tbit) & 1;
                 const int pc = lane ^ (8 << tbit);
                 xchg(g0t, g0b, cb_, pc);

@@ -257,7 +257,7 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
                     f0t = fG[(2 * va) * LDF + vb]; f0b = fG[(2 * va) * LDF + 8 + vb];
                     f1t = fG[(2 * va + 1) * LDF + vb]; f1b = fG[(2 * va + 1) * LDF + 8 + vb];
                     float n2t, n2b;
-                    fs = jacobi16_onesided(f0t, f0b, f1t, f1b, lane, (p.debug_stop >= 20 && p.debug_stop <= 27) ? __builtin_powif(10.f, 20 - p.debug_stop) : kPresolveTol2, (float)normS2, Prec<float>::max_sweeps, fconv, n2t, n2b);
+                    fs = jacobi16_onesided<LDF>(f0t, f0b, f1t, f1b, lane, (p.debug_stop >= 20 && p.debug_stop <= 27) ? __builtin_powif(10.f, 20 - p.debug_stop) : kPresolveTol2, (float)normS2, Prec<float>::max_sweeps, fconv, n2t, n2b, fG);
                     trust = fconv && spectrum_ok(n2t, n2b);
                     if (p.debug_stop == 13) {
                         if (lane == 0 && pstatus != nullptr) pstatus[k] = fs;        // sweeps of the pre-solve
@@ -281,8 +281,11 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
                     for (int t = 0; t < 4; ++t) sB[i * LD + jq + 4 * t] = wrow[t];      // the float factor went through sB: W back in place
                     wsync();
                 } else {
+                // columns of V32 held by this lane: where the one-sided schedule leaves them, or (debug_stop == 11) the two-sided
+                // schedules' layout after an odd / even number of sweeps
                 const bool fnat = fs & 1;
-                const int fit = fnat ? 2 * vb : vb, fib = fnat ? 2 * vb + 1 : 8 + vb;
+                const int fit = (p.debug_stop != 11) ? os_top_end(vb) : (fnat ? 2 * vb : vb);
+                const int fib = (p.debug_stop != 11) ? os_bot_end(vb) : (fnat ? 2 * vb + 1 : 8 + vb);
                 const int mcol = lane & 15;
                 auto cj = [](C w) { return mk<T>(w.x, -w.y); };
                 wsync();
@@ -449,15 +452,14 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
                 Cx<float> g0t = fG[(2 * oa) * LDF + ob], g0b = fG[(2 * oa) * LDF + 8 + ob];
                 Cx<float> g1t = fG[(2 * oa + 1) * LDF + ob], g1b = fG[(2 * oa + 1) * LDF + 8 + ob];
                 float n2t, n2b;
-                const int fs = jacobi16_onesided(g0t, g0b, g1t, g1b, lane, (float)tol2, (float)normS2, max_sweeps, converged, n2t, n2b);
+                (void)jacobi16_onesided<LDF>(g0t, g0b, g1t, g1b, lane, (float)tol2, (float)normS2, max_sweeps, converged, n2t, n2b, fG);
                 const bool trust = converged && spectrum_ok(n2t, n2b);
                 converged = false;
                 wsync();
 #pragma unroll
                 for (int t = 0; t < 4; ++t) sB[i * LD + jq + 4 * t] = wrow[t];          // W back in place (stage 5, or the sweeps below)
                 if (trust) {
-                const bool fnat = fs & 1;
-                const int it_b = fnat ? 2 * ob : ob, ib_b = fnat ? 2 * ob + 1 : 8 + ob;
+                const int it_b = os_top_end(ob), ib_b = os_bot_end(ob);
                 wsync();
                 sA[(2 * oa) * LD + it_b] = mk<T>(g0t.x, g0t.y);
                 sA[(2 * oa) * LD + ib_b] = mk<T>(g0b.x, g0b.y);
