@@ -487,22 +487,23 @@ __device__ __forceinline__ void chol16_f32(const Cx<TS>* sA, int sexp, float del
 // The stop criterion is absolute: columns of small norm (eigenvalues below ~1e-3 of the largest; the null space of a
 // rank-deficient C sits at the shift) weigh nothing in it and may be left askew.  The squared column norms -- the eigenvalues
 // of G G^H -- come back with the columns; the caller looks at them and does not use such a result (gevd16m: `trust`).
-// The one-sided solve runs ONE schedule, the same pairs in the same order in every sweep: r = 15, 14, ..., 1 (round r pairs
-// index i with i ^ r).  Cyclic Jacobi converges faster when a sweep repeats the previous one than when the pairing is
+// The one-sided solve runs ONE schedule, the same pairs in the same order in every sweep, r essentially descending (round r
+// pairs index i with i ^ r).  Cyclic Jacobi converges faster when a sweep repeats the previous one than when the pairing is
 // re-dealt from sweep to sweep, as the two alternating schedules of jacobi16_sweeps do (NumPy model, tools/probes/
 // onesided_proto.py: 5.0 sweeps alternating, 4.8 the same slot schedule with the columns put back where they started,
-// 4.6 this order).  The moves are crossbar permutes here, so a round may shift the bottoms by any slot-XOR (not only the
-// single bits a DPP move reaches); four re-deals per sweep.  Entry r of the nibble strings: delta / (re-deal bit + 1).
+// 4.5-4.6 orders of this kind; this one is r = 15..8, 7, 5, 6, 4, 2, 3, 1, picked among the 48 that need three re-deals).
+// The moves are crossbar permutes here, so a round may shift the bottoms by any slot-XOR (not only the single bits a DPP
+// move reaches).  Entry r of the nibble strings: delta / (re-deal bit + 1).
 constexpr unsigned long long os_pack(const int (&v)[15]) {
     unsigned long long x = 0;
     for (int r = 0; r < 15; ++r) x |= (unsigned long long)v[r] << (4 * r);
     return x;
 }
-constexpr int OS_DELTA_V[15] = {7, 1, 3, 1, 7, 1, 3, 1, 6, 4, 6, 0, 2, 4, 2};
-constexpr int OS_TBIT_V[15] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 2, 0, 3, 0, 2, 0};
+constexpr int OS_DELTA_V[15] = {7, 1, 3, 1, 7, 1, 3, 1, 3, 2, 3, 2, 0, 1, 0};
+constexpr int OS_TBIT_V[15] = {0, 0, 0, 0, 0, 0, 0, 0, 3, 0, 0, 0, 2, 0, 1};
 constexpr unsigned long long OS_DELTA = os_pack(OS_DELTA_V), OS_TBIT = os_pack(OS_TBIT_V);
 // where the columns are after a sweep that started with slot b holding columns (b, 8 + b): nibble b = column in slot b
-constexpr unsigned OS_TOP_END = 0xE6D5B380u, OS_BOT_END = 0xF7C4A291u;     // tops 0,8,3,11,5,13,6,14; bottoms 1,9,2,10,4,12,7,15
+constexpr unsigned OS_TOP_END = 0xFCB87430u, OS_BOT_END = 0xEDA96521u;     // tops 0,3,4,7,8,11,12,15; bottoms 1,2,5,6,9,10,13,14
 __device__ __forceinline__ int os_top_end(int b) { return (OS_TOP_END >> (4 * b)) & 15; }
 __device__ __forceinline__ int os_bot_end(int b) { return (OS_BOT_END >> (4 * b)) & 15; }
 
@@ -534,7 +535,7 @@ __device__ __forceinline__ int jacobi16_onesided(Cx<float>& g0t_, Cx<float>& g0b
         for (int r = 0; r < 15; ++r) {
             const int delta = (int)((OS_DELTA >> (4 * r)) & 15), tbit = (int)((OS_TBIT >> (4 * r)) & 15) - 1;
             if (tbit >= 0) {
-                // re-deal of tops and bottoms between slots b and b ^ (1 << tbit): four times per sweep
+                // re-deal of tops and bottoms between slots b and b ^ (1 << tbit): three times per sweep
                 const bool cb_ = (b >> tbit) & 1;
                 const int pc = lane ^ (8 << tbit);
                 xchg(g0t, g0b, cb_, pc);
