@@ -537,14 +537,11 @@ __device__ __forceinline__ int jacobi16_onesided(Cx<float>& g0t_, Cx<float>& g0b
 #pragma unroll
         for (int r = 0; r < 15; ++r) {
             const int delta = (int)((OS_DELTA >> (4 * r)) & 15), tbit = (int)((OS_TBIT >> (4 * r)) & 15) - 1;
-            if (tbit >= 0) {
-                // re-deal of tops and bottoms between slots b and b ^ (1 << tbit): three times per sweep
-                const bool cb_ = (b >> tbit) & 1;
-                const int pc = lane ^ (8 << tbit);
-                xchg(g0t, g0b, cb_, pc);
-                xchg(g1t, g1b, cb_, pc);
-                xchg_f(nt, nb, cb_, pc);
-            }
+            // re-deal of tops and bottoms between slots b and b ^ (1 << tbit), three times per sweep: the slot is lane bits 3-5,
+            // for which the exchange is a masked row_ror:8 pair, one v_permlane16_swap or one v_permlane32_swap per register
+            if (tbit == 0) { cxswap_row<0>(g0t, g0b); cxswap_row<0>(g1t, g1b); xswap_row<0>(nt, nb); }
+            else if (tbit == 1) { cxswap_row<1>(g0t, g0b); cxswap_row<1>(g1t, g1b); xswap_row<1>(nt, nb); }
+            else if (tbit == 2) { cxswap_row<2>(g0t, g0b); cxswap_row<2>(g1t, g1b); xswap_row<2>(nt, nb); }
             if (delta == 1) {
                 // slot ^ 1 = lane ^ 8: row_ror:8 on the VALU, no trip over the crossbar (the schedule is a compile-time constant and
                 // the round loop unrolls, so this test costs nothing)
