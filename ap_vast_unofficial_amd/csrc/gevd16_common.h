@@ -407,6 +407,92 @@ __device__ __forceinline__ int jacobi16_sweeps(Cx<TT>& tt_, Cx<TT>& tb_, Cx<TT>&
 }
 
 
+// ONE sweep of schedule 0 with its first NR rounds, the schedule a compile-time constant and the rounds unrolled (every round
+// knows its move and its re-deal: no branch, no nibble arithmetic).  NR = 15: a full sweep, the blocks are left in the
+// (2s, 2s+1) layout; NR = 8: the 64 pairs between the index halves, slots back where they started.  This is what the block
+// Jacobi of the order-64 kernel calls for its pair problems.
+template <typename TT, int NR>
+__device__ __forceinline__ void jacobi16_sweep0(Cx<TT>& tt_, Cx<TT>& tb_, Cx<TT>& bt_, Cx<TT>& bb_, Cx<TT>& v0t_, Cx<TT>& v0b_,
+                                                Cx<TT>& v1t_, Cx<TT>& v1b_, TT (*srot)[4], int lane) {
+    using CC = Cx<TT>;
+    const int a = lane >> 3, b = lane & 7;
+    const bool diag = (a == b);
+    CC tt = tt_, tb = tb_, bt = bt_, bb = bb_, v0t = v0t_, v0b = v0b_, v1t = v1t_, v1b = v1b_;
+    TT off = 0;
+    {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int delta = (int)((XS_DELTA0 >> (4 * r)) & 15), tbit = (int)((XS_TBIT0 >> (4 * r)) & 15) - 1;
+            if (tbit >= 0) {
+                // columns first, then rows; the row exchanges and the bit-2 column exchange are masked lane swaps
+                if (tbit == 2) {
+                    cxswap_col4(tt, tb);
+                    cxswap_col4(bt, bb);
+                    cxswap_col4(v0t, v0b);
+                    cxswap_col4(v1t, v1b);
+                    cxswap_row<2>(tt, bt);
+                    cxswap_row<2>(tb, bb);
+                } else {
+                    const bool cb_ = (b >> tbit) & 1;
+                    const int pc = lane ^ (1 << tbit);
+                    xchg(tt, tb, cb_, pc);
+                    xchg(bt, bb, cb_, pc);
+                    xchg(v0t, v0b, cb_, pc);
+                    xchg(v1t, v1b, cb_, pc);
+                    if (tbit == 1) {
+                        cxswap_row<1>(tt, bt);
+                        cxswap_row<1>(tb, bb);
+                    } else {
+                        cxswap_row<0>(tt, bt);
+                        cxswap_row<0>(tb, bb);
+                    }
+                }
+            }
+            switch (delta) {
+                case 1: move_bottoms<1>(tb, bt, bb, v0b, v1b, lane); break;
+                case 2: move_bottoms<2>(tb, bt, bb, v0b, v1b, lane); break;
+                case 4: move_bottoms<4>(tb, bt, bb, v0b, v1b, lane); break;
+                default: break;
+            }
+            if (diag) off += tb.x * tb.x + tb.y * tb.y;
+            TT c, sx, sy;
+            rotation<TT>(tt.x, bb.x, tb.x, tb.y, c, sx, sy);
+            TT ca, sax, say, cb, sbx, sby;
+            if constexpr (sizeof(TT) == 8) {
+                // double: the eight rotations go through LDS (two wide reads per lane instead of twelve ds_bpermute)
+                if (diag) {
+                    srot[a][0] = c;
+                    srot[a][1] = sx;
+                    srot[a][2] = sy;
+                }
+                wsync();
+                ca = srot[a][0]; sax = srot[a][1]; say = srot[a][2];
+                cb = srot[b][0]; sbx = srot[b][1]; sby = srot[b][2];
+            } else {
+                const int da = 9 * a, db = 9 * b;
+                ca = __shfl(c, da, 64); sax = __shfl(sx, da, 64); say = __shfl(sy, da, 64);
+                cb = __shfl(c, db, 64); sbx = __shfl(sx, db, 64); sby = __shfl(sy, db, 64);
+            }
+            const CC sa = mk<TT>(sax, say), sb = mk<TT>(sbx, sby);
+            CC ypp, ypq, yqp, yqq;
+            rot_cols<TT>(cb, sb, tt, tb, ypp, ypq);
+            rot_cols<TT>(cb, sb, bt, bb, yqp, yqq);
+            rot_rows<TT>(ca, sa, ypp, yqp, tt, bt);
+            rot_rows<TT>(ca, sa, ypq, yqq, tb, bb);
+            if (diag) {         // the angle is float-accurate: the residual beta' ~ 1e-7 beta is real data, keep it
+                tt.y = 0;
+                bb.y = 0;
+            }
+            CC w0p, w0q, w1p, w1q;
+            rot_cols<TT>(cb, sb, v0t, v0b, w0p, w0q);
+            rot_cols<TT>(cb, sb, v1t, v1b, w1p, w1q);
+            v0t = w0p; v0b = w0q; v1t = w1p; v1b = w1q;
+        }
+    }
+    (void)off;
+    tt_ = tt; tb_ = tb; bt_ = bt; bb_ = bb; v0t_ = v0t; v0b_ = v0b; v1t_ = v1t; v1b_ = v1b;
+}
+
 // ---- float32 ONE-SIDED Jacobi (Hestenes) for the pre-solve of the float64 order-16 kernel -------------------------------
 // With G G^H = C, column rotations G <- G J leave G G^H alone and end with orthogonal columns G J = U Sigma, so the
 // normalised columns ARE the eigenvectors of C: no accumulation of V, no two-sided update of C.  A round rotates one

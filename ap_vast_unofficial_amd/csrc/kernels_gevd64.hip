@@ -340,9 +340,10 @@ __device__ __forceinline__ void inner_solve(const C64* Cf, C64* U, int r, int w,
     // blocks; the other rounds rotate only the 64 pairs between their two blocks (the first 8 rounds of the
     // schedule, which leave the slots as they were).  Together: every one of the 2016 index pairs once per sweep.
     const bool full = (r == 0);
-    const int ns = jacobi16_sweeps<float>(tt, tb, bt, bb, v0t, v0b, v1t, v1b, (float (*)[4]) nullptr, lane, 0.f, 1.0f, 1, conv, full ? 15 : 8);
+    if (full) jacobi16_sweep0<float, 15>(tt, tb, bt, bb, v0t, v0b, v1t, v1b, (float (*)[4]) nullptr, lane);
+    else jacobi16_sweep0<float, 8>(tt, tb, bt, bb, v0t, v0b, v1t, v1b, (float (*)[4]) nullptr, lane);
     (void)conv;
-    const bool nat = full && (ns & 1);
+    const bool nat = full;
     const int it_b = nat ? 2 * ub : ub, ib_b = nat ? 2 * ub + 1 : 8 + ub;
     U[(2 * ua) * 17 + it_b] = v0t;
     U[(2 * ua) * 17 + ib_b] = v0b;
