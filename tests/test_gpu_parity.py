@@ -328,6 +328,36 @@ def test_corr_bf16_exact_on_rounded_inputs(Engine):
     eng.close()
 
 
+@pytest.mark.parametrize("spectrum", ["geometric", "two_levels", "one_large"])
+def test_spectra_at_the_trust_threshold(Engine, spectrum):
+    """Prescribed eigenvalues spanning just under 1e3 (the widest spectrum for which the float64 order-16 kernel still uses its
+    one-sided float32 pre-solve), with the small ones spread out, in a tight cluster behind a gap, or all but one: the
+    pre-solve leaves the columns of the small eigenvalues orthogonal only to 1e-3 ... 3e-2 there, which the refinement and
+    the guarded path have to absorb.  R_D = I (orthonormal dark slab), R_B = U diag(lam) U^H."""
+    rng = np.random.default_rng(11)
+    K, L, M = 48, 16, 32
+    lam = {"geometric": np.geomspace(1.0, 1.5e-3, L),
+           "two_levels": np.r_[np.linspace(1.0, 0.5, 8), 1.5e-3 * (1 + 1e-3 * np.arange(8))],
+           "one_large": np.r_[1.0, np.linspace(2e-3, 1.5e-3, L - 1)]}[spectrum]
+    ranks = {"geometric": (1, 8, 16), "two_levels": (1, 8, 16), "one_large": (1, 16)}[spectrum]
+    XB = np.zeros((K, M, L), np.complex128)
+    XD = np.zeros((K, M, L), np.complex128)
+    for k in range(K):
+        U = np.linalg.qr(rng.standard_normal((L, L)) + 1j * rng.standard_normal((L, L)))[0]
+        XB[k, :L] = np.sqrt(lam)[:, None] * U.conj().T * 3.0
+        XD[k] = np.linalg.qr(rng.standard_normal((M, L)) + 1j * rng.standard_normal((M, L)))[0]
+    XB, XD = XB.astype(np.complex64), XD.astype(np.complex64)
+    d = cn(rng, K, M)
+    eng = Engine(K, L, M, ranks=ranks, mu=0.1, compute_dtype="f64", out_c128=True)
+    w, lam_gpu, status = eng.update(XB, XD, d)
+    eng.close()
+    w_ref, lam_ref, _ = subband.update(XB, XD, d, 0.1, list(ranks))
+    assert not status.any()
+    assert (np.abs(lam_gpu - lam_ref) / lam_ref[:, :1]).max() < 1e-12
+    e = np.linalg.norm(w - w_ref, axis=-1) / np.linalg.norm(w_ref, axis=-1)
+    assert e.max() < 1e-7, (spectrum, e.max(), np.unravel_index(e.argmax(), e.shape))
+
+
 def test_rank_deficient_bright_matrix_every_bin(Engine):
     """M < L at the headline order, 64 bins, float64, filters returned in complex128: eight eigenvalues of C are zero, which
     the float32 pre-solve sees as eight columns at its shift that it does not orthogonalise against each other.  The float64
