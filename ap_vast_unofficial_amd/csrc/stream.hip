@@ -28,7 +28,6 @@ struct apv_stream {
     void* rir[2];                 // [P][C]  zone A, zone B
     void* trir[2];                // [P][M]  target RIRs (reference loudspeaker, delayed)
     void* xhist[2][2];            // [buf][signal][P-1+H+pad]
-    void* xin;                    // [2][H] staging of the hop
     void* resp[4];                // [C][N] rings: A->A, A->B, B->A, B->B
     void* tresp[2];               // [M][N] rings: target A, target B
     void* inblk;                  // [2][N] rings: input blocks
@@ -41,7 +40,7 @@ struct apv_stream {
     void* tgt;                    // [L][K] target filter spectra (shared by A_t and B_t, apvast.py:389-390)
     void* outspec;                // [n_out][K]
     void* outov;                  // [n_out][N]
-    void* out;                    // [n_out][H]
+    void* out;                    // [n_out][H] samples, then the [2][K] status words of the hop: one copy back
     // perceptual weighting (off when nch == 0)
     int nch, norm_mode;
     double Cs, Ca, Leff;
@@ -50,8 +49,7 @@ struct apv_stream {
     void* Wgt[2];                 // [K][M] per zone
     // pinned staging + one captured hipGraph per phase of the (ring offset, history buffer) cycle
     void* pin_in;                 // [2][H]
-    void* pin_out;                // [n_out][H]
-    int32_t* pin_status;          // [2][K]
+    void* pin_out;                // [n_out][H] samples + [2][K] status words
     int period;                   // hops after which (ring_off, cur) repeat; 0 = graphs off
     // whole-signal path (apv_process_signal): a second set of the hop's spectra, a second stream and four events, so
     // that the front half (FIR + analysis) of hop h+1 runs beside the back half (GEVD + synthesis) of hop h
@@ -63,8 +61,7 @@ struct apv_stream {
     hipEvent_t ev_back[2];        // set p released by the back half
     hipEvent_t ev_chunk[2];       // chunk c & 1 of the pinned staging complete
     void* sig_in;                 // pinned [2][chunk][2][H]
-    void* sig_out;                // pinned [2][chunk][n_out][H]
-    int32_t* sig_status;          // pinned [2][chunk][2][K]
+    void* sig_out;                // pinned [2][chunk] hop results (samples [n_out][H] + status words [2][K] each)
     int sig_chunk;                // hops per half of the pinned staging
     long hop;                     // hops processed
     long not_converged;           // hops in which some bin hit the sweep cap (status 2)
@@ -111,6 +108,13 @@ int upload(apv_handle* h, int f64, void* dst, const std::vector<double>& src) {
 size_t wsz(const apv_handle* h) { return h->cfg.out_c128 ? 16 : 8; }
 size_t lsz(const apv_handle* h) { return h->cfg.out_c128 ? 8 : 4; }
 
+// bytes of one hop's result: [n_out][H] samples and, behind them, the [2][K] status words
+inline size_t hop_out_bytes(const apv_stream* s) { return s->esz * (size_t)s->n_out * s->H; }
+inline size_t hop_result_bytes(const apv_stream* s) { return hop_out_bytes(s) + sizeof(int32_t) * 2 * (size_t)s->K; }
+inline const int32_t* hop_status_of(const apv_stream* s, const void* result) {
+    return reinterpret_cast<const int32_t*>(static_cast<const char*>(result) + hop_out_bytes(s));
+}
+
 // path p: signal sig(p) through the RIRs of zone zone(p): AA, AB, BA, BB
 inline int path_sig(int p) { return p >> 1; }
 inline int path_zone(int p) { return p & 1; }
@@ -121,9 +125,9 @@ void apv_stream_free(apv_handle* h) {
     apv_stream* s = h->st;
     if (!s) return;
     void* bufs[] = {s->rir[0], s->rir[1], s->trir[0], s->trir[1], s->xhist[0][0], s->xhist[0][1], s->xhist[1][0],
-                    s->xhist[1][1], s->xin, s->resp[0], s->resp[1], s->resp[2], s->resp[3], s->tresp[0], s->tresp[1],
+                    s->xhist[1][1], s->resp[0], s->resp[1], s->resp[2], s->resp[3], s->tresp[0], s->tresp[1],
                     s->inblk, s->X[0], s->X[1], s->X[2], s->X[3], s->tspec[0], s->tspec[1], s->inspec, s->w[0],
-                    s->w[1], s->lam[0], s->lam[1], s->status[0], s->tgt, s->outspec, s->outov, s->out,
+                    s->w[1], s->lam[0], s->lam[1], s->tgt, s->outspec, s->outov, s->out,
                     s->G2, s->G2T, s->Wgt[0], s->Wgt[1]};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -131,7 +135,6 @@ void apv_stream_free(apv_handle* h) {
         if (e) (void)hipGraphExecDestroy(e);
     if (s->pin_in) (void)hipHostFree(s->pin_in);
     if (s->pin_out) (void)hipHostFree(s->pin_out);
-    if (s->pin_status) (void)hipHostFree(s->pin_status);
     void* second[] = {s->X1[0], s->X1[1], s->X1[2], s->X1[3], s->tspec1[0], s->tspec1[1], s->inspec1};
     for (void* b : second)
         if (b) (void)hipFree(b);
@@ -143,7 +146,6 @@ void apv_stream_free(apv_handle* h) {
     if (s->front) (void)hipStreamDestroy(s->front);
     if (s->sig_in) (void)hipHostFree(s->sig_in);
     if (s->sig_out) (void)hipHostFree(s->sig_out);
-    if (s->sig_status) (void)hipHostFree(s->sig_status);
     delete s;
     h->st = nullptr;
 }
@@ -170,17 +172,17 @@ static int enqueue_front(apv_handle* h, hipStream_t st, int set, const void* pin
     apv_stream* s = h->st;
     const HopSpectra q = hop_spectra(s, set);
     const int N = s->N, H = s->H, K = s->K, L = s->L, M = s->M, C = s->C, P = s->P, f64 = s->f64;
-    const size_t e1 = s->esz;
     std::string why;
     // hop -> device, input history and input-block rings
-    SCHK(h, hipMemcpyAsync(s->xin, pin_src, e1 * 2 * H, hipMemcpyHostToDevice, st));     // [A | B], contiguous on both sides
+    // the hop [A | B] is read by the input-update kernel straight from the pinned host staging (16 KB over PCIe inside a kernel
+    // that has nothing else to do) instead of through a copy node of its own
     const int nxt = s->cur ^ 1;
     // all rings advance by one hop: logical sample n now lives H further on
     s->ring_off = (s->ring_off + H) % N;
     {
         const void* oh[2] = {s->xhist[s->cur][0], s->xhist[s->cur][1]};
         void* nh[2] = {s->xhist[nxt][0], s->xhist[nxt][1]};
-        SCHK(h, apv_launch_input_update(f64, P, H, s->pad, N, s->ring_off, oh, nh, s->xin, s->inblk, st));   // histories + input-block rings
+        SCHK(h, apv_launch_input_update(f64, P, H, s->pad, N, s->ring_off, oh, nh, pin_src, s->inblk, st));   // histories + input-block rings
     }
     s->cur = nxt;
     // K1: RIR convolution into the response rings (one MFMA launch for all six filter banks)
@@ -248,12 +250,12 @@ static int enqueue_front(apv_handle* h, hipStream_t st, int set, const void* pin
 }
 
 // Back half of a hop on stream `st`: spectra of set `set` -> per-bin filters (K5'-K10), output spectra (K3), synthesis
-// and overlap-add (K4); the emitted samples land in pinned `pin_dst` [n_out][H], the status words in `pin_stat` [2][K].
-static int enqueue_back(apv_handle* h, hipStream_t st, int set, void* pin_dst, int32_t* pin_stat) {
+// and overlap-add (K4); the emitted samples [n_out][H] and, behind them, the status words [2][K] land in pinned `pin_dst`.
+static int enqueue_back(apv_handle* h, hipStream_t st, int set, void* pin_dst) {
     apv_stream* s = h->st;
     const HopSpectra q = hop_spectra(s, set);
     const int N = s->N, H = s->H, K = s->K, L = s->L, f64 = s->f64;
-    const size_t e1 = s->esz, e2 = 2 * s->esz;
+    const size_t e2 = 2 * s->esz;
     const bool runA = s->zones & 1, runB = s->zones & 2;
     std::string why;
     // per-bin update per zone program: A: bright A->A, dark A->B, target A;  B: bright B->B, dark B->A, target B
@@ -298,15 +300,13 @@ static int enqueue_back(apv_handle* h, hipStream_t st, int set, void* pin_dst, i
             oc += L;
         }
         SCHK(h, apv_launch_apply_jobs(K, nj, jin, jw, jt, jout, jf, jtg, h->cfg.out_c128, f64, st));
-        const int zf = runA ? 0 : 1, zn = (runA && runB) ? 2 : 1;
-        SCHK(h, hipMemcpyAsync(pin_stat + (size_t)zf * K, s->status[zf], sizeof(int32_t) * K * zn, hipMemcpyDeviceToHost, st));
     }
     // K4: synthesis + overlap-add + emit
     {
         hipError_t e = apv_launch_synthesis(f64, N, H, s->n_out, s->outspec, K, 1, s->outov, s->out, st, &why);
         if (e != hipSuccess) return apv_fail(h, APV_ERR_HIP, why.empty() ? hipGetErrorString(e) : why);
     }
-    SCHK(h, hipMemcpyAsync(pin_dst, s->out, e1 * (size_t)s->n_out * H, hipMemcpyDeviceToHost, st));
+    SCHK(h, hipMemcpyAsync(pin_dst, s->out, hop_result_bytes(s), hipMemcpyDeviceToHost, st));       // samples + status: one copy
     return APV_OK;
 }
 
@@ -315,7 +315,7 @@ static int enqueue_hop(apv_handle* h) {
     apv_stream* s = h->st;
     int rc = enqueue_front(h, h->stream, 0, s->pin_in);
     if (rc != APV_OK) return rc;
-    return enqueue_back(h, h->stream, 0, s->pin_out, s->pin_status);
+    return enqueue_back(h, h->stream, 0, s->pin_out);
 }
 
 // run one hop whose input is already in the pinned staging; the output is left in the pinned staging
@@ -411,7 +411,7 @@ static int process_block_t(apv_handle* h, const TI* h_in_A, const TI* h_in_B, TI
         const float* po = (const float*)s->pin_out;
         for (size_t i = 0; i < nout; ++i) h_out[i] = (TI)po[i];
     }
-    return scan_hop_status(h, s->pin_status, s->hop - 1);
+    return scan_hop_status(h, hop_status_of(s, s->pin_out), s->hop - 1);
 }
 
 // what the whole-signal path needs beyond the per-hop path; allocated at its first call
@@ -434,9 +434,10 @@ static int signal_prepare(apv_handle* h) {
     }
     // two chunks of pinned staging: the host converts chunk c-1 while the device runs chunk c
     if (!s->sig_in) SCHK(h, hipHostMalloc(&s->sig_in, e1 * 2 * chunk * 2 * H, hipHostMallocDefault));
-    if (!s->sig_out) SCHK(h, hipHostMalloc(&s->sig_out, e1 * 2 * chunk * (size_t)s->n_out * H, hipHostMallocDefault));
-    if (!s->sig_status) SCHK(h, hipHostMalloc((void**)&s->sig_status, sizeof(int32_t) * 2 * chunk * 2 * K, hipHostMallocDefault));
-    std::memset(s->sig_status, 0, sizeof(int32_t) * 2 * chunk * 2 * K);
+    if (!s->sig_out) {
+        SCHK(h, hipHostMalloc(&s->sig_out, 2 * chunk * hop_result_bytes(s), hipHostMallocDefault));
+        std::memset(s->sig_out, 0, 2 * chunk * hop_result_bytes(s));
+    }
     SCHK(h, hipStreamSynchronize(h->stream));               // the zero-fills above
     s->sig_chunk = chunk;
     return APV_OK;
@@ -487,17 +488,17 @@ static int process_signal_t(apv_handle* h, int n_hops, const TI* h_in_A, const T
         const int base = c * chunk, nc = std::min(chunk, n_hops - base);
         hipError_t e = hipEventSynchronize(s->ev_chunk[c & 1]);
         if (e != hipSuccess) return apv_fail(h, APV_ERR_HIP, std::string("apv_process_signal: ") + hipGetErrorString(e));
-        TI* dst = h_out + (size_t)base * nout;
-        const size_t slot = (size_t)(c & 1) * chunk * nout;
-        if (s->f64) {
-            const double* po = (const double*)s->sig_out + slot;
-            for (size_t i = 0; i < nout * nc; ++i) dst[i] = (TI)po[i];
-        } else {
-            const float* po = (const float*)s->sig_out + slot;
-            for (size_t i = 0; i < nout * nc; ++i) dst[i] = (TI)po[i];
-        }
         for (int i = 0; i < nc; ++i) {
-            const int r = scan_hop_status(h, s->sig_status + ((size_t)(c & 1) * chunk + i) * 2 * K, hop_first + base + i);
+            TI* dst = h_out + (size_t)(base + i) * nout;
+            const char* res = (const char*)s->sig_out + ((size_t)(c & 1) * chunk + i) * hop_result_bytes(s);
+            if (s->f64) {
+                const double* po = (const double*)res;
+                for (size_t j = 0; j < nout; ++j) dst[j] = (TI)po[j];
+            } else {
+                const float* po = (const float*)res;
+                for (size_t j = 0; j < nout; ++j) dst[j] = (TI)po[j];
+            }
+            const int r = scan_hop_status(h, hop_status_of(s, res), hop_first + base + i);
             if (r == APV_ERR_NOT_PD && worst != APV_ERR_NOT_PD) { worst = r; worst_msg = h->err; }
             if (r == APV_ERR_NO_CONVERGE && worst == APV_OK) { worst = r; worst_msg = h->err; }
         }
@@ -518,7 +519,7 @@ static int process_signal_t(apv_handle* h, int n_hops, const TI* h_in_A, const T
             }
             if (e == hipSuccess) e = hipStreamWaitEvent(back, s->ev_front[set], 0);
             if (e == hipSuccess) {
-                rc = enqueue_back(h, back, set, (char*)s->sig_out + slot * nout * e1, s->sig_status + slot * 2 * K);
+                rc = enqueue_back(h, back, set, (char*)s->sig_out + slot * hop_result_bytes(s));
                 if (rc != APV_OK) { drain(); return rc; }
                 e = hipEventRecord(s->ev_back[set], back);
             }
@@ -607,7 +608,6 @@ int apv_stream_init(apv_handle* h, int32_t rir_len, const double* h_rir_A, const
     for (int b = 0; b < 2; ++b)
         for (int g = 0; g < 2; ++g)
             if ((rc = dalloc(h, &s->xhist[b][g], hist, e1))) return rc;
-    if ((rc = dalloc(h, &s->xin, (size_t)2 * H, e1))) return rc;
     for (int p = 0; p < 4; ++p) {
         if ((rc = dalloc(h, &s->resp[p], (size_t)C * N, e1))) return rc;
         if ((rc = dalloc(h, &s->X[p], (size_t)K * C, e2))) return rc;
@@ -618,14 +618,19 @@ int apv_stream_init(apv_handle* h, int32_t rir_len, const double* h_rir_A, const
         if ((rc = dalloc(h, &s->w[z], (size_t)K * s->nV * L, wsz(h)))) return rc;
         if ((rc = dalloc(h, &s->lam[z], (size_t)K * L, lsz(h)))) return rc;
     }
-    if ((rc = dalloc(h, &s->status[0], (size_t)2 * K))) return rc;       // [zone A | zone B]: one copy back per hop
-    s->status[1] = s->status[0] + K;
     if ((rc = dalloc(h, &s->inblk, (size_t)2 * N, e1))) return rc;
     if ((rc = dalloc(h, &s->inspec, (size_t)2 * K, e2))) return rc;
     if ((rc = dalloc(h, &s->tgt, (size_t)L * K, e2))) return rc;
     if ((rc = dalloc(h, &s->outspec, (size_t)s->n_out * K, e2))) return rc;
     if ((rc = dalloc(h, &s->outov, (size_t)s->n_out * N, e1))) return rc;
-    if ((rc = dalloc(h, &s->out, (size_t)s->n_out * H, e1))) return rc;
+    {
+        // samples, then the status words [zone A | zone B] of the hop: one copy back
+        char* outbuf = nullptr;
+        if ((rc = dalloc(h, &outbuf, hop_result_bytes(s), 1))) return rc;
+        s->out = outbuf;
+        s->status[0] = reinterpret_cast<int32_t*>(outbuf + hop_out_bytes(s));
+        s->status[1] = s->status[0] + K;
+    }
     // target filter spectra: rfft of a unit impulse at tap modeling_delay of the A reference loudspeaker
     // (apvast.py:389-390, 418, 422: the same filter serves A_t and B_t)
     std::vector<double> tg((size_t)L * K * 2, 0.0);
@@ -645,9 +650,8 @@ int apv_stream_init(apv_handle* h, int32_t rir_len, const double* h_rir_A, const
     if ((rc = upload(h, f64, s->tgt, tg))) return rc;
     s->h_status.assign((size_t)2 * K, 0);
     SCHK(h, hipHostMalloc((void**)&s->pin_in, e1 * 2 * H, hipHostMallocDefault));
-    SCHK(h, hipHostMalloc((void**)&s->pin_out, e1 * (size_t)s->n_out * H, hipHostMallocDefault));
-    SCHK(h, hipHostMalloc((void**)&s->pin_status, sizeof(int32_t) * 2 * K, hipHostMallocDefault));
-    std::memset(s->pin_status, 0, sizeof(int32_t) * 2 * K);
+    SCHK(h, hipHostMalloc((void**)&s->pin_out, hop_result_bytes(s), hipHostMallocDefault));
+    std::memset(s->pin_out, 0, hop_result_bytes(s));
     // the launch sequence of a hop depends on (ring_off, cur) only: ring_off has period N / gcd(N, H), cur period 2
     {
         int a = N, b = H;
