@@ -576,7 +576,7 @@ __device__ __forceinline__ void chol16_f32(const Cx<TS>* sA, int sexp, float del
 // The one-sided solve runs ONE schedule, the same pairs in the same order in every sweep, r essentially descending (round r
 // pairs index i with i ^ r).  Cyclic Jacobi converges faster when a sweep repeats the previous one than when the pairing is
 // re-dealt from sweep to sweep, as the two alternating schedules of jacobi16_sweeps do (NumPy model, tools/probes/
-// onesided_proto.py: 5.0 sweeps alternating, 4.8 the same slot schedule with the columns put back where they started,
+// onesided_schedule_model.py: 5.0 sweeps alternating, 4.7 the same slot schedule with the columns put back where they started,
 // 4.5-4.6 orders of this kind; this one is r = 15..8, 7, 5, 6, 4, 2, 3, 1, picked among the 48 that need three re-deals).
 // The moves are crossbar permutes here, so a round may shift the bottoms by any slot-XOR (not only the single bits a DPP
 // move reaches).  Entry r of the nibble strings: delta / (re-deal bit + 1).
