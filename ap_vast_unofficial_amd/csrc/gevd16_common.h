@@ -91,17 +91,25 @@ __device__ __forceinline__ void correlate16(const XT* __restrict__ X, const XT* 
             const T xr = (T)xv[q].x, xi = (T)xv[q].y;
             re = MM::mac(xr, xr, re);
             re = MM::mac(xi, xi, re);
-            im = MM::mac(xr, xi, im);
-            im = MM::mac(-xi, xr, im);
+            im = MM::mac(xr, xi, im);                            // P = sum xr (x) xi; Im R = P - P^T, formed below
             if (dvec != nullptr) {
                 rx += xr * (T)dv[q].x + xi * (T)dv[q].y;        // conj(x) * d
                 ry += xr * (T)dv[q].y - xi * (T)dv[q].x;
             }
         }
     }
+    // Im R = P - P^T: three MFMAs per k-step instead of four (the f64 matrix pipe is busy half of this kernel's time at the rate
+    // the instruction sustains, profiles/r02/mfma_issue_rate.md); the transpose goes through the destination tile
     const int col = lane & 15;
 #pragma unroll
     for (int t = 0; t < 4; ++t) dst[MM::row(lane, t) * LD + col] = mk<T>(re[t], im[t]);
+    __syncthreads();                                         // one wave per workgroup: an LDS ordering point
+    T pt[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) pt[t] = dst[col * LD + MM::row(lane, t)].y;
+    __syncthreads();                                         // one wave per workgroup: an LDS ordering point
+#pragma unroll
+    for (int t = 0; t < 4; ++t) dst[MM::row(lane, t) * LD + col].y = im[t] - pt[t];
     if (dvec != nullptr) {
         rx += __shfl_xor(rx, 16, 64); ry += __shfl_xor(ry, 16, 64);
         rx += __shfl_xor(rx, 32, 64); ry += __shfl_xor(ry, 32, 64);
