@@ -31,20 +31,37 @@ template <typename T> __device__ __forceinline__ int mfma_row(int lane, int t);
 template <> __device__ __forceinline__ int mfma_row<double>(int lane, int t) { return (lane >> 4) + 4 * t; }
 template <> __device__ __forceinline__ int mfma_row<float>(int lane, int t) { return 4 * (lane >> 4) + t; }
 
+// float64: three real products per k-step instead of four (Karatsuba), in three passes over the k-steps so that two accumulators
+// suffice: P1 = sum ar br, P2 = sum ai bi; re = P1 - P2; the third pass accumulates sum (ar + ai)(br + bi) onto -(P1 + P2), which
+// is the imaginary part.  The f64 matrix pipe is busy ~45 % of this kernel's time at the rate the instruction sustains
+// (profiles/r02/mfma_issue_rate.md), barely overlapped with the VALU: 12 MFMAs and ~30 VALU instructions beat 16 MFMAs.
 template <typename FA, typename FB>
 __device__ __forceinline__ void cmm16(FA fa, FB fb, int lane, Cx<double> out[4]) {
-    d4 re = {0, 0, 0, 0}, im = {0, 0, 0, 0};
+    d4 p1 = {0, 0, 0, 0}, p2 = {0, 0, 0, 0};
     const int rc = lane & 15, kq = lane >> 4;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const Cx<double> a = fa(rc, 4 * s + kq), b = fb(4 * s + kq, rc);
-        re = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.x, re, 0, 0, 0);
-        re = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.y, b.y, re, 0, 0, 0);
-        im = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.y, im, 0, 0, 0);
-        im = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b.x, im, 0, 0, 0);
+        p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.x, p1, 0, 0, 0);
+        p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b.y, p2, 0, 0, 0);
+    }
+    d4 im;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const double u = p1[t], v = p2[t];
+        p1[t] = u - v;                                           // re
+        im[t] = -(u + v);
+    }
+    // (the operands are fetched again -- the compiler barrier keeps it from holding the eight complex numbers of the first two
+    // passes in registers, which the kernel does not have)
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const Cx<double> a = fa(rc, 4 * s + kq), b = fb(4 * s + kq, rc);
+        im = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x + a.y, b.x + b.y, im, 0, 0, 0);
     }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) out[t] = mk<double>(re[t], im[t]);
+    for (int t = 0; t < 4; ++t) out[t] = mk<double>(p1[t], im[t]);
 }
 template <typename FA, typename FB>
 __device__ __forceinline__ void cmm16(FA fa, FB fb, int lane, Cx<float> out[4]) {
