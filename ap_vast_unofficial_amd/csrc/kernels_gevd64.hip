@@ -60,7 +60,9 @@ __device__ __forceinline__ void rr_pair8(int r, int a, int& P, int& Q) {
 // k runs over [k_begin, k_end) in steps of 4.  out element t is (16 ti + (lane >> 4) + 4 t, 16 tj + (lane & 15)).
 template <typename FA, typename FB>
 __device__ __forceinline__ void cmm64_tile(FA fa, FB fb, int ti, int tj, int lane, int k_begin, int k_end, C128 out[4]) {
-    d4 re = {0, 0, 0, 0}, im = {0, 0, 0, 0};
+    // three real products per k-step (Karatsuba): P1 = sum ar br, P2 = sum ai bi, P3 = sum (ar + ai)(br + bi);
+    // re = P1 - P2, im = P3 - P1 - P2.  These phases are bound by the f64 matrix pipe: 12 MFMAs and two adds beat 16 MFMAs.
+    d4 p1 = {0, 0, 0, 0}, p2 = {0, 0, 0, 0}, p3 = {0, 0, 0, 0};
     const int il = lane & 15, kq = lane >> 4;
     const int i = 16 * ti + il, j = 16 * tj + il;
     for (int k0 = k_begin; k0 < k_end; k0 += 16) {
@@ -72,14 +74,13 @@ __device__ __forceinline__ void cmm64_tile(FA fa, FB fb, int ti, int tj, int lan
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            re = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u].x, b[u].x, re, 0, 0, 0);
-            re = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[u].y, b[u].y, re, 0, 0, 0);
-            im = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u].x, b[u].y, im, 0, 0, 0);
-            im = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u].y, b[u].x, im, 0, 0, 0);
+            p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u].x, b[u].x, p1, 0, 0, 0);
+            p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u].y, b[u].y, p2, 0, 0, 0);
+            p3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u].x + a[u].y, b[u].x + b[u].y, p3, 0, 0, 0);
         }
     }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) out[t] = mk<double>(re[t], im[t]);
+    for (int t = 0; t < 4; ++t) out[t] = mk<double>(p1[t] - p2[t], p3[t] - p1[t] - p2[t]);
 }
 
 __device__ __forceinline__ C128 cj(C128 w) { return mk<double>(w.x, -w.y); }
