@@ -567,11 +567,17 @@ __device__ __forceinline__ void chol16_f32(const Cx<TS>* sA, int sexp, float del
         }
         const f2v li2 = {lic.x * inv2, lic.y * inv2};
         const f4v* const part = reinterpret_cast<const f4v*>(&fcol[buf][jq * 4]);
-        const f4v l01 = part[0], l23 = part[1];
-        brow[0] -= pk_cmulc((f2v){l01.x, l01.y}, li2);       // B[i][j] -= B[i][kk] conj(B[j][kk]) / d
-        brow[1] -= pk_cmulc((f2v){l01.z, l01.w}, li2);
-        brow[2] -= pk_cmulc((f2v){l23.x, l23.y}, li2);
-        brow[3] -= pk_cmulc((f2v){l23.z, l23.w}, li2);
+        // column groups entirely at or before the pivot (4t + 3 <= kk, known to the unrolled loop) are never read again
+        if (kk < 7) {
+            const f4v l01 = part[0];
+            if (kk < 3) brow[0] -= pk_cmulc((f2v){l01.x, l01.y}, li2);       // B[i][j] -= B[i][kk] conj(B[j][kk]) / d
+            brow[1] -= pk_cmulc((f2v){l01.z, l01.w}, li2);
+        }
+        if (kk < 15) {
+            const f4v l23 = part[1];
+            if (kk < 11) brow[2] -= pk_cmulc((f2v){l23.x, l23.y}, li2);
+            brow[3] -= pk_cmulc((f2v){l23.z, l23.w}, li2);
+        }
     }
     wsync();
 }

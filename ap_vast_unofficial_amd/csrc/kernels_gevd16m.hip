@@ -162,7 +162,8 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
         if (jq == (kk & 3)) scol[buf][i] = brow[kk >> 2];                       // column kk of the working B
         if (i == kk) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) swr[buf][jq + 4 * t] = wrow[t];         // row kk of the working W
+            for (int t = 0; t < 4; ++t)
+                if (4 * t <= kk) swr[buf][jq + 4 * t] = wrow[t];                // row kk of the working W (zero beyond column kk)
         }
         wsync();
         const T dkk = scol[buf][kk].x;
@@ -173,8 +174,11 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
         // The outer-product update of B runs on the whole Hermitian matrix, without the triangle tests: rows and columns
         // already eliminated only cancel to rounding level and are never read again, and the unconditional update costs less
         // than its predicates.  W: rows past the pivot take the pivot row (zero beyond column kk), the pivot row is scaled.
+        // What the unrolled loop knows at compile time is skipped: column groups of B entirely at or before the pivot
+        // (4t + 3 <= kk) and groups of W entirely beyond it (4t > kk).
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
+            if (4 * t + 3 <= kk) continue;
             const C lj = scol[buf][jq + 4 * t];                  // B[i][j] -= B[i][kk] conj(B[j][kk]) / d
             brow[t].x -= li2.x * lj.x + li2.y * lj.y;
             brow[t].y -= li2.y * lj.x - li2.x * lj.y;
@@ -182,13 +186,15 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
         if (i > kk) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
+                if (4 * t > kk) continue;
                 const C wk = swr[buf][jq + 4 * t];               // W[i][j] -= (B[i][kk]/sqrt d) (W[kk][j]/sqrt d)
                 wrow[t].x -= li2.x * wk.x - li2.y * wk.y;
                 wrow[t].y -= li2.x * wk.y + li2.y * wk.x;
             }
         } else if (i == kk) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) wrow[t] = mk<T>(wrow[t].x * inv, wrow[t].y * inv);
+            for (int t = 0; t < 4; ++t)
+                if (4 * t <= kk) wrow[t] = mk<T>(wrow[t].x * inv, wrow[t].y * inv);
         }
     }
     wsync();
