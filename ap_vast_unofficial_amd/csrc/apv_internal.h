@@ -135,11 +135,11 @@ hipError_t apv_launch_analysis(int f64, int N, int n_ch, const void* x, long x_s
                                int use_win, void* spec, long stride_c, long stride_k, hipStream_t s, std::string* why);
 hipError_t apv_launch_synthesis(int f64, int N, int H, int n_ch, const void* spec, long stride_c, long stride_k,
                                 void* overlap, void* out, hipStream_t s, std::string* why);
-// K1 (RIR convolution of a hop) by fast convolution, float64 front-end: see fir_fft_kernel
-int apv_fir_fft_size(int P, int H);       // segment length F, 0 = use the direct form
-hipError_t apv_launch_fir_spectra(int F, int n_ch, const double* x, int P, void* Hf, hipStream_t s, std::string* why);
-hipError_t apv_launch_fir_input_spectra(int F, const double* x0, const double* x1, int in_len, void* Xf, hipStream_t s);
-hipError_t apv_launch_fir_fft_jobs(int F, int n_jobs, const void* const* Hf, const void* const* Xf, double* const* resp,
+// K1 (RIR convolution of a hop) by fast convolution, float (f64 = 0) or double data: see fir_fft_kernel
+int apv_fir_fft_size(int f64, int P, int H);       // segment length F, 0 = use the direct form
+hipError_t apv_launch_fir_spectra(int f64, int F, int n_ch, const void* x, int P, void* Hf, hipStream_t s, std::string* why);
+hipError_t apv_launch_fir_input_spectra(int f64, int F, const void* x0, const void* x1, int in_len, void* Xf, hipStream_t s);
+hipError_t apv_launch_fir_fft_jobs(int f64, int F, int n_jobs, const void* const* Hf, const void* const* Xf, void* const* resp,
                                    const int* n_ch, int P, int H, int N, int ring_off, hipStream_t s);
 
 // kernels_stream.hip

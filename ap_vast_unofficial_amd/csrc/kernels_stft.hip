@@ -275,34 +275,36 @@ __global__ void __launch_bounds__(STFT_TPB) istft_ola_kernel(FftPlan plan, int H
         for (int n = tid; n < H; n += STFT_TPB) out[(size_t)c * H + n] = zf[n];
 }
 
-// ---- K1 by fast convolution (float64 front-end) ---------------------------------------------------------------
+// ---- K1 by fast convolution ---------------------------------------------------------------------------------
 //   y[n][c] = sum_p xh[P-1+n-p] rir[p][c], n < H                                     apvast.py:171-192 (lfilter)
 // as one overlap-save segment of length F >= P - 1 + H: the history xh[0 .. P-1+H) zero-padded to F has the spectrum Xf
 // (fir_input_spectra_kernel, one transform per input signal and hop), the impulse responses zero-padded to F have the
 // spectra Hf (once, at set-up), and sample P - 1 + n of irfft(Xf Hf[c]) is y[n][c]: the first P - 1 samples of the
 // circular convolution are the wrapped ones and are not used.  One workgroup per control-point channel: 2 (F/2 + 1)
 // spectrum values in, an F/2-point complex transform in LDS, H samples out into the channel's response ring.  At
-// P = 800, H = 1024 (F = 2048) this is 0.25 Gflop and 53 MB per hop where the direct form is 3.4 Gflop.
+// P = 800, H = 1024 (F = 2048) this is 0.25 Gflop and 53 MB (float64) per hop where the direct form is 3.4 Gflop.
 constexpr int FIR_FFT_JOBS = 6;
+template <typename T>
 struct FirFftJobs {
-    const C2<double>* Hf[FIR_FFT_JOBS];    // [C_j][F/2 + 1]
-    const C2<double>* Xf[FIR_FFT_JOBS];    // [F/2 + 1], spectrum of the job's input history
-    double* resp[FIR_FFT_JOBS];            // [C_j][N] ring
-    int ch0[FIR_FFT_JOBS + 1];             // first workgroup of each job
+    const C2<T>* Hf[FIR_FFT_JOBS];    // [C_j][F/2 + 1]
+    const C2<T>* Xf[FIR_FFT_JOBS];    // [F/2 + 1], spectrum of the job's input history
+    T* resp[FIR_FFT_JOBS];            // [C_j][N] ring
+    int ch0[FIR_FFT_JOBS + 1];        // first workgroup of each job
     int n;
 };
 
-__global__ void __launch_bounds__(STFT_TPB) fir_input_spectra_kernel(FftPlan plan, const double* __restrict__ x0,
-                                                                     const double* __restrict__ x1, int in_len,
-                                                                     C2<double>* __restrict__ spec,
-                                                                     const C2<double>* __restrict__ tw) {
-    stft_analysis_body<double>(plan, blockIdx.x ? x1 : x0, in_len, 0, 0, spec + (size_t)blockIdx.x * (plan.Nh + 1), 1, tw, nullptr);
+template <typename T>
+__global__ void __launch_bounds__(STFT_TPB) fir_input_spectra_kernel(FftPlan plan, const T* __restrict__ x0,
+                                                                     const T* __restrict__ x1, int in_len,
+                                                                     C2<T>* __restrict__ spec, const C2<T>* __restrict__ tw) {
+    stft_analysis_body<T>(plan, blockIdx.x ? x1 : x0, in_len, 0, 0, spec + (size_t)blockIdx.x * (plan.Nh + 1), 1, tw, nullptr);
 }
 
-__global__ void __launch_bounds__(STFT_TPB) fir_fft_kernel(FftPlan plan, FirFftJobs jobs, int P, int H, int N, int ring_off,
-                                                           const C2<double>* __restrict__ tw) {
+template <typename T>
+__global__ void __launch_bounds__(STFT_TPB) fir_fft_kernel(FftPlan plan, FirFftJobs<T> jobs, int P, int H, int N, int ring_off,
+                                                           const C2<T>* __restrict__ tw) {
     extern __shared__ unsigned char smem_raw[];
-    using Z = C2<double>;
+    using Z = C2<T>;
     Z* za = reinterpret_cast<Z*>(smem_raw);
     const int Fh = plan.Nh;
     Z* zb = za + Fh;
@@ -320,17 +322,17 @@ __global__ void __launch_bounds__(STFT_TPB) fir_fft_kernel(FftPlan plan, FirFftJ
             a.y = 0;
             bq.y = 0;
         }
-        const Z b = c2<double>(bq.x, -bq.y);
-        const Z e = c2<double>(0.5 * (a.x + b.x), 0.5 * (a.y + b.y));
-        const Z dm = c2<double>(0.5 * (a.x - b.x), 0.5 * (a.y - b.y));
+        const Z b = c2<T>(bq.x, -bq.y);
+        const Z e = c2<T>((T)0.5 * (a.x + b.x), (T)0.5 * (a.y + b.y));
+        const Z dm = c2<T>((T)0.5 * (a.x - b.x), (T)0.5 * (a.y - b.y));
         const Z wk = tw[k];
-        const Z o = cmul(dm, c2<double>(wk.x, -wk.y));
-        za[k] = c2<double>(e.x - o.y, -(e.y + o.x));
+        const Z o = cmul(dm, c2<T>(wk.x, -wk.y));
+        za[k] = c2<T>(e.x - o.y, -(e.y + o.x));
     }
     __syncthreads();
-    const Z* z = fft_forward<double>(plan, za, zb, tw);
-    const double scale = 1.0 / (double)Fh;
-    double* __restrict__ dst = jobs.resp[j] + (size_t)c * N;
+    const Z* z = fft_forward<T>(plan, za, zb, tw);
+    const T scale = (T)1 / (T)Fh;
+    T* __restrict__ dst = jobs.resp[j] + (size_t)c * N;
     for (int i = tid; i < H; i += STFT_TPB) {
         const int n = P - 1 + i;
         const Z v = z[n >> 1];
@@ -482,44 +484,47 @@ hipError_t apv_launch_istft_ola(int N, int H, int n_ch, const float2* spec, floa
 
 // ---- K1 by fast convolution: launchers ------------------------------------------------------------------------------
 // Segment length for (P, H): the power of two >= P - 1 + H, or 0 when the direct form is the better choice (short
-// responses) or the segment does not fit the double-precision transform in LDS.
-int apv_fir_fft_size(int P, int H) {
+// responses) or the segment does not fit the transform in LDS (64 KB: 4096 doubles or 8192 floats).
+int apv_fir_fft_size(int f64, int P, int H) {
     if (P < 64) return 0;
     int F = 64;
     while (F < P - 1 + H) F *= 2;
-    return F <= 4096 ? F : 0;
+    return F <= (f64 ? 4096 : 8192) ? F : 0;
 }
 
 // spectra of n_ch impulse responses held channel-major, x [n_ch][P] -> Hf [n_ch][F/2 + 1]
-hipError_t apv_launch_fir_spectra(int F, int n_ch, const double* x, int P, void* Hf, hipStream_t s, std::string* why) {
-    return launch_analysis<double>(F, n_ch, x, P, P, 0, 0, Hf, F / 2 + 1, 1, s, why);
+hipError_t apv_launch_fir_spectra(int f64, int F, int n_ch, const void* x, int P, void* Hf, hipStream_t s, std::string* why) {
+    return f64 ? launch_analysis<double>(F, n_ch, x, P, P, 0, 0, Hf, F / 2 + 1, 1, s, why)
+               : launch_analysis<float>(F, n_ch, x, P, P, 0, 0, Hf, F / 2 + 1, 1, s, why);
 }
 
-// Xf [2][F/2 + 1] = spectra of the two input histories x0, x1 (in_len = P - 1 + H samples each, zero-padded to F)
-hipError_t apv_launch_fir_input_spectra(int F, const double* x0, const double* x1, int in_len, void* Xf, hipStream_t s) {
+namespace {
+template <typename T>
+hipError_t launch_fir_input_spectra(int F, const void* x0, const void* x1, int in_len, void* Xf, hipStream_t s) {
     FftPlan plan;
     if (!make_plan(F, &plan, nullptr)) return hipErrorInvalidValue;
-    Tables<double> t;
-    hipError_t e = get_tables<double>(F, &t);
+    Tables<T> t;
+    hipError_t e = get_tables<T>(F, &t);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fir_input_spectra_kernel, dim3(2), dim3(STFT_TPB), sizeof(C2<double>) * 2 * plan.Nh, s, plan, x0, x1, in_len,
-                       (C2<double>*)Xf, t.tw);
+    hipLaunchKernelGGL(fir_input_spectra_kernel<T>, dim3(2), dim3(STFT_TPB), sizeof(C2<T>) * 2 * plan.Nh, s, plan, (const T*)x0,
+                       (const T*)x1, in_len, (C2<T>*)Xf, t.tw);
     return hipGetLastError();
 }
 
-hipError_t apv_launch_fir_fft_jobs(int F, int n_jobs, const void* const* Hf, const void* const* Xf, double* const* resp,
-                                   const int* n_ch, int P, int H, int N, int ring_off, hipStream_t s) {
+template <typename T>
+hipError_t launch_fir_fft_jobs(int F, int n_jobs, const void* const* Hf, const void* const* Xf, void* const* resp, const int* n_ch,
+                               int P, int H, int N, int ring_off, hipStream_t s) {
     FftPlan plan;
     if (!make_plan(F, &plan, nullptr) || n_jobs < 1 || n_jobs > FIR_FFT_JOBS || P - 1 + H > F) return hipErrorInvalidValue;
-    Tables<double> t;
-    hipError_t e = get_tables<double>(F, &t);
+    Tables<T> t;
+    hipError_t e = get_tables<T>(F, &t);
     if (e != hipSuccess) return e;
-    FirFftJobs jobs{};
+    FirFftJobs<T> jobs{};
     int total = 0;
     for (int j = 0; j < n_jobs; ++j) {
-        jobs.Hf[j] = (const C2<double>*)Hf[j];
-        jobs.Xf[j] = (const C2<double>*)Xf[j];
-        jobs.resp[j] = resp[j];
+        jobs.Hf[j] = (const C2<T>*)Hf[j];
+        jobs.Xf[j] = (const C2<T>*)Xf[j];
+        jobs.resp[j] = (T*)resp[j];
         jobs.ch0[j] = total;
         total += n_ch[j];
     }
@@ -528,6 +533,18 @@ hipError_t apv_launch_fir_fft_jobs(int F, int n_jobs, const void* const* Hf, con
     if (total <= 0) return hipSuccess;
     int off = ring_off % N;
     if (off < 0) off += N;
-    hipLaunchKernelGGL(fir_fft_kernel, dim3(total), dim3(STFT_TPB), sizeof(C2<double>) * 2 * plan.Nh, s, plan, jobs, P, H, N, off, t.tw);
+    hipLaunchKernelGGL(fir_fft_kernel<T>, dim3(total), dim3(STFT_TPB), sizeof(C2<T>) * 2 * plan.Nh, s, plan, jobs, P, H, N, off, t.tw);
     return hipGetLastError();
+}
+}  // namespace
+
+// Xf [2][F/2 + 1] = spectra of the two input histories x0, x1 (in_len = P - 1 + H samples each, zero-padded to F)
+hipError_t apv_launch_fir_input_spectra(int f64, int F, const void* x0, const void* x1, int in_len, void* Xf, hipStream_t s) {
+    return f64 ? launch_fir_input_spectra<double>(F, x0, x1, in_len, Xf, s) : launch_fir_input_spectra<float>(F, x0, x1, in_len, Xf, s);
+}
+
+hipError_t apv_launch_fir_fft_jobs(int f64, int F, int n_jobs, const void* const* Hf, const void* const* Xf, void* const* resp,
+                                   const int* n_ch, int P, int H, int N, int ring_off, hipStream_t s) {
+    return f64 ? launch_fir_fft_jobs<double>(F, n_jobs, Hf, Xf, resp, n_ch, P, H, N, ring_off, s)
+               : launch_fir_fft_jobs<float>(F, n_jobs, Hf, Xf, resp, n_ch, P, H, N, ring_off, s);
 }

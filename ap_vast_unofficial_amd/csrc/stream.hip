@@ -63,10 +63,10 @@ struct apv_stream {
     void* sig_in;                 // pinned [2][chunk][2][H]
     void* sig_out;                // pinned [2][chunk] hop results (samples [n_out][H] + status words [2][K] each)
     int sig_chunk;                // hops per half of the pinned staging
-    // K1 by fast convolution (float64 front-end, fir_F > 0): spectra of the zero-padded impulse responses and of the
-    // two input histories of the hop
+    // K1 by fast convolution (fir_F > 0): spectra of the zero-padded impulse responses and of the two input histories
+    // of the hop, in the front-end precision
     int fir_F;                    // segment length, 0 = direct form
-    void* rirspec[2];             // [C][fir_F/2 + 1] c128, zone A, zone B
+    void* rirspec[2];             // [C][fir_F/2 + 1] complex, zone A, zone B
     void* trirspec[2];            // [M][fir_F/2 + 1]
     void* xspec;                  // [2][fir_F/2 + 1]
     long hop;                     // hops processed
@@ -192,22 +192,21 @@ static int enqueue_front(apv_handle* h, hipStream_t st, int set, const void* pin
     }
     s->cur = nxt;
     // K1: RIR convolution into the response rings (one MFMA launch for all six filter banks)
-    if (f64 && s->fir_F > 0) {
-        const size_t Kf = (size_t)s->fir_F / 2 + 1;
-        SCHK(h, apv_launch_fir_input_spectra(s->fir_F, (const double*)s->xhist[s->cur][0], (const double*)s->xhist[s->cur][1],
-                                             P - 1 + H, s->xspec, st));
+    if (s->fir_F > 0) {
+        const size_t spec_bytes = ((size_t)s->fir_F / 2 + 1) * 2 * s->esz;
+        SCHK(h, apv_launch_fir_input_spectra(f64, s->fir_F, s->xhist[s->cur][0], s->xhist[s->cur][1], P - 1 + H, s->xspec, st));
         const void *jh[6], *jx[6];
-        double* jr[6];
+        void* jr[6];
         int jc[6];
         for (int p = 0; p < 4; ++p) {
-            jh[p] = s->rirspec[path_zone(p)]; jx[p] = (const double2*)s->xspec + Kf * path_sig(p);
-            jr[p] = (double*)s->resp[p]; jc[p] = C;
+            jh[p] = s->rirspec[path_zone(p)]; jx[p] = (const char*)s->xspec + spec_bytes * path_sig(p);
+            jr[p] = s->resp[p]; jc[p] = C;
         }
         for (int z = 0; z < 2; ++z) {
-            jh[4 + z] = s->trirspec[z]; jx[4 + z] = (const double2*)s->xspec + Kf * z;
-            jr[4 + z] = (double*)s->tresp[z]; jc[4 + z] = M;
+            jh[4 + z] = s->trirspec[z]; jx[4 + z] = (const char*)s->xspec + spec_bytes * z;
+            jr[4 + z] = s->tresp[z]; jc[4 + z] = M;
         }
-        SCHK(h, apv_launch_fir_fft_jobs(s->fir_F, 6, jh, jx, jr, jc, P, H, N, s->ring_off, st));
+        SCHK(h, apv_launch_fir_fft_jobs(f64, s->fir_F, 6, jh, jx, jr, jc, P, H, N, s->ring_off, st));
     } else if (f64) {
         FirJobsD jobs{};
         for (int p = 0; p < 4; ++p) {
@@ -626,38 +625,38 @@ int apv_stream_init(apv_handle* h, int32_t rir_len, const double* h_rir_A, const
         if ((rc = upload(h, f64, s->rir[z], tmp))) return rc;
         if ((rc = upload(h, f64, s->trir[z], ttmp))) return rc;
     }
-    // long responses, float64: the hop's convolution goes through the frequency domain (fir_fft_kernel); APV_FIR_DIRECT
-    // keeps the direct form on the matrix cores (A/B switch)
-    s->fir_F = (f64 && getenv("APV_FIR_DIRECT") == nullptr) ? apv_fir_fft_size(P, H) : 0;
+    // long responses: the hop's convolution goes through the frequency domain (fir_fft_kernel); APV_FIR_DIRECT keeps the
+    // direct form on the matrix cores (A/B switch)
+    s->fir_F = getenv("APV_FIR_DIRECT") == nullptr ? apv_fir_fft_size(f64, P, H) : 0;
     if (s->fir_F > 0) {
         const int F = s->fir_F;
         const size_t Kf = (size_t)F / 2 + 1;
-        double* cm = nullptr;                                // [C][P] channel-major copy of one bank, set-up only
-        if ((rc = dalloc(h, &cm, (size_t)C * P))) return rc;
+        void* cm = nullptr;                                  // [C][P] channel-major copy of one bank, set-up only
+        if ((rc = dalloc(h, &cm, (size_t)C * P, e1))) return rc;
         std::vector<double> tr((size_t)C * P);
         std::string why;
         for (int z = 0; z < 2; ++z) {
             const double* src = z ? h_rir_B : h_rir_A;
             const int ref = z ? reference_index_B : reference_index_A;
-            if ((rc = dalloc(h, &s->rirspec[z], Kf * C, 16))) return rc;
-            if ((rc = dalloc(h, &s->trirspec[z], Kf * M, 16))) return rc;
+            if ((rc = dalloc(h, &s->rirspec[z], Kf * C, e2))) return rc;
+            if ((rc = dalloc(h, &s->trirspec[z], Kf * M, e2))) return rc;
             for (int p = 0; p < P; ++p)
                 for (int l = 0; l < L; ++l)
                     for (int m = 0; m < M; ++m) tr[(size_t)(m * L + l) * P + p] = src[((size_t)p * L + l) * M + m];
-            if ((rc = upload(h, 1, cm, tr))) return rc;
-            hipError_t e = apv_launch_fir_spectra(F, C, cm, P, s->rirspec[z], h->stream, &why);
+            if ((rc = upload(h, f64, cm, tr))) return rc;
+            hipError_t e = apv_launch_fir_spectra(f64, F, C, cm, P, s->rirspec[z], h->stream, &why);
             if (e != hipSuccess) return apv_fail(h, APV_ERR_HIP, why.empty() ? hipGetErrorString(e) : why);
             SCHK(h, hipStreamSynchronize(h->stream));
             std::fill(tr.begin(), tr.end(), 0.0);
             for (int p = modeling_delay; p < P; ++p)
                 for (int m = 0; m < M; ++m) tr[(size_t)m * P + p] = src[((size_t)(p - modeling_delay) * L + ref) * M + m];
-            if ((rc = upload(h, 1, cm, tr))) return rc;
-            e = apv_launch_fir_spectra(F, M, cm, P, s->trirspec[z], h->stream, &why);
+            if ((rc = upload(h, f64, cm, tr))) return rc;
+            e = apv_launch_fir_spectra(f64, F, M, cm, P, s->trirspec[z], h->stream, &why);
             if (e != hipSuccess) return apv_fail(h, APV_ERR_HIP, why.empty() ? hipGetErrorString(e) : why);
             SCHK(h, hipStreamSynchronize(h->stream));
         }
         (void)hipFree(cm);
-        if ((rc = dalloc(h, &s->xspec, 2 * Kf, 16))) return rc;
+        if ((rc = dalloc(h, &s->xspec, 2 * Kf, e2))) return rc;
     }
     const size_t hist = (size_t)P - 1 + H + s->pad;
     for (int b = 0; b < 2; ++b)

@@ -227,6 +227,27 @@ def test_stream_non_power_of_two_block():
     ap.close()
 
 
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("P,block,hop", [(20, 256, 128), (200, 256, 128), (90, 240, 120)])
+def test_stream_fir_direct_and_fast_convolution(P, block, hop, dtype, monkeypatch):
+    """K1 (apvast.py:171-192) has two forms: the direct one on the matrix cores and, for responses of 64 taps or more, an
+    overlap-save segment through the frequency domain.  Both against the oracle's lfilter (float64: spectra at 1e-13);
+    with APV_FIR_DIRECT set the long responses take the direct form too, and the two forms agree to rounding."""
+    rirA, rirB = synth_rirs(P, 4, 8, 11)
+    K = block // 2 + 1
+    runs = {}
+    for form in ("default", "direct"):
+        if form == "direct":
+            monkeypatch.setenv("APV_FIR_DIRECT", "1")
+        ap, orc, got, exp = run_pair(block, hop, rirA, rirB, 5, 1, 2, 2, 1.0, hops=5, dtype=dtype)
+        check_last_hop_state(ap, orc, TOL[dtype], K, 4, 8)
+        check_outputs(got, exp, TOL[dtype]["out"], TOL[dtype]["tgt"])
+        runs[form] = np.stack([ap._eng.get_state(f"spectra{p}", (K, 8, 4), ap._eng.sc_dtype) for p in range(4)])
+        ap.close()
+    scale = np.abs(runs["direct"]).max()
+    assert np.abs(runs["default"] - runs["direct"]).max() <= (1e-14 if dtype == "f64" else 1e-6) * scale
+
+
 @pytest.mark.parametrize("dialect", ["python", "matlab"])
 def test_stream_perceptual_weighting(dialect):
     """perceptual=True: device weighting curves (perceptualModel.m:118-139, 177-190) against the independent NumPy
