@@ -125,6 +125,9 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
     const int lane = threadIdx.x;
     const int k = blockIdx.x;
     int status = 0;
+    // One wave is a long dependent chain; in the streaming pipeline the launch shares the chip with the next hop's transforms,
+    // whose waves would otherwise take every other issue slot: this wave goes first.  (No effect when the kernel runs alone.)
+    __builtin_amdgcn_s_setprio(3);
 
     // ---------------- stage 0 ----------------
     if constexpr (FUSED) {

@@ -100,9 +100,19 @@ __device__ __forceinline__ void stockham_stage(const C2<T>* __restrict__ src, C2
         const int k = j - q * Ns;
         C2<T> u[R];
 #pragma unroll
-        for (int t = 0; t < R; ++t) {
-            u[t] = src[j + t * m];
-            if (t > 0) u[t] = cmul(u[t], tw[t * k * tstep]);       // t k tstep <= (R-1)(Ns-1) N / (Ns R) < N: no wrap
+        for (int t = 0; t < R; ++t) u[t] = src[j + t * m];
+        // twiddles w^t, w = exp(-2 pi i k / (Ns R)): none in the first stage (k = 0); radix 4 fetches w alone and squares and
+        // cubes it (a table read is an L2 round trip on the critical path of the stage, a complex product is four FMAs)
+        if (Ns > 1) {
+            if constexpr (R == 4) {
+                const C2<T> w1 = tw[k * tstep], w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+                u[1] = cmul(u[1], w1);
+                u[2] = cmul(u[2], w2);
+                u[3] = cmul(u[3], w3);
+            } else {
+#pragma unroll
+                for (int t = 1; t < R; ++t) u[t] = cmul(u[t], tw[t * k * tstep]);   // t k tstep <= (R-1)(Ns-1) N / (Ns R) < N: no wrap
+            }
         }
         C2<T> v[R];
         if constexpr (R == 2) {

@@ -60,6 +60,12 @@ struct apv_stream {
     hipEvent_t ev_front[2];       // set p filled by the front half
     hipEvent_t ev_back[2];        // set p released by the back half
     hipEvent_t ev_chunk[2];       // chunk c & 1 of the pinned staging complete
+    // ... and a copy stream with a second device result buffer: the copy back of hop h runs beside the joint
+    // diagonalisation of hop h+1 instead of in front of it
+    void* out1;                   // like out; hops alternate between the two
+    hipStream_t copy;
+    hipEvent_t ev_out[2];         // result buffer b written by the synthesis
+    hipEvent_t ev_copied[2];      // result buffer b copied to the host
     void* sig_in;                 // pinned [2][chunk][2][H]
     void* sig_out;                // pinned [2][chunk] hop results (samples [n_out][H] + status words [2][K] each)
     int sig_chunk;                // hops per half of the pinned staging
@@ -148,8 +154,12 @@ void apv_stream_free(apv_handle* h) {
         if (s->ev_front[p]) (void)hipEventDestroy(s->ev_front[p]);
         if (s->ev_back[p]) (void)hipEventDestroy(s->ev_back[p]);
         if (s->ev_chunk[p]) (void)hipEventDestroy(s->ev_chunk[p]);
+        if (s->ev_out[p]) (void)hipEventDestroy(s->ev_out[p]);
+        if (s->ev_copied[p]) (void)hipEventDestroy(s->ev_copied[p]);
     }
+    if (s->out1) (void)hipFree(s->out1);
     if (s->front) (void)hipStreamDestroy(s->front);
+    if (s->copy) (void)hipStreamDestroy(s->copy);
     if (s->sig_in) (void)hipHostFree(s->sig_in);
     if (s->sig_out) (void)hipHostFree(s->sig_out);
     delete s;
@@ -270,10 +280,22 @@ static int enqueue_front(apv_handle* h, hipStream_t st, int set, const void* pin
     return APV_OK;
 }
 
+// How the whole-signal path runs the back half: which device result buffer, an event to record once the spectra set has
+// been read for the last time (after K3), and a stream of its own for the copy back.  The per-hop path takes the defaults.
+struct BackSchedule {
+    int obuf = 0;
+    hipEvent_t spectra_free = nullptr;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t out_ready = nullptr, copied = nullptr;
+};
+
 // Back half of a hop on stream `st`: spectra of set `set` -> per-bin filters (K5'-K10), output spectra (K3), synthesis
 // and overlap-add (K4); the emitted samples [n_out][H] and, behind them, the status words [2][K] land in pinned `pin_dst`.
-static int enqueue_back(apv_handle* h, hipStream_t st, int set, void* pin_dst) {
+static int enqueue_back(apv_handle* h, hipStream_t st, int set, void* pin_dst, const BackSchedule& sch = BackSchedule()) {
     apv_stream* s = h->st;
+    char* const obuf = static_cast<char*>(sch.obuf ? s->out1 : s->out);
+    int32_t* const ostatus[2] = {reinterpret_cast<int32_t*>(obuf + hop_out_bytes(s)),
+                                 reinterpret_cast<int32_t*>(obuf + hop_out_bytes(s)) + s->K};
     const HopSpectra q = hop_spectra(s, set);
     const int N = s->N, H = s->H, K = s->K, L = s->L, f64 = s->f64;
     const size_t e2 = 2 * s->esz;
@@ -291,11 +313,11 @@ static int enqueue_back(apv_handle* h, hipStream_t st, int set, void* pin_dst) {
         p.d = q.tspec[first];
         p.w = s->w[first];
         p.lam = s->lam[first];
-        p.status = s->status[first];
+        p.status = ostatus[first];
         p.n_zones = (runA && runB) ? 2 : 1;
         if (p.n_zones == 2) {
             p.XB1 = q.X[3]; p.XD1 = q.X[2]; p.d1 = q.tspec[1];
-            p.w1 = s->w[1]; p.lam1 = s->lam[1]; p.status1 = s->status[1];
+            p.w1 = s->w[1]; p.lam1 = s->lam[1]; p.status1 = ostatus[1];
         }
         hipError_t e = apv_launch_gevd(p, h->cfg.compute_dtype, true, st, &why);
         if (e != hipSuccess) return apv_fail(h, APV_ERR_HIP, why.empty() ? hipGetErrorString(e) : why);
@@ -322,12 +344,20 @@ static int enqueue_back(apv_handle* h, hipStream_t st, int set, void* pin_dst) {
         }
         SCHK(h, apv_launch_apply_jobs(K, nj, jin, jw, jt, jout, jf, jtg, h->cfg.out_c128, f64, st));
     }
+    if (sch.spectra_free) SCHK(h, hipEventRecord(sch.spectra_free, st));
     // K4: synthesis + overlap-add + emit
     {
-        hipError_t e = apv_launch_synthesis(f64, N, H, s->n_out, s->outspec, K, 1, s->outov, s->out, st, &why);
+        hipError_t e = apv_launch_synthesis(f64, N, H, s->n_out, s->outspec, K, 1, s->outov, obuf, st, &why);
         if (e != hipSuccess) return apv_fail(h, APV_ERR_HIP, why.empty() ? hipGetErrorString(e) : why);
     }
-    SCHK(h, hipMemcpyAsync(pin_dst, s->out, hop_result_bytes(s), hipMemcpyDeviceToHost, st));       // samples + status: one copy
+    hipStream_t cs = st;
+    if (sch.copy_stream) {
+        cs = sch.copy_stream;
+        SCHK(h, hipEventRecord(sch.out_ready, st));
+        SCHK(h, hipStreamWaitEvent(cs, sch.out_ready, 0));
+    }
+    SCHK(h, hipMemcpyAsync(pin_dst, obuf, hop_result_bytes(s), hipMemcpyDeviceToHost, cs));         // samples + status: one copy
+    if (sch.copy_stream) SCHK(h, hipEventRecord(sch.copied, cs));
     return APV_OK;
 }
 
@@ -447,8 +477,12 @@ static int signal_prepare(apv_handle* h) {
     for (int z = 0; z < 2; ++z)
         if (!s->tspec1[z] && (rc = dalloc(h, &s->tspec1[z], K * M, e2))) return rc;
     if (!s->inspec1 && (rc = dalloc(h, &s->inspec1, 2 * K, e2))) return rc;
+    if (!s->out1 && (rc = dalloc(h, &s->out1, hop_result_bytes(s), 1))) return rc;
     if (!s->front) SCHK(h, hipStreamCreateWithFlags(&s->front, hipStreamNonBlocking));
+    if (!s->copy) SCHK(h, hipStreamCreateWithFlags(&s->copy, hipStreamNonBlocking));
     for (int p = 0; p < 2; ++p) {
+        if (!s->ev_out[p]) SCHK(h, hipEventCreateWithFlags(&s->ev_out[p], hipEventDisableTiming));
+        if (!s->ev_copied[p]) SCHK(h, hipEventCreateWithFlags(&s->ev_copied[p], hipEventDisableTiming));
         if (!s->ev_front[p]) SCHK(h, hipEventCreateWithFlags(&s->ev_front[p], hipEventDisableTiming));
         if (!s->ev_back[p]) SCHK(h, hipEventCreateWithFlags(&s->ev_back[p], hipEventDisableTiming));
         if (!s->ev_chunk[p]) SCHK(h, hipEventCreateWithFlags(&s->ev_chunk[p], hipEventDisableTiming));
@@ -482,9 +516,10 @@ static int process_signal_t(apv_handle* h, int n_hops, const TI* h_in_A, const T
     const int H = s->H, K = s->K, chunk = s->sig_chunk;
     const size_t e1 = s->esz, nout = (size_t)s->n_out * H;
     hipStream_t back = h->stream;
-    auto drain = [&]() { (void)hipStreamSynchronize(s->front); (void)hipStreamSynchronize(back); };
+    auto drain = [&]() { (void)hipStreamSynchronize(s->front); (void)hipStreamSynchronize(back); (void)hipStreamSynchronize(s->copy); };
     int set = 0, last_set = 0;
     bool released[2] = {true, true};                         // nothing reads either set yet
+    bool out_idle[2] = {true, true};                         // no copy of either result buffer pending
     int worst = APV_OK;                                      // first APV_ERR_NO_CONVERGE, overridden by APV_ERR_NOT_PD
     std::string worst_msg;
     const int n_chunks = (n_hops + chunk - 1) / chunk;
@@ -539,10 +574,18 @@ static int process_signal_t(apv_handle* h, int n_hops, const TI* h_in_A, const T
                 e = hipEventRecord(s->ev_front[set], s->front);
             }
             if (e == hipSuccess) e = hipStreamWaitEvent(back, s->ev_front[set], 0);
+            // the result buffer follows the set; hop h-2's copy of it has to be through before this hop's status words land there
+            if (e == hipSuccess && !out_idle[set]) e = hipStreamWaitEvent(back, s->ev_copied[set], 0);
             if (e == hipSuccess) {
-                rc = enqueue_back(h, back, set, (char*)s->sig_out + slot * hop_result_bytes(s));
+                BackSchedule sch;
+                sch.obuf = set;
+                sch.spectra_free = s->ev_back[set];          // recorded after K3, the set's last reader
+                sch.copy_stream = s->copy;
+                sch.out_ready = s->ev_out[set];
+                sch.copied = s->ev_copied[set];
+                rc = enqueue_back(h, back, set, (char*)s->sig_out + slot * hop_result_bytes(s), sch);
                 if (rc != APV_OK) { drain(); return rc; }
-                e = hipEventRecord(s->ev_back[set], back);
+                out_idle[set] = false;
             }
             if (e != hipSuccess) {
                 drain();
@@ -553,7 +596,7 @@ static int process_signal_t(apv_handle* h, int n_hops, const TI* h_in_A, const T
             set ^= 1;
             s->hop++;
         }
-        SCHK(h, hipEventRecord(s->ev_chunk[c & 1], back));   // every front half is upstream of some back half
+        SCHK(h, hipEventRecord(s->ev_chunk[c & 1], s->copy));   // every front and back half is upstream of some copy
         if (c > 0) {
             if ((rc = collect(c - 1)) != APV_OK) { drain(); return rc; }
             c_done = c;
@@ -570,6 +613,7 @@ static int process_signal_t(apv_handle* h, int n_hops, const TI* h_in_A, const T
         SCHK(h, hipMemcpyAsync(s->inspec, s->inspec1, (size_t)2 * K * e2, hipMemcpyDeviceToDevice, back));
     }
     SCHK(h, hipStreamSynchronize(back));
+    SCHK(h, hipStreamSynchronize(s->copy));
     if (worst != APV_OK) return apv_fail(h, worst, worst_msg);
     return APV_OK;
 }
