@@ -28,7 +28,9 @@ struct FftPlan {
     int Nh;                // complex length N/2
     int nstages;
     int radix[MAX_STAGES];
+    int inplace;           // every stage is radix 4 or 2 and short enough for stockham_stage_inplace: ONE LDS buffer of Nh
 };
+constexpr int INPLACE_MAX_IT = 4;      // butterflies per thread and stage the in-place form holds in registers
 
 template <typename T> struct C2 { T x, y; };
 template <typename T> __device__ __forceinline__ C2<T> c2(T a, T b) { C2<T> r; r.x = a; r.y = b; return r; }
@@ -141,9 +143,71 @@ __device__ __forceinline__ void stockham_stage(const C2<T>* __restrict__ src, C2
     }
 }
 
-// forward complex FFT of length plan.Nh on natural-order data in `a`; returns the buffer holding the result
+// The same stage on ONE buffer: every thread reads the inputs of all its butterflies, the workgroup meets, the outputs
+// go back to the same array.  Two barriers per stage instead of one, half the LDS: at 16 KB instead of 32 KB per
+// 2048-point double-precision transform eight workgroups fit a CU instead of five -- and five instead of two beside
+// the streaming pipeline's joint diagonalisation, which holds 80 KB of every CU while the next hop's transforms run.
+template <typename T, int R>
+__device__ __forceinline__ void stockham_stage_inplace(C2<T>* __restrict__ buf, int Nh, int Ns, const C2<T>* __restrict__ tw) {
+    static_assert(R == 2 || R == 4, "in-place stages are radix 2 or 4");
+    const int m = Nh / R;
+    const int tstep = 2 * (Nh / (Ns * R));
+    const int sh = __ffs(Ns) - 1;                      // Ns is a power of two here
+    C2<T> v[INPLACE_MAX_IT][R];
+#pragma unroll
+    for (int it = 0; it < INPLACE_MAX_IT; ++it) {
+        const int j = threadIdx.x + it * STFT_TPB;
+        if (j >= m) break;
+        const int k = j & (Ns - 1);
+        C2<T> u[R];
+#pragma unroll
+        for (int t = 0; t < R; ++t) u[t] = buf[j + t * m];
+        if (Ns > 1) {
+            const C2<T> w1 = tw[k * tstep];
+            u[1] = cmul(u[1], w1);
+            if constexpr (R == 4) {
+                const C2<T> w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+                u[2] = cmul(u[2], w2);
+                u[3] = cmul(u[3], w3);
+            }
+        }
+        if constexpr (R == 2) {
+            v[it][0] = cadd(u[0], u[1]);
+            v[it][1] = csub(u[0], u[1]);
+        } else {
+            const C2<T> a = cadd(u[0], u[2]), b = csub(u[0], u[2]), c = cadd(u[1], u[3]), d = csub(u[1], u[3]);
+            v[it][0] = cadd(a, c);
+            v[it][2] = csub(a, c);
+            v[it][1] = c2<T>(b.x + d.y, b.y - d.x);
+            v[it][3] = c2<T>(b.x - d.y, b.y + d.x);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < INPLACE_MAX_IT; ++it) {
+        const int j = threadIdx.x + it * STFT_TPB;
+        if (j >= m) break;
+        const int q = j >> sh, k = j & (Ns - 1);
+        const int base = q * Ns * R + k;
+#pragma unroll
+        for (int t = 0; t < R; ++t) buf[base + t * Ns] = v[it][t];
+    }
+    __syncthreads();
+}
+
+// forward complex FFT of length plan.Nh on natural-order data in `a`; returns the buffer holding the result (`b` is not
+// touched, and need not exist, when plan.inplace is set)
 template <typename T>
 __device__ __forceinline__ C2<T>* fft_forward(const FftPlan& plan, C2<T>* a, C2<T>* b, const C2<T>* __restrict__ tw) {
+    if (plan.inplace) {
+        int Ns = 1;
+        for (int s = 0; s < plan.nstages; ++s) {
+            if (plan.radix[s] == 4) stockham_stage_inplace<T, 4>(a, plan.Nh, Ns, tw);
+            else stockham_stage_inplace<T, 2>(a, plan.Nh, Ns, tw);
+            Ns *= plan.radix[s];
+        }
+        return a;
+    }
     int Ns = 1;
     C2<T>* src = a;
     C2<T>* dst = b;
@@ -370,8 +434,18 @@ bool make_plan(int N, FftPlan* plan, std::string* why) {
         if (why) *why = "STFT block size / 2 must factor into 2, 3, 5 and 7";
         return false;
     }
+    static const bool pingpong = getenv("APV_FFT_PINGPONG") != nullptr;      // A/B switch: two-buffer stages everywhere
+    plan->inplace = pingpong ? 0 : 1;
+    for (int s = 0; s < plan->nstages; ++s) {
+        const int r = plan->radix[s];
+        if ((r != 2 && r != 4) || plan->Nh / r > INPLACE_MAX_IT * STFT_TPB) plan->inplace = 0;
+    }
     return true;
 }
+
+// LDS bytes of one transform
+template <typename T>
+size_t plan_lds(const FftPlan& plan) { return sizeof(C2<T>) * (plan.inplace ? 1 : 2) * plan.Nh; }
 
 template <typename T>
 hipError_t launch_analysis(int N, int n_ch, const void* x, long x_stride, int in_len, int ring_off, int use_win,
@@ -382,7 +456,7 @@ hipError_t launch_analysis(int N, int n_ch, const void* x, long x_stride, int in
     Tables<T> t;
     hipError_t e = get_tables<T>(N, &t);
     if (e != hipSuccess) return e;
-    const size_t lds = sizeof(C2<T>) * 2 * plan.Nh;
+    const size_t lds = plan_lds<T>(plan);
     int off = ring_off % N;
     if (off < 0) off += N;
     hipLaunchKernelGGL(stft_analysis_kernel<T>, dim3(n_ch), dim3(STFT_TPB), lds, s, plan, (const T*)x, x_stride, in_len,
@@ -403,7 +477,7 @@ hipError_t launch_synthesis(int N, int H, int n_ch, const void* spec, long strid
     Tables<T> t;
     hipError_t e = get_tables<T>(N, &t);
     if (e != hipSuccess) return e;
-    const size_t lds = sizeof(C2<T>) * 2 * plan.Nh;
+    const size_t lds = plan_lds<T>(plan);
     hipLaunchKernelGGL(istft_ola_kernel<T>, dim3(n_ch), dim3(STFT_TPB), lds, s, plan, H, (const C2<T>*)spec, stride_c,
                        stride_k, (T*)overlap, (T*)out, t.tw, t.win);
     return hipGetLastError();
@@ -433,7 +507,7 @@ hipError_t launch_analysis_jobs(const FftPlan& plan, int n_jobs, const void* con
     if (total <= 0) return hipSuccess;
     int off = ring_off % plan.N;
     if (off < 0) off += plan.N;
-    hipLaunchKernelGGL(stft_analysis_jobs_kernel<T>, dim3(total), dim3(STFT_TPB), sizeof(C2<T>) * 2 * plan.Nh, s, plan, jobs, off,
+    hipLaunchKernelGGL(stft_analysis_jobs_kernel<T>, dim3(total), dim3(STFT_TPB), plan_lds<T>(plan), s, plan, jobs, off,
                        t.tw, t.win);
     return hipGetLastError();
 }
@@ -516,7 +590,7 @@ hipError_t launch_fir_input_spectra(int F, const void* x0, const void* x1, int i
     Tables<T> t;
     hipError_t e = get_tables<T>(F, &t);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fir_input_spectra_kernel<T>, dim3(2), dim3(STFT_TPB), sizeof(C2<T>) * 2 * plan.Nh, s, plan, (const T*)x0,
+    hipLaunchKernelGGL(fir_input_spectra_kernel<T>, dim3(2), dim3(STFT_TPB), plan_lds<T>(plan), s, plan, (const T*)x0,
                        (const T*)x1, in_len, (C2<T>*)Xf, t.tw);
     return hipGetLastError();
 }
@@ -543,7 +617,7 @@ hipError_t launch_fir_fft_jobs(int F, int n_jobs, const void* const* Hf, const v
     if (total <= 0) return hipSuccess;
     int off = ring_off % N;
     if (off < 0) off += N;
-    hipLaunchKernelGGL(fir_fft_kernel<T>, dim3(total), dim3(STFT_TPB), sizeof(C2<T>) * 2 * plan.Nh, s, plan, jobs, P, H, N, off, t.tw);
+    hipLaunchKernelGGL(fir_fft_kernel<T>, dim3(total), dim3(STFT_TPB), plan_lds<T>(plan), s, plan, jobs, P, H, N, off, t.tw);
     return hipGetLastError();
 }
 }  // namespace

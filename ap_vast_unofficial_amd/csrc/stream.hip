@@ -60,11 +60,11 @@ struct apv_stream {
     hipEvent_t ev_front[2];       // set p filled by the front half
     hipEvent_t ev_back[2];        // set p released by the back half
     hipEvent_t ev_chunk[2];       // chunk c & 1 of the pinned staging complete
-    // ... and a copy stream with a second device result buffer: the copy back of hop h runs beside the joint
-    // diagonalisation of hop h+1 instead of in front of it
-    void* out1;                   // like out; hops alternate between the two
-    hipStream_t copy;
-    hipEvent_t ev_out[2];         // result buffer b written by the synthesis
+    // ... and a tail stream with second output-spectra and result buffers: synthesis and copy back of hop h run beside
+    // the joint diagonalisation of hop h+1 instead of in front of it
+    void* outspec1;               // like outspec, out; hops alternate between the two
+    void* out1;
+    hipStream_t tail;
     hipEvent_t ev_copied[2];      // result buffer b copied to the host
     void* sig_in;                 // pinned [2][chunk][2][H]
     void* sig_out;                // pinned [2][chunk] hop results (samples [n_out][H] + status words [2][K] each)
@@ -154,12 +154,12 @@ void apv_stream_free(apv_handle* h) {
         if (s->ev_front[p]) (void)hipEventDestroy(s->ev_front[p]);
         if (s->ev_back[p]) (void)hipEventDestroy(s->ev_back[p]);
         if (s->ev_chunk[p]) (void)hipEventDestroy(s->ev_chunk[p]);
-        if (s->ev_out[p]) (void)hipEventDestroy(s->ev_out[p]);
         if (s->ev_copied[p]) (void)hipEventDestroy(s->ev_copied[p]);
     }
     if (s->out1) (void)hipFree(s->out1);
+    if (s->outspec1) (void)hipFree(s->outspec1);
     if (s->front) (void)hipStreamDestroy(s->front);
-    if (s->copy) (void)hipStreamDestroy(s->copy);
+    if (s->tail) (void)hipStreamDestroy(s->tail);
     if (s->sig_in) (void)hipHostFree(s->sig_in);
     if (s->sig_out) (void)hipHostFree(s->sig_out);
     delete s;
@@ -184,7 +184,8 @@ static HopSpectra hop_spectra(const apv_stream* s, int set) {
 // Front half of a hop on stream `st`: pinned hop `pin_src` [2][H] -> input histories, response rings (K1), analysis
 // spectra of set `set` (K2, perceptual weighting).  Advances (ring_off, cur) on the host.  Pure enqueue: also used
 // under stream capture.
-static int enqueue_front(apv_handle* h, hipStream_t st, int set, const void* pin_src) {
+// `set_free` (whole-signal path): event to wait for before the first kernel that writes the spectra set.
+static int enqueue_front(apv_handle* h, hipStream_t st, int set, const void* pin_src, hipEvent_t set_free = nullptr) {
     apv_stream* s = h->st;
     const HopSpectra q = hop_spectra(s, set);
     const int N = s->N, H = s->H, K = s->K, L = s->L, M = s->M, C = s->C, P = s->P, f64 = s->f64;
@@ -249,6 +250,7 @@ static int enqueue_front(apv_handle* h, hipStream_t st, int set, const void* pin
     }
     // K2: analysis, bin-major output
     const bool runA = s->zones & 1, runB = s->zones & 2;
+    if (set_free) SCHK(h, hipStreamWaitEvent(st, set_free, 0));       // histories, rings and K1 above did not need the set
     {
         // every analysis transform of the hop in one launch: the live response paths, both targets, the two inputs
         const void* jx[7];
@@ -280,13 +282,14 @@ static int enqueue_front(apv_handle* h, hipStream_t st, int set, const void* pin
     return APV_OK;
 }
 
-// How the whole-signal path runs the back half: which device result buffer, an event to record once the spectra set has
-// been read for the last time (after K3), and a stream of its own for the copy back.  The per-hop path takes the defaults.
+// How the whole-signal path runs the back half: which output-spectra / result buffers, an event to record once the
+// spectra set has been read for the last time (after K3), and a stream of its own for synthesis and copy back, which
+// start at that event.  The per-hop path takes the defaults.
 struct BackSchedule {
     int obuf = 0;
     hipEvent_t spectra_free = nullptr;
-    hipStream_t copy_stream = nullptr;
-    hipEvent_t out_ready = nullptr, copied = nullptr;
+    hipStream_t tail_stream = nullptr;
+    hipEvent_t copied = nullptr;
 };
 
 // Back half of a hop on stream `st`: spectra of set `set` -> per-bin filters (K5'-K10), output spectra (K3), synthesis
@@ -294,6 +297,7 @@ struct BackSchedule {
 static int enqueue_back(apv_handle* h, hipStream_t st, int set, void* pin_dst, const BackSchedule& sch = BackSchedule()) {
     apv_stream* s = h->st;
     char* const obuf = static_cast<char*>(sch.obuf ? s->out1 : s->out);
+    char* const ospec = static_cast<char*>(sch.obuf ? s->outspec1 : s->outspec);
     int32_t* const ostatus[2] = {reinterpret_cast<int32_t*>(obuf + hop_out_bytes(s)),
                                  reinterpret_cast<int32_t*>(obuf + hop_out_bytes(s)) + s->K};
     const HopSpectra q = hop_spectra(s, set);
@@ -332,32 +336,31 @@ static int enqueue_back(apv_handle* h, hipStream_t st, int set, void* pin_dst, c
         for (int z = 0; z < 2; ++z) {
             if (!(z ? runB : runA)) continue;
             jin[nj] = (const char*)q.inspec + (size_t)z * K * e2; jw[nj] = s->w[z]; jt[nj] = nullptr;
-            jout[nj] = (char*)s->outspec + (size_t)oc * K * e2;
+            jout[nj] = ospec + (size_t)oc * K * e2;
             jf[nj] = s->nV * L; jtg[nj] = 0; ++nj;
             oc += s->nV * L;
         }
         for (int z = 0; z < 2; ++z) {
             jin[nj] = (const char*)q.inspec + (size_t)z * K * e2; jw[nj] = nullptr; jt[nj] = s->tgt;
-            jout[nj] = (char*)s->outspec + (size_t)oc * K * e2;
+            jout[nj] = ospec + (size_t)oc * K * e2;
             jf[nj] = 0; jtg[nj] = L; ++nj;
             oc += L;
         }
         SCHK(h, apv_launch_apply_jobs(K, nj, jin, jw, jt, jout, jf, jtg, h->cfg.out_c128, f64, st));
     }
     if (sch.spectra_free) SCHK(h, hipEventRecord(sch.spectra_free, st));
+    hipStream_t ts = st;
+    if (sch.tail_stream) {
+        ts = sch.tail_stream;
+        SCHK(h, hipStreamWaitEvent(ts, sch.spectra_free, 0));
+    }
     // K4: synthesis + overlap-add + emit
     {
-        hipError_t e = apv_launch_synthesis(f64, N, H, s->n_out, s->outspec, K, 1, s->outov, obuf, st, &why);
+        hipError_t e = apv_launch_synthesis(f64, N, H, s->n_out, ospec, K, 1, s->outov, obuf, ts, &why);
         if (e != hipSuccess) return apv_fail(h, APV_ERR_HIP, why.empty() ? hipGetErrorString(e) : why);
     }
-    hipStream_t cs = st;
-    if (sch.copy_stream) {
-        cs = sch.copy_stream;
-        SCHK(h, hipEventRecord(sch.out_ready, st));
-        SCHK(h, hipStreamWaitEvent(cs, sch.out_ready, 0));
-    }
-    SCHK(h, hipMemcpyAsync(pin_dst, obuf, hop_result_bytes(s), hipMemcpyDeviceToHost, cs));         // samples + status: one copy
-    if (sch.copy_stream) SCHK(h, hipEventRecord(sch.copied, cs));
+    SCHK(h, hipMemcpyAsync(pin_dst, obuf, hop_result_bytes(s), hipMemcpyDeviceToHost, ts));         // samples + status: one copy
+    if (sch.tail_stream) SCHK(h, hipEventRecord(sch.copied, ts));
     return APV_OK;
 }
 
@@ -478,10 +481,10 @@ static int signal_prepare(apv_handle* h) {
         if (!s->tspec1[z] && (rc = dalloc(h, &s->tspec1[z], K * M, e2))) return rc;
     if (!s->inspec1 && (rc = dalloc(h, &s->inspec1, 2 * K, e2))) return rc;
     if (!s->out1 && (rc = dalloc(h, &s->out1, hop_result_bytes(s), 1))) return rc;
+    if (!s->outspec1 && (rc = dalloc(h, &s->outspec1, (size_t)s->n_out * K, e2))) return rc;
     if (!s->front) SCHK(h, hipStreamCreateWithFlags(&s->front, hipStreamNonBlocking));
-    if (!s->copy) SCHK(h, hipStreamCreateWithFlags(&s->copy, hipStreamNonBlocking));
+    if (!s->tail) SCHK(h, hipStreamCreateWithFlags(&s->tail, hipStreamNonBlocking));
     for (int p = 0; p < 2; ++p) {
-        if (!s->ev_out[p]) SCHK(h, hipEventCreateWithFlags(&s->ev_out[p], hipEventDisableTiming));
         if (!s->ev_copied[p]) SCHK(h, hipEventCreateWithFlags(&s->ev_copied[p], hipEventDisableTiming));
         if (!s->ev_front[p]) SCHK(h, hipEventCreateWithFlags(&s->ev_front[p], hipEventDisableTiming));
         if (!s->ev_back[p]) SCHK(h, hipEventCreateWithFlags(&s->ev_back[p], hipEventDisableTiming));
@@ -516,7 +519,7 @@ static int process_signal_t(apv_handle* h, int n_hops, const TI* h_in_A, const T
     const int H = s->H, K = s->K, chunk = s->sig_chunk;
     const size_t e1 = s->esz, nout = (size_t)s->n_out * H;
     hipStream_t back = h->stream;
-    auto drain = [&]() { (void)hipStreamSynchronize(s->front); (void)hipStreamSynchronize(back); (void)hipStreamSynchronize(s->copy); };
+    auto drain = [&]() { (void)hipStreamSynchronize(s->front); (void)hipStreamSynchronize(back); (void)hipStreamSynchronize(s->tail); };
     int set = 0, last_set = 0;
     bool released[2] = {true, true};                         // nothing reads either set yet
     bool out_idle[2] = {true, true};                         // no copy of either result buffer pending
@@ -567,21 +570,20 @@ static int process_signal_t(apv_handle* h, int n_hops, const TI* h_in_A, const T
         for (int i = 0; i < nc; ++i) {
             const size_t slot = (size_t)(c & 1) * chunk + i;
             hipError_t e = hipSuccess;
-            if (!released[set]) e = hipStreamWaitEvent(s->front, s->ev_back[set], 0);      // hop h-2 is done with this set
-            if (e == hipSuccess) {
-                rc = enqueue_front(h, s->front, set, (const char*)s->sig_in + slot * 2 * H * e1);
+            {
+                // hop h-2 has to be done with this set before the analysis transforms write it
+                rc = enqueue_front(h, s->front, set, (const char*)s->sig_in + slot * 2 * H * e1, released[set] ? nullptr : s->ev_back[set]);
                 if (rc != APV_OK) { drain(); return rc; }
                 e = hipEventRecord(s->ev_front[set], s->front);
             }
             if (e == hipSuccess) e = hipStreamWaitEvent(back, s->ev_front[set], 0);
-            // the result buffer follows the set; hop h-2's copy of it has to be through before this hop's status words land there
+            // the output buffers follow the set; hop h-2's synthesis and copy have to be through before this hop writes them
             if (e == hipSuccess && !out_idle[set]) e = hipStreamWaitEvent(back, s->ev_copied[set], 0);
             if (e == hipSuccess) {
                 BackSchedule sch;
                 sch.obuf = set;
                 sch.spectra_free = s->ev_back[set];          // recorded after K3, the set's last reader
-                sch.copy_stream = s->copy;
-                sch.out_ready = s->ev_out[set];
+                sch.tail_stream = s->tail;
                 sch.copied = s->ev_copied[set];
                 rc = enqueue_back(h, back, set, (char*)s->sig_out + slot * hop_result_bytes(s), sch);
                 if (rc != APV_OK) { drain(); return rc; }
@@ -596,7 +598,7 @@ static int process_signal_t(apv_handle* h, int n_hops, const TI* h_in_A, const T
             set ^= 1;
             s->hop++;
         }
-        SCHK(h, hipEventRecord(s->ev_chunk[c & 1], s->copy));   // every front and back half is upstream of some copy
+        SCHK(h, hipEventRecord(s->ev_chunk[c & 1], s->tail));   // every front and back half is upstream of some copy
         if (c > 0) {
             if ((rc = collect(c - 1)) != APV_OK) { drain(); return rc; }
             c_done = c;
@@ -613,7 +615,7 @@ static int process_signal_t(apv_handle* h, int n_hops, const TI* h_in_A, const T
         SCHK(h, hipMemcpyAsync(s->inspec, s->inspec1, (size_t)2 * K * e2, hipMemcpyDeviceToDevice, back));
     }
     SCHK(h, hipStreamSynchronize(back));
-    SCHK(h, hipStreamSynchronize(s->copy));
+    SCHK(h, hipStreamSynchronize(s->tail));
     if (worst != APV_OK) return apv_fail(h, worst, worst_msg);
     return APV_OK;
 }

@@ -18,6 +18,8 @@ for dt in f64 mixed; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stream_$dt -- python3 $REPO/tools/bench_stream.py --hops 100 --dtype $dt > /dev/null 2>&1
   cp $OUT/prof_stream_$dt/*/*kernel_stats.csv $OUT/stream_kernel_stats_$dt.csv; rm -rf $OUT/prof_stream_$dt
 done
+bash $REPO/tools/signal_timeline.sh f64 > $OUT/signal_timeline_f64.md 2>&1; head -1 $OUT/signal_timeline_f64.md
+export TMPDIR=/tmp; cd /tmp
 # the broadband path under the profiler WITH its replayed hipGraphs (this crashed rocprofv3 in round 1; see profiles/r02/rocprof_graph.md)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_jl -- python3 $REPO/tools/probes/jdiag_large_probe.py 2 > $OUT/jdiag_large_graph.log 2>&1; echo "jdiag_large under rocprofv3, graphs on: rc=$?" >> $OUT/jdiag_large_graph.log
 cp $OUT/prof_jl/*/*kernel_stats.csv $OUT/gevd_large_kernel_stats.csv; rm -rf $OUT/prof_jl
