@@ -514,10 +514,11 @@ __device__ __forceinline__ void jacobi16_sweep0(Cx<TT>& tt_, Cx<TT>& tb_, Cx<TT>
 // the VALU (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror: after the first two every lane of a quad holds the quad's
 // sum, and the mirror pairs quad 0 with quad 1) instead of a DPP add and two round trips over the LDS crossbar: a Jacobi round
 // has one such round trip left (the column moves), where the serial chain of the round used to have three.
+// (update_dpp with a zero `old` and bound_ctrl is the form the DPP combiner folds into the add itself, v_add_f32_dpp.)
 __device__ __forceinline__ float colsum8(float v) {
-    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, false));
-    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, false));
-    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xf, 0xf, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));
     return v;
 }
 __device__ __forceinline__ void xchg_f(float& top, float& bot, bool bit, int peer) {
@@ -659,7 +660,17 @@ __device__ __forceinline__ int jacobi16_onesided(Cx<float>& g0t_, Cx<float>& g0b
             }
             // pivot beta = g_top^H g_bottom over the 16 rows
             const f2v part = pk_cmulc((f2v){g0t.x, g0t.y}, (f2v){g0b.x, g0b.y}) + pk_cmulc((f2v){g1t.x, g1t.y}, (f2v){g1b.x, g1b.y});
-            const float bx = colsum8(part.x), by = colsum8(part.y);
+            // The two components are reduced as two scalar chains, interleaved stage by stage: paired into v_pk_add_f32 by the
+            // vectoriser they need a v_mov_b32_dpp per component and stage plus the DPP wait states after every add; alone each
+            // stage is ONE v_add_f32_dpp, and the other chain's add fills one of the two wait states.  (update_dpp with a zero
+            // `old` and bound_ctrl is the form the DPP combiner folds into the add; the empty asm statements keep the
+            // vectoriser from pairing the chains and pin the order.)
+            float bx = part.x, by = part.y;
+#define APV_DPP_ADD(v, ctrl) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, true))
+            APV_DPP_ADD(bx, 0xB1); asm volatile("" : "+v"(bx)); APV_DPP_ADD(by, 0xB1); asm volatile("" : "+v"(by));
+            APV_DPP_ADD(bx, 0x4E); asm volatile("" : "+v"(bx)); APV_DPP_ADD(by, 0x4E); asm volatile("" : "+v"(by));
+            APV_DPP_ADD(bx, 0x141); asm volatile("" : "+v"(bx)); APV_DPP_ADD(by, 0x141);
+#undef APV_DPP_ADD
             const float b2 = bx * bx + by * by;
             off += b2;
             // rotation for [[nt, beta], [conj(beta), nb]]: with zeta = (nb - nt)/2 and D = |zeta| + sqrt(zeta^2 + |beta|^2),
