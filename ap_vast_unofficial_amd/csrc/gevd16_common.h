@@ -659,7 +659,11 @@ __device__ __forceinline__ int jacobi16_onesided(Cx<float>& g0t_, Cx<float>& g0b
                 nb = mv(nb);
             }
             // pivot beta = g_top^H g_bottom over the 16 rows
-            const f2v part = pk_cmulc((f2v){g0t.x, g0t.y}, (f2v){g0b.x, g0b.y}) + pk_cmulc((f2v){g1t.x, g1t.y}, (f2v){g1b.x, g1b.y});
+            // conj(t) b summed over the lane's two rows as A + (B.x, -B.y), A = sum t.x (b.x, b.y), B = sum t.y (b.y, b.x): one
+            // sign at the end (written per product the compiler builds a (t.y, -t.y) vector for each row, two extra instructions)
+            const f2v pa = __builtin_elementwise_fma((f2v){g1t.x, g1t.x}, (f2v){g1b.x, g1b.y}, (f2v){g0t.x, g0t.x} * (f2v){g0b.x, g0b.y});
+            const f2v pb = __builtin_elementwise_fma((f2v){g1t.y, g1t.y}, (f2v){g1b.y, g1b.x}, (f2v){g0t.y, g0t.y} * (f2v){g0b.y, g0b.x});
+            const f2v part = {pa.x + pb.x, pa.y - pb.y};
             // The two components are reduced as two scalar chains, interleaved stage by stage: paired into v_pk_add_f32 by the
             // vectoriser they need a v_mov_b32_dpp per component and stage plus the DPP wait states after every add; alone each
             // stage is ONE v_add_f32_dpp, and the other chain's add fills one of the two wait states.  (update_dpp with a zero
