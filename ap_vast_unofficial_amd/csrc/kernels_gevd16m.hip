@@ -98,6 +98,9 @@ __device__ __forceinline__ void cmm16x(FA fa, FB fb, int lane, Cx<double> out[4]
     for (int t = 0; t < 4; ++t) out[t] = mk<double>(re[t], im[t]);
 }
 
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
 // XT: element type of the fused input slabs (float2 = c64, double2 = c128: the float64 streaming front-end)
 template <typename T, bool FUSED, typename XT>
 __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
@@ -183,16 +186,17 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
         for (int t = 0; t < 4; ++t) {
             if (4 * t + 3 <= kk) continue;
             const C lj = scol[buf][jq + 4 * t];                  // B[i][j] -= B[i][kk] conj(B[j][kk]) / d
-            brow[t].x -= li2.x * lj.x + li2.y * lj.y;
-            brow[t].y -= li2.y * lj.x - li2.x * lj.y;
+            // each component as two chained FMAs (written a -= p q + r s it compiles to a product, an FMA and a subtraction)
+            brow[t].x = fma_t(-li2.y, lj.y, fma_t(-li2.x, lj.x, brow[t].x));
+            brow[t].y = fma_t(li2.x, lj.y, fma_t(-li2.y, lj.x, brow[t].y));
         }
         if (i > kk) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 if (4 * t > kk) continue;
                 const C wk = swr[buf][jq + 4 * t];               // W[i][j] -= (B[i][kk]/sqrt d) (W[kk][j]/sqrt d)
-                wrow[t].x -= li2.x * wk.x - li2.y * wk.y;
-                wrow[t].y -= li2.x * wk.y + li2.y * wk.x;
+                wrow[t].x = fma_t(li2.y, wk.y, fma_t(-li2.x, wk.x, wrow[t].x));
+                wrow[t].y = fma_t(-li2.y, wk.x, fma_t(-li2.x, wk.y, wrow[t].y));
             }
         } else if (i == kk) {
 #pragma unroll
