@@ -53,6 +53,10 @@ using f4 = __attribute__((ext_vector_type(4))) float;
 // stride LD); optional r = X^H d -> sr.  Lane l loads slab element 64 s + l: fully coalesced, and that one register is
 // both the A (X^H) and the B (X) operand of the 16x16x4 MFMA.
 template <typename T> struct Mfma16;
+// a b + c in one rounding, float or double (written a += p q + r s the compiler emits a product, an FMA and an addition)
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
 template <> struct Mfma16<double> {
     using V = d4;
     static __device__ __forceinline__ V mac(double a, double b, V c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
@@ -93,8 +97,8 @@ __device__ __forceinline__ void correlate16(const XT* __restrict__ X, const XT* 
             re = MM::mac(xi, xi, re);
             im = MM::mac(xr, xi, im);                            // P = sum xr (x) xi; Im R = P - P^T, formed below
             if (dvec != nullptr) {
-                rx += xr * (T)dv[q].x + xi * (T)dv[q].y;        // conj(x) * d
-                ry += xr * (T)dv[q].y - xi * (T)dv[q].x;
+                rx = fma_t(xi, (T)dv[q].y, fma_t(xr, (T)dv[q].x, rx));        // conj(x) * d, as chained FMAs
+                ry = fma_t(-xi, (T)dv[q].x, fma_t(xr, (T)dv[q].y, ry));
             }
         }
     }

@@ -98,9 +98,6 @@ __device__ __forceinline__ void cmm16x(FA fa, FB fb, int lane, Cx<double> out[4]
     for (int t = 0; t < 4; ++t) out[t] = mk<double>(re[t], im[t]);
 }
 
-__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
-
 // XT: element type of the fused input slabs (float2 = c64, double2 = c128: the float64 streaming front-end)
 template <typename T, bool FUSED, typename XT>
 __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
@@ -351,9 +348,25 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
                 // eigenvalue terms into the idle coefficient array: nothing of this step stays in registers
                 T* const sLam2 = reinterpret_cast<T*>(&scoef[0]);
                 for (int step = 0; step < 2; ++step) {
+                    {
+                        // Rayleigh quotients S_jj / Gram_jj of the sixteen lanes that hold a diagonal element: the element is
+                        // selected first and divided once, by reciprocal, Newton step and one residual correction (a double
+                        // division per accumulator row under its own branch was ~150 instructions of this step)
+                        T num = (T)0, gd = (T)1;
+                        bool has_diag = false;
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        if (mfma_row<T>(lane, t) == mcol) sLam[mcol] = accC[t].x / accG[t].x;
+                        for (int t = 0; t < 4; ++t) {
+                            const bool d = mfma_row<T>(lane, t) == mcol;
+                            num = d ? accC[t].x : num;
+                            gd = d ? accG[t].x : gd;
+                            has_diag = has_diag || d;
+                        }
+                        T ginv = __builtin_amdgcn_rcp(gd);
+                        ginv = ginv * __builtin_fma(-gd, ginv, (T)2);
+                        T quot = num * ginv;
+                        quot = __builtin_fma(__builtin_fma(-gd, quot, num), ginv, quot);
+                        if (has_diag) sLam[mcol] = quot;
+                    }
                     wsync();
                     bool bad = false, hopeless = false;
 #pragma unroll
@@ -571,8 +584,8 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
             for (int ll = 0; ll < 4; ++ll) {
                 const int l = 4 * q4 + ll;
                 const C v = sA[l * LD + i16], rr = sr[l];
-                sx += v.x * rr.x + v.y * rr.y;
-                sy += v.x * rr.y - v.y * rr.x;
+                sx = fma_t(v.y, rr.y, fma_t(v.x, rr.x, sx));
+                sy = fma_t(-v.y, rr.x, fma_t(v.x, rr.y, sy));
             }
             sx += __shfl_xor(sx, 16, 64); sy += __shfl_xor(sy, 16, 64);
             sx += __shfl_xor(sx, 32, 64); sy += __shfl_xor(sy, 32, 64);
@@ -594,8 +607,8 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
                 for (; done < V; ++done) {
                     const int c = sOrder[done];
                     const C cf = scoef[c], v = sA[lane * LD + c];
-                    ax += cf.x * v.x - cf.y * v.y;
-                    ay += cf.x * v.y + cf.y * v.x;
+                    ax = fma_t(-cf.y, v.y, fma_t(cf.x, v.x, ax));
+                    ay = fma_t(cf.y, v.x, fma_t(cf.x, v.y, ay));
                 }
             }
             const size_t o = ((size_t)k * p.nV + t) * N + lane;

@@ -245,8 +245,8 @@ __device__ __forceinline__ int front64(const GevdParams& p, const Sh& sh, bool z
                 for (int j = kk + 1 + tx; j <= i; j += 32) {
                     const C128 lj = RB[j * LDD + kk];
                     C128 v = RB[i * LDD + j];
-                    v.x -= li.x * lj.x + li.y * lj.y;            // l_i conj(l_j)
-                    v.y -= li.y * lj.x - li.x * lj.y;
+                    v.x = fma_t(-li.y, lj.y, fma_t(-li.x, lj.x, v.x));            // -= l_i conj(l_j), as chained FMAs
+                    v.y = fma_t(li.x, lj.y, fma_t(-li.y, lj.x, v.y));
                     RB[i * LDD + j] = v;
                 }
             }
@@ -267,8 +267,8 @@ __device__ __forceinline__ int front64(const GevdParams& p, const Sh& sh, bool z
                 if (i < N64) {
                     for (int kk = j + 1 + sub; kk <= i; kk += 16) {
                         const C128 w = RB[i * LDD + kk], l = RB[kk * LDD + j];
-                        sx += w.x * l.x - w.y * l.y;
-                        sy += w.x * l.y + w.y * l.x;
+                        sx = fma_t(-w.y, l.y, fma_t(w.x, l.x, sx));
+                        sy = fma_t(w.y, l.x, fma_t(w.x, l.y, sy));
                     }
                 }
                 sx += xcol<1>(sx); sy += xcol<1>(sy);
