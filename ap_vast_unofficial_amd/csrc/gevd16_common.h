@@ -33,6 +33,16 @@ __device__ __forceinline__ double rsq_full(double x) {
     // v_rsq_f64 is good to 5e-8 on gfx950 (measured); one third-order step brings it to 1.4e-16
     return __builtin_fma(ye, pp, y);
 }
+// 1 / x to full precision without the division sequence: v_rcp (5e-8 in double here) and two Newton steps
+__device__ __forceinline__ double rcp_full(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    y = y * __builtin_fma(-x, y, 2.0);
+    return y * __builtin_fma(-x, y, 2.0);
+}
+__device__ __forceinline__ float rcp_full(float x) {
+    const float y = __builtin_amdgcn_rcpf(x);
+    return y * __builtin_fmaf(-x, y, 2.0f);
+}
 __device__ __forceinline__ float rsq_full(float x) {
     float y = __builtin_amdgcn_rsqf(x);
     const float t = x * y;

@@ -590,7 +590,7 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
             sx += __shfl_xor(sx, 16, 64); sy += __shfl_xor(sy, 16, 64);
             sx += __shfl_xor(sx, 32, 64); sy += __shfl_xor(sy, 32, 64);
             if (q4 == 0) {
-                const T den = (T)1 / (sLam[i16] + (T)p.mu);
+                const T den = rcp_full(sLam[i16] + (T)p.mu);
                 scoef[i16] = mk<T>(sx * den, sy * den);
             }
         }
