@@ -139,6 +139,8 @@ hipError_t apv_launch_synthesis(int f64, int N, int H, int n_ch, const void* spe
 int apv_fir_fft_size(int f64, int P, int H);       // segment length F, 0 = use the direct form
 hipError_t apv_launch_fir_spectra(int f64, int F, int n_ch, const void* x, int P, void* Hf, hipStream_t s, std::string* why);
 hipError_t apv_launch_fir_input_spectra(int f64, int F, const void* x0, const void* x1, int in_len, void* Xf, hipStream_t s);
+hipError_t apv_launch_fir_chunk_spectra(int f64, int F, int P, int H, int n_hops, const void* hist0, const void* hist1,
+                                        const void* pin, void* Xf, hipStream_t s);
 hipError_t apv_launch_fir_fft_jobs(int f64, int F, int n_jobs, const void* const* Hf, const void* const* Xf, void* const* resp,
                                    const int* n_ch, int P, int H, int N, int ring_off, hipStream_t s);
 

@@ -228,6 +228,10 @@ __device__ __forceinline__ C2<T>* fft_forward(const FftPlan& plan, C2<T>* a, C2<
 }
 
 template <typename T>
+__device__ __forceinline__ void rfft_from_lds(const FftPlan& plan, C2<T>* za, C2<T>* zb, C2<T>* __restrict__ out, long stride_k,
+                                              const C2<T>* __restrict__ tw);
+
+template <typename T>
 __device__ __forceinline__ void stft_analysis_body(const FftPlan& plan, const T* __restrict__ xin, int in_len, int ring_off,
                                                    int use_win, C2<T>* __restrict__ out, long stride_k,
                                                    const C2<T>* __restrict__ tw, const T* __restrict__ win) {
@@ -248,6 +252,14 @@ __device__ __forceinline__ void stft_analysis_body(const FftPlan& plan, const T*
         za[n] = c2<T>(v0, v1);
     }
     __syncthreads();
+    rfft_from_lds<T>(plan, za, zb, out, stride_k, tw);
+}
+
+// the real series x[2n], x[2n+1] sits in za[n] (and the workgroup has met): spectrum to out[k * stride_k], k <= N/2
+template <typename T>
+__device__ __forceinline__ void rfft_from_lds(const FftPlan& plan, C2<T>* za, C2<T>* zb, C2<T>* __restrict__ out, long stride_k,
+                                              const C2<T>* __restrict__ tw) {
+    const int Nh = plan.Nh, tid = threadIdx.x;
     const C2<T>* z = fft_forward<T>(plan, za, zb, tw);
     // even/odd split: X[k] = E[k] + e^{-2 pi i k/N} O[k]
     for (int k = tid; k <= Nh; k += STFT_TPB) {
@@ -372,6 +384,32 @@ __global__ void __launch_bounds__(STFT_TPB) fir_input_spectra_kernel(FftPlan pla
                                                                      const T* __restrict__ x1, int in_len,
                                                                      C2<T>* __restrict__ spec, const C2<T>* __restrict__ tw) {
     stft_analysis_body<T>(plan, blockIdx.x ? x1 : x0, in_len, 0, 0, spec + (size_t)blockIdx.x * (plan.Nh + 1), 1, tw, nullptr);
+}
+
+// The same spectra for a whole chunk of hops in one launch (blockIdx.x = signal, blockIdx.y = hop of the chunk), before any
+// of them has been through the input update: the history of hop i is samples i H ... i H + P - 1 + H of the stream
+// [last P - 1 samples of the history at the start of the chunk | hop 0 | hop 1 | ...], the hops read from the pinned
+// host staging `pin` [hops][2][H].  Values and arithmetic are those of fir_input_spectra_kernel: the spectra are the same
+// bit for bit; what changes is that no hop of the whole-signal path waits for a two-workgroup launch of its own.
+template <typename T>
+__global__ void __launch_bounds__(STFT_TPB) fir_chunk_spectra_kernel(FftPlan plan, int P, int H, const T* __restrict__ hist0,
+                                                                     const T* __restrict__ hist1, const T* __restrict__ pin,
+                                                                     C2<T>* __restrict__ spec, const C2<T>* __restrict__ tw) {
+    extern __shared__ unsigned char smem_raw[];
+    C2<T>* za = reinterpret_cast<C2<T>*>(smem_raw);
+    C2<T>* zb = za + plan.Nh;
+    const int g = blockIdx.x, hop = blockIdx.y, keep = P - 1, len = keep + H;
+    const T* __restrict__ hist = g ? hist1 : hist0;                 // [P - 1 + H]: its last P - 1 samples precede the chunk
+    auto sample = [&](int n) -> T {                                   // n-th sample of this hop's history
+        if (n >= len) return (T)0;
+        const int m = hop * H + n;                                    // position in the stream described above
+        if (m < keep) return hist[H + m];
+        const int q = (m - keep) / H, t = (m - keep) - q * H;
+        return pin[((size_t)q * 2 + g) * H + t];
+    };
+    for (int n = threadIdx.x; n < plan.Nh; n += STFT_TPB) za[n] = c2<T>(sample(2 * n), sample(2 * n + 1));
+    __syncthreads();
+    rfft_from_lds<T>(plan, za, zb, spec + ((size_t)hop * 2 + g) * (plan.Nh + 1), 1, tw);
 }
 
 template <typename T>
@@ -596,6 +634,19 @@ hipError_t launch_fir_input_spectra(int F, const void* x0, const void* x1, int i
 }
 
 template <typename T>
+hipError_t launch_fir_chunk_spectra(int F, int P, int H, int n_hops, const void* hist0, const void* hist1, const void* pin, void* Xf,
+                                    hipStream_t s) {
+    FftPlan plan;
+    if (!make_plan(F, &plan, nullptr) || P - 1 + H > F || n_hops < 1) return hipErrorInvalidValue;
+    Tables<T> t;
+    hipError_t e = get_tables<T>(F, &t);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(fir_chunk_spectra_kernel<T>, dim3(2, n_hops), dim3(STFT_TPB), plan_lds<T>(plan), s, plan, P, H, (const T*)hist0,
+                       (const T*)hist1, (const T*)pin, (C2<T>*)Xf, t.tw);
+    return hipGetLastError();
+}
+
+template <typename T>
 hipError_t launch_fir_fft_jobs(int F, int n_jobs, const void* const* Hf, const void* const* Xf, void* const* resp, const int* n_ch,
                                int P, int H, int N, int ring_off, hipStream_t s) {
     FftPlan plan;
@@ -625,6 +676,14 @@ hipError_t launch_fir_fft_jobs(int F, int n_jobs, const void* const* Hf, const v
 // Xf [2][F/2 + 1] = spectra of the two input histories x0, x1 (in_len = P - 1 + H samples each, zero-padded to F)
 hipError_t apv_launch_fir_input_spectra(int f64, int F, const void* x0, const void* x1, int in_len, void* Xf, hipStream_t s) {
     return f64 ? launch_fir_input_spectra<double>(F, x0, x1, in_len, Xf, s) : launch_fir_input_spectra<float>(F, x0, x1, in_len, Xf, s);
+}
+
+// Xf [n_hops][2][F/2 + 1] for the hops of a staged chunk (pin [n_hops][2][H], host-pinned), from the histories as they are
+// BEFORE the first of them is processed
+hipError_t apv_launch_fir_chunk_spectra(int f64, int F, int P, int H, int n_hops, const void* hist0, const void* hist1,
+                                        const void* pin, void* Xf, hipStream_t s) {
+    return f64 ? launch_fir_chunk_spectra<double>(F, P, H, n_hops, hist0, hist1, pin, Xf, s)
+               : launch_fir_chunk_spectra<float>(F, P, H, n_hops, hist0, hist1, pin, Xf, s);
 }
 
 hipError_t apv_launch_fir_fft_jobs(int f64, int F, int n_jobs, const void* const* Hf, const void* const* Xf, void* const* resp,

@@ -75,6 +75,7 @@ struct apv_stream {
     void* rirspec[2];             // [C][fir_F/2 + 1] complex, zone A, zone B
     void* trirspec[2];            // [M][fir_F/2 + 1]
     void* xspec;                  // [2][fir_F/2 + 1]
+    void* xspec_chunk;            // [sig_chunk][2][fir_F/2 + 1]: whole-signal path, the spectra of a staged chunk in one launch
     long hop;                     // hops processed
     long not_converged;           // hops in which some bin hit the sweep cap (status 2)
     std::vector<hipGraphExec_t> execs;
@@ -140,7 +141,7 @@ void apv_stream_free(apv_handle* h) {
                     s->xhist[1][1], s->resp[0], s->resp[1], s->resp[2], s->resp[3], s->tresp[0], s->tresp[1],
                     s->inblk, s->X[0], s->X[1], s->X[2], s->X[3], s->tspec[0], s->tspec[1], s->inspec, s->w[0],
                     s->w[1], s->lam[0], s->lam[1], s->tgt, s->outspec, s->outov, s->out,
-                    s->G2, s->G2T, s->Wgt[0], s->Wgt[1], s->rirspec[0], s->rirspec[1], s->trirspec[0], s->trirspec[1], s->xspec};
+                    s->G2, s->G2T, s->Wgt[0], s->Wgt[1], s->rirspec[0], s->rirspec[1], s->trirspec[0], s->trirspec[1], s->xspec, s->xspec_chunk};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (hipGraphExec_t e : s->execs)
@@ -184,8 +185,10 @@ static HopSpectra hop_spectra(const apv_stream* s, int set) {
 // Front half of a hop on stream `st`: pinned hop `pin_src` [2][H] -> input histories, response rings (K1), analysis
 // spectra of set `set` (K2, perceptual weighting).  Advances (ring_off, cur) on the host.  Pure enqueue: also used
 // under stream capture.
-// `set_free` (whole-signal path): event to wait for before the first kernel that writes the spectra set.
-static int enqueue_front(apv_handle* h, hipStream_t st, int set, const void* pin_src, hipEvent_t set_free = nullptr) {
+// `set_free` (whole-signal path): event to wait for before the first kernel that writes the spectra set; `xspec_ready`: the
+// spectra of this hop's input histories, already formed by apv_launch_fir_chunk_spectra.
+static int enqueue_front(apv_handle* h, hipStream_t st, int set, const void* pin_src, hipEvent_t set_free = nullptr,
+                         const void* xspec_ready = nullptr) {
     apv_stream* s = h->st;
     const HopSpectra q = hop_spectra(s, set);
     const int N = s->N, H = s->H, K = s->K, L = s->L, M = s->M, C = s->C, P = s->P, f64 = s->f64;
@@ -205,16 +208,18 @@ static int enqueue_front(apv_handle* h, hipStream_t st, int set, const void* pin
     // K1: RIR convolution into the response rings (one MFMA launch for all six filter banks)
     if (s->fir_F > 0) {
         const size_t spec_bytes = ((size_t)s->fir_F / 2 + 1) * 2 * s->esz;
-        SCHK(h, apv_launch_fir_input_spectra(f64, s->fir_F, s->xhist[s->cur][0], s->xhist[s->cur][1], P - 1 + H, s->xspec, st));
+        const void* const xs = xspec_ready ? xspec_ready : s->xspec;
+        if (!xspec_ready)
+            SCHK(h, apv_launch_fir_input_spectra(f64, s->fir_F, s->xhist[s->cur][0], s->xhist[s->cur][1], P - 1 + H, s->xspec, st));
         const void *jh[6], *jx[6];
         void* jr[6];
         int jc[6];
         for (int p = 0; p < 4; ++p) {
-            jh[p] = s->rirspec[path_zone(p)]; jx[p] = (const char*)s->xspec + spec_bytes * path_sig(p);
+            jh[p] = s->rirspec[path_zone(p)]; jx[p] = (const char*)xs + spec_bytes * path_sig(p);
             jr[p] = s->resp[p]; jc[p] = C;
         }
         for (int z = 0; z < 2; ++z) {
-            jh[4 + z] = s->trirspec[z]; jx[4 + z] = (const char*)s->xspec + spec_bytes * z;
+            jh[4 + z] = s->trirspec[z]; jx[4 + z] = (const char*)xs + spec_bytes * z;
             jr[4 + z] = s->tresp[z]; jc[4 + z] = M;
         }
         SCHK(h, apv_launch_fir_fft_jobs(f64, s->fir_F, 6, jh, jx, jr, jc, P, H, N, s->ring_off, st));
@@ -482,6 +487,7 @@ static int signal_prepare(apv_handle* h) {
     if (!s->inspec1 && (rc = dalloc(h, &s->inspec1, 2 * K, e2))) return rc;
     if (!s->out1 && (rc = dalloc(h, &s->out1, hop_result_bytes(s), 1))) return rc;
     if (!s->outspec1 && (rc = dalloc(h, &s->outspec1, (size_t)s->n_out * K, e2))) return rc;
+    if (s->fir_F > 0 && !s->xspec_chunk && (rc = dalloc(h, &s->xspec_chunk, (size_t)chunk * 2 * (s->fir_F / 2 + 1), e2))) return rc;
     if (!s->front) SCHK(h, hipStreamCreateWithFlags(&s->front, hipStreamNonBlocking));
     if (!s->tail) SCHK(h, hipStreamCreateWithFlags(&s->tail, hipStreamNonBlocking));
     for (int p = 0; p < 2; ++p) {
@@ -567,12 +573,22 @@ static int process_signal_t(apv_handle* h, int n_hops, const TI* h_in_A, const T
     for (int c = 0; c < n_chunks && worst != APV_ERR_NOT_PD; ++c) {
         const int base = c * chunk, nc = std::min(chunk, n_hops - base);
         stage_in(c);                                         // this half was collected when chunk c-2's event came in
+        const size_t xs_bytes = s->fir_F > 0 ? ((size_t)s->fir_F / 2 + 1) * 2 * e1 * 2 : 0;      // one hop's two spectra
+        if (s->fir_F > 0) {
+            // the input spectra K1 starts from, for every hop of the chunk at once: they depend on the staged samples and on
+            // the histories as the previous chunk left them, on nothing of this chunk's processing
+            hipError_t e = apv_launch_fir_chunk_spectra(s->f64, s->fir_F, s->P, H, nc, s->xhist[s->cur][0], s->xhist[s->cur][1],
+                                                        (const char*)s->sig_in + (size_t)(c & 1) * chunk * 2 * H * e1, s->xspec_chunk,
+                                                        s->front);
+            if (e != hipSuccess) { drain(); return apv_fail(h, APV_ERR_HIP, std::string("apv_process_signal: ") + hipGetErrorString(e)); }
+        }
         for (int i = 0; i < nc; ++i) {
             const size_t slot = (size_t)(c & 1) * chunk + i;
             hipError_t e = hipSuccess;
             {
                 // hop h-2 has to be done with this set before the analysis transforms write it
-                rc = enqueue_front(h, s->front, set, (const char*)s->sig_in + slot * 2 * H * e1, released[set] ? nullptr : s->ev_back[set]);
+                rc = enqueue_front(h, s->front, set, (const char*)s->sig_in + slot * 2 * H * e1, released[set] ? nullptr : s->ev_back[set],
+                                   s->fir_F > 0 ? (const char*)s->xspec_chunk + (size_t)i * xs_bytes : nullptr);
                 if (rc != APV_OK) { drain(); return rc; }
                 e = hipEventRecord(s->ev_front[set], s->front);
             }
