@@ -141,8 +141,16 @@ hipError_t apv_launch_fir_spectra(int f64, int F, int n_ch, const void* x, int P
 hipError_t apv_launch_fir_input_spectra(int f64, int F, const void* x0, const void* x1, int in_len, void* Xf, hipStream_t s);
 hipError_t apv_launch_fir_chunk_spectra(int f64, int F, int P, int H, int n_hops, const void* hist0, const void* hist1,
                                         const void* pin, void* Xf, hipStream_t s);
+// upd != nullptr: the launch also carries the hop's input update (what apv_launch_input_update does), see FirFftJobs
+struct ApvInputUpdate {
+    const void* old_hist[2];
+    void* new_hist[2];
+    const void* xin;      // pinned host [2][H]
+    void* inblk;          // [2][N] rings
+    int pad;
+};
 hipError_t apv_launch_fir_fft_jobs(int f64, int F, int n_jobs, const void* const* Hf, const void* const* Xf, void* const* resp,
-                                   const int* n_ch, int P, int H, int N, int ring_off, hipStream_t s);
+                                   const int* n_ch, int P, int H, int N, int ring_off, const ApvInputUpdate* upd, hipStream_t s);
 
 // kernels_stream.hip
 // y = FIR(rir, x) for one hop, appended to the ring response buffers:

@@ -377,6 +377,14 @@ struct FirFftJobs {
     T* resp[FIR_FFT_JOBS];            // [C_j][N] ring
     int ch0[FIR_FFT_JOBS + 1];        // first workgroup of each job
     int n;
+    // optional passenger (whole-signal path, where the hop's input spectra exist before its input update): the input
+    // update of the hop -- new histories [old[H:], hop, zeros(pad)], hop appended to the input-block rings -- done by
+    // upd_wgs extra workgroups per signal at the end of the grid instead of a launch of its own in front of this one
+    int upd_wgs, pad;
+    const T* old_hist[2];
+    T* new_hist[2];
+    const T* xin;                     // pinned host [2][H]
+    T* inblk;                         // [2][N] rings
 };
 
 template <typename T>
@@ -421,6 +429,16 @@ __global__ void __launch_bounds__(STFT_TPB) fir_fft_kernel(FftPlan plan, FirFftJ
     const int Fh = plan.Nh;
     Z* zb = za + Fh;
     const int wg = blockIdx.x, tid = threadIdx.x;
+    if (wg >= jobs.ch0[jobs.n]) {                                   // the passenger: same work as input_update_kernel
+        const int u = wg - jobs.ch0[jobs.n], g = u / jobs.upd_wgs, i = (u - g * jobs.upd_wgs) * STFT_TPB + tid;
+        const T* x = jobs.xin + (size_t)g * H;
+        const int keep = P - 1;
+        if (i < keep) jobs.new_hist[g][i] = jobs.old_hist[g][i + H];
+        else if (i < keep + H) jobs.new_hist[g][i] = x[i - keep];
+        else if (i < keep + H + jobs.pad) jobs.new_hist[g][i] = (T)0;
+        if (i < H) jobs.inblk[(size_t)g * N + (N - H + i + ring_off) % N] = x[i];
+        return;
+    }
     int j = 0;
     while (j + 1 < jobs.n && wg >= jobs.ch0[j + 1]) ++j;
     const int c = wg - jobs.ch0[j];
@@ -648,7 +666,7 @@ hipError_t launch_fir_chunk_spectra(int F, int P, int H, int n_hops, const void*
 
 template <typename T>
 hipError_t launch_fir_fft_jobs(int F, int n_jobs, const void* const* Hf, const void* const* Xf, void* const* resp, const int* n_ch,
-                               int P, int H, int N, int ring_off, hipStream_t s) {
+                               int P, int H, int N, int ring_off, const ApvInputUpdate* upd, hipStream_t s) {
     FftPlan plan;
     if (!make_plan(F, &plan, nullptr) || n_jobs < 1 || n_jobs > FIR_FFT_JOBS || P - 1 + H > F) return hipErrorInvalidValue;
     Tables<T> t;
@@ -668,6 +686,17 @@ hipError_t launch_fir_fft_jobs(int F, int n_jobs, const void* const* Hf, const v
     if (total <= 0) return hipSuccess;
     int off = ring_off % N;
     if (off < 0) off += N;
+    if (upd) {
+        jobs.upd_wgs = (P - 1 + H + upd->pad + STFT_TPB - 1) / STFT_TPB;
+        jobs.pad = upd->pad;
+        for (int g = 0; g < 2; ++g) {
+            jobs.old_hist[g] = (const T*)upd->old_hist[g];
+            jobs.new_hist[g] = (T*)upd->new_hist[g];
+        }
+        jobs.xin = (const T*)upd->xin;
+        jobs.inblk = (T*)upd->inblk;
+        total += 2 * jobs.upd_wgs;
+    }
     hipLaunchKernelGGL(fir_fft_kernel<T>, dim3(total), dim3(STFT_TPB), plan_lds<T>(plan), s, plan, jobs, P, H, N, off, t.tw);
     return hipGetLastError();
 }
@@ -687,7 +716,7 @@ hipError_t apv_launch_fir_chunk_spectra(int f64, int F, int P, int H, int n_hops
 }
 
 hipError_t apv_launch_fir_fft_jobs(int f64, int F, int n_jobs, const void* const* Hf, const void* const* Xf, void* const* resp,
-                                   const int* n_ch, int P, int H, int N, int ring_off, hipStream_t s) {
-    return f64 ? launch_fir_fft_jobs<double>(F, n_jobs, Hf, Xf, resp, n_ch, P, H, N, ring_off, s)
-               : launch_fir_fft_jobs<float>(F, n_jobs, Hf, Xf, resp, n_ch, P, H, N, ring_off, s);
+                                   const int* n_ch, int P, int H, int N, int ring_off, const ApvInputUpdate* upd, hipStream_t s) {
+    return f64 ? launch_fir_fft_jobs<double>(F, n_jobs, Hf, Xf, resp, n_ch, P, H, N, ring_off, upd, s)
+               : launch_fir_fft_jobs<float>(F, n_jobs, Hf, Xf, resp, n_ch, P, H, N, ring_off, upd, s);
 }

@@ -199,11 +199,11 @@ static int enqueue_front(apv_handle* h, hipStream_t st, int set, const void* pin
     const int nxt = s->cur ^ 1;
     // all rings advance by one hop: logical sample n now lives H further on
     s->ring_off = (s->ring_off + H) % N;
-    {
-        const void* oh[2] = {s->xhist[s->cur][0], s->xhist[s->cur][1]};
-        void* nh[2] = {s->xhist[nxt][0], s->xhist[nxt][1]};
-        SCHK(h, apv_launch_input_update(f64, P, H, s->pad, N, s->ring_off, oh, nh, pin_src, s->inblk, st));   // histories + input-block rings
-    }
+    const void* oh[2] = {s->xhist[s->cur][0], s->xhist[s->cur][1]};
+    void* nh[2] = {s->xhist[nxt][0], s->xhist[nxt][1]};
+    // with the hop's input spectra in hand (whole-signal path) K1 does not wait for the input update: it rides in K1's launch
+    const bool ride = xspec_ready != nullptr && s->fir_F > 0;
+    if (!ride) SCHK(h, apv_launch_input_update(f64, P, H, s->pad, N, s->ring_off, oh, nh, pin_src, s->inblk, st));   // histories + input-block rings
     s->cur = nxt;
     // K1: RIR convolution into the response rings (one MFMA launch for all six filter banks)
     if (s->fir_F > 0) {
@@ -222,7 +222,8 @@ static int enqueue_front(apv_handle* h, hipStream_t st, int set, const void* pin
             jh[4 + z] = s->trirspec[z]; jx[4 + z] = (const char*)xs + spec_bytes * z;
             jr[4 + z] = s->tresp[z]; jc[4 + z] = M;
         }
-        SCHK(h, apv_launch_fir_fft_jobs(f64, s->fir_F, 6, jh, jx, jr, jc, P, H, N, s->ring_off, st));
+        ApvInputUpdate upd{{oh[0], oh[1]}, {nh[0], nh[1]}, pin_src, s->inblk, s->pad};
+        SCHK(h, apv_launch_fir_fft_jobs(f64, s->fir_F, 6, jh, jx, jr, jc, P, H, N, s->ring_off, ride ? &upd : nullptr, st));
     } else if (f64) {
         FirJobsD jobs{};
         for (int p = 0; p < 4; ++p) {
