@@ -184,9 +184,9 @@ int  apv_process_block(apv_handle* h, const float* h_in_A, const float* h_in_B, 
 int  apv_process_block_f64(apv_handle* h, const double* h_in_A, const double* h_in_B, double* h_out);
 /* n_hops consecutive hops in one call: h_in_A / h_in_B hold n_hops * H samples, h_out is [n_hops][n_out][H] with the
  * channel order of apv_process_block.  Sample for sample the result is that of n_hops calls of apv_process_block (same
- * kernels, same operands, same order within a hop); the hops are pipelined: FIR + analysis of hop h+1 run on a second
- * stream beside the joint diagonalisation + synthesis of hop h, and the host stages / converts one chunk of 16 hops
- * while the device runs the next.  A hop with a bin that is not positive definite returns APV_ERR_NOT_PD once the
+ * kernels, same operands, same order within a hop); the hops are pipelined: RIR convolution + analysis of hop h+1 run on a second
+ * stream beside the joint diagonalisation of hop h, synthesis and copy back on a third, and the host stages / converts
+ * one chunk of 16 hops while the device runs the next.  A hop with a bin that is not positive definite returns APV_ERR_NOT_PD once the
  * chunks in flight (its own and at most one more) have run (the message names the hop; the stream's state is then that
  * after the last hop run); APV_ERR_NO_CONVERGE is returned after all hops, every output written.
  *                        replaces the hop loop around processInputBuffer, main.m:52-62 / make_python_test.m:44-51 */
