@@ -345,15 +345,17 @@ def _hop_loop(ap, x, h0, h1):
             for q in range(4)]
 
 
-@pytest.mark.parametrize("dtype,run_A,run_B,perceptual", [("f64", True, True, False), ("mixed", True, True, False),
-                                                          ("f32", True, False, False), ("f64", False, True, True)])
-def test_process_signal_equals_hop_loop(dtype, run_A, run_B, perceptual):
-    """process_signal pipelines consecutive hops on two streams over two sets of spectra; per hop the kernels and
+@pytest.mark.parametrize("dtype,run_A,run_B,perceptual,P", [("f64", True, True, False, 70), ("mixed", True, True, False, 70),
+                                                            ("f32", True, False, False, 70), ("f64", False, True, True, 70),
+                                                            ("f64", True, True, False, 20), ("f32", True, True, False, 20)])
+def test_process_signal_equals_hop_loop(dtype, run_A, run_B, perceptual, P):
+    """process_signal pipelines consecutive hops on three streams over two sets of spectra; per hop the kernels and
     their operands are those of process_input_buffers, so every sample, filter and state array must come out bit
     for bit: across chunk boundaries (16 hops per half of the pinned staging), ending on either set, and mixed with per-hop
-    calls before and after."""
+    calls before and after.  P = 70: K1 by fast convolution (input spectra per chunk, input update inside K1's launch on
+    the whole-signal path); P = 20: K1 in its direct form on the matrix cores."""
     from ap_vast_unofficial_amd.apvast import apvast
-    rirA, rirB = synth_rirs(70, 4, 8, 11)
+    rirA, rirB = synth_rirs(P, 4, 8, 11)
     N, H = 128, 64
     mk = lambda: apvast(N, rirA, rirB, 16, 5, 1, 2, 2, 1.0, 4 * N, hop_size=H, run_A=run_A, run_B=run_B, seed=3,
                         dtype=dtype, perceptual=perceptual, sampling_rate=16000)
