@@ -122,6 +122,7 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
     T* const sLam = reinterpret_cast<T*>(&scol[0][0]);                 // [N]
     int* const sOrder = reinterpret_cast<int*>(&scol[1][0]);           // [N]
     T (*const srot)[4] = reinterpret_cast<T(*)[4]>(&swr[0][0]);        // Jacobi: (c, s.x, s.y) of the eight rotations of a round
+    T* const sPiv = reinterpret_cast<T*>(&scoef[0]);                   // [N] stage 1: the pivots (scoef is idle until stage 6)
 
     const int lane = threadIdx.x;
     const int k = blockIdx.x;
@@ -172,12 +173,14 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
         wsync();
         const T dkk = scol[buf][kk].x;
         if (!(dkk > (T)0) || !(dkk < (T)3.0e38)) { status = 1; break; }         // uniform: same LDS word for all lanes
-        const T inv = rsq_full(dkk), inv2 = inv * inv;
+        // 1/d for the updates now; the 1/sqrt(d) that scales row kk of W is taken once, for all rows together, after the loop
+        const T inv2 = rcp_full(dkk);
+        if (lane == 0) sPiv[kk] = dkk;
         const C li = scol[buf][i];
         const C li2 = mk<T>(li.x * inv2, li.y * inv2);
         // The outer-product update of B runs on the whole Hermitian matrix, without the triangle tests: rows and columns
         // already eliminated only cancel to rounding level and are never read again, and the unconditional update costs less
-        // than its predicates.  W: rows past the pivot take the pivot row (zero beyond column kk), the pivot row is scaled.
+        // than its predicates.  W: rows past the pivot take the (unscaled) pivot row, which is zero beyond column kk.
         // What the unrolled loop knows at compile time is skipped: column groups of B entirely at or before the pivot
         // (4t + 3 <= kk) and groups of W entirely beyond it (4t > kk).
 #pragma unroll
@@ -192,17 +195,20 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 if (4 * t > kk) continue;
-                const C wk = swr[buf][jq + 4 * t];               // W[i][j] -= (B[i][kk]/sqrt d) (W[kk][j]/sqrt d)
+                const C wk = swr[buf][jq + 4 * t];               // W[i][j] -= (B[i][kk] / d) W[kk][j]
                 wrow[t].x = fma_t(li2.y, wk.y, fma_t(-li2.x, wk.x, wrow[t].x));
                 wrow[t].y = fma_t(-li2.y, wk.x, fma_t(-li2.x, wk.y, wrow[t].y));
             }
-        } else if (i == kk) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-                if (4 * t <= kk) wrow[t] = mk<T>(wrow[t].x * inv, wrow[t].y * inv);
         }
     }
     wsync();
+    if (status == 0) {
+        // W = D^-1/2 (unit lower factor)^-1: every row by the reciprocal root of its pivot, one rsq for the sixteen rows at once
+        // (inside the loop it was a serial rsq per step and a branch for the pivot row)
+        const T ri = rsq_full(sPiv[i]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) wrow[t] = mk<T>(wrow[t].x * ri, wrow[t].y * ri);
+    }
     if (p.debug_stop == 2) return;
 
     if (status == 0) {
