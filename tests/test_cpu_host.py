@@ -120,8 +120,10 @@ def _free_port():
 
 def _worker(rank, world, port, K, out_dir):
     sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
-    from ap_vast_unofficial_amd.sharding import allgather_filters_host, shard_bins
+    from ap_vast_unofficial_amd.sharding import shard_bins
+    from dist_helpers import allgather_filters_host        # test-only: the product gathers with RCCL
     from oracle import subband                      # stands in for the GPU kernel on a CPU-only box
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -165,7 +167,7 @@ def _rz_worker(rank, world, port, q):
     uid = rz.broadcast(bytes(range(128)) if rank == 0 else None)        # the shape of the RCCL id exchange
     rz.barrier()
     worst = rz.allreduce(1.0 + rank, max)
-    gathered = rz.gather(("rank", rank))
+    gathered = rz.gather(b"rank%d" % rank)
     rz.close()
     q.put((rank, uid, worst, gathered))
 
@@ -186,7 +188,62 @@ def test_rendezvous_without_torch(world):
         assert p.exitcode == 0
     for rank, uid, worst, gathered in res:
         assert uid == bytes(range(128)) and worst == float(world)
-        assert gathered == ([("rank", r) for r in range(world)] if rank == 0 else None)
+        assert gathered == ([b"rank%d" % r for r in range(world)] if rank == 0 else None)
+
+
+def _rz_hub(port, q):
+    sys.path.insert(0, ROOT)
+    from ap_vast_unofficial_amd.rendezvous import Rendezvous
+    rz = Rendezvous(0, 2, "127.0.0.1", port, timeout=30.0)
+    q.put(rz.gather(7))
+    rz.close()
+
+
+def test_rendezvous_rejects_strangers_and_never_unpickles():
+    """ADVICE r02: the hub accepts only a well-formed hello carrying this job's token and a fresh rank in 1..world-1;
+    whatever else connects is dropped, and no value on the wire is ever unpickled."""
+    import multiprocessing as mp
+    import pickle
+    import struct
+    import time
+    from ap_vast_unofficial_amd import rendezvous as R
+    assert "pickle" not in open(R.__file__).read().replace("unpickled", "")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    hub = ctx.Process(target=_rz_hub, args=(port, q))
+    hub.start()
+
+    def connect():
+        for _ in range(200):
+            try:
+                return socket.create_connection(("127.0.0.1", port), timeout=5.0)
+            except OSError:
+                time.sleep(0.05)
+        raise AssertionError("hub never listened")
+
+    token = R._job_token("127.0.0.1", port, 2)
+    bad = [pickle.dumps({"x": 1, "pad": b"p" * 32}),                                             # what the old protocol would have unpickled
+           R.MAGIC + b"\0" * 16 + struct.pack("<I", 1),                          # another job's token
+           R.MAGIC + token + struct.pack("<I", 0),                               # rank 0 is the hub itself
+           R.MAGIC + token + struct.pack("<I", 2)]                               # outside the world
+    for msg in bad:
+        s = connect()
+        s.sendall(msg)
+        s.settimeout(10.0)
+        try:
+            assert s.recv(1) == b""                                              # dropped without an answer
+        except (ConnectionError, socket.timeout):
+            pass
+        s.close()
+    rz = R.Rendezvous(1, 2, "127.0.0.1", port, timeout=30.0)                    # the real peer still gets in
+    rz.gather(35)
+    rz.close()
+    assert q.get(timeout=30) == [7, 35]
+    hub.join(30)
+    assert hub.exitcode == 0
+    with pytest.raises(TypeError):
+        R._send(None, {"a": 1})
 
 
 def test_bench_and_package_do_not_import_torch():
