@@ -56,6 +56,14 @@ class ApvError(RuntimeError):
         self.code = code
 
 
+class ConvergenceWarning(RuntimeWarning):
+    """A hop in which some bin's eigen-iteration stopped at its sweep cap (APV_ERR_NO_CONVERGE).  The C contract
+    (include/apvast_hip.h) returns that code AFTER every output has been written and the stream has advanced, so the streaming
+    entry points hand the outputs over and warn; ``Engine.stream_not_converged()`` counts such hops.  (The reference's
+    schur-based jdiag, apvast.py:30, has no such exit; only a non-positive-definite dark matrix raises there, apvast.py:21-24,
+    and here.)"""
+
+
 _lib = None
 
 
@@ -215,6 +223,19 @@ class Engine:
             # apvast.py:21,24 (cholesky); LAPACK's eigensolvers raise the same class when they do not converge
             raise np.linalg.LinAlgError(msg)
         raise ApvError(rc, msg)
+
+    def _chk_stream(self, rc):
+        """Status of a streaming entry point: APV_ERR_NO_CONVERGE is a warning (the outputs are complete and the stream state has
+        moved on: raising would lose both), everything else as _chk."""
+        if rc == ERR_NO_CONVERGE:
+            import warnings
+            warnings.warn(ConvergenceWarning(self.lib.apv_last_error(self.h).decode()), stacklevel=3)
+            return
+        self._chk(rc)
+
+    def stream_not_converged(self):
+        """Hops so far in which some bin reached the Jacobi sweep cap (subband stream)."""
+        return int(self.lib.apv_stream_not_converged(self.h))
 
     def close(self):
         if self.h is not None:
@@ -408,7 +429,7 @@ class Engine:
         in_B = np.ascontiguousarray(in_B, dtype=dt).ravel()
         out = np.empty((n_out, self.cfg.hop_size), dtype=dt)
         fn = self.lib.apv_process_block_f64 if self.frontend_f64 else self.lib.apv_process_block
-        self._chk(fn(self.h, _ptr(in_A), _ptr(in_B), _ptr(out)))
+        self._chk_stream(fn(self.h, _ptr(in_A), _ptr(in_B), _ptr(out)))
         return out
 
     def process_signal(self, in_A, in_B, n_out, out=None):
@@ -427,7 +448,7 @@ class Engine:
         elif out.shape != (n_hops, n_out, H) or out.dtype != dt or not out.flags.c_contiguous:
             raise ValueError("out must be a C-contiguous %s array of shape %r" % (np.dtype(dt).name, (n_hops, n_out, H)))
         fn = self.lib.apv_process_signal_f64 if self.frontend_f64 else self.lib.apv_process_signal
-        self._chk(fn(self.h, n_hops, _ptr(in_A), _ptr(in_B), _ptr(out)))
+        self._chk_stream(fn(self.h, n_hops, _ptr(in_A), _ptr(in_B), _ptr(out)))
         return out
 
     def stream_statistics(self, zone, want_U=True):
@@ -481,7 +502,7 @@ class Engine:
         in_A = np.ascontiguousarray(in_A, dtype=np.float64).ravel()
         in_B = np.ascontiguousarray(in_B, dtype=np.float64).ravel()
         out = np.empty((n_out, self.cfg.hop_size), dtype=np.float64)
-        self._chk(self.lib.apv_bb_process_block(self.h, _ptr(in_A), _ptr(in_B), _ptr(out)))
+        self._chk_stream(self.lib.apv_bb_process_block(self.h, _ptr(in_A), _ptr(in_B), _ptr(out)))
         return out
 
     def bb_get_state(self, name, shape):

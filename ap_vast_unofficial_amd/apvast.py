@@ -25,6 +25,10 @@ What is different (keyword-only, after ``perceptual``)
     golden outputs of the reference (tests/test_gpu_broadband.py).
   * outputs are fresh arrays (the reference returns views into its overlap buffers that the next
     call overwrites, apvast.py:500-504).
+  * the per-hop attributes (w_*, lambda_*, input_spectrum_*, filter_spectra_*, U_*, R_*, r_*) are fetched from the device
+    WHEN READ, not at the end of every hop: process_input_buffers moves nothing but the hop in and the drive signals out.
+    A hop whose eigen-iteration stops at its sweep cap still returns its outputs and warns (ConvergenceWarning;
+    ``not_converged`` counts such hops); a dark matrix that is not positive definite raises LinAlgError as in the reference.
   * ``perceptual=True``: the reference's Python class calls the third-party
     ``libdetectability`` (apvast.py:4, 77-83), which it does not vendor; here the weighting is the van de Par
     masking model carried by the reference's MATLAB twin (perceptualModel.m), evaluated per block on the
@@ -33,6 +37,7 @@ What is different (keyword-only, after ``perceptual``)
 import numpy as np
 
 from . import _capi
+from ._capi import ConvergenceWarning  # noqa: F401  (re-exported: what a capped eigen-iteration warns with)
 
 EXPERIMENTAL_NORMALIZE_GAINS = True     # apvast.py:6 (only used by the perceptual model)
 EXPERIMENTAL_REGULARIZATION = True      # apvast.py:7: True -> B + 1e-7 I, False -> B + 1e-8 ||B||_2 I
@@ -180,8 +185,7 @@ class apvast:
             resp = [1e-3 * rs.randn(N, L, M) for _ in range(4)]               # A->A, A->B, B->A, B->B
             tresp = [1e-3 * rs.randn(N, M) for _ in range(2)]
             self.set_state({"response": np.stack(resp), "target_response": np.stack(tresp)})
-        self.w_A = self.w_B = None
-        self.lambda_A = self.lambda_B = None
+        self._hops = 0                      # attributes of apvast.py:368-403 exist once a hop has run
         self._sb_cache = {}
 
     # ---- broadband mode: the reference's own time-domain algorithm, float64 on the device ----------
@@ -221,30 +225,43 @@ class apvast:
             resp = [1e-3 * rs.randn(N, L, M) for _ in range(4)]
             tresp = [1e-3 * rs.randn(N, M) for _ in range(2)]
             self.set_state({"response": np.stack(resp), "target_response": np.stack(tresp)})
-        self.w_A = self.w_B = None
-        self.lambda_A = self.lambda_B = None
+        self._hops = 0
         self._bb_cache = None
 
     def _refresh_broadband(self):
-        e, V, n = self._eng, len(self._ranks), self.filter_length * self.number_of_srcs
-        lam = e.bb_get_state("lambda", (2, n))
-        w = e.bb_get_state("w", (2, V, n))
-        r = e.bb_get_state("r", (2, n))
-        spec = e.bb_get_state("input_spectrum", (2, self._K, 2))
-        self.input_spectrum_A = (spec[0, :, 0] + 1j * spec[0, :, 1]).reshape(-1, 1)
-        self.input_spectrum_B = (spec[1, :, 0] + 1j * spec[1, :, 1]).reshape(-1, 1)
-        names = {"A": ("R_A_to_A", "R_A_to_B", 0, 2), "B": ("R_B_to_B", "R_B_to_A", 1, 3)}
-        for zi, (z, run) in enumerate((("A", self.run_A), ("B", self.run_B))):
-            if not run:
-                continue
-            setattr(self, "lambda_" + z, lam[zi].copy())                      # apvast.py:385-387
-            setattr(self, "w_" + z, w[zi][:, :, None].copy())                 # (V, n, 1), apvast.py:393, 398
-            setattr(self, "r_" + z, r[zi][:, None].copy())
-            setattr(self, names[z][0], e.bb_get_state(f"R{names[z][2]}", (n, n)))
-            setattr(self, names[z][1], e.bb_get_state(f"R{names[z][3]}", (n, n)))
-        # the large arrays are fetched when they are read (properties below): U_A / U_B (apvast.py:380-382) and the
-        # filter spectra (apvast.py:394-403, 417-422)
+        """A hop has run: what the attributes hold is stale.  Nothing is fetched here (see _bb_fetch)."""
+        self._hops += 1
         self._bb_cache = {}
+
+    def _bb_fetch(self, name):
+        """Broadband attributes of the last hop, fetched from the device when first read (apvast.py:368-403)."""
+        c = self._bb_cache
+        if c is None or self._hops == 0:
+            return None
+        if name in c:
+            return c[name]
+        e, V, n = self._eng, len(self._ranks), self.filter_length * self.number_of_srcs
+        zone = {"A": 0, "B": 1}.get(name[-1])
+        if zone is not None and not (self.run_A, self.run_B)[zone] and not name.startswith("input_spectrum"):
+            return None
+        if name.startswith("lambda_"):
+            v = e.bb_get_state("lambda", (2, n))[zone].copy()                 # apvast.py:385-387
+        elif name.startswith("w_"):
+            v = e.bb_get_state("w", (2, V, n))[zone][:, :, None].copy()       # (V, n, 1), apvast.py:393, 398
+        elif name.startswith("r_"):
+            v = e.bb_get_state("r", (2, n))[zone][:, None].copy()
+        elif name.startswith("input_spectrum_"):
+            spec = e.bb_get_state("input_spectrum", (2, self._K, 2))
+            v = (spec[zone, :, 0] + 1j * spec[zone, :, 1]).reshape(-1, 1)     # apvast.py:430-431
+        elif name.startswith("R_"):
+            path = {"R_A_to_A": 0, "R_A_to_B": 2, "R_B_to_B": 1, "R_B_to_A": 3}[name]
+            if not (self.run_A, self.run_B)[path & 1]:
+                return None
+            v = e.bb_get_state(f"R{path}", (n, n))
+        else:
+            raise AttributeError(name)
+        c[name] = v
+        return v
 
     # ---- per-hop call (apvast.py:153-165) -------------------------------------------------
     def process_input_buffers(self, input_A, input_B):
@@ -257,7 +274,9 @@ class apvast:
             res = self._split_outputs(out)
             self._refresh_broadband()
             return res
-        out = self._eng.process_block(input_A, input_B, self._n_out).astype(np.float64)
+        out = self._eng.process_block(input_A, input_B, self._n_out)
+        if out.dtype != np.float64:
+            out = out.astype(np.float64)
         res = self._split_outputs(out)
         self._refresh_attributes()
         return res
@@ -276,7 +295,9 @@ class apvast:
             raise NotImplementedError("process_signal: subband mode only (the broadband hop is one serial chain)")
         if input_A.size == 0:
             raise RuntimeError("invalid input size")
-        out = self._eng.process_signal(input_A, input_B, self._n_out).astype(np.float64)      # (n_hops, n_out, H)
+        out = self._eng.process_signal(input_A, input_B, self._n_out)                        # (n_hops, n_out, H)
+        if out.dtype != np.float64:
+            out = out.astype(np.float64)
         L, V, H = self.number_of_srcs, len(self._ranks), self.hop_size
         n = out.shape[0] * H
         pos, res = 0, []
@@ -312,19 +333,41 @@ class apvast:
         return tuple(res)
 
     def _refresh_attributes(self):
+        """A hop (or a whole signal) has run: drop what was fetched for the previous one.  Nothing crosses PCIe here: w_*,
+        lambda_*, input_spectrum_*, filter_spectra_* (and U_*, R_*, r_*) are fetched when they are read (_sb_fetch)."""
+        self._hops += 1
+        self._sb_cache = {}
+
+    def _sb_fetch(self, name):
+        """Subband attributes of the last hop (leading bin axis), fetched from the device when first read."""
+        if self._hops == 0:
+            return None
+        c = self._sb_cache
+        if name in c:
+            return c[name]
         e, K, L, V = self._eng, self._K, self.number_of_srcs, len(self._ranks)
-        self._sb_cache = {}                 # U_*, R_*, r_* of this hop are recomputed on demand (Engine.stream_statistics)
-        spec = e.get_state("input_spectrum", (2, K), e.sc_dtype)
-        self.input_spectrum_A = spec[0].astype(np.complex128).reshape(-1, 1)   # apvast.py:430-431
-        self.input_spectrum_B = spec[1].astype(np.complex128).reshape(-1, 1)
-        for z, run in (("A", self.run_A), ("B", self.run_B)):
-            if not run:
-                continue
+        z = name[-1]
+        if name.startswith("input_spectrum_"):
+            spec = e.get_state("input_spectrum", (2, K), e.sc_dtype)
+            c["input_spectrum_A"] = spec[0].astype(np.complex128).reshape(-1, 1)   # apvast.py:430-431
+            c["input_spectrum_B"] = spec[1].astype(np.complex128).reshape(-1, 1)
+            return c[name]
+        if not (self.run_A if z == "A" else self.run_B):
+            return None
+        if name.startswith("w_") or name.startswith("filter_spectra_"):
             w = e.get_state("w_" + z, (K, V, L), e.w_dtype).astype(np.complex128)
-            lam = e.get_state("lambda_" + z, (K, L), e.lam_dtype).astype(np.float64)
-            setattr(self, "w_" + z, np.ascontiguousarray(w.transpose(1, 0, 2)))           # (V, K, L)
-            setattr(self, "lambda_" + z, lam)
-            setattr(self, "filter_spectra_" + z, [getattr(self, "w_" + z)[i] for i in range(V)])   # V x (K, L)
+            c["w_" + z] = np.ascontiguousarray(w.transpose(1, 0, 2))               # (V, K, L)
+            c["filter_spectra_" + z] = [c["w_" + z][i] for i in range(V)]          # V x (K, L): the filters ARE the spectra
+        elif name.startswith("lambda_"):
+            c[name] = e.get_state(name, (K, L), e.lam_dtype).astype(np.float64)
+        else:
+            raise AttributeError(name)
+        return c[name]
+
+    @property
+    def not_converged(self):
+        """Hops so far in which some bin's eigen-iteration stopped at its sweep cap (each of them warned)."""
+        return self._eng.stream_not_converged()
 
     # ---- attributes the reference sets every hop, fetched from the device when read ------------------------
     def _bb_filter_spectra(self):
@@ -353,7 +396,7 @@ class apvast:
     def _zone_attr(self, z, what):
         """U / R_bright / R_dark / r of zone program z ('A' | 'B'); None for a zone that does not run."""
         zi = "AB".index(z)
-        if not (self.run_A, self.run_B)[zi] or self.lambda_A is None and self.lambda_B is None:
+        if not (self.run_A, self.run_B)[zi] or self._hops == 0:
             return None
         if self.mode == "broadband":
             n = self.filter_length * self.number_of_srcs
@@ -371,22 +414,28 @@ class apvast:
     U_A = property(lambda self: self._zone_attr("A", "U"))
     U_B = property(lambda self: self._zone_attr("B", "U"))
 
+    _LAZY = ("w_A", "w_B", "lambda_A", "lambda_B", "input_spectrum_A", "input_spectrum_B", "filter_spectra_A", "filter_spectra_B",
+             "R_A_to_A", "R_A_to_B", "R_B_to_B", "R_B_to_A", "r_A", "r_B")
+
     def __getattr__(self, name):
-        # attributes that exist only after the first hop and only in one of the modes; plain attribute access otherwise
+        # the attributes the reference assigns in every hop (apvast.py:368-403): read from the device on demand, cached until
+        # the next hop; plain attribute access for everything else
         d = self.__dict__
-        if name.startswith("filter_spectra_") and d.get("mode") == "broadband" and d.get("_bb_cache") is not None:
-            z = name[len("filter_spectra_"):]
-            fs = self._bb_filter_spectra()
-            if z in fs:
-                return fs[z]
-            if z in ("A", "B"):
-                raise AttributeError(name)                                        # that zone does not run (apvast.py:391-400)
-        sub = {"R_A_to_A": ("A", "RB"), "R_A_to_B": ("A", "RD"), "R_B_to_B": ("B", "RB"), "R_B_to_A": ("B", "RD"),
-               "r_A": ("A", "r"), "r_B": ("B", "r")}
-        if name in sub and d.get("mode") == "subband" and d.get("_sb_cache") is not None:
-            v = self._zone_attr(*sub[name])
-            if v is not None:
-                return v
+        if name in apvast._LAZY and "_eng" in d and "_hops" in d:
+            if d.get("mode") == "broadband":
+                if name.startswith("filter_spectra_"):
+                    if d["_hops"] == 0:
+                        return None
+                    fs = self._bb_filter_spectra()
+                    return fs.get(name[len("filter_spectra_"):])                  # None: that zone does not run (apvast.py:391-400)
+                return self._bb_fetch(name)
+            sub = {"R_A_to_A": ("A", "RB"), "R_A_to_B": ("A", "RD"), "R_B_to_B": ("B", "RB"), "R_B_to_A": ("B", "RD"),
+                   "r_A": ("A", "r"), "r_B": ("B", "r")}
+            if name in sub:
+                return self._zone_attr(*sub[name])
+            return self._sb_fetch(name)
+        if name in ("filter_spectra_A_t", "filter_spectra_B_t") and d.get("mode") == "broadband" and d.get("_hops", 0) > 0:
+            return self._bb_filter_spectra()[name[len("filter_spectra_"):]]
         raise AttributeError(f"{type(self).__name__!r} object has no attribute {name!r}")
 
     # ---- checkpoint / fixtures -----------------------------------------

@@ -80,13 +80,17 @@ struct apv_handle {
 
 void apv_stream_free(apv_handle* h);      // stream.hip
 void apv_bb_free(apv_handle* h);          // stream_bb.hip
+long apv_bb_not_converged(const apv_handle* h);   // stream_bb.hip: hops of the broadband stream that hit the sweep cap
 void apv_gevd_large_free(apv_handle* h);  // kernels_gevd_large.hip
 int apv_fail(apv_handle* h, int code, const std::string& msg);
 GevdParams apv_base_params(const apv_handle* h);
 
 // kernels_gevd.hip
 hipError_t apv_launch_gevd(const GevdParams& p, int compute_dtype, bool fused, hipStream_t s, std::string* why);
-size_t apv_gevd_spill_bytes(int n, int K, int compute_dtype);
+// HBM scratch the kernel that WILL run needs for K bins of order n (0 for most configurations): the order-64 kernel's slots when
+// it is eligible, the float64 LDS kernel's parked Cholesky factor at orders 33..64 otherwise.  zones: 1 or 2 zone programs.
+size_t apv_gevd_spill_bytes(int n, int K, int compute_dtype, int reg_mode, double reg_bright, double sweep_tol2, int zones);
+bool apv_gevd64_eligible(int n, int reg_mode, double reg_bright, double sweep_tol2);
 
 // kernels_gevd16m.hip: order-16 fast path (MFMA correlation / whitening / back-transform + register-resident
 // Jacobi); hipErrorNotSupported when the problem does not qualify

@@ -69,13 +69,36 @@ GevdParams apv_base_params(const apv_handle* h) {
 namespace {
 
 int ensure_spill(apv_handle* h, int n, int K) {
-    const size_t need = apv_gevd_spill_bytes(n, K, h->cfg.compute_dtype);
+    const apv_config& c = h->cfg;
+    const size_t need = apv_gevd_spill_bytes(n, K, c.compute_dtype, c.reg_mode, c.reg_bright, c.sweep_tol2, c.n_zones == 3 ? 2 : 1);
     if (need > h->lspill_bytes) {
         if (h->d_Lspill) HIPCHK(h, hipFree(h->d_Lspill));
         h->d_Lspill = nullptr;
         h->lspill_bytes = 0;
         HIPCHK(h, hipMalloc(&h->d_Lspill, need));
         h->lspill_bytes = need;
+    }
+    return APV_OK;
+}
+
+// scratch R of the split float32 update at orders 32 / 64 (apv_update_dev): correlation on the f32 matrix cores -> [2][K][L][L] +
+// [K][L] c64 -> LDS kernel.  Sized at apv_create so that the per-block path never allocates.
+bool split_f32_update(const apv_config& c) {
+    const bool split64 = c.n_srcs == 64 && !apv_gevd64_eligible(c.n_srcs, c.reg_mode, c.reg_bright, c.sweep_tol2);
+    return c.compute_dtype == APV_F32 && (c.n_srcs == 32 || split64) && (c.n_mics % 2) == 0 && c.n_mics >= 8;
+}
+
+int ensure_rscratch(apv_handle* h) {
+    const apv_config& c = h->cfg;
+    if (!split_f32_update(c)) return APV_OK;
+    const size_t K = c.n_bins, L = c.n_srcs;
+    const size_t need = (2 * K * L * L + K * L) * 8;
+    if (need > h->rscratch_bytes) {
+        if (h->d_Rscratch) HIPCHK(h, hipFree(h->d_Rscratch));
+        h->d_Rscratch = nullptr;
+        h->rscratch_bytes = 0;
+        HIPCHK(h, hipMalloc(&h->d_Rscratch, need ? need : 1));
+        h->rscratch_bytes = need;
     }
     return APV_OK;
 }
@@ -160,6 +183,7 @@ int apv_create(const apv_config* cfg, apv_handle** out) {
     CR(hipEventCreate(&h->ev1));
 #undef CR
     int rc = ensure_spill(h, cfg->n_srcs, cfg->n_bins);
+    if (rc == APV_OK) rc = ensure_rscratch(h);
     if (rc != APV_OK) {
         g_create_err = h->err;
         delete h;
@@ -264,20 +288,12 @@ int apv_update_dev(apv_handle* h, const void* d_XB, const void* d_XD, const void
     const apv_config& c = h->cfg;
     hipError_t e;
     // order 64 takes the fused order-64 kernel in either arithmetic (kernels_gevd64.hip) unless that kernel is switched off
-    static const bool no_gevd64 = (getenv("APV_NO_GEVD64") != nullptr);
-    const bool split64 = c.n_srcs == 64 && (no_gevd64 || c.reg_mode != APV_REG_ABS || c.reg_bright != 0.0 || c.sweep_tol2 > 0.0);
-    if (c.compute_dtype == APV_F32 && (c.n_srcs == 32 || split64) && (c.n_mics % 2) == 0 && c.n_mics >= 8) {
+    if (split_f32_update(c)) {
         // large orders in f32: correlation on the f32 matrix cores into a scratch R (HBM round trip of
-        // 2 L^2 c64 per bin, small against the eigen-iteration), then the LDS-resident GEVD from explicit R
+        // 2 L^2 c64 per bin, small against the eigen-iteration), then the LDS-resident GEVD from explicit R.  The scratch was
+        // sized by apv_create (ensure_rscratch): nothing is allocated here.
         const size_t K = c.n_bins, L = c.n_srcs;
-        const size_t need = (2 * K * L * L + K * L) * 8;
-        if (need > h->rscratch_bytes) {
-            if (h->d_Rscratch) HIPCHK(h, hipFree(h->d_Rscratch));
-            h->d_Rscratch = nullptr;
-            h->rscratch_bytes = 0;
-            HIPCHK(h, hipMalloc(&h->d_Rscratch, need));
-            h->rscratch_bytes = need;
-        }
+        if (!h->d_Rscratch || (2 * K * L * L + K * L) * 8 > h->rscratch_bytes) return fail(h, APV_ERR_STATE, "scratch R missing");
         float2* RB = (float2*)h->d_Rscratch;
         float2* RD = RB + K * L * L;
         float2* rr = RD + K * L * L;
@@ -417,7 +433,7 @@ int apv_jdiag_batched(apv_handle* h, int32_t n, int32_t batch, const double* h_A
     HIPCHK(h, hipMalloc(&dl, (size_t)batch * n * 8));
     HIPCHK(h, hipMalloc(&dsv, (size_t)batch * sizeof(int32_t)));
     int32_t* ds = (int32_t*)dsv;
-    const size_t sb = apv_gevd_spill_bytes(n, batch, APV_F64);   // jdiag always runs in f64
+    const size_t sb = apv_gevd_spill_bytes(n, batch, APV_F64, h->cfg.reg_mode, 0.0, 1e-17, 1);   // as launched below: f64, tol 1e-17
     if (sb) HIPCHK(h, hipMalloc(&spill, sb));
     HIPCHK(h, hipMemcpyAsync(dA, h_A, mat, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(dB, h_B, mat, hipMemcpyHostToDevice, h->stream));

@@ -333,12 +333,16 @@ __global__ void __launch_bounds__(TPB) gevd_vast_kernel(const GevdParams p) {
                 const int t = tid & 63;
                 const T x = lo + (hi - lo) * (T)(t + 1) / (T)65;
                 int below = 0;                                                         // eigenvalues < x
+                // Sturm sequence; a vanishing pivot is nudged to the smallest normal number of T (a literal like 1e-300 is zero
+                // in float and the quotient a NaN), and a NaN pivot counts as negative: the count can only err towards "x is
+                // above", i.e. towards a LOWER estimate, never towards an inflated norm
+                constexpr T kTiny = sizeof(T) == 8 ? (T)2.2250738585072014e-308 : (T)1.17549435e-38f;
                 T dq = sLam[0] - x;
-                below += dq < (T)0;
+                below += !(dq >= (T)0);
                 for (int i = 1; i < m; ++i) {
-                    if (dq == (T)0) dq = (T)1e-300;
+                    if (fabs(dq) < kTiny) dq = dq < (T)0 ? -kTiny : kTiny;
                     dq = sLam[i] - x - sDiag[i - 1] * sDiag[i - 1] / dq;
-                    below += dq < (T)0;
+                    below += !(dq >= (T)0);
                 }
                 __syncthreads();
                 if (tid < 64) sMs[t] = (below < m) ? 1 : 0;                            // x_t still below the largest eigenvalue
@@ -638,11 +642,13 @@ hipError_t launch_t(const GevdParams& p, bool fused, hipStream_t s) {
 
 }  // namespace
 
-size_t apv_gevd_spill_bytes(int n, int K, int compute_dtype) {
-    // per (zone program, bin): the order-64 kernel parks C, W (c128) and a float32 matrix; the LDS kernel its Cholesky factor
-    // (either arithmetic: the fused order-64 update runs the float64 kernel for both)
-    (void)compute_dtype;
-    if (n > 32) return (size_t)2 * K * apv_gevd64_slot_bytes();   // leading 2: two-zone launches
+size_t apv_gevd_spill_bytes(int n, int K, int compute_dtype, int reg_mode, double reg_bright, double sweep_tol2, int zones) {
+    // Sized by the kernel that can actually run.  Per (zone program, bin): the order-64 kernel parks C, W (c128), a
+    // float32 matrix and r (either arithmetic: the fused order-64 update runs that kernel for both); the float64 LDS kernel of
+    // orders 33..64 (SPILL instance) parks its Cholesky factor, n x n c128; every other instance keeps everything in LDS.
+    const size_t z = zones > 1 ? 2 : 1;
+    if (apv_gevd64_eligible(n, reg_mode, reg_bright, sweep_tol2)) return z * K * apv_gevd64_slot_bytes();
+    if (n > 32 && compute_dtype == APV_F64) return z * K * (size_t)n * n * 16;
     return 0;
 }
 

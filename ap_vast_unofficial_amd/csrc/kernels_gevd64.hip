@@ -820,6 +820,13 @@ __global__ void __launch_bounds__(1024) gevd64x2_kernel(const GevdParams p) {
 
 size_t apv_gevd64_slot_bytes() { return SLOT_BYTES; }
 
+// the conditions of apv_launch_gevd64 that are known when a handle is created (the arithmetic and fused / explicit are not:
+// a float32 handle reaches this kernel through its fused entry point)
+bool apv_gevd64_eligible(int n, int reg_mode, double reg_bright, double sweep_tol2) {
+    static const bool off = (getenv("APV_NO_GEVD64") != nullptr);
+    return !off && n == 64 && reg_mode == APV_REG_ABS && reg_bright == 0.0 && !(sweep_tol2 > 0.0);
+}
+
 // hipErrorNotSupported when the problem does not qualify (order != 64, float32 arithmetic, relative or bright loading, a
 // caller-set sweep tolerance): the LDS kernel of kernels_gevd.hip then takes it
 hipError_t apv_launch_gevd64(const GevdParams& p, int compute_dtype, bool fused, hipStream_t s) {
@@ -827,8 +834,8 @@ hipError_t apv_launch_gevd64(const GevdParams& p, int compute_dtype, bool fused,
     static const bool single = (getenv("APV_GEVD64_SINGLE") != nullptr);   // A/B switch: one bin per workgroup
     // float32 arithmetic asked for at order 64 gets this kernel too when the inputs are the fused slabs: it is 1.4x as fast
     // as the float LDS kernel and more accurate than asked (explicit float32 statistics still go to the LDS kernel)
-    if (off || p.n != 64 || (compute_dtype != APV_F64 && !fused) || p.reg_mode != APV_REG_ABS || p.reg_bright != 0.0 ||
-        p.sweep_tol2 > 0.0 ||   /* sweep_tol2 < 0: tuning aid, -value = hand-over threshold of the pre-solve */
+    if (off || !apv_gevd64_eligible(p.n, p.reg_mode, p.reg_bright, p.sweep_tol2) || (compute_dtype != APV_F64 && !fused) ||
+        /* sweep_tol2 < 0: tuning aid, -value = hand-over threshold of the pre-solve */
         p.Lspill == nullptr)
         return hipErrorNotSupported;
     if (p.K <= 0) return hipSuccess;

@@ -486,9 +486,10 @@ __global__ void __launch_bounds__(TPB) frob2_kernel(int n, int ld, const double*
     if (threadIdx.x == 0) atomicAdd(out + blockIdx.z, red[0]);
 }
 
-// out[0..count) = 0.  A kernel, not hipMemsetAsync: the two-sweep sequence is captured into a hipGraph, and a graph that
-// holds a memset node brings rocprofv3 --kernel-trace down (segfault at the first replay, ROCm 7.2; profiles/r02/
-// rocprof_graph_segfault.md).  With kernel nodes only the replayed graph traces like any other launch.
+// out[0..count) = 0.  A kernel, not hipMemsetAsync, so that the captured two-sweep hipGraph holds kernel nodes only.  Round 1
+// saw rocprofv3 --kernel-trace segfault at the first replay of this graph and suspected its memset node; in round 2 the crash
+// did not reproduce with or without that node (profiles/r02/rocprof_graph.md: five command lines) -- the likelier causes, a
+// per-thread flag read and an unordered upload, were fixed meanwhile.  The kernel node stays: it traces like any other launch.
 __global__ void __launch_bounds__(64) zero_f64_kernel(int count, double* __restrict__ out) {
     const int i = blockIdx.x * 64 + threadIdx.x;
     if (i < count) out[i] = 0.0;
@@ -620,7 +621,7 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
         LCHK(hipMalloc((void**)&ws.order, sizeof(int) * vs * batch));
     }
     // two sweeps: 2 (nb - 1) block rounds bring the ping-pong buffers back to where they started
-    static const bool memset_node = getenv("APV_GRAPH_MEMSET") != nullptr;      // reproduces the rocprofv3 crash (see zero_f64_kernel)
+    static const bool memset_node = getenv("APV_GRAPH_MEMSET") != nullptr;      // A/B switch: a memset node instead (see zero_f64_kernel)
     auto two_sweeps = [&]() {
         if (memset_node) (void)hipMemsetAsync(ws.acc, 0, sizeof(double) * 2 * batch, st);
         else hipLaunchKernelGGL(zero_f64_kernel, dim3((2 * batch + 63) / 64), dim3(64), 0, st, 2 * batch, ws.acc);

@@ -75,9 +75,15 @@ hipError_t get_tables(int N, Tables<T>* out) {
     if (e != hipSuccess) return e;
     e = hipMalloc(&dwin, sizeof(T) * N);
     if (e != hipSuccess) return e;
-    e = hipMemcpy(dtw, tw.data(), sizeof(C2<T>) * N, hipMemcpyHostToDevice);
+    // The tables are shared by every handle of the device, so they go up on a stream of their own that is drained before the
+    // table is published: no stream of any handle can see them half written, and nothing rides on the null stream.
+    hipStream_t up = nullptr;
+    e = hipStreamCreateWithFlags(&up, hipStreamNonBlocking);
     if (e != hipSuccess) return e;
-    e = hipMemcpy(dwin, win.data(), sizeof(T) * N, hipMemcpyHostToDevice);
+    e = hipMemcpyAsync(dtw, tw.data(), sizeof(C2<T>) * N, hipMemcpyHostToDevice, up);
+    if (e == hipSuccess) e = hipMemcpyAsync(dwin, win.data(), sizeof(T) * N, hipMemcpyHostToDevice, up);
+    if (e == hipSuccess) e = hipStreamSynchronize(up);
+    (void)hipStreamDestroy(up);
     if (e != hipSuccess) return e;
     g_tabs[key] = {dtw, dwin};
     out->tw = (C2<T>*)dtw;

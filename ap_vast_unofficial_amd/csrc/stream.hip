@@ -78,6 +78,9 @@ struct apv_stream {
     void* xspec_chunk;            // [sig_chunk][2][fir_F/2 + 1]: whole-signal path, the spectra of a staged chunk in one launch
     long hop;                     // hops processed
     long not_converged;           // hops in which some bin hit the sweep cap (status 2)
+    // work space of apv_stream_get_statistics (R_B, R_D, r, U, w, lam, spill, status), allocated at its first call and kept
+    void* stat_ws[8];
+    size_t stat_spill_bytes;
     std::vector<hipGraphExec_t> execs;
     std::vector<int32_t> h_status;
 };
@@ -163,6 +166,8 @@ void apv_stream_free(apv_handle* h) {
     if (s->tail) (void)hipStreamDestroy(s->tail);
     if (s->sig_in) (void)hipHostFree(s->sig_in);
     if (s->sig_out) (void)hipHostFree(s->sig_out);
+    for (void* b : s->stat_ws)
+        if (b) (void)hipFree(b);
     delete s;
     h->st = nullptr;
 }
@@ -571,6 +576,19 @@ static int process_signal_t(apv_handle* h, int n_hops, const TI* h_in_A, const T
         return APV_OK;
     };
     int c_done = 0;                                          // chunks collected
+    // Every failure after the first enqueue leaves through here: all three streams are drained (kernels may still be reading the
+    // pinned staging and writing the result buffers), and the message says how far the call got -- the rings, histories and
+    // the hop counter have advanced by the hops ENQUEUED, of which only the hops DELIVERED reached h_out.
+    auto bail = [&](int code, const std::string& msg) {
+        drain();
+        char buf[192];
+        const long enq = s->hop - hop_first;
+        const long deliv = std::min<long>((long)c_done * chunk, enq);
+        std::snprintf(buf, sizeof(buf), " [apv_process_signal: %ld of %d hops delivered, stream state advanced by %ld hops: restore it "
+                      "with apv_set_state or re-initialise before continuing]", deliv, n_hops, enq);
+        return apv_fail(h, code, msg + buf);
+    };
+    auto hipbail = [&](hipError_t e) { return bail(APV_ERR_HIP, std::string("apv_process_signal: ") + hipGetErrorString(e)); };
     for (int c = 0; c < n_chunks && worst != APV_ERR_NOT_PD; ++c) {
         const int base = c * chunk, nc = std::min(chunk, n_hops - base);
         stage_in(c);                                         // this half was collected when chunk c-2's event came in
@@ -581,7 +599,7 @@ static int process_signal_t(apv_handle* h, int n_hops, const TI* h_in_A, const T
             hipError_t e = apv_launch_fir_chunk_spectra(s->f64, s->fir_F, s->P, H, nc, s->xhist[s->cur][0], s->xhist[s->cur][1],
                                                         (const char*)s->sig_in + (size_t)(c & 1) * chunk * 2 * H * e1, s->xspec_chunk,
                                                         s->front);
-            if (e != hipSuccess) { drain(); return apv_fail(h, APV_ERR_HIP, std::string("apv_process_signal: ") + hipGetErrorString(e)); }
+            if (e != hipSuccess) return hipbail(e);
         }
         for (int i = 0; i < nc; ++i) {
             const size_t slot = (size_t)(c & 1) * chunk + i;
@@ -590,7 +608,7 @@ static int process_signal_t(apv_handle* h, int n_hops, const TI* h_in_A, const T
                 // hop h-2 has to be done with this set before the analysis transforms write it
                 rc = enqueue_front(h, s->front, set, (const char*)s->sig_in + slot * 2 * H * e1, released[set] ? nullptr : s->ev_back[set],
                                    s->fir_F > 0 ? (const char*)s->xspec_chunk + (size_t)i * xs_bytes : nullptr);
-                if (rc != APV_OK) { drain(); return rc; }
+                if (rc != APV_OK) return bail(rc, h->err);
                 e = hipEventRecord(s->ev_front[set], s->front);
             }
             if (e == hipSuccess) e = hipStreamWaitEvent(back, s->ev_front[set], 0);
@@ -603,37 +621,46 @@ static int process_signal_t(apv_handle* h, int n_hops, const TI* h_in_A, const T
                 sch.tail_stream = s->tail;
                 sch.copied = s->ev_copied[set];
                 rc = enqueue_back(h, back, set, (char*)s->sig_out + slot * hop_result_bytes(s), sch);
-                if (rc != APV_OK) { drain(); return rc; }
+                if (rc != APV_OK) return bail(rc, h->err);
                 out_idle[set] = false;
             }
-            if (e != hipSuccess) {
-                drain();
-                return apv_fail(h, APV_ERR_HIP, std::string("apv_process_signal: ") + hipGetErrorString(e));
-            }
+            if (e != hipSuccess) return hipbail(e);
             released[set] = false;
             last_set = set;
             set ^= 1;
             s->hop++;
         }
-        SCHK(h, hipEventRecord(s->ev_chunk[c & 1], s->tail));   // every front and back half is upstream of some copy
+        {
+            const hipError_t e = hipEventRecord(s->ev_chunk[c & 1], s->tail);   // every front and back half is upstream of some copy
+            if (e != hipSuccess) return hipbail(e);
+        }
         if (c > 0) {
-            if ((rc = collect(c - 1)) != APV_OK) { drain(); return rc; }
+            if ((rc = collect(c - 1)) != APV_OK) return bail(rc, h->err);
             c_done = c;
         }
     }
     // the chunks still in flight (one, or none if a hop was not positive definite in the last one collected)
-    for (int c = c_done; c < n_chunks && (size_t)c * chunk < (size_t)(s->hop - hop_first); ++c)
-        if ((rc = collect(c)) != APV_OK) { drain(); return rc; }
+    for (int c = c_done; c < n_chunks && (size_t)c * chunk < (size_t)(s->hop - hop_first); ++c) {
+        if ((rc = collect(c)) != APV_OK) return bail(rc, h->err);
+        c_done = c + 1;
+    }
     if (last_set == 1) {
         // the state arrays and apv_process_block live in set 0: bring the last hop's spectra there
         const size_t C = s->C, M = s->M, e2 = 2 * e1;
-        for (int p = 0; p < 4; ++p) SCHK(h, hipMemcpyAsync(s->X[p], s->X1[p], (size_t)K * C * e2, hipMemcpyDeviceToDevice, back));
-        for (int z = 0; z < 2; ++z) SCHK(h, hipMemcpyAsync(s->tspec[z], s->tspec1[z], (size_t)K * M * e2, hipMemcpyDeviceToDevice, back));
-        SCHK(h, hipMemcpyAsync(s->inspec, s->inspec1, (size_t)2 * K * e2, hipMemcpyDeviceToDevice, back));
+        hipError_t e = hipSuccess;
+        for (int p = 0; p < 4 && e == hipSuccess; ++p) e = hipMemcpyAsync(s->X[p], s->X1[p], (size_t)K * C * e2, hipMemcpyDeviceToDevice, back);
+        for (int z = 0; z < 2 && e == hipSuccess; ++z) e = hipMemcpyAsync(s->tspec[z], s->tspec1[z], (size_t)K * M * e2, hipMemcpyDeviceToDevice, back);
+        if (e == hipSuccess) e = hipMemcpyAsync(s->inspec, s->inspec1, (size_t)2 * K * e2, hipMemcpyDeviceToDevice, back);
+        if (e != hipSuccess) return hipbail(e);
     }
-    SCHK(h, hipStreamSynchronize(back));
-    SCHK(h, hipStreamSynchronize(s->tail));
-    if (worst != APV_OK) return apv_fail(h, worst, worst_msg);
+    {
+        hipError_t e = hipStreamSynchronize(s->front);
+        if (e == hipSuccess) e = hipStreamSynchronize(back);
+        if (e == hipSuccess) e = hipStreamSynchronize(s->tail);
+        if (e != hipSuccess) return hipbail(e);
+    }
+    if (worst == APV_ERR_NOT_PD) return bail(worst, worst_msg);     // the hops behind the failing one were not run
+    if (worst != APV_OK) return apv_fail(h, worst, worst_msg);      // APV_ERR_NO_CONVERGE: every hop ran, every output is written
     return APV_OK;
 }
 
@@ -802,7 +829,11 @@ int apv_process_signal_f64(apv_handle* h, int32_t n_hops, const double* h_in_A, 
 
 int apv_stream_is_f64(apv_handle* h) { return (h && h->st) ? h->st->f64 : -1; }
 
-long apv_stream_not_converged(apv_handle* h) { return (h && h->st) ? h->st->not_converged : -1; }
+long apv_stream_not_converged(apv_handle* h) {
+    if (h && h->st) return h->st->not_converged;
+    if (h && h->bb) return apv_bb_not_converged(h);
+    return -1;
+}
 
 // Per-bin statistics and eigenvectors of the CURRENT hop, recomputed in float64 on demand from the hop's control-point
 // spectra (nothing on the per-hop path pays for them).  zone 0: bright A->A, dark A->B, target A; zone 1: B->B, B->A, B.
@@ -816,13 +847,12 @@ int apv_stream_get_statistics(apv_handle* h, int32_t zone, double* h_RB, double*
     hipStream_t st = h->stream;
     const int K = s->K, L = s->L, M = s->M;
     const size_t mat = (size_t)K * L * L * 16, vec = (size_t)K * L * 16;
-    struct Tmp {
-        void* p[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-        ~Tmp() { for (void* q : p) if (q) (void)hipFree(q); }
-    } t;                                                    // freed on every way out
-    void*& dRB = t.p[0]; void*& dRD = t.p[1]; void*& dr = t.p[2]; void*& dU = t.p[3]; void*& dw = t.p[4]; void*& dl = t.p[5];
-    void*& dspill = t.p[6]; void*& dst = t.p[7];
-    SCHK(h, hipMalloc(&dRB, mat)); SCHK(h, hipMalloc(&dRD, mat)); SCHK(h, hipMalloc(&dr, vec));
+    // the work space is sized by (K, L) alone, which a stream never changes: allocated once, kept until apv_stream_free
+    void*& dRB = s->stat_ws[0]; void*& dRD = s->stat_ws[1]; void*& dr = s->stat_ws[2]; void*& dU = s->stat_ws[3];
+    void*& dw = s->stat_ws[4]; void*& dl = s->stat_ws[5]; void*& dspill = s->stat_ws[6]; void*& dst = s->stat_ws[7];
+    if (!dRB) SCHK(h, hipMalloc(&dRB, mat));
+    if (!dRD) SCHK(h, hipMalloc(&dRD, mat));
+    if (!dr) SCHK(h, hipMalloc(&dr, vec));
     const void* XB = zone ? s->X[3] : s->X[0];
     const void* XD = zone ? s->X[2] : s->X[1];
     hipError_t e = s->f64 ? apv_launch_corr_c128(K, M, L, (const double2*)XB, (const double2*)XD, (const double2*)s->tspec[zone],
@@ -831,11 +861,19 @@ int apv_stream_get_statistics(apv_handle* h, int32_t zone, double* h_RB, double*
                                             dr, st);
     if (e != hipSuccess) return apv_fail(h, APV_ERR_HIP, std::string("statistics: ") + hipGetErrorString(e));
     if (h_U || h_lam) {
-        SCHK(h, hipMalloc(&dU, mat)); SCHK(h, hipMalloc(&dw, vec)); SCHK(h, hipMalloc(&dl, (size_t)K * L * 8));
-        SCHK(h, hipMalloc(&dst, (size_t)K * 4));
-        const size_t sb = apv_gevd_spill_bytes(L, K, APV_F64);
-        if (sb) SCHK(h, hipMalloc(&dspill, sb));
+        if (!dU) SCHK(h, hipMalloc(&dU, mat));
+        if (!dw) SCHK(h, hipMalloc(&dw, vec));
+        if (!dl) SCHK(h, hipMalloc(&dl, (size_t)K * L * 8));
+        if (!dst) SCHK(h, hipMalloc(&dst, (size_t)K * 4));
         GevdParams p = apv_base_params(h);
+        const size_t sb = apv_gevd_spill_bytes(L, K, APV_F64, p.reg_mode, p.reg_bright, p.sweep_tol2, 1);
+        if (sb > s->stat_spill_bytes) {
+            if (dspill) SCHK(h, hipFree(dspill));
+            dspill = nullptr;
+            s->stat_spill_bytes = 0;
+            SCHK(h, hipMalloc(&dspill, sb));
+            s->stat_spill_bytes = sb;
+        }
         p.nV = 1; p.ranks[0] = 1; p.out_c128 = 1; p.n_zones = 1;
         p.RB = dRB; p.RD = dRD; p.r = dr; p.w = dw; p.lam = dl; p.status = (int32_t*)dst; p.U = dU; p.Lspill = dspill;
         std::string why;
@@ -883,8 +921,10 @@ int apv_stream_set_perceptual(apv_handle* h, int32_t n_channels, const double* h
     SCHK(h, hipMalloc((void**)&s->G2, sizeof(double) * (size_t)K * n_channels));
     SCHK(h, hipMalloc((void**)&s->G2T, sizeof(double) * (size_t)K * n_channels));
     for (int z = 0; z < 2; ++z) SCHK(h, hipMalloc((void**)&s->Wgt[z], s->esz * (size_t)K * s->M));
-    SCHK(h, hipMemcpy(s->G2, h_G2, sizeof(double) * (size_t)K * n_channels, hipMemcpyHostToDevice));
-    SCHK(h, hipMemcpy(s->G2T, gt.data(), sizeof(double) * gt.size(), hipMemcpyHostToDevice));
+    // on the handle's stream, like every other upload of this file (a null-stream copy is not ordered with it)
+    SCHK(h, hipMemcpyAsync(s->G2, h_G2, sizeof(double) * (size_t)K * n_channels, hipMemcpyHostToDevice, h->stream));
+    SCHK(h, hipMemcpyAsync(s->G2T, gt.data(), sizeof(double) * gt.size(), hipMemcpyHostToDevice, h->stream));
+    SCHK(h, hipStreamSynchronize(h->stream));               // gt goes out of scope; h_G2 is the caller's
     s->nch = n_channels; s->Cs = Cs; s->Ca = Ca; s->Leff = Leff; s->norm_mode = normalisation;
     return APV_OK;
 }
@@ -932,15 +972,16 @@ int apv_get_state(apv_handle* h, const char* name, void* h_dst, size_t bytes) {
     if (rc != APV_OK) return rc;
     if (bytes != need) return apv_fail(h, APV_ERR_STATE, "state size mismatch");
     SCHK(h, hipSetDevice(h->device));
-    SCHK(h, hipStreamSynchronize(h->stream));
     if (rr == 0) {
-        SCHK(h, hipMemcpy(h_dst, d, need, hipMemcpyDeviceToHost));
+        SCHK(h, hipMemcpyAsync(h_dst, d, need, hipMemcpyDeviceToHost, h->stream));
+        SCHK(h, hipStreamSynchronize(h->stream));
         return APV_OK;
     }
     // ring: rotate rows into logical order
     const size_t N = h->st->N, off = h->st->ring_off, e1 = h->st->esz;
     std::vector<char> tmp(need);
-    SCHK(h, hipMemcpy(tmp.data(), d, need, hipMemcpyDeviceToHost));
+    SCHK(h, hipMemcpyAsync(tmp.data(), d, need, hipMemcpyDeviceToHost, h->stream));
+    SCHK(h, hipStreamSynchronize(h->stream));
     char* out = (char*)h_dst;
     for (int r = 0; r < rr; ++r) {
         // logical [0, N - off) = physical [off, N); logical [N - off, N) = physical [0, off)
@@ -957,9 +998,9 @@ int apv_set_state(apv_handle* h, const char* name, const void* h_src, size_t byt
     if (rc != APV_OK) return rc;
     if (bytes != need) return apv_fail(h, APV_ERR_STATE, "state size mismatch");
     SCHK(h, hipSetDevice(h->device));
-    SCHK(h, hipStreamSynchronize(h->stream));
     if (rr == 0) {
-        SCHK(h, hipMemcpy(d, h_src, need, hipMemcpyHostToDevice));
+        SCHK(h, hipMemcpyAsync(d, h_src, need, hipMemcpyHostToDevice, h->stream));
+        SCHK(h, hipStreamSynchronize(h->stream));
         return APV_OK;
     }
     const size_t N = h->st->N, off = h->st->ring_off, e1 = h->st->esz;
@@ -969,7 +1010,8 @@ int apv_set_state(apv_handle* h, const char* name, const void* h_src, size_t byt
         std::memcpy(tmp.data() + ((size_t)r * N + off) * e1, in + ((size_t)r * N) * e1, (N - off) * e1);
         std::memcpy(tmp.data() + ((size_t)r * N) * e1, in + ((size_t)r * N + (N - off)) * e1, off * e1);
     }
-    SCHK(h, hipMemcpy(d, tmp.data(), need, hipMemcpyHostToDevice));
+    SCHK(h, hipMemcpyAsync(d, tmp.data(), need, hipMemcpyHostToDevice, h->stream));
+    SCHK(h, hipStreamSynchronize(h->stream));               // tmp goes out of scope
     return APV_OK;
 }
 

@@ -501,7 +501,8 @@ int apv_bb_init(apv_handle* h, int32_t rir_len, const double* h_rir_A, const dou
     const int nz = ((s->zones & 1) ? 1 : 0) + ((s->zones & 2) ? 1 : 0);
     s->n_out = nz * nsol * L + 2 * L;
     BCHK(h, hipMalloc((void**)&s->d_ranks, sizeof(int) * nsol));
-    BCHK(h, hipMemcpy(s->d_ranks, ranks.data(), sizeof(int) * nsol, hipMemcpyHostToDevice));
+    BCHK(h, hipMemcpyAsync(s->d_ranks, ranks.data(), sizeof(int) * nsol, hipMemcpyHostToDevice, h->stream));
+    BCHK(h, hipStreamSynchronize(h->stream));
     const int C = s->C, P = s->P, K = s->K;
     int rc;
     std::vector<double> tmp((size_t)P * C), ttmp((size_t)P * M);
@@ -739,6 +740,12 @@ int apv_bb_process_block(apv_handle* h, const double* h_in_A, const double* h_in
     return APV_OK;
 }
 
+}  // extern "C"
+
+long apv_bb_not_converged(const apv_handle* h) { return h->bb ? h->bb->not_converged : -1; }
+
+extern "C" {
+
 // Perceptual weighting for the broadband stream (see apv_stream_set_perceptual).      replaces apvast.py:313-324
 int apv_bb_set_perceptual(apv_handle* h, int32_t n_channels, const double* h_G2, double Cs, double Ca, double Leff,
                           int32_t normalisation) {
@@ -765,9 +772,10 @@ int apv_bb_set_perceptual(apv_handle* h, int32_t n_channels, const double* h_G2,
     if ((rc = dalloc(h, &s->G2T, (size_t)K * n_channels))) return rc;
     for (int z = 0; z < 2; ++z)
         if ((rc = dalloc(h, &s->Wgt[z], (size_t)K * s->M))) return rc;
-    BCHK(h, hipStreamSynchronize(h->stream));               // the zero-fills of dalloc are on the handle's stream
-    BCHK(h, hipMemcpy(s->G2, h_G2, sizeof(double) * (size_t)K * n_channels, hipMemcpyHostToDevice));
-    BCHK(h, hipMemcpy(s->G2T, gt.data(), sizeof(double) * gt.size(), hipMemcpyHostToDevice));
+    // behind the zero-fills of dalloc, on the same (the handle's) stream
+    BCHK(h, hipMemcpyAsync(s->G2, h_G2, sizeof(double) * (size_t)K * n_channels, hipMemcpyHostToDevice, h->stream));
+    BCHK(h, hipMemcpyAsync(s->G2T, gt.data(), sizeof(double) * gt.size(), hipMemcpyHostToDevice, h->stream));
+    BCHK(h, hipStreamSynchronize(h->stream));               // gt goes out of scope
     s->nch = n_channels; s->Cs = Cs; s->Ca = Ca; s->Leff = Leff; s->norm_mode = normalisation;
     return APV_OK;
 }
@@ -908,13 +916,14 @@ int apv_bb_get_state(apv_handle* h, const char* name, double* h_dst, size_t coun
     if (rc != APV_OK) return rc;
     if (count != need) return apv_fail(h, APV_ERR_STATE, "state size mismatch");
     BCHK(h, hipSetDevice(h->device));
-    BCHK(h, hipStreamSynchronize(h->stream));
     if (rows == 0) {
-        BCHK(h, hipMemcpy(h_dst, d, sizeof(double) * need, hipMemcpyDeviceToHost));
+        BCHK(h, hipMemcpyAsync(h_dst, d, sizeof(double) * need, hipMemcpyDeviceToHost, h->stream));
+        BCHK(h, hipStreamSynchronize(h->stream));
         return APV_OK;
     }
     std::vector<double> tmp(need);
-    BCHK(h, hipMemcpy(tmp.data(), d, sizeof(double) * need, hipMemcpyDeviceToHost));
+    BCHK(h, hipMemcpyAsync(tmp.data(), d, sizeof(double) * need, hipMemcpyDeviceToHost, h->stream));
+    BCHK(h, hipStreamSynchronize(h->stream));
     for (int r = 0; r < rows; ++r)
         for (int t = 0; t < len; ++t) h_dst[(size_t)r * len + t] = tmp[(size_t)r * len + (t + off) % len];
     return APV_OK;
@@ -927,15 +936,16 @@ int apv_bb_set_state(apv_handle* h, const char* name, const double* h_src, size_
     if (rc != APV_OK) return rc;
     if (count != need) return apv_fail(h, APV_ERR_STATE, "state size mismatch");
     BCHK(h, hipSetDevice(h->device));
-    BCHK(h, hipStreamSynchronize(h->stream));
     if (rows == 0) {
-        BCHK(h, hipMemcpy(d, h_src, sizeof(double) * need, hipMemcpyHostToDevice));
+        BCHK(h, hipMemcpyAsync(d, h_src, sizeof(double) * need, hipMemcpyHostToDevice, h->stream));
+        BCHK(h, hipStreamSynchronize(h->stream));
         return APV_OK;
     }
     std::vector<double> tmp(need);
     for (int r = 0; r < rows; ++r)
         for (int t = 0; t < len; ++t) tmp[(size_t)r * len + (t + off) % len] = h_src[(size_t)r * len + t];
-    BCHK(h, hipMemcpy(d, tmp.data(), sizeof(double) * need, hipMemcpyHostToDevice));
+    BCHK(h, hipMemcpyAsync(d, tmp.data(), sizeof(double) * need, hipMemcpyHostToDevice, h->stream));
+    BCHK(h, hipStreamSynchronize(h->stream));               // tmp goes out of scope
     return APV_OK;
 }
 

@@ -17,7 +17,11 @@
  *     one RCCL communicator.  Handles are thread-compatible, not thread-safe.
  *   - pointer arguments named h_* are HOST pointers, d_* are DEVICE pointers
  *     obtained from apv_dev_alloc() (or any hipMalloc'd memory on the handle's
- *     device).  No entry point allocates on the per-block path.
+ *     device).  No entry point allocates on the per-block path: apv_update_dev, apv_process_block*, apv_process_signal*
+ *     and apv_bb_process_block use buffers sized by apv_create / apv_*_init (apv_process_signal sets up its second
+ *     spectra set and pinned staging at its first call); the on-demand readers (apv_stream_get_statistics) allocate their
+ *     work space once and keep it; the host-buffer conveniences (apv_update, apv_jdiag_*, apv_predict_pressure,
+ *     apv_vast_static) stage through device memory of their own.
  *
  * Data layout (HBM), subband mode -- bin-major so that one bin's control-point
  * matrix is one contiguous, coalesced slab:
@@ -94,8 +98,9 @@ typedef struct apv_config {
                                  irfft are, apvast.py:171-192, 202-203, 461-496), 1 = float32, 2 = float64 */
     int32_t reserved[5];
     double  sweep_tol2;       /* Jacobi stop threshold: a sweep whose pivots satisfy sum |c_pq|^2 <= sweep_tol2 ||C||_F^2 is the
-                                 last one (quadratic convergence leaves ~sweep_tol2^2 behind).  0 = default (1e-10 in float64,
-                                 1e-8 in float32); apv_jdiag_* always iterate to 1e-17 */
+                                 last one (quadratic convergence leaves ~sweep_tol2^2 behind).  0 = default (1e-16 in float64:
+                                 csrc/gevd16_common.h Prec<double>, csrc/kernels_gevd.hip Tol<double>; 1e-8 in float32);
+                                 apv_jdiag_* always iterate to 1e-17 */
 } apv_config;
 
 /* ---- lifetime ---------------------------------------------------------- */
@@ -200,7 +205,8 @@ int  apv_stream_is_f64(apv_handle* h);
  * of them may be NULL.       replaces the attributes R_*, r_*, U_*, lambda_* of apvast.py:368-387, per bin */
 int  apv_stream_get_statistics(apv_handle* h, int32_t zone, double* h_RB, double* h_RD, double* h_r, double* h_U,
                                double* h_lam);
-/* hops so far in which some bin reached the Jacobi sweep cap (each such hop also returned APV_ERR_NO_CONVERGE) */
+/* hops so far (either stream mode) in which some bin reached the Jacobi sweep cap; each such hop also returned
+ * APV_ERR_NO_CONVERGE with its outputs written and the stream advanced: a warning to the caller, not a lost hop */
 long apv_stream_not_converged(apv_handle* h);
 /* Perceptual ("AP") weighting of the control-point and target spectra, evaluated per block on the device from the
  * target spectra (van de Par 2005 model as carried by the reference's MATLAB twin).  h_G2 [K][n_channels] float64
