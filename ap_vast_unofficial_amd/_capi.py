@@ -45,7 +45,8 @@ class Config(C.Structure):
         ("debug_stop", C.c_int32),
         ("dialect", C.c_int32),
         ("frontend", C.c_int32),
-        ("reserved", C.c_int32 * 5),
+        ("out_layout", C.c_int32),
+        ("reserved", C.c_int32 * 4),
         ("sweep_tol2", C.c_double),
     ]
 
@@ -180,7 +181,8 @@ class Engine:
 
     def __init__(self, n_bins, n_srcs, n_mics, ranks=(1,), mu=1.0, compute_dtype="f64", out_c128=None,
                  reg_mode=REG_ABS, reg_dark=1e-7, reg_bright=0.0, device=0, max_sweeps=0,
-                 block_size=0, hop_size=0, n_zones=1, debug_stop=0, dialect="python", frontend=None, sweep_tol2=0.0):
+                 block_size=0, hop_size=0, n_zones=1, debug_stop=0, dialect="python", frontend=None, sweep_tol2=0.0,
+                 out_layout=0):
         self.lib = load()
         self.h = None
         ranks = [int(v) for v in ranks]
@@ -206,6 +208,9 @@ class Engine:
         # streaming front-end precision: None follows compute_dtype; "f32" / "f64" force it
         cfg.frontend = {None: 0, "f32": 1, "f64": 2}[frontend]
         self.frontend_f64 = self.f64 if frontend is None else frontend == "f64"
+        # streaming outputs: 0 = channel-major (n_out, H); 1 = sample-major groups (n_out / L, H, L), see include/apvast_hip.h
+        cfg.out_layout = int(out_layout)
+        self.out_layout = int(out_layout)
         self.cfg = cfg
         self.K, self.L, self.M, self.nV = cfg.n_bins, cfg.n_srcs, cfg.n_mics, cfg.n_ranks
         h = C.c_void_p()
@@ -427,15 +432,17 @@ class Engine:
         dt = np.float64 if self.frontend_f64 else np.float32
         in_A = np.ascontiguousarray(in_A, dtype=dt).ravel()
         in_B = np.ascontiguousarray(in_B, dtype=dt).ravel()
-        out = np.empty((n_out, self.cfg.hop_size), dtype=dt)
+        H = self.cfg.hop_size
+        out = np.empty((n_out // self.L, H, self.L) if self.out_layout == 1 else (n_out, H), dtype=dt)
         fn = self.lib.apv_process_block_f64 if self.frontend_f64 else self.lib.apv_process_block
         self._chk_stream(fn(self.h, _ptr(in_A), _ptr(in_B), _ptr(out)))
         return out
 
     def process_signal(self, in_A, in_B, n_out, out=None):
         """Whole signals (a multiple of hop_size samples each) in one call, hops pipelined on the device; returns
-        (n_hops, n_out, hop_size).  Sample for sample what n_hops calls of process_block return.  `out`: a C-contiguous
-        array of that shape and the front-end's dtype to write into (saves the page faults of a fresh one)."""
+        (n_hops, n_out, hop_size) -- with out_layout = 1: (n_out / L, n_hops * hop_size, L).  Sample for sample what n_hops
+        calls of process_block return.  `out`: a C-contiguous array of that shape and the front-end's dtype to write into
+        (saves the page faults of a fresh one)."""
         dt = np.float64 if self.frontend_f64 else np.float32
         in_A = np.ascontiguousarray(in_A, dtype=dt).ravel()
         in_B = np.ascontiguousarray(in_B, dtype=dt).ravel()
@@ -443,10 +450,11 @@ class Engine:
         if in_A.size != in_B.size or in_A.size % H:
             raise RuntimeError("invalid input size")
         n_hops = in_A.size // H
+        shape = (n_out // self.L, n_hops * H, self.L) if self.out_layout == 1 else (n_hops, n_out, H)
         if out is None:
-            out = np.empty((n_hops, n_out, H), dtype=dt)
-        elif out.shape != (n_hops, n_out, H) or out.dtype != dt or not out.flags.c_contiguous:
-            raise ValueError("out must be a C-contiguous %s array of shape %r" % (np.dtype(dt).name, (n_hops, n_out, H)))
+            out = np.empty(shape, dtype=dt)
+        elif out.shape != shape or out.dtype != dt or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous %s array of shape %r" % (np.dtype(dt).name, shape))
         fn = self.lib.apv_process_signal_f64 if self.frontend_f64 else self.lib.apv_process_signal
         self._chk_stream(fn(self.h, n_hops, _ptr(in_A), _ptr(in_B), _ptr(out)))
         return out

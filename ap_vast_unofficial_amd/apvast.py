@@ -163,7 +163,8 @@ class apvast:
         self._eng = _capi.Engine(self._K, L, M, ranks=self._ranks, mu=mu, compute_dtype="f32" if dtype == "f32" else "f64",
                                  reg_mode=reg_mode, reg_dark=reg_dark, reg_bright=reg_bright, device=device,
                                  block_size=N, hop_size=H, n_zones=zones, frontend="f32" if dtype == "mixed" else None,
-                                 max_sweeps=self._max_sweeps, sweep_tol2=sweep_tol2)
+                                 max_sweeps=self._max_sweeps, sweep_tol2=sweep_tol2,
+                                 out_layout=1)     # the device emits (hop, loudspeaker) arrays: nothing to transpose here
         self._eng.stream_init(rir_A, rir_B, reference_index_A, reference_index_B, modeling_delay)
         if perceptual:
             # the masking model carried by the MATLAB twin (perceptualModel.m); per-block curves are formed on the
@@ -274,19 +275,22 @@ class apvast:
             res = self._split_outputs(out)
             self._refresh_broadband()
             return res
-        out = self._eng.process_block(input_A, input_B, self._n_out)
+        out = self._eng.process_block(input_A, input_B, self._n_out)         # (groups, H, L): one (H, L) array per zone and rank
         if out.dtype != np.float64:
             out = out.astype(np.float64)
-        res = self._split_outputs(out)
+        res = self._split_groups(out)
         self._refresh_attributes()
         return res
 
-    def process_signal(self, input_A, input_B):
+    def process_signal(self, input_A, input_B, out=None):
         """Every hop of two whole signals in one call (subband mode): the hop loop of main.m:52-62 /
         make_python_test.m:44-51 around process_input_buffers, with consecutive hops pipelined on the device.  Returns
         (output_A, output_B, target_A, target_B): per zone a list over the ranks of (n_samples, L) arrays, None for a
         zone that does not run; sample for sample what the per-hop calls return, concatenated.  The attributes
-        afterwards are those of the last hop."""
+        afterwards are those of the last hop.
+        `out`: optional C-contiguous array of shape signal_output_shape(n_samples) and dtype signal_output_dtype to receive
+        the samples (the returned arrays are then slices of it).  A 10 s signal returns 184 MB; a caller that processes many
+        signals saves the first-touch cost of that much fresh memory by passing the same array again."""
         input_A = np.asarray(input_A).ravel()
         input_B = np.asarray(input_B).ravel()
         if input_A.size != input_B.size or input_A.size % self.hop_size:
@@ -295,24 +299,36 @@ class apvast:
             raise NotImplementedError("process_signal: subband mode only (the broadband hop is one serial chain)")
         if input_A.size == 0:
             raise RuntimeError("invalid input size")
-        out = self._eng.process_signal(input_A, input_B, self._n_out)                        # (n_hops, n_out, H)
+        out = self._eng.process_signal(input_A, input_B, self._n_out, out=out)   # (groups, n_samples, L), written in place by the library
         if out.dtype != np.float64:
             out = out.astype(np.float64)
-        L, V, H = self.number_of_srcs, len(self._ranks), self.hop_size
-        n = out.shape[0] * H
-        pos, res = 0, []
+        res = self._split_groups(out)
+        self._refresh_attributes()
+        return res
+
+    def signal_output_shape(self, n_samples):
+        """Shape of process_signal's `out`: (zones x ranks + 2 target paths, n_samples, L)."""
+        return (self._n_out // self.number_of_srcs, int(n_samples), self.number_of_srcs)
+
+    @property
+    def signal_output_dtype(self):
+        return self._eng.s_dtype
+
+    def _split_groups(self, out):
+        """out: (groups, samples, L) with the groups [zone A: rank 1..V][zone B: rank 1..V][A_t][B_t] (zones that run) ->
+        (A, B, A_t, B_t) as the reference returns them (apvast.py:498-506): per zone a list over the ranks of (samples, L)
+        arrays -- slices of `out`, which is fresh for every call -- None for a zone that does not run (apvast.py:433-443)."""
+        V = len(self._ranks)
+        g, res = 0, []
         for run in (self.run_A, self.run_B):
             if run:
-                blk = out[:, pos:pos + V * L].reshape(-1, V, L, H)
-                res.append([np.ascontiguousarray(blk[:, i].transpose(0, 2, 1).reshape(n, L)) for i in range(V)])
-                pos += V * L
+                res.append([out[g + i] for i in range(V)])
+                g += V
             else:
                 res.append(None)
         for _ in range(2):
-            t = np.ascontiguousarray(out[:, pos:pos + L].transpose(0, 2, 1).reshape(n, L))
-            res.append([t.copy() for _ in range(V)])
-            pos += L
-        self._refresh_attributes()
+            res.append([out[g]] + [out[g].copy() for _ in range(V - 1)])         # the same target filter at every rank
+            g += 1
         return tuple(res)
 
     def _split_outputs(self, out):

@@ -25,6 +25,7 @@ struct apv_stream {
     int ring_off;                 // physical index of logical sample 0 in every ring
     int cur;                      // which input-history buffer is current
     int n_out;                    // synthesis channels: zones*nV*L filtered + 2*L target
+    int out_group;                // cfg.out_layout = 1: L (hops are emitted [n_out / L][H][L]); 0 = channel-major [n_out][H]
     void* rir[2];                 // [P][C]  zone A, zone B
     void* trir[2];                // [P][M]  target RIRs (reference loudspeaker, delayed)
     void* xhist[2][2];            // [buf][signal][P-1+H+pad]
@@ -367,7 +368,7 @@ static int enqueue_back(apv_handle* h, hipStream_t st, int set, void* pin_dst, c
     }
     // K4: synthesis + overlap-add + emit
     {
-        hipError_t e = apv_launch_synthesis(f64, N, H, s->n_out, ospec, K, 1, s->outov, obuf, ts, &why);
+        hipError_t e = apv_launch_synthesis(f64, N, H, s->n_out, ospec, K, 1, s->outov, obuf, ts, &why, s->out_group);
         if (e != hipSuccess) return apv_fail(h, APV_ERR_HIP, why.empty() ? hipGetErrorString(e) : why);
     }
     SCHK(h, hipMemcpyAsync(pin_dst, obuf, hop_result_bytes(s), hipMemcpyDeviceToHost, ts));         // samples + status: one copy
@@ -471,10 +472,12 @@ static int process_block_t(apv_handle* h, const TI* h_in_A, const TI* h_in_B, TI
     if (rc != APV_OK) return rc;
     if (s->f64) {
         const double* po = (const double*)s->pin_out;
-        for (size_t i = 0; i < nout; ++i) h_out[i] = (TI)po[i];
+        if (sizeof(TI) == sizeof(double)) std::memcpy(h_out, po, nout * sizeof(double));
+        else for (size_t i = 0; i < nout; ++i) h_out[i] = (TI)po[i];
     } else {
         const float* po = (const float*)s->pin_out;
-        for (size_t i = 0; i < nout; ++i) h_out[i] = (TI)po[i];
+        if (sizeof(TI) == sizeof(float)) std::memcpy(h_out, po, nout * sizeof(float));
+        else for (size_t i = 0; i < nout; ++i) h_out[i] = (TI)po[i];
     }
     return scan_hop_status(h, hop_status_of(s, s->pin_out), s->hop - 1);
 }
@@ -559,15 +562,22 @@ static int process_signal_t(apv_handle* h, int n_hops, const TI* h_in_A, const T
         const int base = c * chunk, nc = std::min(chunk, n_hops - base);
         hipError_t e = hipEventSynchronize(s->ev_chunk[c & 1]);
         if (e != hipSuccess) return apv_fail(h, APV_ERR_HIP, std::string("apv_process_signal: ") + hipGetErrorString(e));
+        // channel-major: h_out [n_hops][n_out][H].  Sample-major: h_out [n_out / L][n_hops * H][L], i.e. the hop's group g, a
+        // contiguous [H][L] block of the result, lands behind the same group of the hop before it (one straight copy per group)
+        const size_t ngrp = s->out_group > 0 ? (size_t)s->n_out / s->out_group : 1, gsz = nout / ngrp;
         for (int i = 0; i < nc; ++i) {
-            TI* dst = h_out + (size_t)(base + i) * nout;
             const char* res = (const char*)s->sig_out + ((size_t)(c & 1) * chunk + i) * hop_result_bytes(s);
-            if (s->f64) {
-                const double* po = (const double*)res;
-                for (size_t j = 0; j < nout; ++j) dst[j] = (TI)po[j];
-            } else {
-                const float* po = (const float*)res;
-                for (size_t j = 0; j < nout; ++j) dst[j] = (TI)po[j];
+            for (size_t g = 0; g < ngrp; ++g) {
+                TI* dst = s->out_group > 0 ? h_out + (g * (size_t)n_hops + (size_t)(base + i)) * gsz : h_out + (size_t)(base + i) * nout;
+                if (s->f64) {
+                    const double* po = (const double*)res + g * gsz;
+                    if (sizeof(TI) == sizeof(double)) std::memcpy(dst, po, gsz * sizeof(double));
+                    else for (size_t j = 0; j < gsz; ++j) dst[j] = (TI)po[j];
+                } else {
+                    const float* po = (const float*)res + g * gsz;
+                    if (sizeof(TI) == sizeof(float)) std::memcpy(dst, po, gsz * sizeof(float));
+                    else for (size_t j = 0; j < gsz; ++j) dst[j] = (TI)po[j];
+                }
             }
             const int r = scan_hop_status(h, hop_status_of(s, res), hop_first + base + i);
             if (r == APV_ERR_NOT_PD && worst != APV_ERR_NOT_PD) { worst = r; worst_msg = h->err; }
@@ -676,6 +686,7 @@ int apv_stream_init(apv_handle* h, int32_t rir_len, const double* h_rir_A, const
         if (!apv_stft_size_ok(N, &why)) return apv_fail(h, APV_ERR_ARG, why);
     }
     if (c.frontend < 0 || c.frontend > 2) return apv_fail(h, APV_ERR_ARG, "cfg.frontend must be 0 (follow compute_dtype), 1 (float32) or 2 (float64)");
+    if (c.out_layout != 0 && c.out_layout != 1) return apv_fail(h, APV_ERR_ARG, "cfg.out_layout must be 0 (channel-major) or 1 (sample-major groups)");
     const int f64 = frontend_f64(c);
     if (f64 && N > 4096) return apv_fail(h, APV_ERR_ARG, "float64 front-end: block_size <= 4096 (double-precision FFT in LDS)");
     if (H < 1 || H > N) return apv_fail(h, APV_ERR_ARG, "hop_size must be in 1..block_size");
@@ -695,6 +706,7 @@ int apv_stream_init(apv_handle* h, int32_t rir_len, const double* h_rir_A, const
     s->ring_off = 0; s->cur = 0;
     const int nz = ((s->zones & 1) ? 1 : 0) + ((s->zones & 2) ? 1 : 0);
     s->n_out = nz * s->nV * s->L + 2 * s->L;
+    s->out_group = c.out_layout == 1 ? s->L : 0;
     const int L = s->L, M = s->M, C = s->C, P = s->P, K = s->K;
     const size_t e1 = s->esz, e2 = 2 * s->esz;
     int rc;

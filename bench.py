@@ -7,20 +7,31 @@ of the hot path (correlate R_B/R_D/r -> joint diagonalisation -> variable-span f
 resident batch of `--blocks` blocks, i.e. blocks*1024 independent bin-updates in one launch.
 Inputs are resident in HBM before the timed region; PCIe is not in `value`.
 
-    python bench.py                                  # 1 GPU: cfg2, 32 blocks x 1024 bins resident
+    python bench.py                      # 1 GPU: cfg2, 32 blocks x 1024 bins resident; also.cfg3, also.cfg5, cpu_baseline
+    python bench.py --gpus N             # N GPUs of this node: the program starts its own N ranks (below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N         # N GPUs: cfg4, 4096 bins/block sharded, RCCL all-gather of w
+           --master-port P bench.py --gpus N         # the same under an external launcher
 
 At N GPUs the workload is BASELINE config 4: blocks of 4096 bins, rank g owns bins [g 4096/N, (g+1) 4096/N) of every
 block, 8 N blocks resident -- the same 32 768 bin-updates per GPU per step as the 1-GPU run (weak scaling) -- and the
 per-bin filters are reassembled on every rank by one RCCL all-gather per step, overlapped with the next step's update.
-The launcher only provides RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*: nothing here imports torch; the RCCL id is
-exchanged over a TCP hub (ap_vast_unofficial_amd/rendezvous.py) and barriers are one-word RCCL all-reduces.
-Prints ONE JSON line on rank 0.
+
+Launching.  A launcher (torchrun) provides RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*.  Without one, `--gpus N` makes
+THIS process the launcher: before anything touches a GPU it starts N children of itself (one per GPU, the same
+environment variables set, rendezvous on 127.0.0.1 and a free port), relays rank 0's JSON line and exits non-zero if any
+rank fails.  The parent never initialises HIP and nothing is ever re-exec'd.  Nothing here imports torch: the RCCL id
+is exchanged over a TCP hub (ap_vast_unofficial_amd/rendezvous.py) and barriers are one-word RCCL all-reduces.
+
+Rank 0 prints ONE JSON line.  At N = 1 it also carries:
+  also.cfg3   BASELINE config 3 through the drop-in class: 468 hops of 10 s pink noise, 16 x 32, N = 2048, float64, once
+              through apvast.process_input_buffers (one call per hop) and once through apvast.process_signal
+  also.cfg5   BASELINE config 5 at kernel level: 64 x 128 x 2048 bins in float64, with its own roofline
+  cpu_baseline  the oracle's per-bin loop on the host cores (one single-threaded process per core)
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -33,15 +44,22 @@ if ROOT not in sys.path:
 L, M, BINS = 16, 32, 1024
 HBM_PEAK = 8.0e12            # B/s, MI355X_MICROARCH.md "HBM3E peak BW"
 PEAK_FLOPS = {"f64": 78.6e12, "f32": 157.3e12}   # vector peaks
-FLOP_PER_UPDATE = 16 * M * L * L + 8 * M * L + 45 * L ** 3 + 16 * (L // 2) * L
 
 
-def bytes_per_update(nV):
+def flop_per_update(L_, M_, V_):
+    """correlation 16 M L^2 + 8 M L, joint diagonalisation ~45 L^3, filter 16 V L."""
+    return 16 * M_ * L_ * L_ + 8 * M_ * L_ + 45 * L_ ** 3 + 16 * V_ * L_
+
+
+FLOP_PER_UPDATE = flop_per_update(L, M, L // 2)
+
+
+def bytes_per_update(nV, L_=L, M_=M):
     """read X_B, X_D, d once (c64), write w once (c64)."""
-    return 2 * M * L * 8 + M * 8 + nV * L * 8
+    return 2 * M_ * L_ * 8 + M_ * 8 + nV * L_ * 8
 
 
-def synth(n_bins, seed):
+def synth(n_bins, seed, L_=L, M_=M):
     rng = np.random.default_rng(seed)
 
     def cn(*s):
@@ -49,12 +67,16 @@ def synth(n_bins, seed):
         out.real = rng.standard_normal(s, dtype=np.float32) * np.float32(np.sqrt(0.5))
         out.imag = rng.standard_normal(s, dtype=np.float32) * np.float32(np.sqrt(0.5))
         return out
-    return cn(n_bins, M, L), cn(n_bins, M, L), cn(n_bins, M)
+    return cn(n_bins, M_, L_), cn(n_bins, M_, L_), cn(n_bins, M_)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle on the host cores
+# ---------------------------------------------------------------------------------------------------------------------
 def _cpu_loop_worker(job):
-    """One worker of the all-core CPU leg: `reps` passes of the per-bin loop over its own 2048-bin sample, 1 BLAS thread."""
-    seed, reps, ranks, mu = job
+    """One worker of the all-core CPU leg: `reps` passes of the per-bin loop over its own 2048-bin sample and `vreps` passes
+    of the batched-LAPACK variant, 1 BLAS thread (the pool has one worker per core: nothing is oversubscribed)."""
+    seed, reps, vreps, ranks, mu = job
     os.environ.setdefault("OMP_NUM_THREADS", "1")
     from oracle import subband
     try:
@@ -69,7 +91,13 @@ def _cpu_loop_worker(job):
         t0 = time.perf_counter()
         for _ in range(reps):
             subband.update(XB, XD, d, mu, list(ranks))
-        return reps * 2048, time.perf_counter() - t0
+        t_loop = time.perf_counter() - t0
+        subband.update_vectorised(XB[:64], XD[:64], d[:64], mu, list(ranks))
+        t0 = time.perf_counter()
+        for _ in range(vreps):
+            subband.update_vectorised(XB, XD, d, mu, list(ranks))
+        t_vec = time.perf_counter() - t0
+    return reps * 2048, t_loop, vreps * 2048, t_vec
 
 
 def cpu_model():
@@ -82,9 +110,62 @@ def cpu_model():
     return "unknown"
 
 
+def host_cores():
+    """How many single-threaded workers this process may usefully run: one per PHYSICAL core of the host, clipped by what
+    the box grants this process (scheduler affinity, cgroup CPU quota).  Returns (workers, description dict)."""
+    logical = os.cpu_count() or 1
+    info = {"host_cpus": logical}
+    cores = set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    physical = len(cores) or logical
+    info["physical_cores"] = physical
+    n = physical
+    try:
+        aff = len(os.sched_getaffinity(0))
+        info["affinity_cpus"] = aff
+        if aff < logical:
+            n = min(n, aff)              # a restricted mask: what it grants, hyper-threads or not
+    except AttributeError:  # pragma: no cover
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    q = int(txt[0]) / int(txt[1])
+                    info["cgroup_cpu_quota"] = q
+                    n = min(n, max(1, int(q)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    info["cgroup_cpu_quota"] = q / per
+                    n = min(n, max(1, int(q / per)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    if os.environ.get("APV_BENCH_CPU_PROCS"):
+        n = max(1, int(os.environ["APV_BENCH_CPU_PROCS"]))
+        info["override"] = "APV_BENCH_CPU_PROCS"
+    return max(1, n), info
+
+
 def cpu_baseline(ranks, mu, budget_s=8.0):
     """The oracle (a NumPy port of apvast.py:20-36 + 329-364 + 406-414 per bin) on the host cores: the per-bin loop on
-    one core and on all cores (one process per core), and the batched-LAPACK variant."""
+    one core and on every core this process is granted (one single-threaded process per physical core), and
+    the batched-LAPACK variant in the same pool (one BLAS thread per worker)."""
     from oracle import subband
     try:
         from threadpoolctl import threadpool_limits
@@ -93,53 +174,245 @@ def cpu_baseline(ranks, mu, budget_s=8.0):
     import contextlib
     XB, XD, d = synth(2048, 4321)
     n = 256
-    subband.update(XB[:n], XD[:n], d[:n], mu, list(ranks))          # warm-up (first LAPACK calls are slow)
-    t0 = time.perf_counter()
-    subband.update(XB[:n], XD[:n], d[:n], mu, list(ranks))
-    dt = time.perf_counter() - t0
-    reps = int(min(64, max(1, round(budget_s / max(dt * 8, 1e-3)))))      # passes over the 2048-bin sample
-    with (threadpool_limits(limits=1) if threadpool_limits else contextlib.nullcontext()):
+    one = (lambda: threadpool_limits(limits=1)) if threadpool_limits else contextlib.nullcontext
+    with one():
+        subband.update(XB[:n], XD[:n], d[:n], mu, list(ranks))          # warm-up (first LAPACK calls are slow)
+        t0 = time.perf_counter()
+        subband.update(XB[:n], XD[:n], d[:n], mu, list(ranks))
+        dt = time.perf_counter() - t0
+        reps = int(min(64, max(1, round(budget_s / max(dt * 8, 1e-3)))))      # passes over the 2048-bin sample
         t0 = time.perf_counter()
         for _ in range(reps):
             subband.update(XB, XD, d, mu, list(ranks))
         loop1 = reps * 2048 / (time.perf_counter() - t0)
+        subband.update_vectorised(XB[:n], XD[:n], d[:n], mu, list(ranks))
+        t0 = time.perf_counter()
+        subband.update_vectorised(XB, XD, d, mu, list(ranks))
+        dtv = time.perf_counter() - t0
+    vreps = int(min(64, max(1, round(0.25 * budget_s / max(dtv, 1e-3)))))
     # all cores: the loop is interpreter-bound, so one process per core (spawned: this process holds a GPU context)
-    ncpu = os.cpu_count() or 1
-    try:
-        ncpu = min(ncpu, len(os.sched_getaffinity(0)))
-    except AttributeError:  # pragma: no cover
-        pass
-    nproc = max(1, min(ncpu, int(os.environ.get("APV_BENCH_CPU_PROCS", "16"))))
-    loop_all = None
+    nproc, cores_info = host_cores()
+    loop_all = vec_all = None
+    pool_wall = None
     try:
         import multiprocessing as mp
         with mp.get_context("spawn").Pool(nproc) as pool:
             t0 = time.perf_counter()
-            res = pool.map(_cpu_loop_worker, [(5000 + i, reps, tuple(ranks), mu) for i in range(nproc)])
-            wall = time.perf_counter() - t0
+            res = pool.map(_cpu_loop_worker, [(5000 + i, reps, vreps, tuple(ranks), mu) for i in range(nproc)], chunksize=1)
+            pool_wall = time.perf_counter() - t0
         # rate while every worker was inside its timed loop: total updates / slowest worker's loop time
         loop_all = sum(r[0] for r in res) / max(r[1] for r in res)
-        pool_wall = wall
+        vec_all = sum(r[2] for r in res) / max(r[3] for r in res)
     except Exception as ex:  # pragma: no cover
         print(f"[bench] all-core CPU leg failed: {ex}", file=sys.stderr)
-        pool_wall = None
-    t0 = time.perf_counter()
-    for _ in range(max(1, reps // 2)):
-        subband.update_vectorised(XB, XD, d, mu, list(ranks))
-    vec = max(1, reps // 2) * 2048 / (time.perf_counter() - t0)
     out = {"value": loop_all if loop_all else loop1, "unit": "updates/s", "cores": nproc if loop_all else 1, "kind": "port",
            "sample": f"{reps} passes over 2048 bins of the same 16x32 workload per worker, per-bin jdiag loop "
-                     f"(oracle/subband.py), {nproc if loop_all else 1} single-threaded processes",
+                     f"(oracle/subband.py), {nproc if loop_all else 1} single-threaded processes, one per core granted",
            "one_core_value": loop1, "one_core_sample": f"{reps * 2048} bin-updates, 1 thread",
-           "vectorised_value": vec, "vectorised_cores": os.cpu_count(),
-           "vectorised_sample": "same sample, batched numpy cholesky+eigh, default BLAS threading",
-           "host_cpus": os.cpu_count(), "cpu_model": cpu_model(), "pool_wall_s": pool_wall}
+           "vectorised_value": vec_all, "vectorised_cores": nproc if vec_all else None,
+           "vectorised_sample": f"{vreps} passes over the same sample per worker, batched numpy cholesky+eigh, one BLAS thread "
+                                "per worker (the same pool)",
+           "cpu_model": cpu_model(), "pool_wall_s": pool_wall}
+    out.update(cores_info)
     try:
         from threadpoolctl import threadpool_info
         out["blas"] = [{k: i.get(k) for k in ("internal_api", "version", "num_threads")} for i in threadpool_info()]
     except Exception:  # pragma: no cover
         pass
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# sub-records of the N = 1 line
+# ---------------------------------------------------------------------------------------------------------------------
+def pink(n, seed):
+    """SURVEY.md 8(d) cfg3 input: white N(0,1) shaped by 1/sqrt(f) in the rfft domain, DC zeroed, unit RMS."""
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((2, n))
+    X = np.fft.rfft(x, axis=1)
+    f = np.arange(X.shape[1], dtype=float)
+    f[0] = 1.0
+    X /= np.sqrt(f)
+    X[:, 0] = 0.0
+    y = np.fft.irfft(X, n, axis=1)
+    return y / np.sqrt((y ** 2).mean(axis=1, keepdims=True))
+
+
+def also_cfg3(device, hops=468):
+    """BASELINE config 3 through the class a reference caller uses (ap_vast_unofficial_amd.apvast): 10 s of pink noise at
+    48 kHz, N = 2048, H = 1024, 16 loudspeakers x 32 control points per zone, 800-tap synthetic responses, both zone
+    programs, V = 1, float64 end to end.  Timed: `hops` calls of process_input_buffers (H2D of the hop and D2H of the
+    (H, L) outputs inside), then ONE process_signal call over the same samples."""
+    from ap_vast_unofficial_amd.apvast import apvast
+    N, H, L3, M3, P = 2048, 1024, 16, 32, 800
+    rng = np.random.default_rng(99)
+    env = np.exp(-np.arange(P) / 120.0)[:, None, None]
+    rirA = rng.standard_normal((P, L3, M3)) * env * 1e-3
+    rirB = rng.standard_normal((P, L3, M3)) * env * 1e-3
+    x = pink(hops * H, 2024)
+    rec = {"workload": f"cfg3: streaming, {hops} hops = {hops * H / 48000.0:.2f} s at 48 kHz, N={N} H={H} L={L3} M={M3} V=1 "
+                       f"rir_len={P}, both zone programs, pink noise, through class apvast",
+           "dtype": "f64", "hops": hops, "bins_per_hop": N // 2 + 1}
+    obj = apvast(N, rirA, rirB, 100, 20, 0, 0, 1, 1.0, 4 * N, hop_size=H, sampling_rate=48000, perceptual=False,
+                 dtype="f64", seed=0, device=device)
+    try:
+        for h in range(4):                                     # graph capture of both ring phases, first-touch costs
+            obj.process_input_buffers(x[0, h * H:(h + 1) * H], x[1, h * H:(h + 1) * H])
+        t0 = time.perf_counter()
+        for h in range(hops):
+            out = obj.process_input_buffers(x[0, h * H:(h + 1) * H], x[1, h * H:(h + 1) * H])
+        dt = time.perf_counter() - t0
+        assert out[0][0].shape == (H, L3)
+        rec["process_input_buffers"] = {"ms_per_hop": dt / hops * 1e3, "blocks_per_s": hops / dt,
+                                        "realtime_factor": (hops * H / 48000.0) / dt,
+                                        "subband_updates_per_s": hops * (N // 2 + 1) * 2 / dt}
+        obj.process_signal(x[0, :32 * H], x[1, :32 * H])       # sets up the pipelined path (second spectra set, staging)
+        # the caller's output array, touched once: 10 s of drive signals are 184 MB and first-touch page faults of that much
+        # fresh memory would otherwise be what is timed (apvast.process_signal(..., out=))
+        buf = np.zeros(obj.signal_output_shape(hops * H), obj.signal_output_dtype)
+        t0 = time.perf_counter()
+        res = obj.process_signal(x[0], x[1], out=buf)
+        dt = time.perf_counter() - t0
+        assert res[0][0].shape == (hops * H, L3)
+        rec["process_signal"] = {"ms_per_hop": dt / hops * 1e3, "blocks_per_s": hops / dt,
+                                 "realtime_factor": (hops * H / 48000.0) / dt,
+                                 "subband_updates_per_s": hops * (N // 2 + 1) * 2 / dt,
+                                 "output": "caller-provided array (out=), touched before the call"}
+        rec["not_converged_hops"] = obj.not_converged
+    finally:
+        obj.close()
+    return rec
+
+
+def load_traffic(tag, K, dtype):
+    """HBM bytes per launch of the dominant kernel from the committed counter passes (profiles/traffic*.json: rocprofv3
+    --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, corrected as MI355X_MICROARCH.md prescribes); None unless the
+    record is for exactly this workload."""
+    tpath = os.path.join(ROOT, "profiles", tag)
+    try:
+        tj = json.load(open(tpath))
+        if tj.get("updates_per_launch", tj.get("blocks", 0) * BINS) == K and tj.get("dtype") == dtype:
+            return tj.get("hbm_bytes_per_launch")
+    except Exception:
+        pass
+    return None
+
+
+def also_cfg5(Engine, device, steps=10, warmup=3):
+    """BASELINE config 5 at kernel level: 64 loudspeakers x 128 control points x 2048 bins, float64, V in {1, 32, 64}."""
+    L5, M5, K5 = 64, 128, 2048
+    ranks = (1, 32, 64)
+    eng = Engine(K5, L5, M5, ranks=ranks, mu=1.0, compute_dtype="f64", out_c128=False, device=device)
+    try:
+        XB, XD, d = synth(K5, 1234, L5, M5)
+        dXB, dXD, dd = eng.to_device(XB), eng.to_device(XD), eng.to_device(d)
+        dw, ds = eng.alloc(K5 * len(ranks) * L5 * 8), eng.alloc(K5 * 4)
+        for _ in range(warmup):
+            eng.update_dev(dXB, dXD, dd, dw, None, ds)
+        eng.sync()
+        t0 = time.perf_counter()
+        eng.timer_start()
+        for _ in range(steps):
+            eng.update_dev(dXB, dXD, dd, dw, None, ds)
+        kern_ms = eng.timer_stop() / steps
+        eng.sync()
+        wall = time.perf_counter() - t0
+        st = ds.download((K5,), np.int32)
+    finally:
+        eng.close()
+    bpu = bytes_per_update(len(ranks), L5, M5)
+    fpu = flop_per_update(L5, M5, L5)
+    ach = bpu * K5 / (kern_ms * 1e-3)
+    alu = K5 / (kern_ms * 1e-3) * fpu
+    return {"workload": "cfg5: 64 loudspeakers x 128 control points x 2048 bins, fused correlate+GEVD+VAST filter, 1 zone "
+                        "program, V in {1, 32, 64}, c64 in / c64 out",
+            "dtype": "f64", "steps": steps, "value": steps * K5 / wall, "unit": "updates/s", "ms_per_step": wall / steps * 1e3,
+            "status_nonzero_bins": int((st != 0).sum()),
+            "roofline": {"bound": "mfma", "kernel": "gevd64x2_kernel<fused>", "kernel_ms": kern_ms,
+                         "achieved": alu / 1e12, "peak": PEAK_FLOPS["f64"] / 1e12, "unit": "TFLOP/s", "frac": alu / PEAK_FLOPS["f64"],
+                         "flop_per_update": fpu, "updates_per_launch": K5,
+                         "note": "SURVEY.md 8(d) prices cfg5 against the float64 vector/matrix peak (78.6 TFLOP/s: the same number on "
+                                 "MI355X) with its LAPACK-style flop count; the HBM fraction is reported beside it",
+                         "hbm": {"algorithmic_bytes_per_update": bpu, "achieved_gbps": ach / 1e9, "peak_gbps": HBM_PEAK / 1e9,
+                                 "frac": ach / HBM_PEAK, "traffic": load_traffic("traffic_cfg5.json", K5, "f64")}}}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# self-launch
+# ---------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n, argv):
+    """`--gpus n` without a launcher: start n children of this program, one per GPU, and relay rank 0's line.  Runs before
+    anything in this process has touched a GPU (it never does).  Returns the exit code."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "APV_BENCH_CHILD": "1"})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL needs it)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    print(f"[bench] launcher: {n} ranks started (pids {[p.pid for p in procs]}), rendezvous 127.0.0.1:{port}",
+          file=sys.stderr, flush=True)
+    rc = 0
+    deadline = time.time() + float(os.environ.get("APV_BENCH_LAUNCH_TIMEOUT", "1500"))
+    pending = set(range(n))
+    while pending:
+        for r in list(pending):
+            code = procs[r].poll()
+            if code is not None:
+                pending.discard(r)
+                if code != 0:
+                    print(f"[bench] rank {r} exited with code {code}", file=sys.stderr, flush=True)
+                    rc = rc or (code if code > 0 else 1)
+        if (rc or time.time() > deadline) and pending:
+            # one rank failed (or nothing finished in time): the others would wait for it in a collective.  End exactly the
+            # processes started above.
+            for r in pending:
+                procs[r].terminate()
+            for r in pending:
+                try:
+                    procs[r].wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    procs[r].kill()
+            rc = rc or 1
+            pending = set()
+        elif pending:
+            time.sleep(0.05)
+    out = procs[0].stdout.read().decode() if procs[0].stdout else ""
+    if rc == 0:
+        sys.stdout.write(out)
+        sys.stdout.flush()
+    else:
+        sys.stderr.write(out)
+    return rc
+
+
+def dryrun_rank():
+    """APV_BENCH_DRYRUN=1 (CPU test of the launcher): the rank's bootstrap without a GPU -- rendezvous over the TCP hub, the
+    128-byte id broadcast, the max-reduction of the elapsed time -- and rank 0's line."""
+    from ap_vast_unofficial_amd.rendezvous import Rendezvous
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("APV_BENCH_DRYRUN_FAIL_RANK") == str(rank):
+        raise SystemExit(7)                                  # the launcher's failure path: this rank dies before the rendezvous
+    rz = Rendezvous.from_env()
+    uid = rz.broadcast(bytes(range(128)) if rank == 0 else None)
+    assert uid == bytes(range(128))
+    worst = rz.allreduce(1.0 + rank, max)
+    ranks_seen = rz.allreduce(1 << rank, lambda v: sum(v))
+    rz.close()
+    if rank == 0:
+        print(json.dumps({"dryrun": True, "n_gpus": world, "max_elapsed": worst, "rank_mask": ranks_seen,
+                          "local_rank": int(os.environ.get("LOCAL_RANK", "-1"))}), flush=True)
 
 
 def main():
@@ -153,7 +426,14 @@ def main():
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--prespin", type=float, default=0.3, help="seconds of untimed launches before the counted warm-up (clock ramp)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the cfg3 / cfg5 sub-records of the 1-GPU line")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not os.environ.get("APV_BENCH_FORCE_DIST"):
+        # no launcher: be one.  Nothing above or below this line has loaded HIP in this process.
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if os.environ.get("APV_BENCH_DRYRUN"):
+        return dryrun_rank()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -255,20 +535,13 @@ def main():
         elapsed = rz.allreduce(elapsed, max)
         gather_ms = rz.allreduce(gather_ms, max)
 
+    out = None
     if rank == 0:
         updates = args.steps * K * world
         value = updates / elapsed
         bpu = bytes_per_update(len(ranks))
         achieved = bpu * K / (kern_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("updates_per_launch", tj.get("blocks", 0) * BINS) == K and tj.get("dtype") == args.dtype:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic = load_traffic("traffic.json", K, args.dtype)
         alu = (K / (kern_ms * 1e-3)) * FLOP_PER_UPDATE
         out = {
             "metric": "subband filter-updates/sec (blocks x bins / s), 16-spk/32-mic/1024-bin",
@@ -280,9 +553,13 @@ def main():
                        "updates_per_rank_per_step": K, "updates_per_step": K * world,
                        "input": "complex64", "output": "complex64",
                        "parallelism": f"bins sharded x{world}" if multi else "single GPU",
-                       "collective": collective, "prespin_launches": n_spin, "device": eng.device_info()},
+                       "collective": collective, "prespin_launches": n_spin, "device": eng.device_info(),
+                       "launcher": "self (bench.py started its own ranks)" if os.environ.get("APV_BENCH_CHILD") else
+                                   ("external (RANK/WORLD_SIZE from the environment)" if world > 1 else "none")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved * 1e9 / HBM_PEAK, "traffic": traffic,
+                         "traffic_source": "profiles/traffic.json (rocprofv3 --pmc passes of this command, committed; not re-measured "
+                                           "in this run)" if traffic else None,
                          "kernel": "gevd16m_kernel_f64<fused>" if args.dtype == "f64" else "gevd16m_kernel<float, fused>", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_update": bpu, "updates_per_launch": K,
                          "alu": {"flop_per_update": FLOP_PER_UPDATE, "achieved_tflops": alu / 1e12,
@@ -296,13 +573,27 @@ def main():
             out["collective_us"] = gather_ms * 1e3
             out["collective_bytes_per_rank"] = gather_bytes
             out["collective_gbps_per_link"] = gather_bytes / (gather_ms * 1e-3) / 1e9 if gather_ms > 0 else None
-        if not args.no_cpu_baseline and world == 1 and not multi:
-            out["cpu_baseline"] = cpu_baseline(ranks, mu)
-        print(json.dumps(out), flush=True)
 
+    # the headline's buffers go before the sub-records allocate theirs
+    for b in (dXB, dXD, dd, dw, dw2, dstatus, dw_all):
+        if b is not None:
+            b.free()
     eng.close()
     if rz is not None:
         rz.close()
+
+    if rank == 0:
+        if world == 1 and not multi and not args.no_also:
+            also = {}
+            for name, fn in (("cfg3", lambda: also_cfg3(local_rank)), ("cfg5", lambda: also_cfg5(Engine, local_rank))):
+                try:
+                    also[name] = fn()
+                except Exception as ex:  # the headline stands on its own: a failing sub-record is reported, not fatal
+                    also[name] = {"error": f"{type(ex).__name__}: {ex}"}
+            out["also"] = also
+        if not args.no_cpu_baseline and world == 1 and not multi:
+            out["cpu_baseline"] = cpu_baseline(ranks, mu)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

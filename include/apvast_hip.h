@@ -96,7 +96,11 @@ typedef struct apv_config {
     int32_t frontend;         /* streaming (subband) front-end precision -- RIRs, FIR, rings, STFT, spectra, overlap-add:
                                  0 = follow compute_dtype (APV_F64: everything float64, as the reference's lfilter / rfft /
                                  irfft are, apvast.py:171-192, 202-203, 461-496), 1 = float32, 2 = float64 */
-    int32_t reserved[5];
+    int32_t out_layout;       /* streaming (subband) outputs: 0 = channel-major h_out [n_out][H]; 1 = sample-major in groups of L channels
+                                 (one zone program and rank each), h_out [n_out / L][H][L] -- the (hop, loudspeaker) arrays the
+                                 reference's caller receives (apvast.py:498-504), so the host binding reshapes instead of
+                                 transposing; apv_process_signal* then writes [n_out / L][n_hops * H][L] */
+    int32_t reserved[4];
     double  sweep_tol2;       /* Jacobi stop threshold: a sweep whose pivots satisfy sum |c_pq|^2 <= sweep_tol2 ||C||_F^2 is the
                                  last one (quadratic convergence leaves ~sweep_tol2^2 behind).  0 = default (1e-16 in float64:
                                  csrc/gevd16_common.h Prec<double>, csrc/kernels_gevd.hip Tol<double>; 1e-8 in float32);
@@ -180,7 +184,8 @@ int  apv_istft_ola_dev(apv_handle* h, int32_t n_ch, const void* d_spec, float* d
 int  apv_stream_init(apv_handle* h, int32_t rir_len, const double* h_rir_A, const double* h_rir_B,
                      int32_t reference_index_A, int32_t reference_index_B, int32_t modeling_delay);
 /* One hop of both input signals (H float32 samples each).  h_out: [n_out][H] float32 with channels
- * [zone A: nV x L][zone B: nV x L] (zones that run) followed by [A_t: L][B_t: L].
+ * [zone A: nV x L][zone B: nV x L] (zones that run) followed by [A_t: L][B_t: L]  (cfg.out_layout = 1: the same groups of L
+ * channels, each written [H][L]).
  *                                                         replaces process_input_buffers, apvast.py:153-165 */
 int  apv_process_block(apv_handle* h, const float* h_in_A, const float* h_in_B, float* h_out);
 /* The same with float64 samples on the host side (lossless with the float64 front-end; either entry point works

@@ -246,6 +246,45 @@ def test_rendezvous_rejects_strangers_and_never_unpickles():
         R._send(None, {"a": 1})
 
 
+def test_bench_launches_its_own_ranks():
+    """`bench.py --gpus N` without a launcher starts N ranks itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in
+    their environment), relays rank 0's line and fails when a rank fails.  APV_BENCH_DRYRUN keeps the ranks off the GPU: they run
+    the real bootstrap (TCP hub, id broadcast, max-reduction) and stop there."""
+    import json
+    import subprocess
+    env = dict(os.environ, APV_BENCH_DRYRUN="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1                                   # ONE line, rank 0's
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["rank_mask"] == 0b11 and rec["max_elapsed"] == 2.0 and rec["local_rank"] == 0
+    assert "2 ranks started" in r.stderr
+    # a rank that dies takes the job down with a non-zero exit instead of leaving the others in the rendezvous
+    env["APV_BENCH_DRYRUN_FAIL_RANK"] = "1"
+    env["APV_BENCH_LAUNCH_TIMEOUT"] = "60"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True,
+                       timeout=120)
+    assert r.returncode != 0 and r.stdout.strip() == "" and "rank 1 exited with code 7" in r.stderr
+    # under an external launcher (WORLD_SIZE set) the program is a rank, not a launcher
+    env.pop("APV_BENCH_DRYRUN_FAIL_RANK")
+    env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], env=env, capture_output=True, text=True,
+                       timeout=120)
+    assert r.returncode == 0 and json.loads(r.stdout)["n_gpus"] == 1 and "ranks started" not in r.stderr
+
+
+def test_host_cores_counts_what_the_box_grants():
+    sys.path.insert(0, ROOT)
+    import bench
+    n, info = bench.host_cores()
+    assert 1 <= n <= info["host_cpus"] and info["physical_cores"] >= 1
+    assert n <= info.get("affinity_cpus", n) or info.get("override")
+
+
 def test_bench_and_package_do_not_import_torch():
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "import torch" not in src
