@@ -31,7 +31,7 @@ EXPORTS = (
     "apv_bb_set_rank_list", "apv_bb_init", "apv_bb_set_perceptual", "apv_bb_process_block", "apv_bb_get_state", "apv_bb_set_state",
     "apv_predict_pressure", "apv_vast_static",
     "apv_comm_unique_id", "apv_comm_init", "apv_allgather_filters_dev", "apv_comm_last_gather", "apv_comm_barrier",
-    "apv_device_sync", "apv_device_info",
+    "apv_debug_set_stamps", "apv_device_sync", "apv_device_info",
 )
 
 
@@ -126,6 +126,7 @@ def load():
     lib.apv_allgather_filters_dev.argtypes = [vp, vp, vp]
     lib.apv_comm_last_gather.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(sz)]
     lib.apv_comm_barrier.argtypes = [vp]
+    lib.apv_debug_set_stamps.argtypes = [vp, vp]
     lib.apv_device_sync.argtypes = [vp]
     lib.apv_device_info.argtypes = [vp, C.c_char_p, C.POINTER(i32), C.POINTER(i32)]
     for name in EXPORTS:
@@ -571,6 +572,10 @@ class Engine:
 
     def comm_barrier(self):
         self._chk(self.lib.apv_comm_barrier(self.h))
+
+    def debug_set_stamps(self, dbuf):
+        """Diagnostics: register (or, with None, remove) the stage-stamp buffer of the order-16 kernel's diagnostic instantiation."""
+        self._chk(self.lib.apv_debug_set_stamps(self.h, dbuf.ptr if dbuf is not None else None))
 
     def device_sync(self):
         self._chk(self.lib.apv_device_sync(self.h))

@@ -44,6 +44,11 @@ struct GevdParams {
     void* w1;
     void* lam1;
     int32_t* status1;
+    // streaming: 1 = this launch shares the chip with the transforms of the NEXT chunk of hops, which are the longer chain
+    // (chunked whole-signal path): the waves keep the default issue priority instead of raising theirs
+    int yield_issue;
+    // diagnostic builds only (tools/probes/stage_stamps.py): s_memtime at the stage boundaries, [zones][K][16]; null in normal use
+    unsigned long long* stamps;
 };
 
 struct apv_handle {
@@ -62,6 +67,7 @@ struct apv_handle {
     size_t lspill_bytes;
     void* d_Rscratch;  // [2][K][L][L] + [K][L] c64: MFMA correlation output of the split n in {32, 64} f32 update
     size_t rscratch_bytes;
+    unsigned long long* d_stamps;   // apv_debug_set_stamps: stage-stamp buffer of the diagnostic kernel instantiation (caller's)
     struct apv_stream* st;   // streaming state (apv_stream_init), owned
     struct apv_bb* bb;       // broadband streaming state (apv_bb_init), owned
     std::vector<int> bb_rank_list;   // apv_bb_set_rank_list: ranks of the next apv_bb_init (empty = 1..V)
@@ -157,6 +163,18 @@ struct ApvInputUpdate {
 };
 hipError_t apv_launch_fir_fft_jobs(int f64, int F, int n_jobs, const void* const* Hf, const void* const* Xf, void* const* resp,
                                    const int* n_ch, int P, int H, int N, int ring_off, const ApvInputUpdate* upd, hipStream_t s);
+
+// whole-signal path, a chunk of hops per launch (kernels_stft.hip / kernels_stream.hip; see process_signal_chunked_t in stream.hip)
+hipError_t apv_launch_stft_analysis_chunk(int f64, int N, int n_jobs, const void* const* x, const int* n_ch, void* const* spec,
+                                          const long* stride_c, const long* stride_k, long x_stride, long x_hop, const long* spec_hop,
+                                          int n_hops, hipStream_t s, std::string* why);
+hipError_t apv_launch_fir_fft_chunk(int f64, int F, int n_jobs, const void* const* Hf, const void* const* Xf, long x_hop_stride,
+                                    void* const* resp, const int* n_ch, int P, int H, int row_stride, int pos0, int n_hops,
+                                    hipStream_t s);
+hipError_t apv_launch_rows_copy(int f64, int rows, int len, void* dst, long ds, int d0, int dmod, const void* src, long ss, int s0,
+                                int smod, hipStream_t s);
+hipError_t apv_launch_chunk_inputs(int f64, int P, int H, int N, int nc, int pad, int RL, const void* const old_hist[2],
+                                   void* const new_hist[2], const void* pin, void* inL, hipStream_t s);
 
 // kernels_stream.hip
 // y = FIR(rir, x) for one hop, appended to the ring response buffers:

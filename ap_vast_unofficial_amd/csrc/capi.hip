@@ -63,6 +63,7 @@ GevdParams apv_base_params(const apv_handle* h) {
     p.sweep_tol2 = c.sweep_tol2;
     p.out_c128 = c.out_c128;
     p.Lspill = h->d_Lspill;
+    p.stamps = h->d_stamps;
     return p;
 }
 
@@ -155,6 +156,7 @@ int apv_create(const apv_config* cfg, apv_handle** out) {
     h->lspill_bytes = 0;
     h->d_Rscratch = nullptr;
     h->rscratch_bytes = 0;
+    h->d_stamps = nullptr;
     h->st = nullptr;
     h->bb = nullptr;
     h->gl_ws = nullptr;
@@ -625,6 +627,12 @@ int apv_comm_barrier(apv_handle* h) {
     ncclResult_t r = ncclAllReduce(h->d_bar, h->d_bar, 1, ncclInt32, ncclSum, (ncclComm_t)h->comm, h->comm_stream);
     if (r != ncclSuccess) return fail(h, APV_ERR_RCCL, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
     HIPCHK(h, hipStreamSynchronize(h->comm_stream));
+    return APV_OK;
+}
+
+int apv_debug_set_stamps(apv_handle* h, void* d_stamps) {
+    if (!h) return APV_ERR_ARG;
+    h->d_stamps = static_cast<unsigned long long*>(d_stamps);
     return APV_OK;
 }
 

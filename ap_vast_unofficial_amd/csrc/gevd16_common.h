@@ -80,9 +80,11 @@ template <> struct Mfma16<float> {
     static __device__ __forceinline__ int row(int lane, int t) { return 4 * (lane >> 4) + t; }
 };
 
-template <typename T, typename XT>
+struct NoStamp { __device__ __forceinline__ void operator()(int) const {} };
+// `stamp(i)`: diagnostic hook (stage stamps of the diagnostic kernel instantiation; NoStamp in the product)
+template <typename T, typename XT, typename ST = NoStamp>
 __device__ __forceinline__ void correlate16(const XT* __restrict__ X, const XT* __restrict__ dvec, int M,
-                                            Cx<T>* dst, Cx<T>* sr, int lane) {
+                                            Cx<T>* dst, Cx<T>* sr, int lane, ST stamp = ST(), int stamp_base = 0) {
     using MM = Mfma16<T>;
     typename MM::V re = {0, 0, 0, 0}, im = {0, 0, 0, 0};
     T rx = 0, ry = 0;
@@ -99,6 +101,10 @@ __device__ __forceinline__ void correlate16(const XT* __restrict__ X, const XT* 
             const bool ok = m < M;
             xv[q] = ok ? X[(size_t)(mc + 4 * q) * N + lane] : zero;
             dv[q] = (ok && dvec != nullptr) ? dvec[m] : zero;
+        }
+        if constexpr (!__is_same(ST, NoStamp)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            stamp(stamp_base);                                   // the chunk's loads have landed
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -117,6 +123,7 @@ __device__ __forceinline__ void correlate16(const XT* __restrict__ X, const XT* 
     const int col = lane & 15;
 #pragma unroll
     for (int t = 0; t < 4; ++t) dst[MM::row(lane, t) * LD + col] = mk<T>(re[t], im[t]);
+    stamp(stamp_base + 1);                                   // MFMAs retired (the stores above read the accumulators)
     __syncthreads();                                         // one wave per workgroup: an LDS ordering point
     T pt[4];
 #pragma unroll

@@ -100,8 +100,21 @@ __device__ __forceinline__ void cmm16x(FA fa, FB fb, int lane, Cx<double> out[4]
 }
 
 // XT: element type of the fused input slabs (float2 = c64, double2 = c128: the float64 streaming front-end)
-template <typename T, bool FUSED, typename XT>
+// DBG: the diagnostic instantiation.  It alone carries the run-time `debug_stop` tests (stage cuts and A/B switches of the
+// probes under tools/probes/) and the in-kernel stage stamps (p.stamps); in the product instantiation `dstop` is the constant 0
+// and all of it folds away, the round-2a two-sided pre-solve included.
+template <typename T, bool FUSED, typename XT, bool DBG>
 __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
+    const int dstop = DBG ? p.debug_stop : 0;
+    // stage stamps (diagnostic build only): s_memtime of lane 0 at the stage boundaries, 8 per bin, into a buffer of their own
+    auto stamp = [&](int i) {
+        if constexpr (DBG) {
+            if (p.stamps != nullptr && threadIdx.x == 0)
+                p.stamps[((size_t)blockIdx.y * p.K + blockIdx.x) * 16 + i] = __builtin_amdgcn_s_memtime();
+        }
+    };
+    stamp(0);
+    if constexpr (DBG) { if (p.stamps != nullptr && threadIdx.x == 0) p.stamps[((size_t)blockIdx.y * p.K + blockIdx.x) * 16 + 15] = __builtin_amdgcn_s_memrealtime(); }
     // zone program of a two-zone launch (blockIdx.y); the argument block itself stays in scalar registers
     const bool z1 = (blockIdx.y == 1);
     const XT* const pXB = reinterpret_cast<const XT*>(z1 ? p.XB1 : p.XB);
@@ -127,15 +140,22 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
     const int lane = threadIdx.x;
     const int k = blockIdx.x;
     int status = 0;
-    // One wave is a long dependent chain; in the streaming pipeline the launch shares the chip with the next hop's transforms,
-    // whose waves would otherwise take every other issue slot: this wave goes first.  (No effect when the kernel runs alone.)
-    __builtin_amdgcn_s_setprio(3);
+    // One wave is a long dependent chain; in the per-hop streaming pipeline the launch shares the chip with the next hop's
+    // transforms, whose waves would otherwise take every other issue slot: this wave goes first.  (No effect when the kernel runs
+    // alone.)  The chunked whole-signal path asks for the opposite (yield_issue): there the transforms are the longer chain.
+    if (!p.yield_issue) __builtin_amdgcn_s_setprio(3);
 
     // ---------------- stage 0 ----------------
     if constexpr (FUSED) {
         const size_t slab = (size_t)k * p.M * N;
-        correlate16<T, XT>(pXB + slab, pd + (size_t)k * p.M, p.M, sA, sr, lane);
-        correlate16<T, XT>(pXD + slab, (const XT*)nullptr, p.M, sB, sr, lane);
+        if constexpr (DBG) {
+            correlate16<T, XT>(pXB + slab, pd + (size_t)k * p.M, p.M, sA, sr, lane, stamp, 8);
+            stamp(10);
+            correlate16<T, XT>(pXD + slab, (const XT*)nullptr, p.M, sB, sr, lane, stamp, 11);
+        } else {
+            correlate16<T, XT>(pXB + slab, pd + (size_t)k * p.M, p.M, sA, sr, lane);
+            correlate16<T, XT>(pXD + slab, (const XT*)nullptr, p.M, sB, sr, lane);
+        }
     } else {
         const C* RB = reinterpret_cast<const C*>(p.RB) + (size_t)k * N * N;
         const C* RD = reinterpret_cast<const C*>(p.RD) + (size_t)k * N * N;
@@ -148,7 +168,8 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
         if (lane < N) sr[lane] = p.r ? reinterpret_cast<const C*>(p.r)[(size_t)k * N + lane] : mk<T>(0, 0);
     }
     wsync();
-    if (p.debug_stop == 1) return;
+    stamp(1);
+    if (dstop == 1) return;
 
     // ---------------- stage 1: Cholesky of B + reg I with W = L^-1 ----------------
     // lane (i = lane>>2, jq = lane&3) owns B[i][jq+4t] and W[i][jq+4t], t = 0..3, in registers
@@ -209,7 +230,8 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) wrow[t] = mk<T>(wrow[t].x * ri, wrow[t].y * ri);
     }
-    if (p.debug_stop == 2) return;
+    stamp(2);
+    if (dstop == 2) return;
 
     if (status == 0) {
         // W -> sB (R_D is spent)
@@ -237,7 +259,8 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
         }
         const T normF2 = wave_sum(nrm);
         wsync();
-        if (p.debug_stop == 3) return;
+        stamp(3);
+        if (dstop == 3) return;
 
         // ---------------- stage 3: register-resident Jacobi, XOR schedule ----------------
         const int a = lane >> 3, b = lane & 7;
@@ -267,7 +290,7 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
             // The sweeps are the cost of the kernel and packed-float ones cost a fraction of double ones, so C is first
             // diagonalised in float32: V32 with V32^H C V32 diagonal to ~1e-7.  V32 is then refined against the exact float64 C on
             // the matrix cores (below); W waits in registers meanwhile.
-            if (p.debug_stop != 4) {
+            if (dstop != 4) {
                 using CF = Cx<float>;
                 // looser than the float kernel's own 1e-8: the refinement follows anyway, so the float sweep that would only confirm
                 // convergence is not run (1e-6 measured best: at 1e-5 so many more bins need a second refinement step that the launch
@@ -277,7 +300,7 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
                 bool fconv = false, trust = true;
                 int fs;
                 int va = a, vb = b;                                                   // (row pair, slot) of this lane's part of V32
-                if (p.debug_stop != 11) {
+                if (dstop != 11) {
                     // one-sided form on the float Cholesky factor of 2^sexp C + delta I (same eigenvectors; the shift keeps the
                     // float pivots positive when C is singular to float precision).  The factor goes through sB, which is free
                     // until V32 lands there (W waits in registers), its column staging through the spent Cholesky staging.
@@ -286,14 +309,16 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
                     CF* const fG = reinterpret_cast<CF*>(&sB[0]);
                     CF (*const fcol)[16] = reinterpret_cast<CF(*)[16]>(&scol[0][0]);
                     chol16_f32<T, LD, LDF>(sA, sexp, kShift * sqrtf((float)normS2), fG, fcol, lane);
-                    if (p.debug_stop == 12) return;                                   // timing aids: 12 after the float factor, 13 after the sweeps
+                    stamp(4);
+                    if (dstop == 12) return;                                   // timing aids: 12 after the float factor, 13 after the sweeps
                     va = lane & 7; vb = lane >> 3;                                   // the one-sided solve's layout: lane = a + 8 b
                     f0t = fG[(2 * va) * LDF + vb]; f0b = fG[(2 * va) * LDF + 8 + vb];
                     f1t = fG[(2 * va + 1) * LDF + vb]; f1b = fG[(2 * va + 1) * LDF + 8 + vb];
                     float n2t, n2b;
-                    fs = jacobi16_onesided<LDF>(f0t, f0b, f1t, f1b, lane, (p.debug_stop >= 20 && p.debug_stop <= 27) ? __builtin_powif(10.f, 20 - p.debug_stop) : kPresolveTol2, (float)normS2, Prec<float>::max_sweeps, fconv, n2t, n2b, fG);
+                    fs = jacobi16_onesided<LDF>(f0t, f0b, f1t, f1b, lane, (dstop >= 20 && dstop <= 27) ? __builtin_powif(10.f, 20 - dstop) : kPresolveTol2, (float)normS2, Prec<float>::max_sweeps, fconv, n2t, n2b, fG);
                     trust = fconv && spectrum_ok(n2t, n2b);
-                    if (p.debug_stop == 13) {
+                    stamp(5);
+                    if (dstop == 13) {
                         if (lane == 0 && pstatus != nullptr) pstatus[k] = fs;        // sweeps of the pre-solve
                         return;
                     }
@@ -318,8 +343,8 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
                 // columns of V32 held by this lane: where the one-sided schedule leaves them, or (debug_stop == 11) the two-sided
                 // schedules' layout after an odd / even number of sweeps
                 const bool fnat = fs & 1;
-                const int fit = (p.debug_stop != 11) ? os_top_end(vb) : (fnat ? 2 * vb : vb);
-                const int fib = (p.debug_stop != 11) ? os_bot_end(vb) : (fnat ? 2 * vb + 1 : 8 + vb);
+                const int fit = (dstop != 11) ? os_top_end(vb) : (fnat ? 2 * vb : vb);
+                const int fib = (dstop != 11) ? os_bot_end(vb) : (fnat ? 2 * vb + 1 : 8 + vb);
                 const int mcol = lane & 15;
                 auto cj = [](C w) { return mk<T>(w.x, -w.y); };
                 wsync();
@@ -350,7 +375,7 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
                 constexpr double kSecondStep2 = 1e-4;
                 // debug_stop == 5: always the double sweeps (A/B timing); a caller-set sweep tolerance (jdiag: 1e-17) asks for more
                 // than the refinement's 1e-9 and gets the sweeps too
-                const bool refine_ok = (p.debug_stop != 5) && !(p.sweep_tol2 > 0.0);
+                const bool refine_ok = (dstop != 5) && !(p.sweep_tol2 > 0.0);
                 // Z goes straight into sA (T = C V is spent: every lane is past the third product) and the second-order
                 // eigenvalue terms into the idle coefficient array: nothing of this step stays in registers
                 T* const sLam2 = reinterpret_cast<T*>(&scoef[0]);
@@ -407,8 +432,8 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
                         l2 += xrow<1>(l2, lane);
                         if (mcol == 0) sLam2[row] = l2 + di;
                     }
-                    const bool pass = !__any(bad) || p.debug_stop == 10;                 // 10: guard off (timing aid, results invalid)
-                    if (p.debug_stop == 9 && !pass) status = 8 << step;                  // 9: mark the bins by the step they miss
+                    const bool pass = !__any(bad) || dstop == 10;                 // 10: guard off (timing aid, results invalid)
+                    if (dstop == 9 && !pass) status = 8 << step;                  // 9: mark the bins by the step they miss
                     // the double sweeps start from the triple (V, S, Gram) as it is: leave before anything of it is touched
                     if (!refine_ok || (!pass && (step == 1 || __any(hopeless)))) break;
                     wsync();
@@ -491,7 +516,7 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
         if constexpr (sizeof(T) == 4) {
             // float kernel: the one-sided form IS the solve (debug_stop == 11: the two-sided sweeps below, for A/B timing).
             // Eigenvalues are the squared column norms less the shift, eigenvectors the normalised columns.
-            if (p.debug_stop != 11) {
+            if (dstop != 11) {
                 constexpr int LDF = 17;
                 constexpr float kShift = 8e-6f;
                 const float delta = kShift * sqrtf((float)normS2);
@@ -557,6 +582,7 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
             wsync();
         }
 
+        stamp(6);
         // ---------------- stage 4: descending order ----------------
         // all 64 lanes: lane (i = lane & 15, q = lane >> 4) compares eigenvalue i with four others, the counts meet over q
         {
@@ -637,15 +663,16 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
         }
     }
     if (pstatus != nullptr && lane == 0) pstatus[k] = status;
+    stamp(7);
 }
 
 // The double kernel is held to four waves per SIMD (its float32 pre-solve and the re-orthonormalisation products would
 // otherwise raise the register count past 128 and cost a wave); the float kernel is left to the compiler.
-template <typename T, bool FUSED, typename XT>
-__global__ void __launch_bounds__(64) gevd16m_kernel(const GevdParams p) { gevd16m_body<T, FUSED, XT>(p); }
-template <bool FUSED, typename XT>
+template <typename T, bool FUSED, typename XT, bool DBG = false>
+__global__ void __launch_bounds__(64) gevd16m_kernel(const GevdParams p) { gevd16m_body<T, FUSED, XT, DBG>(p); }
+template <bool FUSED, typename XT, bool DBG = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) gevd16m_kernel_f64(const GevdParams p) {
-    gevd16m_body<double, FUSED, XT>(p);
+    gevd16m_body<double, FUSED, XT, DBG>(p);
 }
 
 }  // namespace
@@ -655,6 +682,19 @@ hipError_t apv_launch_gevd16m(const GevdParams& p, int compute_dtype, bool fused
     if (p.K <= 0) return hipSuccess;
     const dim3 grid(p.K, p.n_zones > 1 ? 2 : 1);
     const bool xd = fused && p.x_c128;
+    if (p.debug_stop != 0 || p.stamps != nullptr) {
+        // diagnostic instantiations (probes only): stage cuts, A/B switches, stage stamps
+        if (compute_dtype == APV_F64) {
+            if (xd) hipLaunchKernelGGL((gevd16m_kernel_f64<true, double2, true>), grid, dim3(64), 0, s, p);
+            else if (fused) hipLaunchKernelGGL((gevd16m_kernel_f64<true, float2, true>), grid, dim3(64), 0, s, p);
+            else hipLaunchKernelGGL((gevd16m_kernel_f64<false, float2, true>), grid, dim3(64), 0, s, p);
+        } else {
+            if (xd) hipLaunchKernelGGL((gevd16m_kernel<float, true, double2, true>), grid, dim3(64), 0, s, p);
+            else if (fused) hipLaunchKernelGGL((gevd16m_kernel<float, true, float2, true>), grid, dim3(64), 0, s, p);
+            else hipLaunchKernelGGL((gevd16m_kernel<float, false, float2, true>), grid, dim3(64), 0, s, p);
+        }
+        return hipGetLastError();
+    }
     if (compute_dtype == APV_F64) {
         if (xd) hipLaunchKernelGGL((gevd16m_kernel_f64<true, double2>), grid, dim3(64), 0, s, p);
         else if (fused) hipLaunchKernelGGL((gevd16m_kernel_f64<true, float2>), grid, dim3(64), 0, s, p);

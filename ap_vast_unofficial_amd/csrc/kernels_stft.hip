@@ -301,6 +301,10 @@ struct StftJobs {
     long stride_c[STFT_MAX_JOBS], stride_k[STFT_MAX_JOBS];
     int ch0[STFT_MAX_JOBS + 1];                  // first workgroup of each job
     int n;
+    // a whole chunk of hops in one launch (blockIdx.y = hop of the chunk): channel rows are x_stride samples apart, hop i reads
+    // its block x_hop samples further on and writes its spectra spec_hop[j] elements further on.  One hop: x_stride = N, rest 0
+    long x_stride, x_hop;
+    long spec_hop[STFT_MAX_JOBS];
 };
 template <typename T>
 __global__ void __launch_bounds__(STFT_TPB) stft_analysis_jobs_kernel(FftPlan plan, StftJobs<T> jobs, int ring_off,
@@ -316,8 +320,9 @@ __global__ void __launch_bounds__(STFT_TPB) stft_analysis_jobs_kernel(FftPlan pl
     int j = 0;
     while (j + 1 < jobs.n && wg >= jobs.ch0[j + 1]) ++j;
     const int c = wg - jobs.ch0[j];
-    stft_analysis_body<T>(plan, jobs.x[j] + (size_t)c * plan.N, plan.N, ring_off, 1, jobs.spec[j] + (size_t)c * jobs.stride_c[j],
-                          jobs.stride_k[j], tw, win);
+    const size_t hop = blockIdx.y;
+    stft_analysis_body<T>(plan, jobs.x[j] + (size_t)c * jobs.x_stride + hop * jobs.x_hop, plan.N, ring_off, 1,
+                          jobs.spec[j] + hop * jobs.spec_hop[j] + (size_t)c * jobs.stride_c[j], jobs.stride_k[j], tw, win);
 }
 
 template <typename T>
@@ -389,9 +394,13 @@ template <typename T>
 struct FirFftJobs {
     const C2<T>* Hf[FIR_FFT_JOBS];    // [C_j][F/2 + 1]
     const C2<T>* Xf[FIR_FFT_JOBS];    // [F/2 + 1], spectrum of the job's input history
-    T* resp[FIR_FFT_JOBS];            // [C_j][N] ring
+    T* resp[FIR_FFT_JOBS];            // [C_j][row_stride]: ring of N samples (one hop) or linear buffer (a chunk of hops)
     int ch0[FIR_FFT_JOBS + 1];        // first workgroup of each job
     int n;
+    // where the H new samples of hop blockIdx.y go: (pos0 + hop H + i) mod row_stride of the channel's row; the input spectra of
+    // hop i are x_hop_stride elements behind those of hop 0.  One hop: row_stride = N, pos0 = (N - H + ring offset) mod N
+    int row_stride, pos0;
+    long x_hop_stride;
     // optional passenger (whole-signal path, where the hop's input spectra exist before its input update): the input
     // update of the hop -- new histories [old[H:], hop, zeros(pad)], hop appended to the input-block rings -- done by
     // upd_wgs extra workgroups per signal at the end of the grid instead of a launch of its own in front of this one
@@ -458,7 +467,8 @@ __global__ void __launch_bounds__(STFT_TPB) fir_fft_kernel(FftPlan plan, FirFftJ
     while (j + 1 < jobs.n && wg >= jobs.ch0[j + 1]) ++j;
     const int c = wg - jobs.ch0[j];
     const Z* __restrict__ Hc = jobs.Hf[j] + (size_t)c * (Fh + 1);
-    const Z* __restrict__ X = jobs.Xf[j];
+    const int hop = blockIdx.y;
+    const Z* __restrict__ X = jobs.Xf[j] + (size_t)hop * jobs.x_hop_stride;
     // product spectrum, packed for the half-length inverse transform exactly as in istft_ola_kernel
     for (int k = tid; k < Fh; k += STFT_TPB) {
         Z a = cmul(X[k], Hc[k]);
@@ -477,11 +487,12 @@ __global__ void __launch_bounds__(STFT_TPB) fir_fft_kernel(FftPlan plan, FirFftJ
     __syncthreads();
     const Z* z = fft_forward<T>(plan, za, zb, tw);
     const T scale = (T)1 / (T)Fh;
-    T* __restrict__ dst = jobs.resp[j] + (size_t)c * N;
+    T* __restrict__ dst = jobs.resp[j] + (size_t)c * jobs.row_stride;
+    const int p0 = jobs.pos0 + hop * H;
     for (int i = tid; i < H; i += STFT_TPB) {
         const int n = P - 1 + i;
         const Z v = z[n >> 1];
-        dst[(N - H + i + ring_off) % N] = ((n & 1) ? -v.y : v.x) * scale;
+        dst[(p0 + i) % jobs.row_stride] = ((n & 1) ? -v.y : v.x) * scale;
     }
 }
 
@@ -559,7 +570,8 @@ hipError_t launch_synthesis(int N, int H, int n_ch, const void* spec, long strid
 namespace {
 template <typename T>
 hipError_t launch_analysis_jobs(const FftPlan& plan, int n_jobs, const void* const* x, const int* n_ch, void* const* spec,
-                                const long* stride_c, const long* stride_k, int ring_off, hipStream_t s) {
+                                const long* stride_c, const long* stride_k, int ring_off, hipStream_t s, long x_stride = 0,
+                                long x_hop = 0, const long* spec_hop = nullptr, int n_hops = 1) {
     Tables<T> t;
     hipError_t e = get_tables<T>(plan.N, &t);
     if (e != hipSuccess) return e;
@@ -570,15 +582,18 @@ hipError_t launch_analysis_jobs(const FftPlan& plan, int n_jobs, const void* con
         jobs.spec[j] = (C2<T>*)spec[j];
         jobs.stride_c[j] = stride_c[j];
         jobs.stride_k[j] = stride_k[j];
+        jobs.spec_hop[j] = spec_hop ? spec_hop[j] : 0;
         jobs.ch0[j] = total;
         total += n_ch[j];
     }
     jobs.ch0[n_jobs] = total;
     jobs.n = n_jobs;
-    if (total <= 0) return hipSuccess;
+    jobs.x_stride = x_stride > 0 ? x_stride : plan.N;
+    jobs.x_hop = x_hop;
+    if (total <= 0 || n_hops <= 0) return hipSuccess;
     int off = ring_off % plan.N;
     if (off < 0) off += plan.N;
-    hipLaunchKernelGGL(stft_analysis_jobs_kernel<T>, dim3(total), dim3(STFT_TPB), plan_lds<T>(plan), s, plan, jobs, off,
+    hipLaunchKernelGGL(stft_analysis_jobs_kernel<T>, dim3(total, n_hops), dim3(STFT_TPB), plan_lds<T>(plan), s, plan, jobs, off,
                        t.tw, t.win);
     return hipGetLastError();
 }
@@ -592,6 +607,18 @@ hipError_t apv_launch_stft_analysis_jobs(int f64, int N, int n_jobs, const void*
     if (n_jobs < 1 || n_jobs > STFT_MAX_JOBS) return hipErrorInvalidValue;
     return f64 ? launch_analysis_jobs<double>(plan, n_jobs, x, n_ch, spec, stride_c, stride_k, ring_off, s)
                : launch_analysis_jobs<float>(plan, n_jobs, x, n_ch, spec, stride_c, stride_k, ring_off, s);
+}
+
+// The analysis transforms of a whole chunk of hops in one launch (whole-signal path): the blocks of hop i start x_hop * i samples
+// into rows that are x_stride samples long (linear buffers: no ring offset), its spectra go spec_hop[j] * i elements further on
+hipError_t apv_launch_stft_analysis_chunk(int f64, int N, int n_jobs, const void* const* x, const int* n_ch, void* const* spec,
+                                          const long* stride_c, const long* stride_k, long x_stride, long x_hop, const long* spec_hop,
+                                          int n_hops, hipStream_t s, std::string* why) {
+    FftPlan plan;
+    if (!make_plan(N, &plan, why)) return hipErrorInvalidValue;
+    if (n_jobs < 1 || n_jobs > STFT_MAX_JOBS || n_hops < 1 || n_hops > 65535) return hipErrorInvalidValue;
+    return f64 ? launch_analysis_jobs<double>(plan, n_jobs, x, n_ch, spec, stride_c, stride_k, 0, s, x_stride, x_hop, spec_hop, n_hops)
+               : launch_analysis_jobs<float>(plan, n_jobs, x, n_ch, spec, stride_c, stride_k, 0, s, x_stride, x_hop, spec_hop, n_hops);
 }
 
 // build (or find) the twiddle / window tables now, so that no allocation happens on the per-hop path
@@ -681,7 +708,8 @@ hipError_t launch_fir_chunk_spectra(int F, int P, int H, int n_hops, const void*
 
 template <typename T>
 hipError_t launch_fir_fft_jobs(int F, int n_jobs, const void* const* Hf, const void* const* Xf, void* const* resp, const int* n_ch,
-                               int P, int H, int N, int ring_off, const ApvInputUpdate* upd, hipStream_t s) {
+                               int P, int H, int N, int ring_off, const ApvInputUpdate* upd, hipStream_t s, int row_stride = 0,
+                               int pos0 = 0, long x_hop_stride = 0, int n_hops = 1) {
     FftPlan plan;
     if (!make_plan(F, &plan, nullptr) || n_jobs < 1 || n_jobs > FIR_FFT_JOBS || P - 1 + H > F) return hipErrorInvalidValue;
     Tables<T> t;
@@ -701,6 +729,17 @@ hipError_t launch_fir_fft_jobs(int F, int n_jobs, const void* const* Hf, const v
     if (total <= 0) return hipSuccess;
     int off = ring_off % N;
     if (off < 0) off += N;
+    if (row_stride > 0) {                      // a chunk of hops into linear buffers
+        jobs.row_stride = row_stride;
+        jobs.pos0 = pos0;
+        jobs.x_hop_stride = x_hop_stride;
+        if (upd || n_hops < 1 || n_hops > 65535 || pos0 + (long)n_hops * H > row_stride) return hipErrorInvalidValue;
+    } else {
+        jobs.row_stride = N;
+        jobs.pos0 = (N - H + off) % N;
+        jobs.x_hop_stride = 0;
+        n_hops = 1;
+    }
     if (upd) {
         jobs.upd_wgs = (P - 1 + H + upd->pad + STFT_TPB - 1) / STFT_TPB;
         jobs.pad = upd->pad;
@@ -712,10 +751,19 @@ hipError_t launch_fir_fft_jobs(int F, int n_jobs, const void* const* Hf, const v
         jobs.inblk = (T*)upd->inblk;
         total += 2 * jobs.upd_wgs;
     }
-    hipLaunchKernelGGL(fir_fft_kernel<T>, dim3(total), dim3(STFT_TPB), plan_lds<T>(plan), s, plan, jobs, P, H, N, off, t.tw);
+    hipLaunchKernelGGL(fir_fft_kernel<T>, dim3(total, n_hops), dim3(STFT_TPB), plan_lds<T>(plan), s, plan, jobs, P, H, N, off, t.tw);
     return hipGetLastError();
 }
 }  // namespace
+
+// K1 of a whole chunk of hops in one launch: Xf[j] points at the input spectrum of the chunk's first hop (the following hops'
+// x_hop_stride complex elements apart), resp[j] at rows of row_stride samples whose positions pos0 + i H ... take hop i
+hipError_t apv_launch_fir_fft_chunk(int f64, int F, int n_jobs, const void* const* Hf, const void* const* Xf, long x_hop_stride,
+                                    void* const* resp, const int* n_ch, int P, int H, int row_stride, int pos0, int n_hops,
+                                    hipStream_t s) {
+    return f64 ? launch_fir_fft_jobs<double>(F, n_jobs, Hf, Xf, resp, n_ch, P, H, row_stride, 0, nullptr, s, row_stride, pos0, x_hop_stride, n_hops)
+               : launch_fir_fft_jobs<float>(F, n_jobs, Hf, Xf, resp, n_ch, P, H, row_stride, 0, nullptr, s, row_stride, pos0, x_hop_stride, n_hops);
+}
 
 // Xf [2][F/2 + 1] = spectra of the two input histories x0, x1 (in_len = P - 1 + H samples each, zero-padded to F)
 hipError_t apv_launch_fir_input_spectra(int f64, int F, const void* x0, const void* x1, int in_len, void* Xf, hipStream_t s) {

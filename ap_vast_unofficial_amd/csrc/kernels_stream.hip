@@ -429,6 +429,70 @@ hipError_t apv_launch_input_update(int f64, int P, int H, int pad, int N, int ri
     return hipGetLastError();
 }
 
+// ---- whole-signal path: a chunk of hops at a time (stream.hip, process_signal_chunked_t) -------------------------------------
+// rows of `len` samples between buffers with their own row strides and ring positions:
+//   dst[r ds + (d0 + m) mod dmod] = src[r ss + (s0 + m) mod smod],  m < len
+template <typename T>
+__global__ void __launch_bounds__(256) rows_copy_kernel(T* __restrict__ dst, long ds, int d0, int dmod, const T* __restrict__ src,
+                                                        long ss, int s0, int smod, int len) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= len) return;
+    const size_t r = blockIdx.y;
+    dst[r * ds + (d0 + m) % dmod] = src[r * ss + (s0 + m) % smod];
+}
+
+// The input side of a chunk of nc hops (pinned staging pin [nc][2][H]) in one launch: the hops appended to the linear
+// input-block buffers inL [2][RL] at positions N - H + i H ..., and the input histories as they are AFTER the chunk, i.e. what nc
+// input updates (input_update_kernel) would leave: the last P - 1 + H samples of [old history's last P - 1 | hop 0 | hop 1 ...]
+// (length P - 1 + nc H), then `pad` zeros.
+template <typename T>
+__global__ void __launch_bounds__(256) chunk_inputs_kernel(int P, int H, int N, int nc, int pad, int RL, InputUpdate<T> u,
+                                                           const T* __restrict__ pin, T* __restrict__ inL) {
+    const int g = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    const int keep = P - 1;
+    if (i < nc * H) {
+        const int q = i / H, t = i - q * H;
+        inL[(size_t)g * RL + (N - H) + i] = pin[((size_t)q * 2 + g) * H + t];
+    }
+    if (i < keep + H) {
+        // with S = [old history's last P - 1 | hop 0 | hop 1 ...] the history hop j works from is S[j H ... j H + P - 1 + H): after
+        // the chunk's last hop, j = nc - 1
+        const int m = (nc - 1) * H + i;
+        T v;
+        if (m < keep) v = u.old_hist[g][H + m];
+        else {
+            const int q = (m - keep) / H, t = (m - keep) - q * H;
+            v = pin[((size_t)q * 2 + g) * H + t];
+        }
+        u.new_hist[g][i] = v;
+    } else if (i < keep + H + pad) {
+        u.new_hist[g][i] = (T)0;
+    }
+}
+
+hipError_t apv_launch_rows_copy(int f64, int rows, int len, void* dst, long ds, int d0, int dmod, const void* src, long ss, int s0,
+                                int smod, hipStream_t s) {
+    if (rows <= 0 || len <= 0) return hipSuccess;
+    const dim3 grid((len + 255) / 256, rows);
+    if (f64) hipLaunchKernelGGL(rows_copy_kernel<double>, grid, dim3(256), 0, s, (double*)dst, ds, d0, dmod, (const double*)src, ss, s0, smod, len);
+    else hipLaunchKernelGGL(rows_copy_kernel<float>, grid, dim3(256), 0, s, (float*)dst, ds, d0, dmod, (const float*)src, ss, s0, smod, len);
+    return hipGetLastError();
+}
+
+hipError_t apv_launch_chunk_inputs(int f64, int P, int H, int N, int nc, int pad, int RL, const void* const old_hist[2],
+                                   void* const new_hist[2], const void* pin, void* inL, hipStream_t s) {
+    const int span = (nc * H > P - 1 + H + pad) ? nc * H : P - 1 + H + pad;
+    const dim3 grid((span + 255) / 256, 2);
+    if (f64) {
+        InputUpdate<double> u{{(const double*)old_hist[0], (const double*)old_hist[1]}, {(double*)new_hist[0], (double*)new_hist[1]}};
+        hipLaunchKernelGGL(chunk_inputs_kernel<double>, grid, dim3(256), 0, s, P, H, N, nc, pad, RL, u, (const double*)pin, (double*)inL);
+    } else {
+        InputUpdate<float> u{{(const float*)old_hist[0], (const float*)old_hist[1]}, {(float*)new_hist[0], (float*)new_hist[1]}};
+        hipLaunchKernelGGL(chunk_inputs_kernel<float>, grid, dim3(256), 0, s, P, H, N, nc, pad, RL, u, (const float*)pin, (float*)inL);
+    }
+    return hipGetLastError();
+}
+
 int apv_fir_pad() { return 128; }      // history buffers are padded so that a 128-sample tile never reads past the end
 
 hipError_t apv_launch_fir_jobs(const FirJobs& jobs, int P, int H, int N, int ring_off, hipStream_t s) {

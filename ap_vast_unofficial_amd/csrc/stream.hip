@@ -13,10 +13,15 @@
 #include "apv_internal.h"
 
 #include <algorithm>
+#include <chrono>
+#include <functional>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+
+constexpr int CK_NB = 3;      // back streams of the chunked whole-signal path
+constexpr int CK_NS = 3;      // pinned staging slots (chunks) of that path
 
 struct apv_stream {
     int N, H, K, L, M, C, P, nV, zones, pad;
@@ -79,6 +84,26 @@ struct apv_stream {
     void* xspec_chunk;            // [sig_chunk][2][fir_F/2 + 1]: whole-signal path, the spectra of a staged chunk in one launch
     long hop;                     // hops processed
     long not_converged;           // hops in which some bin hit the sweep cap (status 2)
+    // chunked whole-signal path (process_signal_chunked_t): the FRONT half of a whole chunk of hops is three launches (input side,
+    // K1, analysis) into linear buffers and one spectra set per hop; the back halves of consecutive hops alternate between two
+    // streams with their own filters, output spectra and result buffers.  Everything is allocated at the path's first call.
+    int ck_RL;                    // row length of the linear buffers: N - H + sig_chunk H (0 = not set up)
+    void* ck_resp[2][4];          // [chunk parity][path]: [C][RL]
+    void* ck_tresp[2][2];         // [M][RL]
+    void* ck_in[2];               // [2][RL]
+    void* ck_X[4];                // [2 sig_chunk][K][C]: set (parity, i) = parity sig_chunk + i
+    void* ck_tspec[2];            // [2 sig_chunk][K][M]
+    void* ck_inspec;              // [2 sig_chunk][2][K]
+    void* ck_w[CK_NB - 1][2];     // [K][nV][L] per zone: filters of back streams 1 ... (back stream 0 uses w, lam)
+    void* ck_lam[CK_NB - 1][2];
+    hipStream_t ck_back[CK_NB - 1];
+    void* ck_pin_in;              // pinned [CK_NS][sig_chunk][2][H]: the host stages chunk c + 1 while chunks c - 1 and c are in flight
+    void* ck_pin_out;             // pinned [CK_NS][sig_chunk] hop results
+    hipEvent_t ck_done[CK_NS];    // the chunk in staging slot q has been copied back
+    void* ck_out;                 // [2 sig_chunk] hop results (samples [n_out][H] + status words [2][K]): one slot per hop of two chunks
+    void* ck_ospec;               // [2 sig_chunk][n_out][K] output spectra, likewise
+    hipEvent_t ck_backdone[2][CK_NB]; // [chunk parity][back stream]: that stream has read the parity's spectra sets for the last time
+    hipEvent_t ck_k3[CK_NB];      // [back stream]: output spectra written (the tail stream starts the synthesis there)
     // work space of apv_stream_get_statistics (R_B, R_D, r, U, w, lam, spill, status), allocated at its first call and kept
     void* stat_ws[8];
     size_t stat_spill_bytes;
@@ -169,6 +194,34 @@ void apv_stream_free(apv_handle* h) {
     if (s->sig_out) (void)hipHostFree(s->sig_out);
     for (void* b : s->stat_ws)
         if (b) (void)hipFree(b);
+    for (int q = 0; q < 2; ++q) {
+        for (int p = 0; p < 4; ++p)
+            if (s->ck_resp[q][p]) (void)hipFree(s->ck_resp[q][p]);
+        for (int z = 0; z < 2; ++z)
+            if (s->ck_tresp[q][z]) (void)hipFree(s->ck_tresp[q][z]);
+        if (s->ck_in[q]) (void)hipFree(s->ck_in[q]);
+        if (s->ck_tspec[q]) (void)hipFree(s->ck_tspec[q]);
+        for (int b = 0; b < CK_NB; ++b)
+            if (s->ck_backdone[q][b]) (void)hipEventDestroy(s->ck_backdone[q][b]);
+    }
+    for (int b = 0; b < CK_NB; ++b)
+        if (s->ck_k3[b]) (void)hipEventDestroy(s->ck_k3[b]);
+    for (int b = 0; b + 1 < CK_NB; ++b) {
+        for (int z = 0; z < 2; ++z) {
+            if (s->ck_w[b][z]) (void)hipFree(s->ck_w[b][z]);
+            if (s->ck_lam[b][z]) (void)hipFree(s->ck_lam[b][z]);
+        }
+        if (s->ck_back[b]) (void)hipStreamDestroy(s->ck_back[b]);
+    }
+    for (int q = 0; q < CK_NS; ++q)
+        if (s->ck_done[q]) (void)hipEventDestroy(s->ck_done[q]);
+    if (s->ck_pin_in) (void)hipHostFree(s->ck_pin_in);
+    if (s->ck_pin_out) (void)hipHostFree(s->ck_pin_out);
+    for (int p = 0; p < 4; ++p)
+        if (s->ck_X[p]) (void)hipFree(s->ck_X[p]);
+    if (s->ck_inspec) (void)hipFree(s->ck_inspec);
+    if (s->ck_out) (void)hipFree(s->ck_out);
+    if (s->ck_ospec) (void)hipFree(s->ck_ospec);
     delete s;
     h->st = nullptr;
 }
@@ -298,21 +351,27 @@ static int enqueue_front(apv_handle* h, hipStream_t st, int set, const void* pin
 // spectra set has been read for the last time (after K3), and a stream of its own for synthesis and copy back, which
 // start at that event.  The per-hop path takes the defaults.
 struct BackSchedule {
+    int yield_issue = 0;      // GevdParams::yield_issue
     int obuf = 0;
     hipEvent_t spectra_free = nullptr;
     hipStream_t tail_stream = nullptr;
     hipEvent_t copied = nullptr;
+    // chunked whole-signal path: the hop's own result and output-spectra slots (then `obuf` is not used) and no copy back per
+    // hop (one copy per chunk, by the caller)
+    void* result = nullptr;
+    void* ospec = nullptr;
+    bool no_copy = false;
 };
 
 // Back half of a hop on stream `st`: spectra of set `set` -> per-bin filters (K5'-K10), output spectra (K3), synthesis
 // and overlap-add (K4); the emitted samples [n_out][H] and, behind them, the status words [2][K] land in pinned `pin_dst`.
-static int enqueue_back(apv_handle* h, hipStream_t st, int set, void* pin_dst, const BackSchedule& sch = BackSchedule()) {
+static int enqueue_back(apv_handle* h, hipStream_t st, const HopSpectra& q, void* const* wz, void* const* lamz, void* pin_dst,
+                        const BackSchedule& sch = BackSchedule()) {
     apv_stream* s = h->st;
-    char* const obuf = static_cast<char*>(sch.obuf ? s->out1 : s->out);
-    char* const ospec = static_cast<char*>(sch.obuf ? s->outspec1 : s->outspec);
+    char* const obuf = static_cast<char*>(sch.result ? sch.result : (sch.obuf ? s->out1 : s->out));
+    char* const ospec = static_cast<char*>(sch.ospec ? sch.ospec : (sch.obuf ? s->outspec1 : s->outspec));
     int32_t* const ostatus[2] = {reinterpret_cast<int32_t*>(obuf + hop_out_bytes(s)),
                                  reinterpret_cast<int32_t*>(obuf + hop_out_bytes(s)) + s->K};
-    const HopSpectra q = hop_spectra(s, set);
     const int N = s->N, H = s->H, K = s->K, L = s->L, f64 = s->f64;
     const size_t e2 = 2 * s->esz;
     const bool runA = s->zones & 1, runB = s->zones & 2;
@@ -327,13 +386,14 @@ static int enqueue_back(apv_handle* h, hipStream_t st, int set, void* pin_dst, c
         p.XB = first ? q.X[3] : q.X[0];
         p.XD = first ? q.X[2] : q.X[1];
         p.d = q.tspec[first];
-        p.w = s->w[first];
-        p.lam = s->lam[first];
+        p.w = wz[first];
+        p.lam = lamz[first];
         p.status = ostatus[first];
         p.n_zones = (runA && runB) ? 2 : 1;
+        p.yield_issue = sch.yield_issue;
         if (p.n_zones == 2) {
             p.XB1 = q.X[3]; p.XD1 = q.X[2]; p.d1 = q.tspec[1];
-            p.w1 = s->w[1]; p.lam1 = s->lam[1]; p.status1 = ostatus[1];
+            p.w1 = wz[1]; p.lam1 = lamz[1]; p.status1 = ostatus[1];
         }
         hipError_t e = apv_launch_gevd(p, h->cfg.compute_dtype, true, st, &why);
         if (e != hipSuccess) return apv_fail(h, APV_ERR_HIP, why.empty() ? hipGetErrorString(e) : why);
@@ -347,7 +407,7 @@ static int enqueue_back(apv_handle* h, hipStream_t st, int set, void* pin_dst, c
         int jf[4], jtg[4], nj = 0;
         for (int z = 0; z < 2; ++z) {
             if (!(z ? runB : runA)) continue;
-            jin[nj] = (const char*)q.inspec + (size_t)z * K * e2; jw[nj] = s->w[z]; jt[nj] = nullptr;
+            jin[nj] = (const char*)q.inspec + (size_t)z * K * e2; jw[nj] = wz[z]; jt[nj] = nullptr;
             jout[nj] = ospec + (size_t)oc * K * e2;
             jf[nj] = s->nV * L; jtg[nj] = 0; ++nj;
             oc += s->nV * L;
@@ -371,6 +431,7 @@ static int enqueue_back(apv_handle* h, hipStream_t st, int set, void* pin_dst, c
         hipError_t e = apv_launch_synthesis(f64, N, H, s->n_out, ospec, K, 1, s->outov, obuf, ts, &why, s->out_group);
         if (e != hipSuccess) return apv_fail(h, APV_ERR_HIP, why.empty() ? hipGetErrorString(e) : why);
     }
+    if (sch.no_copy) return APV_OK;
     SCHK(h, hipMemcpyAsync(pin_dst, obuf, hop_result_bytes(s), hipMemcpyDeviceToHost, ts));         // samples + status: one copy
     if (sch.tail_stream) SCHK(h, hipEventRecord(sch.copied, ts));
     return APV_OK;
@@ -381,7 +442,7 @@ static int enqueue_hop(apv_handle* h) {
     apv_stream* s = h->st;
     int rc = enqueue_front(h, h->stream, 0, s->pin_in);
     if (rc != APV_OK) return rc;
-    return enqueue_back(h, h->stream, 0, s->pin_out);
+    return enqueue_back(h, h->stream, hop_spectra(s, 0), s->w, s->lam, s->pin_out);
 }
 
 // run one hop whose input is already in the pinned staging; the output is left in the pinned staging
@@ -497,8 +558,13 @@ static int signal_prepare(apv_handle* h) {
     if (!s->out1 && (rc = dalloc(h, &s->out1, hop_result_bytes(s), 1))) return rc;
     if (!s->outspec1 && (rc = dalloc(h, &s->outspec1, (size_t)s->n_out * K, e2))) return rc;
     if (s->fir_F > 0 && !s->xspec_chunk && (rc = dalloc(h, &s->xspec_chunk, (size_t)chunk * 2 * (s->fir_F / 2 + 1), e2))) return rc;
-    if (!s->front) SCHK(h, hipStreamCreateWithFlags(&s->front, hipStreamNonBlocking));
-    if (!s->tail) SCHK(h, hipStreamCreateWithFlags(&s->tail, hipStreamNonBlocking));
+    // Front and tail run at the highest stream priority: their kernels are short or bandwidth-shaped and everything downstream
+    // waits for them, while the joint diagonalisations they run beside (handle's stream, back1: default priority) fill every SIMD
+    // with 60-90 us waves and would otherwise keep the front half of the NEXT chunk out until the current one has drained.
+    int prio_least = 0, prio_greatest = 0;
+    SCHK(h, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    if (!s->front) SCHK(h, hipStreamCreateWithPriority(&s->front, hipStreamNonBlocking, prio_greatest));
+    if (!s->tail) SCHK(h, hipStreamCreateWithPriority(&s->tail, hipStreamNonBlocking, prio_greatest));
     for (int p = 0; p < 2; ++p) {
         if (!s->ev_copied[p]) SCHK(h, hipEventCreateWithFlags(&s->ev_copied[p], hipEventDisableTiming));
         if (!s->ev_front[p]) SCHK(h, hipEventCreateWithFlags(&s->ev_front[p], hipEventDisableTiming));
@@ -522,12 +588,19 @@ static int signal_prepare(apv_handle* h) {
 // alternating between two sets, and the host never waits for a hop: it stages and converts one chunk of hops while the
 // device works on the next.
 template <typename TI>
+static int process_signal_chunked_t(apv_handle* h, int n_hops, const TI* h_in_A, const TI* h_in_B, TI* h_out);
+
+template <typename TI>
 static int process_signal_t(apv_handle* h, int n_hops, const TI* h_in_A, const TI* h_in_B, TI* h_out) {
     if (!h || !h_in_A || !h_in_B || !h_out) return apv_fail(h, APV_ERR_ARG, "null argument");
     apv_stream* s = h->st;
     if (!s) return apv_fail(h, APV_ERR_ARG, "apv_stream_init has not been called");
     if (n_hops < 0) return apv_fail(h, APV_ERR_ARG, "n_hops must be >= 0");
     if (n_hops == 0) return APV_OK;
+    // responses of 64 taps or more (K1 by fast convolution): a chunk of hops per launch, two back streams (below); short
+    // responses, APV_FIR_DIRECT and APV_SIGNAL_PER_HOP (A/B switch) keep the hop-by-hop pipeline of this function
+    static const bool per_hop = getenv("APV_SIGNAL_PER_HOP") != nullptr;
+    if (s->fir_F > 0 && !per_hop) return process_signal_chunked_t<TI>(h, n_hops, h_in_A, h_in_B, h_out);
     SCHK(h, hipSetDevice(h->device));
     int rc = signal_prepare(h);
     if (rc != APV_OK) return rc;
@@ -630,7 +703,7 @@ static int process_signal_t(apv_handle* h, int n_hops, const TI* h_in_A, const T
                 sch.spectra_free = s->ev_back[set];          // recorded after K3, the set's last reader
                 sch.tail_stream = s->tail;
                 sch.copied = s->ev_copied[set];
-                rc = enqueue_back(h, back, set, (char*)s->sig_out + slot * hop_result_bytes(s), sch);
+                rc = enqueue_back(h, back, hop_spectra(s, set), s->w, s->lam, (char*)s->sig_out + slot * hop_result_bytes(s), sch);
                 if (rc != APV_OK) return bail(rc, h->err);
                 out_idle[set] = false;
             }
@@ -669,6 +742,342 @@ static int process_signal_t(apv_handle* h, int n_hops, const TI* h_in_A, const T
         if (e == hipSuccess) e = hipStreamSynchronize(s->tail);
         if (e != hipSuccess) return hipbail(e);
     }
+    if (worst == APV_ERR_NOT_PD) return bail(worst, worst_msg);     // the hops behind the failing one were not run
+    if (worst != APV_OK) return apv_fail(h, worst, worst_msg);      // APV_ERR_NO_CONVERGE: every hop ran, every output is written
+    return APV_OK;
+}
+
+// what the chunked whole-signal path needs beyond signal_prepare(); allocated at its first call
+static int chunk_prepare(apv_handle* h) {
+    apv_stream* s = h->st;
+    if (s->ck_RL > 0) return APV_OK;
+    int rc = signal_prepare(h);
+    if (rc != APV_OK) return rc;
+    const size_t K = s->K, C = s->C, M = s->M, L = s->L, e1 = s->esz, e2 = 2 * s->esz;
+    const int chunk = s->sig_chunk;
+    const size_t RL = (size_t)s->N - s->H + (size_t)chunk * s->H;
+    for (int q = 0; q < 2; ++q) {
+        for (int p = 0; p < 4; ++p)
+            if ((rc = dalloc(h, &s->ck_resp[q][p], C * RL, e1))) return rc;
+        for (int z = 0; z < 2; ++z)
+            if ((rc = dalloc(h, &s->ck_tresp[q][z], M * RL, e1))) return rc;
+        if ((rc = dalloc(h, &s->ck_in[q], 2 * RL, e1))) return rc;
+        if ((rc = dalloc(h, &s->ck_tspec[q], (size_t)2 * chunk * K * M, e2))) return rc;
+        for (int b = 0; b < CK_NB; ++b) SCHK(h, hipEventCreateWithFlags(&s->ck_backdone[q][b], hipEventDisableTiming));
+    }
+    for (int b = 0; b < CK_NB; ++b) SCHK(h, hipEventCreateWithFlags(&s->ck_k3[b], hipEventDisableTiming));
+    for (int b = 0; b + 1 < CK_NB; ++b) {
+        for (int z = 0; z < 2; ++z) {
+            if ((rc = dalloc(h, &s->ck_w[b][z], K * s->nV * L, wsz(h)))) return rc;
+            if ((rc = dalloc(h, &s->ck_lam[b][z], K * L, lsz(h)))) return rc;
+        }
+        SCHK(h, hipStreamCreateWithFlags(&s->ck_back[b], hipStreamNonBlocking));
+    }
+    for (int q = 0; q < CK_NS; ++q) SCHK(h, hipEventCreateWithFlags(&s->ck_done[q], hipEventDisableTiming));
+    SCHK(h, hipHostMalloc(&s->ck_pin_in, e1 * CK_NS * chunk * 2 * s->H, hipHostMallocDefault));
+    SCHK(h, hipHostMalloc(&s->ck_pin_out, (size_t)CK_NS * chunk * hop_result_bytes(s), hipHostMallocDefault));
+    std::memset(s->ck_pin_out, 0, (size_t)CK_NS * chunk * hop_result_bytes(s));
+    for (int p = 0; p < 4; ++p)
+        if ((rc = dalloc(h, &s->ck_X[p], (size_t)2 * chunk * K * C, e2))) return rc;
+    if ((rc = dalloc(h, &s->ck_inspec, (size_t)2 * chunk * 2 * K, e2))) return rc;
+    if ((rc = dalloc(h, &s->ck_out, (size_t)2 * chunk * hop_result_bytes(s), 1))) return rc;
+    if ((rc = dalloc(h, &s->ck_ospec, (size_t)2 * chunk * s->n_out * K, e2))) return rc;
+    SCHK(h, hipStreamSynchronize(h->stream));               // the zero-fills above
+    s->ck_RL = (int)RL;
+    return APV_OK;
+}
+
+// n_hops consecutive hops in one call, a CHUNK of hops at a time (responses of >= 64 taps, i.e. K1 by fast convolution).
+//
+// Nothing in the front half of a hop (input histories, K1, analysis transforms, perceptual weighting) depends on any hop's
+// filters, and the whole signal is in hand: the front halves of the 16 hops of a chunk are therefore THREE launches -- the input
+// side (hops into the input-block buffers, histories as after the chunk), K1 for every (hop, channel), the analysis transform
+// of every (hop, channel) -- into linear buffers [channel][N - H + 16 H] whose head is the tail of the previous chunk's, and
+// into one spectra set per hop.  Each (hop, channel) is the workgroup the per-hop launch would have run, on the same operands in
+// the same order: the samples returned are those of apv_process_block bit for bit.  The back halves (joint diagonalisation,
+// output spectra) of consecutive hops are independent of each other and alternate between two streams with their own filters,
+// output spectra and result buffers, so two hops' diagonalisations share the chip (four waves per SIMD instead of two);
+// synthesis, overlap-add and the copy back stay in hop order on the tail stream.  The host stages chunk c + 1 and collects
+// chunk c - 1 while the device runs chunk c.  On return the rings, histories, spectra, filters and counters are what n_hops
+// calls of apv_process_block would have left (apv_get_state, the per-hop entry points and their captured graphs carry on).
+template <typename TI>
+static int process_signal_chunked_t(apv_handle* h, int n_hops, const TI* h_in_A, const TI* h_in_B, TI* h_out) {
+    apv_stream* s = h->st;
+    SCHK(h, hipSetDevice(h->device));
+    int rc = chunk_prepare(h);
+    if (rc != APV_OK) return rc;
+    const int N = s->N, H = s->H, K = s->K, L = s->L, M = s->M, C = s->C, P = s->P, f64 = s->f64, chunk = s->sig_chunk, RL = s->ck_RL;
+    const size_t e1 = s->esz, e2 = 2 * s->esz, nout = (size_t)s->n_out * H;
+    const bool runA = s->zones & 1, runB = s->zones & 2;
+    hipStream_t bs[CK_NB];
+    void* wset[CK_NB][2];
+    void* lset[CK_NB][2];
+    for (int b = 0; b < CK_NB; ++b) {
+        bs[b] = b ? s->ck_back[b - 1] : h->stream;
+        for (int z = 0; z < 2; ++z) {
+            wset[b][z] = b ? s->ck_w[b - 1][z] : s->w[z];
+            lset[b][z] = b ? s->ck_lam[b - 1][z] : s->lam[z];
+        }
+    }
+    auto drain = [&]() {
+        (void)hipStreamSynchronize(s->front);
+        for (int b = 0; b < CK_NB; ++b) (void)hipStreamSynchronize(bs[b]);
+        (void)hipStreamSynchronize(s->tail);
+    };
+    const int n_chunks = (n_hops + chunk - 1) / chunk;
+    const long hop_first = s->hop;
+    const int ring_first = s->ring_off, cur_first = s->cur;
+    static const bool timing = getenv("APV_SIGNAL_TIMING") != nullptr;      // host-side seconds per phase, to stderr
+    double t_stage = 0, t_enq = 0, t_wait = 0, t_copy = 0;
+    std::vector<hipEvent_t> tev;                             // timing aid: [chunk][front start, front end, back0 start, back end 0, back end 1, copied]
+    auto tmark = [&](hipStream_t st) { if (timing) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, st); tev.push_back(e); } };
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    int worst = APV_OK;
+    std::string worst_msg;
+    int c_done = 0;
+    auto bail = [&](int code, const std::string& msg) {
+        drain();
+        char buf[192];
+        const long enq = s->hop - hop_first;
+        const long deliv = std::min<long>((long)c_done * chunk, enq);
+        std::snprintf(buf, sizeof(buf), " [apv_process_signal: %ld of %d hops delivered, stream state advanced by %ld hops: restore it "
+                      "with apv_set_state or re-initialise before continuing]", deliv, n_hops, enq);
+        return apv_fail(h, code, msg + buf);
+    };
+    auto hipbail = [&](hipError_t e) { return bail(APV_ERR_HIP, std::string("apv_process_signal: ") + hipGetErrorString(e)); };
+#define CK(call) do { hipError_t _e = (call); if (_e != hipSuccess) return hipbail(_e); } while (0)
+    auto stage_in = [&](int c) {
+        const int base = c * chunk, nc = std::min(chunk, n_hops - base);
+        for (int i = 0; i < nc; ++i) {
+            const TI* a = h_in_A + (size_t)(base + i) * H;
+            const TI* b = h_in_B + (size_t)(base + i) * H;
+            const size_t slot = ((size_t)(c % CK_NS) * chunk + i) * 2 * H;
+            if (s->f64) {
+                double* pi = (double*)s->ck_pin_in + slot;
+                for (int t = 0; t < H; ++t) { pi[t] = (double)a[t]; pi[H + t] = (double)b[t]; }
+            } else {
+                float* pi = (float*)s->ck_pin_in + slot;
+                for (int t = 0; t < H; ++t) { pi[t] = (float)a[t]; pi[H + t] = (float)b[t]; }
+            }
+        }
+    };
+    auto collect = [&](int c) -> int {
+        const int base = c * chunk, nc = std::min(chunk, n_hops - base);
+        double tc0 = now();
+        hipError_t e = hipEventSynchronize(s->ck_done[c % CK_NS]);
+        if (e != hipSuccess) return apv_fail(h, APV_ERR_HIP, std::string("apv_process_signal: ") + hipGetErrorString(e));
+        t_wait += now() - tc0; tc0 = now();
+        struct Acc { double& t; double t0; std::function<double()> f; ~Acc() { t += f() - t0; } } acc{t_copy, tc0, now};
+        const size_t ngrp = s->out_group > 0 ? (size_t)s->n_out / s->out_group : 1, gsz = nout / ngrp;
+        for (int i = 0; i < nc; ++i) {
+            const char* res = (const char*)s->ck_pin_out + ((size_t)(c % CK_NS) * chunk + i) * hop_result_bytes(s);
+            for (size_t g = 0; g < ngrp; ++g) {
+                TI* dst = s->out_group > 0 ? h_out + (g * (size_t)n_hops + (size_t)(base + i)) * gsz : h_out + (size_t)(base + i) * nout;
+                if (s->f64) {
+                    const double* po = (const double*)res + g * gsz;
+                    if (sizeof(TI) == sizeof(double)) std::memcpy(dst, po, gsz * sizeof(double));
+                    else for (size_t j = 0; j < gsz; ++j) dst[j] = (TI)po[j];
+                } else {
+                    const float* po = (const float*)res + g * gsz;
+                    if (sizeof(TI) == sizeof(float)) std::memcpy(dst, po, gsz * sizeof(float));
+                    else for (size_t j = 0; j < gsz; ++j) dst[j] = (TI)po[j];
+                }
+            }
+            const int r = scan_hop_status(h, hop_status_of(s, res), hop_first + base + i);
+            if (r == APV_ERR_NOT_PD && worst != APV_ERR_NOT_PD) { worst = r; worst_msg = h->err; }
+            if (r == APV_ERR_NO_CONVERGE && worst == APV_OK) { worst = r; worst_msg = h->err; }
+        }
+        return APV_OK;
+    };
+    // the spectra set of hop i of a chunk of parity par
+    auto set_of = [&](int par, int i) {
+        HopSpectra q;
+        const size_t idx = (size_t)par * chunk + i;
+        for (int p = 0; p < 4; ++p) q.X[p] = (char*)s->ck_X[p] + idx * K * C * e2;
+        for (int z = 0; z < 2; ++z) q.tspec[z] = (char*)s->ck_tspec[z] + idx * K * M * e2;
+        q.inspec = (char*)s->ck_inspec + idx * 2 * K * e2;
+        return q;
+    };
+    const size_t spec_bytes = ((size_t)s->fir_F / 2 + 1) * e2;       // one input spectrum of K1
+    int last_par = 0, last_nc = 0, last_b = 0;
+    std::string why;
+    for (int c = 0; c < n_chunks && worst != APV_ERR_NOT_PD; ++c) {
+        const int base = c * chunk, nc = std::min(chunk, n_hops - base), par = c & 1;
+        double t0 = now();
+        stage_in(c);                                         // staging slot c mod 3: chunk c - 3 was collected an iteration ago
+        t_stage += now() - t0; t0 = now();
+        const char* pin = (const char*)s->ck_pin_in + (size_t)(c % CK_NS) * chunk * 2 * H * e1;
+        // ---------------- front half of the whole chunk ----------------
+        // the spectra sets and linear buffers of this parity were last read by the back halves of chunk c - 2
+        if (c >= 2)
+            for (int b = 0; b < CK_NB; ++b) CK(hipStreamWaitEvent(s->front, s->ck_backdone[par][b], 0));
+        tmark(s->front);
+        CK(apv_launch_fir_chunk_spectra(f64, s->fir_F, P, H, nc, s->xhist[s->cur][0], s->xhist[s->cur][1], pin, s->xspec_chunk, s->front));
+        // heads of the linear buffers: the newest N - H samples before the chunk, from the rings (first chunk) or from the tail
+        // of the previous chunk's buffers
+        {
+            const int prev = par ^ 1, prev_nc = chunk;               // every chunk but the last is full
+            auto head = [&](void* dst, const void* ring, const void* lin_prev, int rows) -> hipError_t {
+                if (c == 0) return apv_launch_rows_copy(f64, rows, N - H, dst, RL, 0, RL, ring, N, (H + ring_first) % N, N, s->front);
+                return apv_launch_rows_copy(f64, rows, N - H, dst, RL, 0, RL, lin_prev, RL, prev_nc * H, RL, s->front);
+            };
+            for (int p = 0; p < 4; ++p) CK(head(s->ck_resp[par][p], s->resp[p], s->ck_resp[prev][p], C));
+            for (int z = 0; z < 2; ++z) CK(head(s->ck_tresp[par][z], s->tresp[z], s->ck_tresp[prev][z], M));
+            CK(head(s->ck_in[par], s->inblk, s->ck_in[prev], 2));
+        }
+        {
+            const void* oh[2] = {s->xhist[s->cur][0], s->xhist[s->cur][1]};
+            void* nh[2] = {s->xhist[s->cur ^ 1][0], s->xhist[s->cur ^ 1][1]};
+            CK(apv_launch_chunk_inputs(f64, P, H, N, nc, s->pad, RL, oh, nh, pin, s->ck_in[par], s->front));
+            s->cur ^= 1;
+        }
+        {
+            // K1: every (hop, channel) of the chunk in one launch
+            const void *jh[6], *jx[6];
+            void* jr[6];
+            int jc[6];
+            for (int p = 0; p < 4; ++p) {
+                jh[p] = s->rirspec[path_zone(p)]; jx[p] = (const char*)s->xspec_chunk + spec_bytes * path_sig(p);
+                jr[p] = s->ck_resp[par][p]; jc[p] = C;
+            }
+            for (int z = 0; z < 2; ++z) {
+                jh[4 + z] = s->trirspec[z]; jx[4 + z] = (const char*)s->xspec_chunk + spec_bytes * z;
+                jr[4 + z] = s->ck_tresp[par][z]; jc[4 + z] = M;
+            }
+            CK(apv_launch_fir_fft_chunk(f64, s->fir_F, 6, jh, jx, (long)(2 * (s->fir_F / 2 + 1)), jr, jc, P, H, RL, N - H, nc, s->front));
+        }
+        {
+            // K2: every analysis transform of the chunk in one launch; hop i's block starts i H samples into the rows
+            const HopSpectra q0 = set_of(par, 0);
+            const void* jx[7];
+            void* jspec[7];
+            int jch[7], nj = 0;
+            long jsc[7], jsk[7], jhop[7];
+            for (int p = 0; p < 4; ++p) {
+                const bool need = (p < 2) ? runA : runB;
+                if (!need) continue;
+                jx[nj] = s->ck_resp[par][p]; jspec[nj] = q0.X[p]; jch[nj] = C; jsc[nj] = 1; jsk[nj] = C; jhop[nj] = (long)K * C; ++nj;
+            }
+            for (int z = 0; z < 2; ++z) {
+                jx[nj] = s->ck_tresp[par][z]; jspec[nj] = q0.tspec[z]; jch[nj] = M; jsc[nj] = 1; jsk[nj] = M; jhop[nj] = (long)K * M; ++nj;
+            }
+            jx[nj] = s->ck_in[par]; jspec[nj] = q0.inspec; jch[nj] = 2; jsc[nj] = K; jsk[nj] = 1; jhop[nj] = 2L * K; ++nj;
+            hipError_t e = apv_launch_stft_analysis_chunk(f64, N, nj, jx, jch, jspec, jsc, jsk, RL, H, jhop, nc, s->front, &why);
+            if (e != hipSuccess) return bail(APV_ERR_HIP, why.empty() ? hipGetErrorString(e) : why);
+        }
+        if (s->nch > 0) {
+            for (int i = 0; i < nc; ++i) {
+                const HopSpectra q = set_of(par, i);
+                for (int z = 0; z < 2; ++z)
+                    CK(apv_launch_perceptual_weights(f64, K, M, s->nch, q.tspec[z], s->G2, s->G2T, s->Cs, s->Ca, s->Leff, N, s->norm_mode,
+                                                     s->Wgt[z], s->front));
+                for (int p = 0; p < 4; ++p) {
+                    const bool need = (p < 2) ? runA : runB;
+                    if (need) CK(apv_launch_scale_spectra(f64, K, C, L, q.X[p], s->Wgt[path_zone(p)], s->front));
+                }
+                for (int z = 0; z < 2; ++z) CK(apv_launch_scale_spectra(f64, K, M, 1, q.tspec[z], s->Wgt[z], s->front));
+            }
+        }
+        CK(hipEventRecord(s->ev_front[par], s->front));
+        tmark(s->front);
+        // ---------------- back halves, hop by hop, alternating between the two back streams ----------------
+        for (int i = 0; i < nc; ++i) {
+            const int b = (int)((s->hop - hop_first) % CK_NB);
+            if (i < CK_NB) {
+                CK(hipStreamWaitEvent(bs[b], s->ev_front[par], 0));
+                // the result slots of this parity are being copied back for chunk c - 2 (still in flight: the host collects two
+                // chunks behind)
+                if (c >= 2) CK(hipStreamWaitEvent(bs[b], s->ck_done[(c - 2) % CK_NS], 0));
+            }
+            if (i == 0) tmark(bs[b]);
+            // Every hop of the two chunks in flight has result and output-spectra slots of its own, so a back stream never waits
+            // for the tail stream inside a chunk: its next diagonalisation follows the previous one directly.
+            const size_t slot = (size_t)par * chunk + i;
+            BackSchedule sch;
+            sch.spectra_free = s->ck_k3[b];                  // recorded after K3: the tail stream starts the synthesis there
+            sch.tail_stream = s->tail;
+            sch.result = (char*)s->ck_out + slot * hop_result_bytes(s);
+            sch.ospec = (char*)s->ck_ospec + slot * (size_t)s->n_out * K * e2;
+            sch.no_copy = true;
+            static const bool no_yield = getenv("APV_SIGNAL_NO_YIELD") != nullptr;       // A/B switch
+            sch.yield_issue = no_yield ? 0 : 1;
+            rc = enqueue_back(h, bs[b], set_of(par, i), wset[b], lset[b], nullptr, sch);
+            if (rc != APV_OK) return bail(rc, h->err);
+            if (i + CK_NB >= nc) CK(hipEventRecord(s->ck_backdone[par][b], bs[b]));   // this stream's last hop of the chunk
+            if (i + 2 >= nc && nc >= 2) tmark(bs[b]);
+            last_par = par; last_nc = nc; last_b = b;
+            s->hop++;
+        }
+        // the chunk's results in ONE copy behind its last synthesis (16 hops: 6.4 MB at cfg3)
+        CK(hipMemcpyAsync((char*)s->ck_pin_out + (size_t)(c % CK_NS) * chunk * hop_result_bytes(s),
+                          (char*)s->ck_out + (size_t)par * chunk * hop_result_bytes(s), (size_t)nc * hop_result_bytes(s),
+                          hipMemcpyDeviceToHost, s->tail));
+        CK(hipEventRecord(s->ck_done[c % CK_NS], s->tail)); // every front and back half of the chunk is upstream of this copy
+        tmark(s->tail);
+        t_enq += now() - t0;
+        // the host collects TWO chunks behind: while it waits for chunk c - 2 and copies it out, chunks c - 1 and c are queued on
+        // the device, so the front half of chunk c runs beside the back halves of chunk c - 1 whatever the host is doing
+        if (c > 1) {
+            if ((rc = collect(c - 2)) != APV_OK) return bail(rc, h->err);
+            c_done = c - 1;
+        }
+    }
+    for (int c = c_done; c < n_chunks && (size_t)c * chunk < (size_t)(s->hop - hop_first); ++c) {
+        if ((rc = collect(c)) != APV_OK) return bail(rc, h->err);
+        c_done = c + 1;
+    }
+    // ---------------- the state n_hops per-hop calls would have left ----------------
+    {
+        hipError_t e = hipStreamSynchronize(s->front);
+        for (int b = 1; b < CK_NB && e == hipSuccess; ++b) e = hipStreamSynchronize(bs[b]);
+        if (e == hipSuccess) e = hipStreamSynchronize(s->tail);
+        if (e == hipSuccess) e = hipStreamSynchronize(bs[0]);
+        if (e != hipSuccess) return hipbail(e);
+    }
+    const long done = s->hop - hop_first;
+    if (done > 0) {
+        hipStream_t st = bs[0];
+        // rings: the last hop's block, written at the ring offset the per-hop path (and its captured graphs) expects after
+        // `done` more hops
+        s->ring_off = (int)((ring_first + done * H) % N);
+        const int src0 = (last_nc - 1) * H;
+        for (int p = 0; p < 4; ++p) CK(apv_launch_rows_copy(f64, C, N, s->resp[p], N, s->ring_off, N, s->ck_resp[last_par][p], RL, src0, RL, st));
+        for (int z = 0; z < 2; ++z) CK(apv_launch_rows_copy(f64, M, N, s->tresp[z], N, s->ring_off, N, s->ck_tresp[last_par][z], RL, src0, RL, st));
+        CK(apv_launch_rows_copy(f64, 2, N, s->inblk, N, s->ring_off, N, s->ck_in[last_par], RL, src0, RL, st));
+        // histories: the per-hop path alternates the two buffers every hop
+        const int cur_expected = cur_first ^ (int)(done & 1);
+        if (s->cur != cur_expected) {
+            const size_t hb = ((size_t)P - 1 + H + s->pad) * e1;
+            for (int g = 0; g < 2; ++g) CK(hipMemcpyAsync(s->xhist[cur_expected][g], s->xhist[s->cur][g], hb, hipMemcpyDeviceToDevice, st));
+            s->cur = cur_expected;
+        }
+        // the last hop's spectra, filters and eigenvalues where the state arrays and the per-hop path keep them
+        const HopSpectra q = set_of(last_par, last_nc - 1);
+        for (int p = 0; p < 4; ++p) CK(hipMemcpyAsync(s->X[p], q.X[p], (size_t)K * C * e2, hipMemcpyDeviceToDevice, st));
+        for (int z = 0; z < 2; ++z) CK(hipMemcpyAsync(s->tspec[z], q.tspec[z], (size_t)K * M * e2, hipMemcpyDeviceToDevice, st));
+        CK(hipMemcpyAsync(s->inspec, q.inspec, (size_t)2 * K * e2, hipMemcpyDeviceToDevice, st));
+        if (last_b != 0) {
+            for (int z = 0; z < 2; ++z) {
+                CK(hipMemcpyAsync(s->w[z], wset[last_b][z], (size_t)K * s->nV * L * wsz(h), hipMemcpyDeviceToDevice, st));
+                CK(hipMemcpyAsync(s->lam[z], lset[last_b][z], (size_t)K * L * lsz(h), hipMemcpyDeviceToDevice, st));
+            }
+        }
+        CK(hipStreamSynchronize(st));
+    }
+#undef CK
+    if (timing && tev.size() >= 6) {
+        fprintf(stderr, "[apv signal] device schedule, ms from the first chunk's front start: chunk | front start - end | back start - end of two of its streams | copied\n");
+        for (size_t c = 0; c + 1 <= tev.size() / 6; ++c) {
+            float v[6];
+            for (int q = 0; q < 6; ++q) (void)hipEventElapsedTime(&v[q], tev[0], tev[6 * c + q]);
+            if (c < 3 || c + 3 >= tev.size() / 6)
+                fprintf(stderr, "[apv signal]   %2zu | %7.3f - %7.3f | %7.3f - %7.3f, %7.3f | %7.3f\n", c, v[0], v[1], v[2], v[3], v[4], v[5]);
+        }
+    }
+    for (hipEvent_t e : tev) (void)hipEventDestroy(e);
+    if (timing)
+        fprintf(stderr, "[apv signal] %d hops: host stage-in %.3f ms, enqueue %.3f ms, waiting for chunks %.3f ms, copy-out %.3f ms\n", n_hops,
+                t_stage * 1e3, t_enq * 1e3, t_wait * 1e3, t_copy * 1e3);
     if (worst == APV_ERR_NOT_PD) return bail(worst, worst_msg);     // the hops behind the failing one were not run
     if (worst != APV_OK) return apv_fail(h, worst, worst_msg);      // APV_ERR_NO_CONVERGE: every hop ran, every output is written
     return APV_OK;

@@ -276,6 +276,10 @@ int  apv_allgather_filters_dev(apv_handle* h, const void* d_w_shard, void* d_w_a
 int  apv_comm_last_gather(apv_handle* h, float* elapsed_ms, size_t* bytes_per_rank);
 /* all ranks of the communicator meet here (one-word ncclAllReduce); also drains the handle's compute stream */
 int  apv_comm_barrier(apv_handle* h);
+/* Diagnostics (tools/probes/stage_stamps.py; never set in normal use): with a device buffer of [zones][K][16] uint64 registered,
+ * the order-16 update runs its diagnostic instantiation, in which lane 0 of every bin's wave stores the shader clock (s_memtime)
+ * at the stage boundaries; NULL switches it off again.  The stamps go to this buffer only; no result depends on them. */
+int  apv_debug_set_stamps(apv_handle* h, void* d_stamps);
 /* hipDeviceSynchronize on the handle's device, and what that device is */
 int  apv_device_sync(apv_handle* h);
 int  apv_device_info(apv_handle* h, char name_out[128], int32_t* n_cus, int32_t* clock_mhz);
