@@ -480,6 +480,12 @@ class Engine:
         """dtype of the stream's spectra."""
         return np.complex128 if self.frontend_f64 else np.complex64
 
+    def state_bytes(self, name):
+        """Size in bytes of a named state array of the subband stream (apv_state_bytes)."""
+        n = C.c_size_t()
+        self._chk(self.lib.apv_state_bytes(self.h, name.encode(), C.byref(n)))
+        return n.value
+
     def get_state(self, name, shape, dtype):
         out = np.empty(shape, dtype=dtype)
         self._chk(self.lib.apv_get_state(self.h, name.encode(), _ptr(out), out.nbytes))

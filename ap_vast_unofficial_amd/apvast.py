@@ -484,7 +484,8 @@ class apvast:
             "response": resp.transpose(0, 3, 2, 1).astype(np.float64),           # (4, N, L, M)
             "target_response": tresp.transpose(0, 2, 1).astype(np.float64),      # (2, N, M)
             "input_block": e.get_state("input_block", (2, N), sd).astype(np.float64),
-            "input_history": np.stack([e.get_state(f"input_history{g}", (self.rir_length - 1 + self.hop_size,),
+            # rir_length - 1 + hop_size samples; more when the RIR convolution is uniformly partitioned (long responses)
+            "input_history": np.stack([e.get_state(f"input_history{g}", (e.state_bytes(f"input_history{g}") // np.dtype(sd).itemsize,),
                                                    sd) for g in range(2)]).astype(np.float64),
             "out_overlap": e.get_state("out_overlap", (self._n_out, N), sd).astype(np.float64),
         }

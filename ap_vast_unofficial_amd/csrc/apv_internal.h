@@ -161,8 +161,16 @@ struct ApvInputUpdate {
     void* inblk;          // [2][N] rings
     int pad;
 };
+// n_part > 1: uniformly partitioned (partitions of H taps, F = 2 H): Hf[j] is [n_part][C_j][F/2 + 1], Xf[j] points at the job's
+// signal inside [n_part][2][F/2 + 1]
 hipError_t apv_launch_fir_fft_jobs(int f64, int F, int n_jobs, const void* const* Hf, const void* const* Xf, void* const* resp,
-                                   const int* n_ch, int P, int H, int N, int ring_off, const ApvInputUpdate* upd, hipStream_t s);
+                                   const int* n_ch, int P, int H, int N, int ring_off, const ApvInputUpdate* upd, hipStream_t s,
+                                   int n_part = 1);
+hipError_t apv_launch_fir_input_spectra_parts(int f64, int F, int n_part, const void* x0, const void* x1, void* Xf, hipStream_t s);
+hipError_t apv_launch_fir_spectra_part(int f64, int F, int n_ch, const void* x, long x_stride, int taps, void* Hf, hipStream_t s,
+                                       std::string* why);
+// uniformly partitioned K1 for (P, H): number of partitions (segments of 2 H samples), 0 when it does not apply
+int apv_fir_partitions(int f64, int P, int H);
 
 // whole-signal path, a chunk of hops per launch (kernels_stft.hip / kernels_stream.hip; see process_signal_chunked_t in stream.hip)
 hipError_t apv_launch_stft_analysis_chunk(int f64, int N, int n_jobs, const void* const* x, const int* n_ch, void* const* spec,

@@ -325,6 +325,10 @@ __global__ void __launch_bounds__(STFT_TPB) stft_analysis_jobs_kernel(FftPlan pl
                           jobs.spec[j] + hop * jobs.spec_hop[j] + (size_t)c * jobs.stride_c[j], jobs.stride_k[j], tw, win);
 }
 
+// (Four neighbouring channels per 1024-thread workgroup, so that every bin's four values go out as one 64-byte line instead of four
+// 16-byte pieces, was tried for the chunk launches and lost: 470 us against 440 us per chunk of 16 hops at cfg3.  The transforms are
+// bound by their LDS round trips and barriers, not by the partial-line writes, and sixteen waves in step hide less of them than four
+// independent workgroups.)
 template <typename T>
 __global__ void __launch_bounds__(STFT_TPB) istft_ola_kernel(FftPlan plan, int H, const C2<T>* __restrict__ spec,
                                                              long stride_c, long stride_k, T* __restrict__ overlap,
@@ -389,6 +393,13 @@ __global__ void __launch_bounds__(STFT_TPB) istft_ola_kernel(FftPlan plan, int H
 // circular convolution are the wrapped ones and are not used.  One workgroup per control-point channel: 2 (F/2 + 1)
 // spectrum values in, an F/2-point complex transform in LDS, H samples out into the channel's response ring.  At
 // P = 800, H = 1024 (F = 2048) this is 0.25 Gflop and 53 MB (float64) per hop where the direct form is 3.4 Gflop.
+//
+// Responses too long for one segment in LDS (F > 4096 doubles / 8192 floats) are UNIFORMLY PARTITIONED (n_part > 1): partitions of
+// H taps, segments of F = 2 H samples.  With X_q the spectrum of the input samples [(t - q - 1) H, (t - q + 1) H) of hop t and
+// H_q[c] the spectrum of taps [q H, (q + 1) H) of channel c zero-padded to 2 H,
+//     y_t[c] = last H samples of irfft( sum_q X_q H_q[c] ),
+// i.e. the same kernel with a sum over the partitions in front of the inverse transform.  The n_part input spectra of a hop are
+// formed afresh from the input history every hop (2 n_part small transforms): there is no delay line to checkpoint.
 constexpr int FIR_FFT_JOBS = 6;
 template <typename T>
 struct FirFftJobs {
@@ -399,8 +410,13 @@ struct FirFftJobs {
     int n;
     // where the H new samples of hop blockIdx.y go: (pos0 + hop H + i) mod row_stride of the channel's row; the input spectra of
     // hop i are x_hop_stride elements behind those of hop 0.  One hop: row_stride = N, pos0 = (N - H + ring offset) mod N
-    int row_stride, pos0;
+    int row_stride, pos0, n_hops;
     long x_hop_stride;
+    // partitioned convolution: n_part partitions; partition q of job j's responses lies h_part_stride[j] elements behind partition
+    // q - 1, of its input spectra x_part_stride elements; `skip` = first valid sample of the circular convolution (P - 1, or H when
+    // partitioned).  One segment: n_part = 1
+    int n_part, skip;
+    long h_part_stride[FIR_FFT_JOBS], x_part_stride;
     // optional passenger (whole-signal path, where the hop's input spectra exist before its input update): the input
     // update of the hop -- new histories [old[H:], hop, zeros(pad)], hop appended to the input-block rings -- done by
     // upd_wgs extra workgroups per signal at the end of the grid instead of a launch of its own in front of this one
@@ -411,11 +427,15 @@ struct FirFftJobs {
     T* inblk;                         // [2][N] rings
 };
 
+// blockIdx.y = partition q (one segment: gridDim.y = 1, part_step = 0): its segment starts part_step samples EARLIER in the history
+// than that of partition q - 1, and its spectra go behind those of partition q - 1
 template <typename T>
 __global__ void __launch_bounds__(STFT_TPB) fir_input_spectra_kernel(FftPlan plan, const T* __restrict__ x0,
-                                                                     const T* __restrict__ x1, int in_len,
+                                                                     const T* __restrict__ x1, int in_len, int part_step,
                                                                      C2<T>* __restrict__ spec, const C2<T>* __restrict__ tw) {
-    stft_analysis_body<T>(plan, blockIdx.x ? x1 : x0, in_len, 0, 0, spec + (size_t)blockIdx.x * (plan.Nh + 1), 1, tw, nullptr);
+    const int q = blockIdx.y, nq = gridDim.y;
+    const T* x = (blockIdx.x ? x1 : x0) + (size_t)(nq - 1 - q) * part_step;
+    stft_analysis_body<T>(plan, x, in_len, 0, 0, spec + ((size_t)q * 2 + blockIdx.x) * (plan.Nh + 1), 1, tw, nullptr);
 }
 
 // The same spectra for a whole chunk of hops in one launch (blockIdx.x = signal, blockIdx.y = hop of the chunk), before any
@@ -444,6 +464,9 @@ __global__ void __launch_bounds__(STFT_TPB) fir_chunk_spectra_kernel(FftPlan pla
     rfft_from_lds<T>(plan, za, zb, spec + ((size_t)hop * 2 + g) * (plan.Nh + 1), 1, tw);
 }
 
+// (Four hops of a channel per 1024-thread workgroup, so that the channel's response spectrum comes from L2 once per four hops, was
+// tried for the chunk launches and lost: 430 us against 300 us per chunk of 16 hops at cfg3 -- sixteen waves meeting at the same
+// barriers hide less than eight independent workgroups of four.)
 template <typename T>
 __global__ void __launch_bounds__(STFT_TPB) fir_fft_kernel(FftPlan plan, FirFftJobs<T> jobs, int P, int H, int N, int ring_off,
                                                            const C2<T>* __restrict__ tw) {
@@ -469,10 +492,16 @@ __global__ void __launch_bounds__(STFT_TPB) fir_fft_kernel(FftPlan plan, FirFftJ
     const Z* __restrict__ Hc = jobs.Hf[j] + (size_t)c * (Fh + 1);
     const int hop = blockIdx.y;
     const Z* __restrict__ X = jobs.Xf[j] + (size_t)hop * jobs.x_hop_stride;
-    // product spectrum, packed for the half-length inverse transform exactly as in istft_ola_kernel
+    // product spectrum (summed over the partitions), packed for the half-length inverse transform exactly as in istft_ola_kernel
+    const int n_part = jobs.n_part;
+    const long hps = jobs.h_part_stride[j], xps = jobs.x_part_stride;
     for (int k = tid; k < Fh; k += STFT_TPB) {
         Z a = cmul(X[k], Hc[k]);
         Z bq = cmul(X[Fh - k], Hc[Fh - k]);
+        for (int q = 1; q < n_part; ++q) {
+            a = cadd(a, cmul(X[q * xps + k], Hc[q * hps + k]));
+            bq = cadd(bq, cmul(X[q * xps + Fh - k], Hc[q * hps + Fh - k]));
+        }
         if (k == 0) {
             a.y = 0;
             bq.y = 0;
@@ -490,7 +519,7 @@ __global__ void __launch_bounds__(STFT_TPB) fir_fft_kernel(FftPlan plan, FirFftJ
     T* __restrict__ dst = jobs.resp[j] + (size_t)c * jobs.row_stride;
     const int p0 = jobs.pos0 + hop * H;
     for (int i = tid; i < H; i += STFT_TPB) {
-        const int n = P - 1 + i;
+        const int n = jobs.skip + i;
         const Z v = z[n >> 1];
         dst[(p0 + i) % jobs.row_stride] = ((n & 1) ? -v.y : v.x) * scale;
     }
@@ -597,6 +626,7 @@ hipError_t launch_analysis_jobs(const FftPlan& plan, int n_jobs, const void* con
                        t.tw, t.win);
     return hipGetLastError();
 }
+
 }  // namespace
 
 hipError_t apv_launch_stft_analysis_jobs(int f64, int N, int n_jobs, const void* const* x, const int* n_ch, void* const* spec,
@@ -674,22 +704,40 @@ int apv_fir_fft_size(int f64, int P, int H) {
     return F <= (f64 ? 4096 : 8192) ? F : 0;
 }
 
+// Responses too long for one segment: partitions of H taps in segments of 2 H samples, when such a segment transforms in LDS and the
+// history reaches back at least one hop (P - 1 >= H: otherwise the response is short and H is what is long; the direct form stays)
+int apv_fir_partitions(int f64, int P, int H) {
+    if (apv_fir_fft_size(f64, P, H) != 0 || P < 64 || P - 1 < H) return 0;
+    const int F = 2 * H;
+    if (F > (f64 ? 4096 : 8192) || !apv_stft_size_ok(F, nullptr)) return 0;
+    FftPlan plan;
+    if (!make_plan(F, &plan, nullptr)) return 0;
+    return (P + H - 1) / H;
+}
+
 // spectra of n_ch impulse responses held channel-major, x [n_ch][P] -> Hf [n_ch][F/2 + 1]
 hipError_t apv_launch_fir_spectra(int f64, int F, int n_ch, const void* x, int P, void* Hf, hipStream_t s, std::string* why) {
     return f64 ? launch_analysis<double>(F, n_ch, x, P, P, 0, 0, Hf, F / 2 + 1, 1, s, why)
                : launch_analysis<float>(F, n_ch, x, P, P, 0, 0, Hf, F / 2 + 1, 1, s, why);
 }
+// one partition: `taps` taps of every channel starting at x (rows x_stride samples apart), zero-padded to F
+hipError_t apv_launch_fir_spectra_part(int f64, int F, int n_ch, const void* x, long x_stride, int taps, void* Hf, hipStream_t s,
+                                       std::string* why) {
+    return f64 ? launch_analysis<double>(F, n_ch, x, x_stride, taps, 0, 0, Hf, F / 2 + 1, 1, s, why)
+               : launch_analysis<float>(F, n_ch, x, x_stride, taps, 0, 0, Hf, F / 2 + 1, 1, s, why);
+}
 
 namespace {
 template <typename T>
-hipError_t launch_fir_input_spectra(int F, const void* x0, const void* x1, int in_len, void* Xf, hipStream_t s) {
+hipError_t launch_fir_input_spectra(int F, const void* x0, const void* x1, int in_len, void* Xf, hipStream_t s, int n_part = 1,
+                                    int part_step = 0) {
     FftPlan plan;
     if (!make_plan(F, &plan, nullptr)) return hipErrorInvalidValue;
     Tables<T> t;
     hipError_t e = get_tables<T>(F, &t);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fir_input_spectra_kernel<T>, dim3(2), dim3(STFT_TPB), plan_lds<T>(plan), s, plan, (const T*)x0,
-                       (const T*)x1, in_len, (C2<T>*)Xf, t.tw);
+    hipLaunchKernelGGL(fir_input_spectra_kernel<T>, dim3(2, n_part), dim3(STFT_TPB), plan_lds<T>(plan), s, plan, (const T*)x0,
+                       (const T*)x1, in_len, part_step, (C2<T>*)Xf, t.tw);
     return hipGetLastError();
 }
 
@@ -709,9 +757,10 @@ hipError_t launch_fir_chunk_spectra(int F, int P, int H, int n_hops, const void*
 template <typename T>
 hipError_t launch_fir_fft_jobs(int F, int n_jobs, const void* const* Hf, const void* const* Xf, void* const* resp, const int* n_ch,
                                int P, int H, int N, int ring_off, const ApvInputUpdate* upd, hipStream_t s, int row_stride = 0,
-                               int pos0 = 0, long x_hop_stride = 0, int n_hops = 1) {
+                               int pos0 = 0, long x_hop_stride = 0, int n_hops = 1, int n_part = 1) {
     FftPlan plan;
-    if (!make_plan(F, &plan, nullptr) || n_jobs < 1 || n_jobs > FIR_FFT_JOBS || P - 1 + H > F) return hipErrorInvalidValue;
+    if (!make_plan(F, &plan, nullptr) || n_jobs < 1 || n_jobs > FIR_FFT_JOBS || n_part < 1) return hipErrorInvalidValue;
+    if (n_part == 1 ? (P - 1 + H > F) : (F != 2 * H || (long)n_part * H < P)) return hipErrorInvalidValue;
     Tables<T> t;
     hipError_t e = get_tables<T>(F, &t);
     if (e != hipSuccess) return e;
@@ -721,11 +770,15 @@ hipError_t launch_fir_fft_jobs(int F, int n_jobs, const void* const* Hf, const v
         jobs.Hf[j] = (const C2<T>*)Hf[j];
         jobs.Xf[j] = (const C2<T>*)Xf[j];
         jobs.resp[j] = (T*)resp[j];
+        jobs.h_part_stride[j] = (long)n_ch[j] * (F / 2 + 1);        // responses partition-major: Hf[q][c][F/2 + 1]
         jobs.ch0[j] = total;
         total += n_ch[j];
     }
     jobs.ch0[n_jobs] = total;
     jobs.n = n_jobs;
+    jobs.n_part = n_part;
+    jobs.x_part_stride = 2L * (F / 2 + 1);                          // input spectra [q][signal][F/2 + 1]
+    jobs.skip = n_part == 1 ? P - 1 : F - H;
     if (total <= 0) return hipSuccess;
     int off = ring_off % N;
     if (off < 0) off += N;
@@ -733,12 +786,14 @@ hipError_t launch_fir_fft_jobs(int F, int n_jobs, const void* const* Hf, const v
         jobs.row_stride = row_stride;
         jobs.pos0 = pos0;
         jobs.x_hop_stride = x_hop_stride;
+        jobs.n_hops = n_hops;
         if (upd || n_hops < 1 || n_hops > 65535 || pos0 + (long)n_hops * H > row_stride) return hipErrorInvalidValue;
     } else {
         jobs.row_stride = N;
         jobs.pos0 = (N - H + off) % N;
         jobs.x_hop_stride = 0;
         n_hops = 1;
+        jobs.n_hops = 1;
     }
     if (upd) {
         jobs.upd_wgs = (P - 1 + H + upd->pad + STFT_TPB - 1) / STFT_TPB;
@@ -770,6 +825,13 @@ hipError_t apv_launch_fir_input_spectra(int f64, int F, const void* x0, const vo
     return f64 ? launch_fir_input_spectra<double>(F, x0, x1, in_len, Xf, s) : launch_fir_input_spectra<float>(F, x0, x1, in_len, Xf, s);
 }
 
+// partitioned K1: Xf [n_part][2][F/2 + 1], partition q = spectrum of the F = 2 H history samples that end q H samples before the
+// history's end; x0, x1: histories of (n_part + 1) H samples
+hipError_t apv_launch_fir_input_spectra_parts(int f64, int F, int n_part, const void* x0, const void* x1, void* Xf, hipStream_t s) {
+    if (n_part < 1 || n_part > 65535) return hipErrorInvalidValue;
+    return f64 ? launch_fir_input_spectra<double>(F, x0, x1, F, Xf, s, n_part, F / 2) : launch_fir_input_spectra<float>(F, x0, x1, F, Xf, s, n_part, F / 2);
+}
+
 // Xf [n_hops][2][F/2 + 1] for the hops of a staged chunk (pin [n_hops][2][H], host-pinned), from the histories as they are
 // BEFORE the first of them is processed
 hipError_t apv_launch_fir_chunk_spectra(int f64, int F, int P, int H, int n_hops, const void* hist0, const void* hist1,
@@ -779,7 +841,7 @@ hipError_t apv_launch_fir_chunk_spectra(int f64, int F, int P, int H, int n_hops
 }
 
 hipError_t apv_launch_fir_fft_jobs(int f64, int F, int n_jobs, const void* const* Hf, const void* const* Xf, void* const* resp,
-                                   const int* n_ch, int P, int H, int N, int ring_off, const ApvInputUpdate* upd, hipStream_t s) {
-    return f64 ? launch_fir_fft_jobs<double>(F, n_jobs, Hf, Xf, resp, n_ch, P, H, N, ring_off, upd, s)
-               : launch_fir_fft_jobs<float>(F, n_jobs, Hf, Xf, resp, n_ch, P, H, N, ring_off, upd, s);
+                                   const int* n_ch, int P, int H, int N, int ring_off, const ApvInputUpdate* upd, hipStream_t s, int n_part) {
+    return f64 ? launch_fir_fft_jobs<double>(F, n_jobs, Hf, Xf, resp, n_ch, P, H, N, ring_off, upd, s, 0, 0, 0, 1, n_part)
+               : launch_fir_fft_jobs<float>(F, n_jobs, Hf, Xf, resp, n_ch, P, H, N, ring_off, upd, s, 0, 0, 0, 1, n_part);
 }

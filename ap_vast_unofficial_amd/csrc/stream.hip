@@ -33,7 +33,7 @@ struct apv_stream {
     int out_group;                // cfg.out_layout = 1: L (hops are emitted [n_out / L][H][L]); 0 = channel-major [n_out][H]
     void* rir[2];                 // [P][C]  zone A, zone B
     void* trir[2];                // [P][M]  target RIRs (reference loudspeaker, delayed)
-    void* xhist[2][2];            // [buf][signal][P-1+H+pad]
+    void* xhist[2][2];            // [buf][signal][keep+H+pad]
     void* resp[4];                // [C][N] rings: A->A, A->B, B->A, B->B
     void* tresp[2];               // [M][N] rings: target A, target B
     void* inblk;                  // [2][N] rings: input blocks
@@ -78,9 +78,11 @@ struct apv_stream {
     // K1 by fast convolution (fir_F > 0): spectra of the zero-padded impulse responses and of the two input histories
     // of the hop, in the front-end precision
     int fir_F;                    // segment length, 0 = direct form
-    void* rirspec[2];             // [C][fir_F/2 + 1] complex, zone A, zone B
-    void* trirspec[2];            // [M][fir_F/2 + 1]
-    void* xspec;                  // [2][fir_F/2 + 1]
+    int fir_np;                   // partitions of the uniformly partitioned form (responses too long for one segment), else 1
+    int keep;                     // input samples the histories keep in front of the hop: P - 1, or fir_np H when partitioned
+    void* rirspec[2];             // [fir_np][C][fir_F/2 + 1] complex, zone A, zone B
+    void* trirspec[2];            // [fir_np][M][fir_F/2 + 1]
+    void* xspec;                  // [fir_np][2][fir_F/2 + 1]
     void* xspec_chunk;            // [sig_chunk][2][fir_F/2 + 1]: whole-signal path, the spectra of a staged chunk in one launch
     long hop;                     // hops processed
     long not_converged;           // hops in which some bin hit the sweep cap (status 2)
@@ -261,14 +263,17 @@ static int enqueue_front(apv_handle* h, hipStream_t st, int set, const void* pin
     const void* oh[2] = {s->xhist[s->cur][0], s->xhist[s->cur][1]};
     void* nh[2] = {s->xhist[nxt][0], s->xhist[nxt][1]};
     // with the hop's input spectra in hand (whole-signal path) K1 does not wait for the input update: it rides in K1's launch
-    const bool ride = xspec_ready != nullptr && s->fir_F > 0;
-    if (!ride) SCHK(h, apv_launch_input_update(f64, P, H, s->pad, N, s->ring_off, oh, nh, pin_src, s->inblk, st));   // histories + input-block rings
+    const bool ride = xspec_ready != nullptr && s->fir_F > 0 && s->fir_np == 1;
+    // (the histories keep s->keep samples in front of the hop: P - 1, more when K1 is partitioned)
+    if (!ride) SCHK(h, apv_launch_input_update(f64, s->keep + 1, H, s->pad, N, s->ring_off, oh, nh, pin_src, s->inblk, st));   // histories + input-block rings
     s->cur = nxt;
     // K1: RIR convolution into the response rings (one MFMA launch for all six filter banks)
     if (s->fir_F > 0) {
         const size_t spec_bytes = ((size_t)s->fir_F / 2 + 1) * 2 * s->esz;
-        const void* const xs = xspec_ready ? xspec_ready : s->xspec;
-        if (!xspec_ready)
+        const void* const xs = (xspec_ready && s->fir_np == 1) ? xspec_ready : s->xspec;
+        if (s->fir_np > 1)
+            SCHK(h, apv_launch_fir_input_spectra_parts(f64, s->fir_F, s->fir_np, s->xhist[s->cur][0], s->xhist[s->cur][1], s->xspec, st));
+        else if (!xspec_ready)
             SCHK(h, apv_launch_fir_input_spectra(f64, s->fir_F, s->xhist[s->cur][0], s->xhist[s->cur][1], P - 1 + H, s->xspec, st));
         const void *jh[6], *jx[6];
         void* jr[6];
@@ -282,7 +287,7 @@ static int enqueue_front(apv_handle* h, hipStream_t st, int set, const void* pin
             jr[4 + z] = s->tresp[z]; jc[4 + z] = M;
         }
         ApvInputUpdate upd{{oh[0], oh[1]}, {nh[0], nh[1]}, pin_src, s->inblk, s->pad};
-        SCHK(h, apv_launch_fir_fft_jobs(f64, s->fir_F, 6, jh, jx, jr, jc, P, H, N, s->ring_off, ride ? &upd : nullptr, st));
+        SCHK(h, apv_launch_fir_fft_jobs(f64, s->fir_F, 6, jh, jx, jr, jc, P, H, N, s->ring_off, ride ? &upd : nullptr, st, s->fir_np));
     } else if (f64) {
         FirJobsD jobs{};
         for (int p = 0; p < 4; ++p) {
@@ -600,7 +605,7 @@ static int process_signal_t(apv_handle* h, int n_hops, const TI* h_in_A, const T
     // responses of 64 taps or more (K1 by fast convolution): a chunk of hops per launch, two back streams (below); short
     // responses, APV_FIR_DIRECT and APV_SIGNAL_PER_HOP (A/B switch) keep the hop-by-hop pipeline of this function
     static const bool per_hop = getenv("APV_SIGNAL_PER_HOP") != nullptr;
-    if (s->fir_F > 0 && !per_hop) return process_signal_chunked_t<TI>(h, n_hops, h_in_A, h_in_B, h_out);
+    if (s->fir_F > 0 && s->fir_np == 1 && !per_hop) return process_signal_chunked_t<TI>(h, n_hops, h_in_A, h_in_B, h_out);
     SCHK(h, hipSetDevice(h->device));
     int rc = signal_prepare(h);
     if (rc != APV_OK) return rc;
@@ -676,7 +681,7 @@ static int process_signal_t(apv_handle* h, int n_hops, const TI* h_in_A, const T
         const int base = c * chunk, nc = std::min(chunk, n_hops - base);
         stage_in(c);                                         // this half was collected when chunk c-2's event came in
         const size_t xs_bytes = s->fir_F > 0 ? ((size_t)s->fir_F / 2 + 1) * 2 * e1 * 2 : 0;      // one hop's two spectra
-        if (s->fir_F > 0) {
+        if (s->fir_F > 0 && s->fir_np == 1) {
             // the input spectra K1 starts from, for every hop of the chunk at once: they depend on the staged samples and on
             // the histories as the previous chunk left them, on nothing of this chunk's processing
             hipError_t e = apv_launch_fir_chunk_spectra(s->f64, s->fir_F, s->P, H, nc, s->xhist[s->cur][0], s->xhist[s->cur][1],
@@ -690,7 +695,7 @@ static int process_signal_t(apv_handle* h, int n_hops, const TI* h_in_A, const T
             {
                 // hop h-2 has to be done with this set before the analysis transforms write it
                 rc = enqueue_front(h, s->front, set, (const char*)s->sig_in + slot * 2 * H * e1, released[set] ? nullptr : s->ev_back[set],
-                                   s->fir_F > 0 ? (const char*)s->xspec_chunk + (size_t)i * xs_bytes : nullptr);
+                                   (s->fir_F > 0 && s->fir_np == 1) ? (const char*)s->xspec_chunk + (size_t)i * xs_bytes : nullptr);
                 if (rc != APV_OK) return bail(rc, h->err);
                 e = hipEventRecord(s->ev_front[set], s->front);
             }
@@ -1139,8 +1144,19 @@ int apv_stream_init(apv_handle* h, int32_t rir_len, const double* h_rir_A, const
     // long responses: the hop's convolution goes through the frequency domain (fir_fft_kernel); APV_FIR_DIRECT keeps the
     // direct form on the matrix cores (A/B switch)
     s->fir_F = getenv("APV_FIR_DIRECT") == nullptr ? apv_fir_fft_size(f64, P, H) : 0;
+    s->fir_np = 1;
+    s->keep = P - 1;
+    if (s->fir_F == 0 && getenv("APV_FIR_DIRECT") == nullptr) {
+        // too long for one segment in LDS: uniformly partitioned, partitions of H taps in segments of 2 H samples
+        const int np = apv_fir_partitions(f64, P, H);
+        if (np > 0) {
+            s->fir_F = 2 * H;
+            s->fir_np = np;
+            s->keep = np * H;
+        }
+    }
     if (s->fir_F > 0) {
-        const int F = s->fir_F;
+        const int F = s->fir_F, np = s->fir_np;
         const size_t Kf = (size_t)F / 2 + 1;
         void* cm = nullptr;                                  // [C][P] channel-major copy of one bank, set-up only
         if ((rc = dalloc(h, &cm, (size_t)C * P, e1))) return rc;
@@ -1149,27 +1165,38 @@ int apv_stream_init(apv_handle* h, int32_t rir_len, const double* h_rir_A, const
         for (int z = 0; z < 2; ++z) {
             const double* src = z ? h_rir_B : h_rir_A;
             const int ref = z ? reference_index_B : reference_index_A;
-            if ((rc = dalloc(h, &s->rirspec[z], Kf * C, e2))) return rc;
-            if ((rc = dalloc(h, &s->trirspec[z], Kf * M, e2))) return rc;
+            if ((rc = dalloc(h, &s->rirspec[z], (size_t)np * Kf * C, e2))) return rc;
+            if ((rc = dalloc(h, &s->trirspec[z], (size_t)np * Kf * M, e2))) return rc;
             for (int p = 0; p < P; ++p)
                 for (int l = 0; l < L; ++l)
                     for (int m = 0; m < M; ++m) tr[(size_t)(m * L + l) * P + p] = src[((size_t)p * L + l) * M + m];
             if ((rc = upload(h, f64, cm, tr))) return rc;
-            hipError_t e = apv_launch_fir_spectra(f64, F, C, cm, P, s->rirspec[z], h->stream, &why);
+            hipError_t e = hipSuccess;
+            // (one segment: the whole response; partitioned: taps [q H, (q + 1) H) of every channel, partition-major)
+            for (int q = 0; q < np && e == hipSuccess; ++q) {
+                const int taps = np == 1 ? P : std::min(H, P - q * H);
+                e = apv_launch_fir_spectra_part(f64, F, C, (const char*)cm + (size_t)q * (np == 1 ? 0 : H) * e1, P, taps,
+                                                (char*)s->rirspec[z] + (size_t)q * Kf * C * e2, h->stream, &why);
+            }
             if (e != hipSuccess) return apv_fail(h, APV_ERR_HIP, why.empty() ? hipGetErrorString(e) : why);
             SCHK(h, hipStreamSynchronize(h->stream));
             std::fill(tr.begin(), tr.end(), 0.0);
             for (int p = modeling_delay; p < P; ++p)
                 for (int m = 0; m < M; ++m) tr[(size_t)m * P + p] = src[((size_t)(p - modeling_delay) * L + ref) * M + m];
             if ((rc = upload(h, f64, cm, tr))) return rc;
-            e = apv_launch_fir_spectra(f64, F, M, cm, P, s->trirspec[z], h->stream, &why);
+            e = hipSuccess;
+            for (int q = 0; q < np && e == hipSuccess; ++q) {
+                const int taps = np == 1 ? P : std::min(H, P - q * H);
+                e = apv_launch_fir_spectra_part(f64, F, M, (const char*)cm + (size_t)q * (np == 1 ? 0 : H) * e1, P, taps,
+                                                (char*)s->trirspec[z] + (size_t)q * Kf * M * e2, h->stream, &why);
+            }
             if (e != hipSuccess) return apv_fail(h, APV_ERR_HIP, why.empty() ? hipGetErrorString(e) : why);
             SCHK(h, hipStreamSynchronize(h->stream));
         }
         (void)hipFree(cm);
-        if ((rc = dalloc(h, &s->xspec, 2 * Kf, e2))) return rc;
+        if ((rc = dalloc(h, &s->xspec, (size_t)np * 2 * Kf, e2))) return rc;
     }
-    const size_t hist = (size_t)P - 1 + H + s->pad;
+    const size_t hist = (size_t)s->keep + H + s->pad;
     for (int b = 0; b < 2; ++b)
         for (int g = 0; g < 2; ++g)
             if ((rc = dalloc(h, &s->xhist[b][g], hist, e1))) return rc;
@@ -1353,7 +1380,7 @@ int apv_stream_set_perceptual(apv_handle* h, int32_t n_channels, const double* h
 // Named state arrays, as stored on the device: real samples are float32 (float64 with the float64 front-end),
 // spectra the matching complex type; rings are returned in LOGICAL order:
 //   "response<p>"     [C][N]           "target_response<z>" [M][N]       "input_block" [2][N]
-//   "input_history<g>" [P-1+H]         "out_overlap"        [n_out][N]
+//   "input_history<g>" [keep+H] (keep = P-1; fir_np H when K1 is partitioned: apv_state_bytes tells)   "out_overlap" [n_out][N]
 //   "spectra<p>"      [K][C] complex   "target_spectra<z>"  [K][M] complex   "input_spectrum" [2][K] complex
 //   "weights<z>"      [K][M]
 //   "w_A" / "w_B"     [K][nV][L] c64|c128        "lambda_A" / "lambda_B" [K][L] f32|f64   (cfg.out_c128)
@@ -1368,7 +1395,7 @@ static int state_lookup(apv_handle* h, const char* name, void** dptr, size_t* by
         *dptr = s->tresp[n.back() - '0']; *bytes = M * N * e1; *ring_rows = (int)M; return APV_OK; }
     if (n == "input_block") { *dptr = s->inblk; *bytes = 2 * N * e1; *ring_rows = 2; return APV_OK; }
     if (n == "input_history0" || n == "input_history1") {
-        *dptr = s->xhist[s->cur][n.back() - '0']; *bytes = (size_t)(s->P - 1 + s->H) * e1; return APV_OK; }
+        *dptr = s->xhist[s->cur][n.back() - '0']; *bytes = (size_t)(s->keep + s->H) * e1; return APV_OK; }
     if (n == "out_overlap") { *dptr = s->outov; *bytes = (size_t)s->n_out * N * e1; return APV_OK; }
     if (n.rfind("spectra", 0) == 0 && n.size() == 8 && n[7] >= '0' && n[7] <= '3') {
         *dptr = s->X[n[7] - '0']; *bytes = K * C * e2; return APV_OK; }

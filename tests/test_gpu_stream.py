@@ -248,6 +248,40 @@ def test_stream_fir_direct_and_fast_convolution(P, block, hop, dtype, monkeypatc
     assert np.abs(runs["default"] - runs["direct"]).max() <= (1e-14 if dtype == "f64" else 1e-6) * scale
 
 
+@pytest.mark.parametrize("P,block,hop,dtype", [(4800, 2048, 1024, "f64"),      # five partitions of 1024 taps
+                                                (4200, 256, 128, "f64"),        # 33 partitions
+                                                (9000, 256, 128, "f32")])       # 71 partitions, float32 front-end
+def test_stream_partitioned_convolution(P, block, hop, dtype):
+    """K1 (apvast.py:171-192) for responses too long for ONE overlap-save segment in LDS (P - 1 + H beyond 4096 doubles / 8192
+    floats): uniformly partitioned, partitions of H taps in segments of 2 H samples, against the oracle's lfilter at the plain
+    tolerances of the stream; the state arrays resume bit for bit (the input history is longer in this form: apv_state_bytes),
+    and the whole-signal entry point returns the hop loop's samples."""
+    from ap_vast_unofficial_amd.apvast import apvast
+    L, M = 2, 4
+    rirA, rirB = synth_rirs(P, L, M, 31)
+    K = block // 2 + 1
+    ap, orc, got, exp = run_pair(block, hop, rirA, rirB, 5, 1, 0, 2, 1.0, hops=7, dtype=dtype)
+    e = ap._eng
+    n_part = -(-P // hop)
+    assert e.state_bytes("input_history0") == (n_part + 1) * hop * np.dtype(e.s_dtype).itemsize      # the partitioned form ran
+    check_last_hop_state(ap, orc, TOL[dtype], K, L, M)
+    check_outputs(got, exp, TOL[dtype]["out"], TOL[dtype]["tgt"])
+    # resume: a second object set to this one's state continues bit for bit, per hop and through process_signal
+    b = apvast(block, rirA, rirB, 16, 5, 1, 0, 2, 1.0, 4 * block, hop_size=hop, perceptual=False, seed=9, dtype=dtype)
+    b.set_state(ap.get_state())
+    x = np.random.default_rng(4).standard_normal((2, 5 * hop))
+    ref = [ap.process_input_buffers(x[0, h * hop:(h + 1) * hop], x[1, h * hop:(h + 1) * hop]) for h in range(5)]
+    sig = b.process_signal(x[0], x[1])
+    for q in range(4):
+        for v in range(2):
+            assert np.array_equal(np.concatenate([r[q][v] for r in ref]), sig[q][v]), (q, v)
+    sa, sb = ap.get_state(), b.get_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+    ap.close()
+    b.close()
+
+
 @pytest.mark.parametrize("dialect", ["python", "matlab"])
 def test_stream_perceptual_weighting(dialect):
     """perceptual=True: device weighting curves (perceptualModel.m:118-139, 177-190) against the independent NumPy
