@@ -50,6 +50,15 @@ __device__ __forceinline__ float rsq_full(float x) {
     return __builtin_fmaf(y * e, 0.5f, y);
 }
 
+// wave-level ordering point between phases that exchange data through LDS.  One wave per workgroup (the default): the
+// workgroup barrier, which is that.  APV_WSYNC_WAVE_LOCAL (workgroups of several waves that go their own ways): the wave's own
+// LDS operations complete in order, so draining them (and keeping the compiler from moving LDS accesses across) is all it takes.
+#ifdef APV_WSYNC_WAVE_LOCAL
+__device__ __forceinline__ void wsync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#else
+__device__ __forceinline__ void wsync() { __syncthreads(); }
+#endif
+
 template <typename T> __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -124,11 +133,11 @@ __device__ __forceinline__ void correlate16(const XT* __restrict__ X, const XT* 
 #pragma unroll
     for (int t = 0; t < 4; ++t) dst[MM::row(lane, t) * LD + col] = mk<T>(re[t], im[t]);
     stamp(stamp_base + 1);                                   // MFMAs retired (the stores above read the accumulators)
-    __syncthreads();                                         // one wave per workgroup: an LDS ordering point
+    wsync();
     T pt[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) pt[t] = dst[col * LD + MM::row(lane, t)].y;
-    __syncthreads();                                         // one wave per workgroup: an LDS ordering point
+    wsync();
 #pragma unroll
     for (int t = 0; t < 4; ++t) dst[MM::row(lane, t) * LD + col].y = im[t] - pt[t];
     if (dvec != nullptr) {
@@ -138,8 +147,7 @@ __device__ __forceinline__ void correlate16(const XT* __restrict__ X, const XT* 
     }
 }
 
-// wave-level ordering point between phases that exchange data through LDS (one wave per workgroup)
-__device__ __forceinline__ void wsync() { __syncthreads(); }
+
 
 // XOR-schedule for the register-resident Jacobi (JAC == 1).  Pairs of round r are {i, i^r}; the 15 values of r
 // are visited grouped by their highest (odd sweeps: lowest) set bit so that between two rounds only the
@@ -730,5 +738,81 @@ __device__ __forceinline__ int jacobi16_onesided(Cx<float>& g0t_, Cx<float>& g0b
     converged_ = converged;
     return sweeps_done;
 }
+
+// ---- complex 16 x 16 x 16 products on the matrix cores (shared by the order-16 kernels) ----------------------------------------
+// complex 16x16x16 product on the matrix cores.  fa(i, k) / fb(k, j) fetch operand elements; out[t] is the
+// element (mfma_row<T>(lane, t), lane & 15).
+template <typename T> __device__ __forceinline__ int mfma_row(int lane, int t);
+template <> __device__ __forceinline__ int mfma_row<double>(int lane, int t) { return (lane >> 4) + 4 * t; }
+template <> __device__ __forceinline__ int mfma_row<float>(int lane, int t) { return 4 * (lane >> 4) + t; }
+
+// float64: three real products per k-step instead of four (Karatsuba), in three passes over the k-steps so that two accumulators
+// suffice: P1 = sum ar br, P2 = sum ai bi; re = P1 - P2; the third pass accumulates sum (ar + ai)(br + bi) onto -(P1 + P2), which
+// is the imaginary part.  The f64 matrix pipe is busy ~45 % of this kernel's time at the rate the instruction sustains
+// (profiles/r02/mfma_issue_rate.md), barely overlapped with the VALU: 12 MFMAs and ~30 VALU instructions beat 16 MFMAs.
+template <typename FA, typename FB>
+__device__ __forceinline__ void cmm16(FA fa, FB fb, int lane, Cx<double> out[4]) {
+    d4 p1 = {0, 0, 0, 0}, p2 = {0, 0, 0, 0};
+    const int rc = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const Cx<double> a = fa(rc, 4 * s + kq), b = fb(4 * s + kq, rc);
+        p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.x, p1, 0, 0, 0);
+        p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b.y, p2, 0, 0, 0);
+    }
+    d4 im;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const double u = p1[t], v = p2[t];
+        p1[t] = u - v;                                           // re
+        im[t] = -(u + v);                                        // (written -u - v it saves four sign flips per product and costs
+                                                                 //  a register spill on the common path: 8 -> 55 MB written per launch)
+    }
+    // (the operands are fetched again -- the compiler barrier keeps it from holding the eight complex numbers of the first two
+    // passes in registers, which the kernel does not have)
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const Cx<double> a = fa(rc, 4 * s + kq), b = fb(4 * s + kq, rc);
+        im = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x + a.y, b.x + b.y, im, 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) out[t] = mk<double>(p1[t], im[t]);
+}
+template <typename FA, typename FB>
+__device__ __forceinline__ void cmm16(FA fa, FB fb, int lane, Cx<float> out[4]) {
+    f4 re = {0, 0, 0, 0}, im = {0, 0, 0, 0};
+    const int rc = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const Cx<float> a = fa(rc, 4 * s + kq), b = fb(4 * s + kq, rc);
+        re = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, re, 0, 0, 0);
+        re = __builtin_amdgcn_mfma_f32_16x16x4f32(-a.y, b.y, re, 0, 0, 0);
+        im = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.y, im, 0, 0, 0);
+        im = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.x, im, 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) out[t] = mk<float>(re[t], im[t]);
+}
+
+// The same product with operand lambdas that also receive the k-step s: the accumulator layout of a product X,
+// out[t] = X[(lane >> 4) + 4 t][lane & 15], is at once the B operand X of the next product (fb = out[s]) and the A operand
+// X^T (fa = out[s]), so a result can feed a product without a round trip through LDS.
+template <typename FA, typename FB>
+__device__ __forceinline__ void cmm16x(FA fa, FB fb, int lane, Cx<double> out[4]) {
+    d4 re = {0, 0, 0, 0}, im = {0, 0, 0, 0};
+    const int rc = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const Cx<double> a = fa(s, rc, 4 * s + kq), b = fb(s, 4 * s + kq, rc);
+        re = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.x, re, 0, 0, 0);
+        re = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.y, b.y, re, 0, 0, 0);
+        im = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.y, im, 0, 0, 0);
+        im = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b.x, im, 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) out[t] = mk<double>(re[t], im[t]);
+}
+
 
 }  // namespace

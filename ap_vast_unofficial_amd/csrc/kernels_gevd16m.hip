@@ -25,98 +25,23 @@
 
 namespace {
 
-// complex 16x16x16 product on the matrix cores.  fa(i, k) / fb(k, j) fetch operand elements; out[t] is the
-// element (mfma_row<T>(lane, t), lane & 15).
-template <typename T> __device__ __forceinline__ int mfma_row(int lane, int t);
-template <> __device__ __forceinline__ int mfma_row<double>(int lane, int t) { return (lane >> 4) + 4 * t; }
-template <> __device__ __forceinline__ int mfma_row<float>(int lane, int t) { return 4 * (lane >> 4) + t; }
-
-// float64: three real products per k-step instead of four (Karatsuba), in three passes over the k-steps so that two accumulators
-// suffice: P1 = sum ar br, P2 = sum ai bi; re = P1 - P2; the third pass accumulates sum (ar + ai)(br + bi) onto -(P1 + P2), which
-// is the imaginary part.  The f64 matrix pipe is busy ~45 % of this kernel's time at the rate the instruction sustains
-// (profiles/r02/mfma_issue_rate.md), barely overlapped with the VALU: 12 MFMAs and ~30 VALU instructions beat 16 MFMAs.
-template <typename FA, typename FB>
-__device__ __forceinline__ void cmm16(FA fa, FB fb, int lane, Cx<double> out[4]) {
-    d4 p1 = {0, 0, 0, 0}, p2 = {0, 0, 0, 0};
-    const int rc = lane & 15, kq = lane >> 4;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const Cx<double> a = fa(rc, 4 * s + kq), b = fb(4 * s + kq, rc);
-        p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.x, p1, 0, 0, 0);
-        p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b.y, p2, 0, 0, 0);
-    }
-    d4 im;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const double u = p1[t], v = p2[t];
-        p1[t] = u - v;                                           // re
-        im[t] = -(u + v);                                        // (written -u - v it saves four sign flips per product and costs
-                                                                 //  a register spill on the common path: 8 -> 55 MB written per launch)
-    }
-    // (the operands are fetched again -- the compiler barrier keeps it from holding the eight complex numbers of the first two
-    // passes in registers, which the kernel does not have)
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const Cx<double> a = fa(rc, 4 * s + kq), b = fb(4 * s + kq, rc);
-        im = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x + a.y, b.x + b.y, im, 0, 0, 0);
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) out[t] = mk<double>(p1[t], im[t]);
-}
-template <typename FA, typename FB>
-__device__ __forceinline__ void cmm16(FA fa, FB fb, int lane, Cx<float> out[4]) {
-    f4 re = {0, 0, 0, 0}, im = {0, 0, 0, 0};
-    const int rc = lane & 15, kq = lane >> 4;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const Cx<float> a = fa(rc, 4 * s + kq), b = fb(4 * s + kq, rc);
-        re = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, re, 0, 0, 0);
-        re = __builtin_amdgcn_mfma_f32_16x16x4f32(-a.y, b.y, re, 0, 0, 0);
-        im = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.y, im, 0, 0, 0);
-        im = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.x, im, 0, 0, 0);
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) out[t] = mk<float>(re[t], im[t]);
-}
-
-// The same product with operand lambdas that also receive the k-step s: the accumulator layout of a product X,
-// out[t] = X[(lane >> 4) + 4 t][lane & 15], is at once the B operand X of the next product (fb = out[s]) and the A operand
-// X^T (fa = out[s]), so a result can feed a product without a round trip through LDS.
-template <typename FA, typename FB>
-__device__ __forceinline__ void cmm16x(FA fa, FB fb, int lane, Cx<double> out[4]) {
-    d4 re = {0, 0, 0, 0}, im = {0, 0, 0, 0};
-    const int rc = lane & 15, kq = lane >> 4;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const Cx<double> a = fa(s, rc, 4 * s + kq), b = fb(s, 4 * s + kq, rc);
-        re = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.x, re, 0, 0, 0);
-        re = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.y, b.y, re, 0, 0, 0);
-        im = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.y, im, 0, 0, 0);
-        im = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b.x, im, 0, 0, 0);
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) out[t] = mk<double>(re[t], im[t]);
-}
-
 // XT: element type of the fused input slabs (float2 = c64, double2 = c128: the float64 streaming front-end)
 // DBG: the diagnostic instantiation.  It alone carries the run-time `debug_stop` tests (stage cuts and A/B switches of the
 // probes under tools/probes/) and the in-kernel stage stamps (p.stamps); in the product instantiation `dstop` is the constant 0
 // and all of it folds away, the round-2a two-sided pre-solve included.
 template <typename T, bool FUSED, typename XT, bool DBG>
-__device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
+__device__ __forceinline__ void gevd16m_body(const GevdParams& p, const int k, const bool z1) {
     const int dstop = DBG ? p.debug_stop : 0;
     // stage stamps (diagnostic build only): s_memtime of lane 0 at the stage boundaries, 8 per bin, into a buffer of their own
     auto stamp = [&](int i) {
         if constexpr (DBG) {
             if (p.stamps != nullptr && threadIdx.x == 0)
-                p.stamps[((size_t)blockIdx.y * p.K + blockIdx.x) * 16 + i] = __builtin_amdgcn_s_memtime();
+                p.stamps[((size_t)(z1 ? 1 : 0) * p.K + k) * 16 + i] = __builtin_amdgcn_s_memtime();
         }
     };
     stamp(0);
-    if constexpr (DBG) { if (p.stamps != nullptr && threadIdx.x == 0) p.stamps[((size_t)blockIdx.y * p.K + blockIdx.x) * 16 + 15] = __builtin_amdgcn_s_memrealtime(); }
-    // zone program of a two-zone launch (blockIdx.y); the argument block itself stays in scalar registers
-    const bool z1 = (blockIdx.y == 1);
+    if constexpr (DBG) { if (p.stamps != nullptr && threadIdx.x == 0) p.stamps[((size_t)(z1 ? 1 : 0) * p.K + k) * 16 + 15] = __builtin_amdgcn_s_memrealtime(); }
+    // zone program of a two-zone launch (z1); the argument block itself stays in scalar registers
     const XT* const pXB = reinterpret_cast<const XT*>(z1 ? p.XB1 : p.XB);
     const XT* const pXD = reinterpret_cast<const XT*>(z1 ? p.XD1 : p.XD);
     const XT* const pd = reinterpret_cast<const XT*>(z1 ? p.d1 : p.d);
@@ -138,7 +63,6 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
     T* const sPiv = reinterpret_cast<T*>(&scoef[0]);                   // [N] stage 1: the pivots (scoef is idle until stage 6)
 
     const int lane = threadIdx.x;
-    const int k = blockIdx.x;
     int status = 0;
     // One wave is a long dependent chain; in the per-hop streaming pipeline the launch shares the chip with the next hop's
     // transforms, whose waves would otherwise take every other issue slot: this wave goes first.  (No effect when the kernel runs
@@ -669,10 +593,21 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p) {
 // The double kernel is held to four waves per SIMD (its float32 pre-solve and the re-orthonormalisation products would
 // otherwise raise the register count past 128 and cost a wave); the float kernel is left to the compiler.
 template <typename T, bool FUSED, typename XT, bool DBG = false>
-__global__ void __launch_bounds__(64) gevd16m_kernel(const GevdParams p) { gevd16m_body<T, FUSED, XT, DBG>(p); }
+__global__ void __launch_bounds__(64) gevd16m_kernel(const GevdParams p) { gevd16m_body<T, FUSED, XT, DBG>(p, blockIdx.x, blockIdx.y == 1); }
 template <bool FUSED, typename XT, bool DBG = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) gevd16m_kernel_f64(const GevdParams p) {
-    gevd16m_body<double, FUSED, XT, DBG>(p);
+    gevd16m_body<double, FUSED, XT, DBG>(p, blockIdx.x, blockIdx.y == 1);
+}
+// LIST form: the (zone, bin) entries of the redo list of the two-bins-per-wave kernel (kernels_gevd16x2.hip), a fixed small grid
+// walking the list; an empty list costs the launch and one load per wave
+template <typename XT>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) gevd16m_redo_kernel_f64(const GevdParams p) {
+    const int cnt = *p.redo_count;
+    for (int idx = blockIdx.x; idx < cnt; idx += gridDim.x) {
+        const int e = p.redo_list[idx];
+        gevd16m_body<double, true, XT, false>(p, e & 0x3fffffff, ((e >> 30) & 1) != 0);
+        __syncthreads();
+    }
 }
 
 }  // namespace
@@ -680,6 +615,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 hipError_t apv_launch_gevd16m(const GevdParams& p, int compute_dtype, bool fused, hipStream_t s) {
     if (p.n != 16 || p.reg_mode != APV_REG_ABS || p.reg_bright != 0.0) return hipErrorNotSupported;
     if (p.K <= 0) return hipSuccess;
+    {
+        // float64 fused updates: two bins per wave (kernels_gevd16x2.hip), then the bins it handed back, one per wave
+        const hipError_t e2 = apv_launch_gevd16x2(p, compute_dtype, fused, s);
+        if (e2 == hipSuccess) {
+            if (p.x_c128) hipLaunchKernelGGL((gevd16m_redo_kernel_f64<double2>), dim3(256), dim3(64), 0, s, p);
+            else hipLaunchKernelGGL((gevd16m_redo_kernel_f64<float2>), dim3(256), dim3(64), 0, s, p);
+            return hipGetLastError();
+        }
+        if (e2 != hipErrorNotSupported) return e2;
+    }
     const dim3 grid(p.K, p.n_zones > 1 ? 2 : 1);
     const bool xd = fused && p.x_c128;
     if (p.debug_stop != 0 || p.stamps != nullptr) {
