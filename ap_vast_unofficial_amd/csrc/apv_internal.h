@@ -47,10 +47,6 @@ struct GevdParams {
     // streaming: 1 = this launch shares the chip with the transforms of the NEXT chunk of hops, which are the longer chain
     // (chunked whole-signal path): the waves keep the default issue priority instead of raising theirs
     int yield_issue;
-    // two-bins-per-wave order-16 kernel: the (zone << 30 | bin) entries it hands back to the one-bin kernel, and their count
-    // (zeroed by the launcher in front of every launch); null = that kernel is not used
-    int* redo_list;
-    int* redo_count;
     // diagnostic builds only (tools/probes/stage_stamps.py): s_memtime at the stage boundaries, [zones][K][16]; null in normal use
     unsigned long long* stamps;
 };
@@ -71,7 +67,6 @@ struct apv_handle {
     size_t lspill_bytes;
     void* d_Rscratch;  // [2][K][L][L] + [K][L] c64: MFMA correlation output of the split n in {32, 64} f32 update
     size_t rscratch_bytes;
-    int* d_redo;                    // [1 + 2 K]: redo count and list of the two-bins-per-wave order-16 kernel (apv_create, n_srcs == 16)
     unsigned long long* d_stamps;   // apv_debug_set_stamps: stage-stamp buffer of the diagnostic kernel instantiation (caller's)
     struct apv_stream* st;   // streaming state (apv_stream_init), owned
     struct apv_bb* bb;       // broadband streaming state (apv_bb_init), owned
@@ -106,9 +101,6 @@ bool apv_gevd64_eligible(int n, int reg_mode, double reg_bright, double sweep_to
 // kernels_gevd16m.hip: order-16 fast path (MFMA correlation / whitening / back-transform + register-resident
 // Jacobi); hipErrorNotSupported when the problem does not qualify
 hipError_t apv_launch_gevd16m(const GevdParams& p, int compute_dtype, bool fused, hipStream_t s);
-// kernels_gevd16x2.hip: two bins per wave (float64, fused slabs, absolute loading, default tolerances); hipErrorNotSupported otherwise.
-// Zeroes p.redo_count on the stream, launches, and leaves the bins it could not finish in p.redo_list for apv_launch_gevd16m
-hipError_t apv_launch_gevd16x2(const GevdParams& p, int compute_dtype, bool fused, hipStream_t s);
 
 // kernels_gevd64.hip: order-64 float64 path (float32 block Jacobi on the f32 MFMA + float64 refinement on the f64 MFMA);
 // hipErrorNotSupported when the problem does not qualify.  Needs p.Lspill with apv_gevd_spill_bytes() bytes.

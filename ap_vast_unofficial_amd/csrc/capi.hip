@@ -64,8 +64,6 @@ GevdParams apv_base_params(const apv_handle* h) {
     p.out_c128 = c.out_c128;
     p.Lspill = h->d_Lspill;
     p.stamps = h->d_stamps;
-    p.redo_count = h->d_redo;
-    p.redo_list = h->d_redo ? h->d_redo + 1 : nullptr;
     return p;
 }
 
@@ -159,7 +157,6 @@ int apv_create(const apv_config* cfg, apv_handle** out) {
     h->d_Rscratch = nullptr;
     h->rscratch_bytes = 0;
     h->d_stamps = nullptr;
-    h->d_redo = nullptr;
     h->st = nullptr;
     h->bb = nullptr;
     h->gl_ws = nullptr;
@@ -189,10 +186,6 @@ int apv_create(const apv_config* cfg, apv_handle** out) {
 #undef CR
     int rc = ensure_spill(h, cfg->n_srcs, cfg->n_bins);
     if (rc == APV_OK) rc = ensure_rscratch(h);
-    if (rc == APV_OK && cfg->n_srcs == 16) {
-        hipError_t e = hipMalloc((void**)&h->d_redo, sizeof(int) * (1 + 2 * (size_t)(cfg->n_bins > 0 ? cfg->n_bins : 1)));
-        if (e != hipSuccess) rc = hipfail(h, e, "hipMalloc(redo list)");
-    }
     if (rc != APV_OK) {
         g_create_err = h->err;
         delete h;
@@ -218,7 +211,7 @@ int apv_destroy(apv_handle* h) {
     if (h->ev_ag1) (void)hipEventDestroy(h->ev_ag1);
     if (h->d_bar) (void)hipFree(h->d_bar);
     if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
-    void* bufs[] = {h->d_XB, h->d_XD, h->d_d, h->d_w, h->d_lam, h->d_status, h->d_Lspill, h->d_Rscratch, h->d_redo};
+    void* bufs[] = {h->d_XB, h->d_XD, h->d_d, h->d_w, h->d_lam, h->d_status, h->d_Lspill, h->d_Rscratch};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (h->ev0) (void)hipEventDestroy(h->ev0);

@@ -50,14 +50,8 @@ __device__ __forceinline__ float rsq_full(float x) {
     return __builtin_fmaf(y * e, 0.5f, y);
 }
 
-// wave-level ordering point between phases that exchange data through LDS.  One wave per workgroup (the default): the
-// workgroup barrier, which is that.  APV_WSYNC_WAVE_LOCAL (workgroups of several waves that go their own ways): the wave's own
-// LDS operations complete in order, so draining them (and keeping the compiler from moving LDS accesses across) is all it takes.
-#ifdef APV_WSYNC_WAVE_LOCAL
-__device__ __forceinline__ void wsync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-#else
+// wave-level ordering point between phases that exchange data through LDS (one wave per workgroup)
 __device__ __forceinline__ void wsync() { __syncthreads(); }
-#endif
 
 template <typename T> __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll

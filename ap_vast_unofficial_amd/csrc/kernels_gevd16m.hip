@@ -598,33 +598,12 @@ template <bool FUSED, typename XT, bool DBG = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) gevd16m_kernel_f64(const GevdParams p) {
     gevd16m_body<double, FUSED, XT, DBG>(p, blockIdx.x, blockIdx.y == 1);
 }
-// LIST form: the (zone, bin) entries of the redo list of the two-bins-per-wave kernel (kernels_gevd16x2.hip), a fixed small grid
-// walking the list; an empty list costs the launch and one load per wave
-template <typename XT>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) gevd16m_redo_kernel_f64(const GevdParams p) {
-    const int cnt = *p.redo_count;
-    for (int idx = blockIdx.x; idx < cnt; idx += gridDim.x) {
-        const int e = p.redo_list[idx];
-        gevd16m_body<double, true, XT, false>(p, e & 0x3fffffff, ((e >> 30) & 1) != 0);
-        __syncthreads();
-    }
-}
 
 }  // namespace
 
 hipError_t apv_launch_gevd16m(const GevdParams& p, int compute_dtype, bool fused, hipStream_t s) {
     if (p.n != 16 || p.reg_mode != APV_REG_ABS || p.reg_bright != 0.0) return hipErrorNotSupported;
     if (p.K <= 0) return hipSuccess;
-    {
-        // float64 fused updates: two bins per wave (kernels_gevd16x2.hip), then the bins it handed back, one per wave
-        const hipError_t e2 = apv_launch_gevd16x2(p, compute_dtype, fused, s);
-        if (e2 == hipSuccess) {
-            if (p.x_c128) hipLaunchKernelGGL((gevd16m_redo_kernel_f64<double2>), dim3(256), dim3(64), 0, s, p);
-            else hipLaunchKernelGGL((gevd16m_redo_kernel_f64<float2>), dim3(256), dim3(64), 0, s, p);
-            return hipGetLastError();
-        }
-        if (e2 != hipErrorNotSupported) return e2;
-    }
     const dim3 grid(p.K, p.n_zones > 1 ? 2 : 1);
     const bool xd = fused && p.x_c128;
     if (p.debug_stop != 0 || p.stamps != nullptr) {
