@@ -127,8 +127,6 @@ __device__ __forceinline__ int front64(const GevdParams& p, const Sh& sh, bool z
     C128* const RB = reinterpret_cast<C128*>(sh.regB);
     C128* const sr = sh.sr;
     double* const sDinv = sh.sDinv;
-    double (*const sPart)[N64] = sh.sPart;
-    double (*const sPartI)[N64] = sh.sPartI;
     double* const sRed = sh.sRed;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int il = lane & 15, kq = lane >> 4;
@@ -140,74 +138,116 @@ __device__ __forceinline__ int front64(const GevdParams& p, const Sh& sh, bool z
     // ---------------- stage 0 ----------------
     if constexpr (FUSED) {
         const int M = p.M;
-        // both matrices in one loop, 16 control points of each per step: 16 loads are in flight before the first MFMA of a
-        // step, so a wave meets the memory latency M / 16 times in all instead of M / 16 times per matrix
+        // Both slabs go through LDS, 16 control points of each per chunk: every thread of the workgroup fetches 16 contiguous bytes
+        // of the chunk (whole lines, each slab element read from memory ONCE) while the matrix cores work on the chunk before, and
+        // the sixteen waves take their operands from LDS.  (Round 2 had every wave fetch its own operands from L2: each element
+        // eight times, in 128-byte pieces, and the loop waited for memory M / 16 times: 85 us per bin against 28 us of MFMA time.)
+        // Per k-step THREE real products: Re R = sum xr (x) xr + xi (x) xi, and P = sum xr (x) xi with Im R = P - P^T, the transpose
+        // taken through the LDS tile of the mirrored wave when R is written (as in the order-16 kernel).
         const XT* XBk = pXB + (size_t)k * M * N64;
         const XT* XDk = pXD + (size_t)k * M * N64;
-        d4 bre = {0, 0, 0, 0}, bim = {0, 0, 0, 0}, dre = {0, 0, 0, 0}, dim_ = {0, 0, 0, 0};
-        XT zero;
-        zero.x = 0;
-        zero.y = 0;
-        for (int m0 = 0; m0 < M; m0 += 16) {
-            XT ba[4], bb_[4], da[4], db[4];
+        const XT* dvk = pd + (size_t)k * M;
+        constexpr int CH = 16;                                              // control points per chunk
+        constexpr int CHUNK_ELEMS = CH * N64;                               // elements of one slab per chunk
+        constexpr int VEC = 16 / (int)sizeof(XT);                           // elements per 16-byte fetch: 2 (c64) or 1 (c128)
+        constexpr int FETCHES = 2 * CHUNK_ELEMS / VEC / 1024;               // 16-byte fetches per thread and chunk: 1 (c64) or 2 (c128)
+        using V16 = __attribute__((ext_vector_type(4))) unsigned;
+        // two chunk buffers [2 slabs][CH][64] XT each, in region A (R is written there only after the loop)
+        XT* const sX = reinterpret_cast<XT*>(sh.regA);
+        XT* const sD = sX + 2 * 2 * CHUNK_ELEMS;                            // [2][CH] target samples of the chunk
+        d4 bre = {0, 0, 0, 0}, bp = {0, 0, 0, 0}, dre = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
+        double rx = 0, ry = 0;
+        const int n_chunks = (M + CH - 1) / CH;
+        V16 stage[FETCHES];
+        XT dstage;
+        auto fetch = [&](int c) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int m = m0 + 4 * u + kq;
-                const bool ok = m < M;
-                const size_t o = (size_t)m * N64;
-                ba[u] = ok ? XBk[o + 16 * ti + il] : zero;
-                bb_[u] = ok ? XBk[o + 16 * tj + il] : zero;
-                da[u] = ok ? XDk[o + 16 * ti + il] : zero;
-                db[u] = ok ? XDk[o + 16 * tj + il] : zero;
+            for (int f = 0; f < FETCHES; ++f) {
+                const int e = (f * 1024 + tid) * VEC;                       // element of the [2][CH][64] chunk pair
+                const int slab = e / CHUNK_ELEMS, off = e - slab * CHUNK_ELEMS;
+                const int m = c * CH + off / N64;
+                const XT* src = (slab ? XDk : XBk) + (size_t)c * CHUNK_ELEMS + off;
+                V16 v = {0u, 0u, 0u, 0u};
+                if (m < M) v = *reinterpret_cast<const V16*>(src);          // rows are 64 elements: a 16-byte piece never straddles one
+                stage[f] = v;
             }
+            dstage.x = 0;
+            dstage.y = 0;
+            if (tid < CH && c * CH + tid < M) dstage = dvk[c * CH + tid];
+        };
+        auto stash = [&](int buf) {
+#pragma unroll
+            for (int f = 0; f < FETCHES; ++f)
+                *reinterpret_cast<V16*>(sX + (size_t)buf * 2 * CHUNK_ELEMS + (size_t)(f * 1024 + tid) * VEC) = stage[f];
+            if (tid < CH) sD[buf * CH + tid] = dstage;
+        };
+        fetch(0);
+        for (int c = 0; c < n_chunks; ++c) {
+            const int buf = c & 1;
+            stash(buf);
+            __syncthreads();
+            if (c + 1 < n_chunks) fetch(c + 1);                             // in flight while the MFMAs below run
+            const XT* cb = sX + (size_t)buf * 2 * CHUNK_ELEMS;
+            const XT* cd = cb + CHUNK_ELEMS;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                // conj(x_i) x_j: re = ar br + ai bi, im = ar bi - ai br
-                double ar = ba[u].x, ai = ba[u].y, br = bb_[u].x, bi = bb_[u].y;
+                const int row = (4 * u + kq) * N64;
+                const XT ba = cb[row + 16 * ti + il], bb_ = cb[row + 16 * tj + il];
+                const XT da = cd[row + 16 * ti + il], db = cd[row + 16 * tj + il];
+                double ar = ba.x, ai = ba.y, br = bb_.x, bi = bb_.y;
                 bre = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, bre, 0, 0, 0);
                 bre = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bi, bre, 0, 0, 0);
-                bim = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, bim, 0, 0, 0);
-                bim = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, br, bim, 0, 0, 0);
-                ar = da[u].x; ai = da[u].y; br = db[u].x; bi = db[u].y;
+                bp = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, bp, 0, 0, 0);          // P = sum xr (x) xi
+                ar = da.x; ai = da.y; br = db.x; bi = db.y;
                 dre = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, dre, 0, 0, 0);
                 dre = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bi, dre, 0, 0, 0);
-                dim_ = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, dim_, 0, 0, 0);
-                dim_ = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, br, dim_, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, dp, 0, 0, 0);
             }
+            // r = X_B^H d: wave w takes control point w of the chunk, lane l loudspeaker l; the sixteen partial sums meet below
+            {
+                const XT xv = cb[wave * N64 + lane], dm = sD[buf * CH + wave];
+                rx = fma_t((double)xv.y, (double)dm.y, fma_t((double)xv.x, (double)dm.x, rx));       // conj(x) * d
+                ry = fma_t(-(double)xv.y, (double)dm.x, fma_t((double)xv.x, (double)dm.y, ry));
+            }
+            // (the next pass writes the OTHER buffer; this one is written again two passes on, behind the next pass's barrier)
         }
+        __syncthreads();                                                    // every wave is done with the chunk buffers (region A)
+        // the sixteen partial sums of r meet in region A (the chunk buffers are spent, R is not there yet), in a fixed order
+        {
+            double (*const sR16)[N64] = reinterpret_cast<double(*)[N64]>(sh.regA);          // [32][64]: re, then im
+            sR16[wave][lane] = rx;
+            sR16[16 + wave][lane] = ry;
+            __syncthreads();
+            if (tid < N64) {
+                double sx = 0, sy = 0;
+#pragma unroll
+                for (int w2 = 0; w2 < 16; ++w2) {
+                    sx += sR16[w2][tid];
+                    sy += sR16[16 + w2][tid];
+                }
+                sr[tid] = mk<double>(sx, sy);
+            }
+            __syncthreads();
+        }
+        // R with Im R = P - P^T: P to LDS first (imaginary slot), the transposed element read back from the mirrored tile
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            RA[(16 * ti + kq + 4 * t) * LDD + 16 * tj + il] = mk<double>(bre[t], bim[t]);
-            RB[(16 * ti + kq + 4 * t) * LDD + 16 * tj + il] = mk<double>(dre[t], dim_[t]);
-        }
-        // r = X_B^H d: four waves take every fourth control point each (eight loads in flight), partial sums meet in LDS
-        if (tid < 256) {
-            const XT* X = pXB + (size_t)k * M * N64;
-            const XT* dv = pd + (size_t)k * M;
-            const int l = tid & 63, q = tid >> 6;
-            double rx = 0, ry = 0;
-            for (int m0 = q; m0 < M; m0 += 32) {
-                XT xv[8], dm[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int m = m0 + 4 * u;
-                    const bool ok = m < M;
-                    xv[u] = ok ? X[(size_t)m * N64 + l] : zero;
-                    dm[u] = ok ? dv[m] : zero;
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    rx += (double)xv[u].x * (double)dm[u].x + (double)xv[u].y * (double)dm[u].y;     // conj(x) * d
-                    ry += (double)xv[u].x * (double)dm[u].y - (double)xv[u].y * (double)dm[u].x;
-                }
-            }
-            sPart[q][l] = rx;
-            sPartI[q][l] = ry;
+            RA[(16 * ti + kq + 4 * t) * LDD + 16 * tj + il] = mk<double>(bre[t], bp[t]);
+            RB[(16 * ti + kq + 4 * t) * LDD + 16 * tj + il] = mk<double>(dre[t], dp[t]);
         }
         __syncthreads();
-        if (tid < N64)
-            sr[tid] = mk<double>(sPart[0][tid] + sPart[1][tid] + sPart[2][tid] + sPart[3][tid],
-                                 sPartI[0][tid] + sPartI[1][tid] + sPartI[2][tid] + sPartI[3][tid]);
+        double pbt[4], pdt[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            pbt[t] = RA[(16 * tj + il) * LDD + 16 * ti + kq + 4 * t].y;                   // P[col][row]
+            pdt[t] = RB[(16 * tj + il) * LDD + 16 * ti + kq + 4 * t].y;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            RA[(16 * ti + kq + 4 * t) * LDD + 16 * tj + il].y = bp[t] - pbt[t];
+            RB[(16 * ti + kq + 4 * t) * LDD + 16 * tj + il].y = dp[t] - pdt[t];
+        }
     } else {
         const C128* gRB = reinterpret_cast<const C128*>(p.RB) + (size_t)k * N64 * N64;
         const C128* gRD = reinterpret_cast<const C128*>(p.RD) + (size_t)k * N64 * N64;
