@@ -59,6 +59,12 @@ template <typename T> __device__ __forceinline__ T wave_sum(T v) {
     return __shfl(v, 0, 64);
 }
 
+// a value that is the same in every lane, moved to scalar registers (the compiler cannot prove uniformity of a shuffle's result)
+__device__ __forceinline__ float uniform_scalar(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ double uniform_scalar(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
 using d4 = __attribute__((ext_vector_type(4))) double;
 using f4 = __attribute__((ext_vector_type(4))) float;
 

@@ -181,7 +181,9 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p, const int k, c
             sA[row * LD + col] = acc[t];                                                    // C
             nrm += acc[t].x * acc[t].x + acc[t].y * acc[t].y;
         }
-        const T normF2 = wave_sum(nrm);
+        // (wave-uniform: kept in scalar registers -- the vector registers of this kernel are all spoken for; as a vector value the
+        // scaled norm was spilled on the common path, 8 bytes per lane = 17 MB of scratch written per launch)
+        const T normF2 = uniform_scalar(wave_sum(nrm));
         wsync();
         stamp(3);
         if (dstop == 3) return;
@@ -194,8 +196,8 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p, const int k, c
         // the scale exponent is wave-uniform: kept in a scalar register, the factors are re-formed where they are used
         const int sexp = __builtin_amdgcn_readfirstlane((normF2 > (T)0) ? -((sizeof(T) == 8 ? ilogb((double)normF2) : ilogbf((float)normF2)) / 2) : 0);
         T normS2;
-        if constexpr (sizeof(T) == 8) normS2 = (T)ldexp((double)normF2, 2 * sexp);
-        else normS2 = (T)ldexpf((float)normF2, 2 * sexp);
+        if constexpr (sizeof(T) == 8) normS2 = uniform_scalar((T)ldexp((double)normF2, 2 * sexp));
+        else normS2 = uniform_scalar((T)ldexpf((float)normF2, 2 * sexp));
         bool v_in_lds = false, refined = false;
         // A one-sided solve is used only if it converged and its eigenvalues (the squared column norms) span less than 1e3: its
         // stop criterion is absolute, so columns of smaller norm (the null space of a rank-deficient C sits at the shift) may be

@@ -8,7 +8,7 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--steps 100 --warmup 20 --no-cpu-baseline $*"
+ARGS="--steps 100 --warmup 20 --no-cpu-baseline --no-also $*"
 echo "[profile] kernel trace"; 
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$REPO/bench.py" $ARGS > "$OUT/trace.log" 2>&1
 echo "[profile] pmc FETCH_SIZE"
@@ -17,6 +17,8 @@ echo "[profile] pmc WRITE_SIZE"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$REPO/bench.py" $ARGS > "$OUT/pmc_write.log" 2>&1
 echo "[profile] pmc SQ"
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES --output-format csv -d "$OUT/pmc_sq" -- python3 "$REPO/bench.py" $ARGS > "$OUT/pmc_sq.log" 2>&1 || echo "SQ pass failed"
+echo "[profile] pmc SQ (matrix pipe)"
+rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_sq2" -- python3 "$REPO/bench.py" $ARGS > "$OUT/pmc_sq2.log" 2>&1 || echo "SQ2 pass failed"
 find "$OUT" -name "*.csv" | head -30
 python3 "$REPO/tools/summarise_profile.py" "$OUT" "$TAG" $ARGS
 mkdir -p "$REPO/gpurun_out/profiles_out" && cp "$REPO"/profiles/*.md "$REPO"/profiles/*.json "$REPO/gpurun_out/profiles_out/"
