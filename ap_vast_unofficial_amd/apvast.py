@@ -55,7 +55,8 @@ _jdiag_engine = None
 
 def jdiag(A, B, device=0):
     """Joint diagonalisation on the GPU: (U, D) with U^H (B + reg I) U = I, U^H A U = D, D descending
-    and returned as a diagonal MATRIX, as apvast.py:20-36 does.  Real or complex Hermitian, n <= 64.
+    and returned as a diagonal MATRIX, as apvast.py:20-36 does.  Real symmetric pairs up to n = 2048, complex Hermitian
+    pairs up to n = 1024 (beyond 64 through the real embedding of order 2n, csrc/kernels_jdiag_cplx.hip).
     Raises numpy.linalg.LinAlgError when the loaded B is not positive definite (apvast.py:21)."""
     global _jdiag_engine
     A = np.asarray(A)
@@ -64,17 +65,16 @@ def jdiag(A, B, device=0):
     if A.shape != (n, n) or B.shape != (n, n):
         raise ValueError("jdiag expects two square matrices of equal size")
     cplx = np.iscomplexobj(A) or np.iscomplexobj(B)
-    if n > _capi.MAX_N and (cplx or n > 2048):
-        # stated limit of the boundary (include/apvast_hip.h): complex Hermitian pairs are the per-bin problems, whose
-        # order is the loudspeaker count (<= 64); the reference's own call sites (apvast.py:380-382) are real symmetric
-        raise NotImplementedError("GPU jdiag: complex Hermitian pairs up to n = 64; real symmetric pairs up to n = 2048")
+    if n > _capi.MAX_N and n > (1024 if cplx else 2048):
+        raise NotImplementedError("GPU jdiag: complex Hermitian pairs up to n = 1024; real symmetric pairs up to n = 2048")
     mode = _capi.REG_ABS if EXPERIMENTAL_REGULARIZATION else _capi.REG_REL
     key = (device, mode)
     if _jdiag_engine is None or _jdiag_engine[0] != key:
         eng = _capi.Engine(1, 4, 4, reg_mode=mode, reg_dark=1e-7 if mode == _capi.REG_ABS else 1e-8, device=device)
         _jdiag_engine = (key, eng)
     if n > _capi.MAX_N:
-        U, lam = _jdiag_engine[1].jdiag_large(A[None], B[None])
+        eng = _jdiag_engine[1]
+        U, lam = eng.jdiag_large_complex(A[None], B[None]) if cplx else eng.jdiag_large(A[None], B[None])
         return U[0], np.diag(lam[0])
     U, lam = _jdiag_engine[1].jdiag_batched(A[None], B[None])
     U, lam = U[0], lam[0]

@@ -72,6 +72,7 @@ struct apv_handle {
     struct apv_bb* bb;       // broadband streaming state (apv_bb_init), owned
     std::vector<int> bb_rank_list;   // apv_bb_set_rank_list: ranks of the next apv_bb_init (empty = 1..V)
     void* gl_ws;             // workspace + captured sweep graph of apv_gevd_large, owned
+    double gl_tol2;          // > 0: stop threshold of apv_gevd_large's sweeps for the next call (the complex path asks for accurate eigenVECTORS)
     void* comm;       // ncclComm_t
     int comm_rank, comm_world;
     hipStream_t comm_stream;      // the all-gather runs here so that it overlaps the next block's kernels

@@ -160,6 +160,7 @@ int apv_create(const apv_config* cfg, apv_handle** out) {
     h->st = nullptr;
     h->bb = nullptr;
     h->gl_ws = nullptr;
+    h->gl_tol2 = 0.0;
     h->comm_stream = nullptr;
     h->ev_ready = nullptr;
     for (auto& g : h->gather_done) { g.ptr = nullptr; g.ev = nullptr; }

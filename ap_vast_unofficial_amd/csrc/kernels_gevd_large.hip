@@ -692,7 +692,7 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
         LCHK(hipStreamSynchronize(st));
         converged = true;                     // judged on the second sweep of the pair
         for (int z = 0; z < batch; ++z)
-            if (!(hacc[batch + z] <= kLargeTol2 * norm2[z])) converged = false;
+            if (!(hacc[batch + z] <= (h->gl_tol2 > 0.0 ? h->gl_tol2 : kLargeTol2) * norm2[z])) converged = false;
     }
     const auto t_sweeps = std::chrono::steady_clock::now();
     if (!converged)

@@ -166,6 +166,13 @@ int  apv_jdiag_batched(apv_handle* h, int32_t n, int32_t batch, const double* h_
  * the sizes of its call sites apvast.py:380, 382 */
 int  apv_jdiag_large(apv_handle* h, int32_t n, int32_t batch, const double* h_A, const double* h_B,
                      double* h_U, double* h_lam, int32_t* h_status);
+/* Complex Hermitian pairs beyond the per-bin orders, n <= 1024 (apvast.py:20-36 takes any order; apv_jdiag_batched stops at
+ * 64): A, B, U are [batch][n][n] complex128 row-major, lam [batch][n] f64.  Runs the real symmetric solver above on the
+ * embedding [Re -Im; Im Re] of order 2n and keeps n of its 2n eigenvectors that are independent over C
+ * (kernels_jdiag_cplx.hip).  status 3 / APV_ERR_NO_CONVERGE: an eigenvalue cluster of ~40 or more coincident values.
+ *                                                         replaces apvast.py:20-36 */
+int  apv_jdiag_large_c128(apv_handle* h, int32_t n, int32_t batch, const void* h_A, const void* h_B,
+                          void* h_U, double* h_lam, int32_t* h_status);
 
 /* ---- STFT stages (K2-K4) ------------------------------------------------ */
 /* spectra[c][k] = rfft(window * x[c][:])  for `n_ch` channels of length N (f32 in, c64 out,

@@ -287,6 +287,35 @@ def g7_relative_loading(ref):
                         c_A=Ac, c_B=Bc, c_lam=lamc)
 
 
+def g8_jdiag_complex_large(ref):
+    """G8: reference jdiag on ONE complex Hermitian pair beyond the per-bin orders (n = 96 from 192 snapshots), in both
+    loading branches of apvast.py:22-27; eigenvalues, filters for three ranks, and the reference's own residuals."""
+    rng = np.random.default_rng(11)
+    n, M, ranks = 96, 192, (1, 48, 96)
+    def cn(*s):
+        return ((rng.standard_normal(s) + 1j * rng.standard_normal(s)) * np.sqrt(0.5)).astype(np.complex64)
+    XB, XD, d = cn(M, n), cn(M, n), cn(M)
+    XB128, XD128, d128 = (a.astype(np.complex128) for a in (XB, XD, d))
+    A = XB128.conj().T @ XB128
+    B = XD128.conj().T @ XD128
+    r = XB128.conj().T @ d128
+    out = {}
+    keep = ref.EXPERIMENTAL_REGULARIZATION
+    try:
+        for tag, flag in (("abs", True), ("rel", False)):
+            ref.EXPERIMENTAL_REGULARIZATION = flag
+            U, D = ref.jdiag(A, B)                                  # apvast.py:20-36
+            lk = np.real(np.diag(D))
+            Bl = B + (1e-7 if flag else 1e-8 * np.linalg.norm(B, 2)) * np.eye(n)
+            coef = (U.conj().T @ r) / (lk + 1.0)
+            out["lam_" + tag] = lk
+            out["w_" + tag] = np.stack([U[:, :V] @ coef[:V] for V in ranks])
+            out["ortho_err_" + tag] = np.abs(U.conj().T @ Bl @ U - np.eye(n)).max()
+    finally:
+        ref.EXPERIMENTAL_REGULARIZATION = keep
+    np.savez_compressed(os.path.join(OUT, "g8_jdiag_c_96.npz"), XB=XB, XD=XD, d=d, mu=1.0, ranks=np.array(ranks), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     ref = load_reference()
@@ -296,6 +325,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "g7":
         g7_relative_loading(ref)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "g8":
+        g8_jdiag_complex_large(ref)
+        sys.exit(0)
     g1_broadband(ref)
     g4_stft_stage(ref)
     g1b_single_zone(ref)
@@ -304,5 +336,6 @@ if __name__ == "__main__":
     g5_known_answers(ref)
     g6_errors(ref)
     g7_relative_loading(ref)
+    g8_jdiag_complex_large(ref)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -280,6 +280,79 @@ def test_jdiag_large_vs_oracle(Engine, n, batch):
         eng2.jdiag_large(np.eye(70)[None], -np.eye(70)[None])
 
 
+def _g8_pair(g):
+    XB, XD, d = (g[k].astype(np.complex128) for k in ("XB", "XD", "d"))
+    return XB.conj().T @ XB, XD.conj().T @ XD, XB.conj().T @ d
+
+
+@pytest.mark.parametrize("tag", ["abs", "rel"])
+def test_jdiag_complex_beyond_64_golden(golden, tag):
+    """G8: `jdiag` on a complex Hermitian pair of order 96 against the reference's own (apvast.py:20-36 takes any order), both
+    loading branches: eigenvalues 1e-9, the filters of apvast.py:406-414 built from U 1e-7, jdiag's contract on U."""
+    from ap_vast_unofficial_amd import apvast as host
+    g = golden("g8_jdiag_c_96")
+    A, B, r = _g8_pair(g)
+    n = A.shape[0]
+    keep = host.EXPERIMENTAL_REGULARIZATION
+    host.EXPERIMENTAL_REGULARIZATION = (tag == "abs")
+    try:
+        U, D = host.jdiag(A, B)
+    finally:
+        host.EXPERIMENTAL_REGULARIZATION = keep
+    lam = np.diag(D)
+    assert U.dtype == np.complex128 and D.shape == (n, n)
+    assert np.abs(lam / g["lam_" + tag] - 1).max() < 1e-9
+    load = 1e-7 if tag == "abs" else 1e-8 * np.linalg.norm(B, 2)
+    assert np.abs(U.conj().T @ (B + load * np.eye(n)) @ U - np.eye(n)).max() < 1e-10
+    assert np.abs(U.conj().T @ A @ U - D).max() < 1e-9 * lam[0]
+    coef = (U.conj().T @ r) / (lam + float(g["mu"]))
+    for t, V in enumerate(g["ranks"]):
+        w = U[:, :V] @ coef[:V]
+        assert np.linalg.norm(w - g["w_" + tag][t]) < 1e-7 * np.linalg.norm(g["w_" + tag][t])
+
+
+@pytest.mark.parametrize("n,batch", [(65, 2), (200, 1), (512, 1)])
+def test_jdiag_large_complex_vs_oracle(Engine, n, batch):
+    rng = np.random.default_rng(n)
+    Y = rng.standard_normal((batch, 2 * n, n)) + 1j * rng.standard_normal((batch, 2 * n, n))
+    Z = rng.standard_normal((batch, 2 * n, n)) + 1j * rng.standard_normal((batch, 2 * n, n))
+    A = np.einsum("kmi,kmj->kij", Y.conj(), Y)
+    B = np.einsum("kmi,kmj->kij", Z.conj(), Z)
+    eng = Engine(1, 4, 4)
+    U, lam = eng.jdiag_large_complex(A, B)
+    eng.close()
+    for k in range(batch):
+        _, lam_ref = gevd.jdiag(A[k], B[k])
+        assert np.abs(lam[k] / lam_ref - 1).max() < 1e-9
+        G = U[k].conj().T @ (B[k] + 1e-7 * np.eye(n)) @ U[k]
+        assert np.abs(G - np.eye(n)).max() < 1e-10
+        D = U[k].conj().T @ A[k] @ U[k]
+        assert np.abs(D - np.diag(lam[k])).max() < 1e-9 * lam[k, 0]
+    with pytest.raises(np.linalg.LinAlgError):
+        eng2 = Engine(1, 4, 4)
+        eng2.jdiag_large_complex(np.eye(70, dtype=complex)[None], -np.eye(70, dtype=complex)[None])
+
+
+def test_jdiag_large_complex_repeated_eigenvalues(Engine):
+    """Eigenvalue clusters: the real embedding returns an arbitrary real basis of each eigenspace; the selection must still
+    hand back n vectors that are independent over C and meet jdiag's contract.  A = B Hermitian-congruent to
+    diag(3, 3, 3, 3, 2, 2, 1, ..., 1): clusters of 4, 2 and n - 6."""
+    rng = np.random.default_rng(8)
+    n = 72
+    T = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    B = T.conj().T @ T
+    d = np.ones(n)
+    d[:4], d[4:6] = 3.0, 2.0
+    A = T.conj().T @ np.diag(d) @ T
+    eng = Engine(1, 4, 4, reg_dark=0.0)
+    U, lam = eng.jdiag_large_complex(A[None], B[None])
+    eng.close()
+    U, lam = U[0], lam[0]
+    assert np.abs(lam - d).max() < 1e-9
+    assert np.abs(U.conj().T @ B @ U - np.eye(n)).max() < 1e-9
+    assert np.abs(U.conj().T @ A @ U - np.diag(lam)).max() < 1e-8
+
+
 @pytest.mark.parametrize("L,M", [(64, 128), (32, 48)])
 def test_corr_mfma_f32_and_bf16(Engine, L, M):
     """BASELINE config 5: correlation accumulated in fp32 (exact-product f32 MFMA) and from bf16 inputs (bf16 MFMA,

@@ -114,6 +114,26 @@ def test_g3_jdiag_complex(golden, name):
     assert g["ortho_err"].max() < 1e-9          # KA-3 held for the reference itself
 
 
+def _g8_pair(g):
+    XB, XD, d = (g[k].astype(np.complex128) for k in ("XB", "XD", "d"))
+    return XB.conj().T @ XB, XD.conj().T @ XD, XB.conj().T @ d
+
+
+@pytest.mark.parametrize("tag,mode", [("abs", gevd.REG_MODE_ABS), ("rel", gevd.REG_MODE_REL)])
+def test_g8_jdiag_complex_order_96(golden, tag, mode):
+    """G8: the oracle's jdiag == the reference's on a complex Hermitian pair of order 96, both loading branches
+    (apvast.py:22-27)."""
+    g = golden("g8_jdiag_c_96")
+    A, B, r = _g8_pair(g)
+    U, lam = gevd.jdiag(A, B, reg_mode=mode)
+    assert np.abs(lam / g["lam_" + tag] - 1).max() < 1e-9
+    coef = (U.conj().T @ r) / (lam + float(g["mu"]))
+    for t, V in enumerate(g["ranks"]):
+        w = U[:, :V] @ coef[:V]
+        assert np.linalg.norm(w - g["w_" + tag][t]) < 1e-8 * np.linalg.norm(g["w_" + tag][t])
+    assert float(g["ortho_err_" + tag]) < 1e-9
+
+
 def test_g5_ka1_delay0(golden, rirs):
     """KA-1: with modeling_delay=0 the target path is the input delayed by N-H."""
     g = golden("g5_ka1_delay0")
