@@ -98,6 +98,11 @@ __device__ __forceinline__ double block_sum(double v, double* red, int tid) {
 }
 
 
+// stage stamps (apv_debug_set_stamps; tools/probes/stage_stamps64.py): s_memtime of thread 0 at a phase boundary of bin k
+__device__ __forceinline__ void stamp64(const GevdParams& p, bool z1, int k, int i) {
+    if (p.stamps != nullptr && threadIdx.x == 0) p.stamps[((size_t)(z1 ? 1 : 0) * p.K + k) * 16 + i] = __builtin_amdgcn_s_memtime();
+}
+
 // ---- shared memory of a workgroup, handed to the stage functions ------------------------------------------------------
 struct Sh {
     unsigned char* regA;
@@ -260,12 +265,15 @@ __device__ __forceinline__ int front64(const GevdParams& p, const Sh& sh, bool z
     }
     __syncthreads();
 
+    stamp64(p, z1, k, 8);
     if (p.debug_stop == 1) return -1;
 
-    // ---------------- stage 1: Cholesky of B + reg I (lower, in place), then W = L^-1 in place ----------------
+    // ---------------- stage 1: Cholesky of B + reg I (lower, in place), then W = L^-1 ----------------
     if (tid < N64) RB[tid * LDD + tid] = mk<double>(RB[tid * LDD + tid].x + p.reg_dark, 0);
     __syncthreads();
     {
+        // Right-looking, ONE barrier per step: the trailing update takes the unscaled column, R_ij -= R_ik conj(R_jk) / d_k, so
+        // nothing has to be scaled before it; column k gets its 1/sqrt(d_k) during step k + 1, when nobody reads it any more.
         const int ty = tid >> 5, tx = tid & 31;
         for (int kk = 0; kk < N64; ++kk) {
             const double dkk = RB[kk * LDD + kk].x;
@@ -273,69 +281,97 @@ __device__ __forceinline__ int front64(const GevdParams& p, const Sh& sh, bool z
                 status = 1;
                 break;
             }
-            const double inv = rsq_full(dkk);
-            if (tid == 0) sDinv[kk] = inv;
-            for (int i = kk + 1 + tid; i < N64; i += 1024) {
-                const C128 v = RB[i * LDD + kk];
-                RB[i * LDD + kk] = mk<double>(v.x * inv, v.y * inv);
-            }
-            __syncthreads();
+            const double inv = rcp_full(dkk);
+            if (tid == 0) sDinv[kk] = rsq_full(dkk);
             for (int i = kk + 1 + ty; i < N64; i += 32) {
                 const C128 li = RB[i * LDD + kk];
+                const double lix = li.x * inv, liy = li.y * inv;
                 for (int j = kk + 1 + tx; j <= i; j += 32) {
                     const C128 lj = RB[j * LDD + kk];
                     C128 v = RB[i * LDD + j];
-                    v.x = fma_t(-li.y, lj.y, fma_t(-li.x, lj.x, v.x));            // -= l_i conj(l_j), as chained FMAs
-                    v.y = fma_t(li.x, lj.y, fma_t(-li.y, lj.x, v.y));
+                    v.x = fma_t(-liy, lj.y, fma_t(-lix, lj.x, v.x));            // -= (l_i / d) conj(l_j), as chained FMAs
+                    v.y = fma_t(lix, lj.y, fma_t(-liy, lj.x, v.y));
                     RB[i * LDD + j] = v;
+                }
+            }
+            if (kk > 0 && tid >= 960) {                      // the previous column, by the wave with the least to do above
+                const double sc = sDinv[kk - 1];
+                const int i = kk + (tid - 960);
+                if (i < N64) {
+                    const C128 v = RB[i * LDD + kk - 1];
+                    RB[i * LDD + kk - 1] = mk<double>(v.x * sc, v.y * sc);
                 }
             }
             __syncthreads();
         }
     }
+    stamp64(p, z1, k, 9);
     if (p.debug_stop == 2) return -1;
     if (status == 0) {
-        // W = L^-1, column by column from the right: W[i][j] = -(sum_{j<k<=i} W[i][k] L[k][j]) / L[j][j].  Sixteen lanes share a
-        // row; the column of L is overwritten only after every row has read it.
-        if (tid < N64) RB[tid * LDD + tid] = mk<double>(sDinv[tid], 0);
-        __syncthreads();
-        {
-            const int rrow = tid >> 4, sub = tid & 15;
-            for (int j = N64 - 2; j >= 0; --j) {
-                const int i = j + 1 + rrow;
-                double sx = 0, sy = 0;
-                if (i < N64) {
-                    for (int kk = j + 1 + sub; kk <= i; kk += 16) {
-                        const C128 w = RB[i * LDD + kk], l = RB[kk * LDD + j];
-                        sx = fma_t(-w.y, l.y, fma_t(w.x, l.x, sx));
-                        sy = fma_t(w.y, l.x, fma_t(w.x, l.y, sy));
-                    }
+        // W = L^-1 in 16 x 16 blocks; W^H goes to the UPPER triangle of the region with its diagonal (W_ij at [j][i], conjugated);
+        // nothing below reads L's diagonal.  L stays where it is until the last block is done.
+        //   (1) the four diagonal blocks at once, one wave: lane 16 a + c solves L_aa w = e_c by forward substitution
+        if (wave == 0) {
+            const int a = lane >> 4, c = lane & 15, o = 16 * a;
+            double wx[16], wy[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                double sx = (i == c) ? 1.0 : 0.0, sy = 0.0;
+#pragma unroll
+                for (int q = 0; q < i; ++q) {
+                    const C128 l = RB[(o + i) * LDD + o + q];                   // the same word for the 16 lanes of a block
+                    sx = fma_t(l.y, wy[q], fma_t(-l.x, wx[q], sx));
+                    sy = fma_t(-l.y, wx[q], fma_t(-l.x, wy[q], sy));
                 }
-                sx += xcol<1>(sx); sy += xcol<1>(sy);
-                sx += xcol<2>(sx); sy += xcol<2>(sy);
-                sx += xcol<4>(sx); sy += xcol<4>(sy);
-                sx += xrow<1>(sx, lane); sy += xrow<1>(sy, lane);
-                __syncthreads();
-                if (i < N64 && sub == 0) {
-                    const double dj = sDinv[j];
-                    RB[i * LDD + j] = mk<double>(-sx * dj, -sy * dj);
-                }
-                __syncthreads();
+                const double di = sDinv[o + i];
+                wx[i] = (i < c) ? 0.0 : sx * di;
+                wy[i] = (i < c) ? 0.0 : sy * di;
             }
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (i >= c) RB[(o + c) * LDD + o + i] = mk<double>(wx[i], -wy[i]);  // conj(W[o + i][o + c]) at the mirrored place
+        }
+        __syncthreads();
+        //   (2) the blocks below the diagonal, one block diagonal after the other: W_ba = -W_bb (sum_{a <= k < b} L_bk W_ka).  The
+        //       accumulator of the inner sum is the B operand of the second product as it stands (register t is row 4 t + kq).
+        auto Wel = [&](int i, int kk) { return cj(RB[kk * LDD + i]); };          // W[i][kk], kk <= i (the diagonal is real)
+        for (int dgl = 1; dgl < 4; ++dgl) {
+            if (wave < 4 - dgl) {
+                const int a = wave, b = wave + dgl;
+                C128 sacc[4];
+                cmm64_tile([&](int i, int kk) { return RB[i * LDD + kk]; },
+                           [&](int kk, int j) { return kk >= j ? Wel(kk, j) : mk<double>(0, 0); }, b, a, lane, 16 * a, 16 * b, sacc);
+                d4 p1 = {0, 0, 0, 0}, p2 = {0, 0, 0, 0}, p3 = {0, 0, 0, 0};
+                const int i = 16 * b + il;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int kk = 16 * b + 4 * t + kq;
+                    const C128 w = kk <= i ? Wel(i, kk) : mk<double>(0, 0);
+                    p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w.x, sacc[t].x, p1, 0, 0, 0);
+                    p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(w.y, sacc[t].y, p2, 0, 0, 0);
+                    p3 = __builtin_amdgcn_mfma_f64_16x16x4f64(w.x + w.y, sacc[t].x + sacc[t].y, p3, 0, 0, 0);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {                                    // element (16 b + kq + 4 t, 16 a + il) of -W_bb S, conjugated
+                    RB[(16 * a + il) * LDD + 16 * b + kq + 4 * t] = mk<double>(-(p1[t] - p2[t]), p3[t] - p1[t] - p2[t]);
+                }
+            }
+            __syncthreads();
         }
 
+        stamp64(p, z1, k, 10);
         if (p.debug_stop == 3) return -1;
         // ---------------- stage 2: C = W A W^H ----------------
         C128 acc[4];
         // W is lower triangular: W[i][k] = 0 for k > i (the upper triangle of the region still holds R_D)
-        cmm64_tile([&](int i, int kk) { return kk <= i ? RB[i * LDD + kk] : mk<double>(0, 0); },
+        cmm64_tile([&](int i, int kk) { return kk <= i ? Wel(i, kk) : mk<double>(0, 0); },
                    [&](int kk, int j) { return RA[kk * LDD + j]; }, ti, tj, lane, 0, 16 * (ti + 1), acc);       // T = W A
         __syncthreads();
 #pragma unroll
         for (int t = 0; t < 4; ++t) RA[(16 * ti + kq + 4 * t) * LDD + 16 * tj + il] = acc[t];
         __syncthreads();
         cmm64_tile([&](int i, int kk) { return RA[i * LDD + kk]; },
-                   [&](int kk, int j) { return kk <= j ? cj(RB[j * LDD + kk]) : mk<double>(0, 0); }, ti, tj, lane, 0, 16 * (tj + 1),
+                   [&](int kk, int j) { return kk <= j ? cj(Wel(j, kk)) : mk<double>(0, 0); }, ti, tj, lane, 0, 16 * (tj + 1),
                    acc);                                                                                          // C = T W^H
         double nrm = 0;
 #pragma unroll
@@ -348,7 +384,7 @@ __device__ __forceinline__ int front64(const GevdParams& p, const Sh& sh, bool z
         // W to the scratch slot, zeros above the diagonal
         for (int idx = tid; idx < N64 * N64; idx += 1024) {
             const int i = idx >> 6, j = idx & 63;
-            gW[idx] = j <= i ? RB[i * LDD + j] : mk<double>(0, 0);
+            gW[idx] = j <= i ? Wel(i, j) : mk<double>(0, 0);
         }
         normF2 = block_sum(nrm, sRed, tid);          // (its barriers also end every read of T in region A)
         const int sexp = (normF2 > 0.0) ? -(ilogb(normF2) / 2) : 0;
@@ -592,6 +628,7 @@ __device__ __forceinline__ void back64(const GevdParams& p, const Sh& sh, bool z
             __syncthreads();
         }
         if (!converged) status = 2;
+        stamp64(p, z1, k, 11);
         if (p.debug_stop == 6) {                       // profiling aid: sweeps and refinement steps this bin took
             if (pstatus != nullptr && tid == 0) pstatus[k] = 100 * n_sweeps + n_ref;
             return;
@@ -752,11 +789,13 @@ __global__ void __launch_bounds__(1024) gevd64x2_kernel(const GevdParams p) {
     auto Vfb = [&](int b) { return Cfb(b) + N64 * LDF; };
     int status0 = 0, status1 = 1;
     double normF2_0 = 0, normF2_1 = 0, scl0 = 1, scl1 = 1;
+    stamp64(p, z1, k0, 0);
     // float64 front stages, one bin after the other; the scaled float32 copy of C goes to the scratch slot
     status0 = front64<FUSED, XT>(p, sh, z1, k0, gCb(0), gWb(0), gFb(0), N64, nullptr, normF2_0, scl0);
     if (status0 < 0) return;
     if (tid < N64) gRb(0)[tid] = sr[tid];
     __syncthreads();
+    stamp64(p, z1, k0, 1);
     if (nb == 2) {
         status1 = front64<FUSED, XT>(p, sh, z1, k0 + 1, gCb(1), gWb(1), gFb(1), N64, nullptr, normF2_1, scl1);
         if (tid < N64) gRb(1)[tid] = sr[tid];
@@ -774,6 +813,7 @@ __global__ void __launch_bounds__(1024) gevd64x2_kernel(const GevdParams p) {
         }
     }
     __syncthreads();
+    stamp64(p, z1, k0, 2);
     // ---------------- stage 3a for both bins: in every step four waves solve the pair problems of one bin's next round
     // while the other twelve apply the factors of the other bin's current round (10 Hermitian tiles of C with their mirrors
     // + 16 tiles of V = 36 products of 16^3, three per wave); the bins swap roles from step to step
@@ -783,6 +823,10 @@ __global__ void __launch_bounds__(1024) gevd64x2_kernel(const GevdParams p) {
     double offp0 = 1e300, offp1 = 1e300;
     const int max_sweeps = p.max_sweeps > 0 ? p.max_sweeps : 14;
     const double kPreTol = p.sweep_tol2 < 0.0 ? -p.sweep_tol2 : 1e-8;
+    // probe (apv_debug_set_stamps): cycles waves 0 (pair solves), 4 (a C tile + a V tile) and 15 (three V tiles) work per step, and
+    // the steps' whole length with the barrier: slots 12 / 13 / 14 of the first bin's row, the latter in slot 15
+    const bool dbg_t = (p.stamps != nullptr) && lane == 0 && (wave == 0 || wave == 4 || wave == 15);
+    unsigned long long t_work = 0, t_all = 0;
     for (int step = 0; step < 2 * (NBLK - 1) * max_sweeps + 4 && !(st0 == DONE && st1 == DONE); ++step) {
         const int bS = step & 1, bU = bS ^ 1;
         const int stS = bS ? st1 : st0, stU = bU ? st1 : st0;
@@ -790,6 +834,7 @@ __global__ void __launch_bounds__(1024) gevd64x2_kernel(const GevdParams p) {
         const bool do_inner = (stS == INNER), do_outer = (stU == OUTER);
         const bool sweep_end = do_outer && rU == NBLK - 2;
         float offw = 0.f;
+        const unsigned long long tw0 = dbg_t ? __builtin_amdgcn_s_memtime() : 0ull;
         if (wave < 4) {
             if (do_inner) inner_solve(Cfb(bS), sU[bS][wave], rS, wave, lane);
         } else if (do_outer) {
@@ -812,7 +857,12 @@ __global__ void __launch_bounds__(1024) gevd64x2_kernel(const GevdParams p) {
             const float w = wave_sum(offw);
             if (lane == 0) sOffW[step & 1][wave] = w;
         }
+        if (dbg_t) {
+            __builtin_amdgcn_s_waitcnt(0);                       // the wave's LDS stores have landed: its work is done
+            t_work += __builtin_amdgcn_s_memtime() - tw0;
+        }
         __syncthreads();
+        if (dbg_t) t_all += __builtin_amdgcn_s_memtime() - tw0;
         if (do_inner) {
             if (bS) st1 = OUTER; else st0 = OUTER;
         }
@@ -832,6 +882,12 @@ __global__ void __launch_bounds__(1024) gevd64x2_kernel(const GevdParams p) {
         }
     }
     __syncthreads();
+    if (dbg_t) {
+        unsigned long long* row = p.stamps + ((size_t)(z1 ? 1 : 0) * p.K + k0) * 16;
+        row[wave == 0 ? 12 : (wave == 4 ? 13 : 14)] = t_work;
+        if (wave == 0) row[15] = t_all;
+    }
+    stamp64(p, z1, k0, 3);
     // the float32 eigenvector matrices wait in the scratch slots while the float64 back stages use all of the LDS
     for (int b = 0; b < nb; ++b) {
         if ((b ? status1 : status0) != 0) continue;
@@ -847,13 +903,16 @@ __global__ void __launch_bounds__(1024) gevd64x2_kernel(const GevdParams p) {
     }
     if (tid < N64) sr[tid] = gRb(0)[tid];
     __syncthreads();
+    stamp64(p, z1, k0, 4);
     back64<XT>(p, sh, z1, k0, gCb(0), gWb(0), gFb(0), N64, status0, swp0);
+    stamp64(p, z1, k0, 5);
     if (nb == 2) {
         __syncthreads();
         if (tid < N64) sr[tid] = gRb(1)[tid];
         __syncthreads();
         back64<XT>(p, sh, z1, k0 + 1, gCb(1), gWb(1), gFb(1), N64, status1, swp1);
     }
+    stamp64(p, z1, k0, 6);
 }
 
 }  // namespace
