@@ -28,7 +28,7 @@ EXPORTS = (
     "apv_update_dev", "apv_update", "apv_corr_dev", "apv_corr_bf16_dev", "apv_to_bf16_dev", "apv_gevd_vast_dev", "apv_jdiag_batched", "apv_jdiag_large", "apv_jdiag_large_c128",
     "apv_stft_analysis_dev", "apv_istft_ola_dev",
     "apv_stream_init", "apv_stream_set_perceptual", "apv_process_block", "apv_process_block_f64", "apv_process_signal", "apv_process_signal_f64", "apv_stream_is_f64", "apv_stream_get_statistics", "apv_stream_not_converged", "apv_state_bytes", "apv_get_state", "apv_set_state",
-    "apv_bb_set_rank_list", "apv_bb_init", "apv_bb_set_perceptual", "apv_bb_process_block", "apv_bb_get_state", "apv_bb_set_state",
+    "apv_bb_set_rank_list", "apv_bb_init", "apv_bb_set_perceptual", "apv_bb_process_block", "apv_bb_process_signal", "apv_bb_get_state", "apv_bb_set_state",
     "apv_predict_pressure", "apv_vast_static",
     "apv_comm_unique_id", "apv_comm_init", "apv_allgather_filters_dev", "apv_comm_last_gather", "apv_comm_barrier",
     "apv_debug_set_stamps", "apv_device_sync", "apv_device_info",
@@ -118,6 +118,7 @@ def load():
     lib.apv_bb_set_rank_list.argtypes = [vp, i32, vp]
     lib.apv_bb_set_perceptual.argtypes = [vp, i32, vp, C.c_double, C.c_double, C.c_double, i32]
     lib.apv_bb_process_block.argtypes = [vp, vp, vp, vp]
+    lib.apv_bb_process_signal.argtypes = [vp, i32, vp, vp, vp]
     lib.apv_bb_get_state.argtypes = [vp, C.c_char_p, vp, sz]
     lib.apv_bb_set_state.argtypes = [vp, C.c_char_p, vp, sz]
     lib.apv_predict_pressure.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp]
@@ -532,6 +533,18 @@ class Engine:
         in_B = np.ascontiguousarray(in_B, dtype=np.float64).ravel()
         out = np.empty((n_out, self.cfg.hop_size), dtype=np.float64)
         self._chk_stream(self.lib.apv_bb_process_block(self.h, _ptr(in_A), _ptr(in_B), _ptr(out)))
+        return out
+
+    def bb_process_signal(self, in_A, in_B, n_out):
+        """n_hops hops in one call: (n_hops, n_out, H) float64; the joint diagonalisations of up to 8 consecutive hops are one batch."""
+        in_A = np.ascontiguousarray(in_A, dtype=np.float64).ravel()
+        in_B = np.ascontiguousarray(in_B, dtype=np.float64).ravel()
+        H = self.cfg.hop_size
+        if in_A.size != in_B.size or in_A.size % H:
+            raise ValueError("inputs must hold a whole number of hops")
+        n_hops = in_A.size // H
+        out = np.empty((n_hops, n_out, H), dtype=np.float64)
+        self._chk_stream(self.lib.apv_bb_process_signal(self.h, n_hops, _ptr(in_A), _ptr(in_B), _ptr(out)))
         return out
 
     def bb_get_state(self, name, shape):

@@ -283,8 +283,9 @@ class apvast:
         return res
 
     def process_signal(self, input_A, input_B, out=None):
-        """Every hop of two whole signals in one call (subband mode): the hop loop of main.m:52-62 /
-        make_python_test.m:44-51 around process_input_buffers, with consecutive hops pipelined on the device.  Returns
+        """Every hop of two whole signals in one call: the hop loop of main.m:52-62 / make_python_test.m:44-51 around
+        process_input_buffers, with consecutive hops pipelined on the device (subband mode) or their joint
+        diagonalisations solved as one batch (broadband mode; `out` is not used there).  Returns
         (output_A, output_B, target_A, target_B): per zone a list over the ranks of (n_samples, L) arrays, None for a
         zone that does not run; sample for sample what the per-hop calls return, concatenated.  The attributes
         afterwards are those of the last hop.
@@ -295,10 +296,18 @@ class apvast:
         input_B = np.asarray(input_B).ravel()
         if input_A.size != input_B.size or input_A.size % self.hop_size:
             raise RuntimeError("invalid input size")
-        if self.mode == "broadband":
-            raise NotImplementedError("process_signal: subband mode only (the broadband hop is one serial chain)")
         if input_A.size == 0:
             raise RuntimeError("invalid input size")
+        if self.mode == "broadband":
+            # the joint diagonalisations of up to 8 consecutive hops are solved as one batch (apv_bb_process_signal)
+            blocks = self._eng.bb_process_signal(input_A, input_B, self._n_out)          # (hops, n_out, H)
+            L, V = self.number_of_srcs, len(self._ranks)
+            sig = np.ascontiguousarray(blocks.transpose(1, 0, 2)).reshape(self._n_out, -1)      # (n_out, samples)
+            grp = sig.reshape(self._n_out // L, L, -1).transpose(0, 2, 1)                 # (groups, samples, L)
+            res = self._split_groups(np.ascontiguousarray(grp))
+            self._hops += blocks.shape[0] - 1
+            self._refresh_broadband()
+            return res
         out = self._eng.process_signal(input_A, input_B, self._n_out, out=out)   # (groups, n_samples, L), written in place by the library
         if out.dtype != np.float64:
             out = out.astype(np.float64)

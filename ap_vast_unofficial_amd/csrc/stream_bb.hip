@@ -60,6 +60,17 @@ struct apv_bb {
     double* G2T;           // [nch][K]
     double* tspec[2];      // [M][K] c128 target spectra (kept: the curves come from both zones before any scaling)
     double* Wgt[2];        // [M][K]
+    // apv_bb_process_signal: G consecutive hops share ONE batched joint diagonalisation (allocated on first use)
+    int grp;               // hops per group the buffers below are sized for (0: not allocated)
+    double* g_xin;         // [grp][2][H] the group's input hops
+    double* g_RA;          // [grp * nz][n][n] bright matrices, (hop, zone that runs) major
+    double* g_RB;          // [grp * nz][n][n] dark matrices
+    double* g_U;           // [grp * nz][n][n]
+    double* g_lam;         // [grp * nz][n]
+    double* g_r;           // [grp * nz][n]
+    double* g_w;           // [grp * nz][V][n]
+    double* g_nrm;         // [grp][4] + [grp * nz] dark norms in batch order
+    double* g_inspec;      // [grp][2][K] c128
 };
 
 namespace {
@@ -435,7 +446,8 @@ void apv_bb_free(apv_handle* h) {
                       s->xhist[1][1], s->xin, s->resp[0], s->resp[1], s->resp[2], s->resp[3], s->tresp[0], s->tresp[1],
                       s->inblk, s->spec, s->ov[0], s->ov[1], s->ov[2], s->ov[3], s->tov[0], s->tov[1], s->stats[0],
                       s->stats[1], s->stats[2], s->stats[3], s->tstats[0], s->tstats[1], s->R, s->r, s->U, s->lam, s->w,
-                      s->fspec, s->inspec, s->outov, s->out, s->G2, s->G2T, s->tspec[0], s->tspec[1], s->Wgt[0], s->Wgt[1], s->nrm};
+                      s->fspec, s->inspec, s->outov, s->out, s->G2, s->G2T, s->tspec[0], s->tspec[1], s->Wgt[0], s->Wgt[1], s->nrm,
+                      s->g_xin, s->g_RA, s->g_RB, s->g_U, s->g_lam, s->g_r, s->g_w, s->g_nrm, s->g_inspec};
     for (double* b : bufs)
         if (b) (void)hipFree(b);
     if (s->d_ranks) (void)hipFree(s->d_ranks);
@@ -571,38 +583,57 @@ int apv_bb_init(apv_handle* h, int32_t rir_len, const double* h_rir_A, const dou
     return APV_OK;
 }
 
-int apv_bb_process_block(apv_handle* h, const double* h_in_A, const double* h_in_B, double* h_out) {
-    if (!h || !h_in_A || !h_in_B || !h_out) return apv_fail(h, APV_ERR_ARG, "null argument");
-    apv_bb* s = h->bb;
-    if (!s) return apv_fail(h, APV_ERR_ARG, "apv_bb_init has not been called");
-    BCHK(h, hipSetDevice(h->device));
+// Where one hop's statistics and solution live: the handle's own arrays for apv_bb_process_block, slices of the group buffers
+// for apv_bb_process_signal.
+struct BbHop {
+    const double* xin;     // [2][H] the hop's input samples (device)
+    double* Rq[4];         // bright A->A, B->B; dark A->B, B->A (zones that do not run: unused)
+    double* r[2];          // per zone
+    double* nrm;           // [4] ||R_q||_2
+    double* nrm_dark;      // first dark norm in the order the batch holds the matrices (relative loading of the Python dialect)
+    double* inspec;        // [2][K] c128
+    double* w[2];          // per zone [V][n]
+};
+
+static BbHop bb_own_hop(apv_bb* s) {
+    const size_t nn = (size_t)s->n * s->n;
+    BbHop q{};
+    q.xin = s->xin;
+    for (int i = 0; i < 4; ++i) q.Rq[i] = s->R + i * nn;
+    for (int z = 0; z < 2; ++z) {
+        q.r[z] = s->r + (size_t)z * s->n;
+        q.w[z] = s->w + (size_t)z * s->V * s->n;
+    }
+    q.nrm = s->nrm;
+    q.nrm_dark = s->nrm + 2 + ((s->zones & 1) ? 0 : 1);
+    q.inspec = s->inspec;
+    return q;
+}
+
+// stages 1-3 of a hop (and the input spectra of stage 6, which depend on the input ring as it stands now): everything in front
+// of the joint diagonalisation.  t_stage: optional wall times of the stages (APV_BB_TIMING).
+static int bb_front(apv_handle* h, apv_bb* s, const BbHop& q, double* t_stage) {
     hipStream_t st = h->stream;
-    const int N = s->N, H = s->H, K = s->K, L = s->L, M = s->M, C = s->C, P = s->P, J = s->J, S = s->S, V = s->V, n = s->n;
+    const int N = s->N, H = s->H, K = s->K, L = s->L, M = s->M, C = s->C, P = s->P, J = s->J, S = s->S, n = s->n;
     std::string why;
-    // APV_BB_TIMING=1: synchronise at the stage boundaries and print the wall time of each (profiling aid;
-    // rocprofv3 cannot trace this path, see DESIGN.md section 6)
-    static const bool timing = getenv("APV_BB_TIMING") != nullptr;
-    double t_stage[8] = {0};
     int n_stage = 0;
     auto t_prev = std::chrono::steady_clock::now();
     auto stage_done = [&]() {
-        if (!timing) return;
+        if (!t_stage) return;
         (void)hipStreamSynchronize(st);
         const auto now = std::chrono::steady_clock::now();
         t_stage[n_stage++] = std::chrono::duration<double, std::milli>(now - t_prev).count();
         t_prev = now;
     };
-    BCHK(h, hipMemcpyAsync(s->xin, h_in_A, sizeof(double) * H, hipMemcpyHostToDevice, st));
-    BCHK(h, hipMemcpyAsync(s->xin + H, h_in_B, sizeof(double) * H, hipMemcpyHostToDevice, st));
     const int nxt = s->cur ^ 1;
     const int hist_total = P - 1 + H + s->pad;
     for (int g = 0; g < 2; ++g)
         hipLaunchKernelGGL(hist_f64_kernel, dim3((hist_total + 255) / 256), dim3(256), 0, st, P, H, s->pad,
-                           s->xhist[s->cur][g], s->xin + (size_t)g * H, s->xhist[nxt][g]);
+                           s->xhist[s->cur][g], q.xin + (size_t)g * H, s->xhist[nxt][g]);
     s->cur = nxt;
     s->ring_off = (s->ring_off + H) % N;
     s->stat_off = (s->stat_off + H) % S;
-    hipLaunchKernelGGL(ring_append_f64_kernel, dim3((H + 255) / 256, 2), dim3(256), 0, st, N, H, s->ring_off, s->xin,
+    hipLaunchKernelGGL(ring_append_f64_kernel, dim3((H + 255) / 256, 2), dim3(256), 0, st, N, H, s->ring_off, q.xin,
                        (long)H, s->inblk);
     // 1: RIR convolution
     {
@@ -655,87 +686,239 @@ int apv_bb_process_block(apv_handle* h, const double* h_in_A, const double* h_in
     {
         SyrkJobs jobs{};
         int nj = 0;
-        for (int q = 0; q < 4; ++q) {
-            const bool live = (q == 0 || q == 2) ? runA : runB;
+        for (int i = 0; i < 4; ++i) {
+            const bool live = (i == 0 || i == 2) ? runA : runB;
             if (!live) continue;
-            jobs.stats[nj] = s->stats[stat_src[q]];
-            jobs.R[nj++] = s->R + (size_t)q * n * n;
+            jobs.stats[nj] = s->stats[stat_src[i]];
+            jobs.R[nj++] = q.Rq[i];
         }
         launch_syrk(st, n, J, L, M, S, s->stat_off, s->skip, s->ncols, nj, jobs);
     }
-    if (runA) hipLaunchKernelGGL(xcorr_hankel_kernel, dim3(n), dim3(256), 0, st, n, J, L, M, S, s->stat_off, s->skip, s->ncols, s->toff, s->stats[0], s->tstats[0], s->r);
-    if (runB) hipLaunchKernelGGL(xcorr_hankel_kernel, dim3(n), dim3(256), 0, st, n, J, L, M, S, s->stat_off, s->skip, s->ncols, s->toff, s->stats[3], s->tstats[1], s->r + n);
+    if (runA) hipLaunchKernelGGL(xcorr_hankel_kernel, dim3(n), dim3(256), 0, st, n, J, L, M, S, s->stat_off, s->skip, s->ncols, s->toff, s->stats[0], s->tstats[0], q.r[0]);
+    if (runB) hipLaunchKernelGGL(xcorr_hankel_kernel, dim3(n), dim3(256), 0, st, n, J, L, M, S, s->stat_off, s->skip, s->ncols, s->toff, s->stats[3], s->tstats[1], q.r[1]);
     const size_t nn = (size_t)n * n;
     if (s->dialect == APV_DIALECT_MATLAB) {
         // apVast.m:448-456: everything / ((S - J + 1) M)
         const double f = 1.0 / ((double)s->ncols * (double)M);
-        for (int q = 0; q < 4; ++q) {
-            const bool live = (q == 0 || q == 2) ? runA : runB;
-            if (live) hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, nn, s->R + q * nn, f);
+        for (int i = 0; i < 4; ++i) {
+            const bool live = (i == 0 || i == 2) ? runA : runB;
+            if (live) hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, nn, q.Rq[i], f);
         }
-        hipLaunchKernelGGL(scale_kernel, dim3((2 * n + 255) / 256), dim3(256), 0, st, (size_t)2 * n, s->r, f);
+        for (int z = 0; z < 2; ++z)
+            if (z ? runB : runA) hipLaunchKernelGGL(scale_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (size_t)n, q.r[z], f);
     }
     if (s->rel_loading || s->rel_dark_py) {
         const double* mats[4];
-        for (int q = 0; q < 4; ++q) mats[q] = s->R + q * nn;
-        BCHK(h, apv_launch_norm2(n, 4, mats, s->nrm, st));
+        for (int i = 0; i < 4; ++i) mats[i] = ((i == 0 || i == 2) ? runA : runB) ? q.Rq[i] : q.Rq[(i & 2) | (runA ? 0 : 1)];
+        BCHK(h, apv_launch_norm2(n, 4, mats, q.nrm, st));
+        if (q.nrm_dark != q.nrm + 2 + (runA ? 0 : 1)) {
+            // the batch wants the dark norms of the zones that run side by side
+            const int first = runA ? 0 : 1, cnt = (runA && runB) ? 2 : 1;
+            BCHK(h, hipMemcpyAsync(q.nrm_dark, q.nrm + 2 + first, sizeof(double) * cnt, hipMemcpyDeviceToDevice, st));
+        }
     }
     if (s->rel_loading) {
         // apVast.m:552-569: bright += reg_bright ||R||_2, dark += reg_dark ||R||_2, in place like the reference
-        for (int q = 0; q < 4; ++q) {
-            const bool live = (q == 0 || q == 2) ? runA : runB;
+        for (int i = 0; i < 4; ++i) {
+            const bool live = (i == 0 || i == 2) ? runA : runB;
             if (!live) continue;
-            const double coef = q < 2 ? h->cfg.reg_bright : h->cfg.reg_dark;
-            hipLaunchKernelGGL(add_rel_diag_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, s->R + q * nn, coef, s->nrm + q);
+            const double coef = i < 2 ? h->cfg.reg_bright : h->cfg.reg_dark;
+            hipLaunchKernelGGL(add_rel_diag_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, q.Rq[i], coef, q.nrm + i);
         }
     }
+    // 6a: the spectra of the two input blocks as the ring holds them now
+    BCHK(h, apv_launch_analysis(1, N, 2, s->inblk, N, N, s->ring_off, 1, q.inspec, K, 1, st, &why));
     stage_done();
+    return APV_OK;
+}
+
+// stages 5-6 of a hop: filter spectra, outputs, overlap-add; h_out [n_out][H] (the copy is queued on the handle's stream)
+static int bb_back(apv_handle* h, apv_bb* s, const BbHop& q, double* h_out) {
+    hipStream_t st = h->stream;
+    const int N = s->N, H = s->H, K = s->K, L = s->L, J = s->J, V = s->V;
+    std::string why;
+    const bool runA = s->zones & 1, runB = s->zones & 2;
+    // 5: filter spectra: channel (v, l) = taps w[v][l*J : (l+1)*J] zero-padded to N, no window
+    int oc = 0;
+    for (int z = 0; z < 2; ++z) {
+        if (!(z ? runB : runA)) continue;
+        BCHK(h, apv_launch_analysis(1, N, V * L, q.w[z], J, J, 0, 0, s->fspec + (size_t)oc * K * 2, K, 1, st, &why));
+        oc += V * L;
+    }
+    // 6: outputs
+    oc = 0;
+    for (int z = 0; z < 2; ++z) {
+        if (!(z ? runB : runA)) continue;
+        hipLaunchKernelGGL(apply_f64_kernel, dim3((K + 255) / 256, V * L), dim3(256), 0, st, K, V * L,
+                           (const double2*)q.inspec + (size_t)z * K, (const double2*)s->fspec + (size_t)oc * K,
+                           (double2*)s->spec + (size_t)oc * K);
+        oc += V * L;
+    }
+    for (int z = 0; z < 2; ++z) {
+        hipLaunchKernelGGL(apply_f64_kernel, dim3((K + 255) / 256, L), dim3(256), 0, st, K, L,
+                           (const double2*)q.inspec + (size_t)z * K, (const double2*)s->fspec + (size_t)oc * K,
+                           (double2*)s->spec + (size_t)oc * K);
+        oc += L;
+    }
+    BCHK(h, apv_launch_synthesis(1, N, H, s->n_out, s->spec, K, 1, s->outov, s->out, st, &why));
+    BCHK(h, hipMemcpyAsync(h_out, s->out, sizeof(double) * (size_t)s->n_out * H, hipMemcpyDeviceToHost, st));
+    return APV_OK;
+}
+
+int apv_bb_process_block(apv_handle* h, const double* h_in_A, const double* h_in_B, double* h_out) {
+    if (!h || !h_in_A || !h_in_B || !h_out) return apv_fail(h, APV_ERR_ARG, "null argument");
+    apv_bb* s = h->bb;
+    if (!s) return apv_fail(h, APV_ERR_ARG, "apv_bb_init has not been called");
+    BCHK(h, hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    const int H = s->H, V = s->V, n = s->n;
+    // APV_BB_TIMING=1: synchronise at the stage boundaries and print the wall time of each (profiling aid;
+    // rocprofv3 cannot trace this path, see DESIGN.md section 6)
+    static const bool timing = getenv("APV_BB_TIMING") != nullptr;
+    double t_stage[8] = {0};
+    BCHK(h, hipMemcpyAsync(s->xin, h_in_A, sizeof(double) * H, hipMemcpyHostToDevice, st));
+    BCHK(h, hipMemcpyAsync(s->xin + H, h_in_B, sizeof(double) * H, hipMemcpyHostToDevice, st));
+    const BbHop q = bb_own_hop(s);
+    int rc = bb_front(h, s, q, timing ? t_stage : nullptr);
+    if (rc != APV_OK) return rc;
+    const bool runA = s->zones & 1, runB = s->zones & 2;
+    const size_t nn = (size_t)n * n;
+    auto t_prev = std::chrono::steady_clock::now();
     // 4: jdiag + filters; both zone programs in one batch when both run
     int32_t status[2] = {0, 0};
     {
         const int first = runA ? 0 : 1, batch = (runA && runB) ? 2 : 1;
         // Python dialect, EXPERIMENTAL_REGULARIZATION = False: jdiag loads a copy of the dark matrix with reg_dark ||B||_2
         // (apvast.py:26-27); the R_* attributes stay as accumulated
-        int rc = apv_gevd_large(h, n, batch, s->R + first * nn, s->R + (2 + first) * nn, s->rel_loading ? 0.0 : h->cfg.reg_dark,
-                                s->rel_dark_py ? s->nrm + 2 + first : nullptr, s->U + first * nn, s->lam + (size_t)first * n, s->r + (size_t)first * n, h->cfg.mu, V, s->d_ranks,
-                                s->w + (size_t)first * V * n, status);
+        rc = apv_gevd_large(h, n, batch, s->R + first * nn, s->R + (2 + first) * nn, s->rel_loading ? 0.0 : h->cfg.reg_dark,
+                            s->rel_dark_py ? s->nrm + 2 + first : nullptr, s->U + first * nn, s->lam + (size_t)first * n, s->r + (size_t)first * n, h->cfg.mu, V, s->d_ranks,
+                            s->w + (size_t)first * V * n, status);
         if (rc != APV_OK) return rc;
     }
-    stage_done();
-    // 5: filter spectra: channel (v, l) = taps w[v][l*J : (l+1)*J] zero-padded to N, no window
-    int oc = 0;
-    for (int z = 0; z < 2; ++z) {
-        if (!(z ? runB : runA)) continue;
-        BCHK(h, apv_launch_analysis(1, N, V * L, s->w + (size_t)z * V * n, J, J, 0, 0, s->fspec + (size_t)oc * K * 2, K, 1, st, &why));
-        oc += V * L;
+    if (timing) {
+        (void)hipStreamSynchronize(st);
+        t_stage[3] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_prev).count();
+        t_prev = std::chrono::steady_clock::now();
     }
-    // 6: outputs
-    BCHK(h, apv_launch_analysis(1, N, 2, s->inblk, N, N, s->ring_off, 1, s->inspec, K, 1, st, &why));
-    oc = 0;
-    for (int z = 0; z < 2; ++z) {
-        if (!(z ? runB : runA)) continue;
-        hipLaunchKernelGGL(apply_f64_kernel, dim3((K + 255) / 256, V * L), dim3(256), 0, st, K, V * L,
-                           (const double2*)s->inspec + (size_t)z * K, (const double2*)s->fspec + (size_t)oc * K,
-                           (double2*)s->spec + (size_t)oc * K);
-        oc += V * L;
-    }
-    for (int z = 0; z < 2; ++z) {
-        hipLaunchKernelGGL(apply_f64_kernel, dim3((K + 255) / 256, L), dim3(256), 0, st, K, L,
-                           (const double2*)s->inspec + (size_t)z * K, (const double2*)s->fspec + (size_t)oc * K,
-                           (double2*)s->spec + (size_t)oc * K);
-        oc += L;
-    }
-    BCHK(h, apv_launch_synthesis(1, N, H, s->n_out, s->spec, K, 1, s->outov, s->out, st, &why));
-    BCHK(h, hipMemcpyAsync(h_out, s->out, sizeof(double) * (size_t)s->n_out * H, hipMemcpyDeviceToHost, st));
+    rc = bb_back(h, s, q, h_out);
+    if (rc != APV_OK) return rc;
     BCHK(h, hipStreamSynchronize(st));
     BCHK(h, hipGetLastError());
-    stage_done();
     if (timing)
         fprintf(stderr, "[apv bb] fir %.3f  wola %.3f  stats %.3f  gevd %.3f  out %.3f ms\n", t_stage[0], t_stage[1],
-                t_stage[2], t_stage[3], t_stage[4]);
+                t_stage[2], t_stage[3], std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_prev).count());
     if (status[0] == 2 || status[1] == 2) {
         s->not_converged++;
         return apv_fail(h, APV_ERR_NO_CONVERGE, "eigen-iteration did not converge (Jacobi sweep cap reached); the outputs of this hop were written");
+    }
+    return APV_OK;
+}
+
+// n_hops consecutive hops in one call.  A hop's statistics depend on the input alone, never on an earlier hop's filters, so the
+// joint diagonalisations of G consecutive hops are independent problems: the front stages of the G hops run one after the other
+// (rings and overlap buffers are sequential state), ONE batched apv_gevd_large call solves their 2 G pairs -- a single
+// n = 256 pair keeps 36 workgroups busy through ~180 dependent launches, G pairs ride in the same launches -- and the
+// output stages follow in order.  Sample for sample the result is that of n_hops calls of apv_bb_process_block up to the
+// rounding of the eigen-iteration (a batch sweeps until its slowest member has converged).
+//                                                          replaces the hop loop of main.m:52-62 around apvast.py:153-165
+int apv_bb_process_signal(apv_handle* h, int32_t n_hops, const double* h_in_A, const double* h_in_B, double* h_out) {
+    if (!h || !h_in_A || !h_in_B || !h_out) return apv_fail(h, APV_ERR_ARG, "null argument");
+    apv_bb* s = h->bb;
+    if (!s) return apv_fail(h, APV_ERR_ARG, "apv_bb_init has not been called");
+    if (n_hops < 0) return apv_fail(h, APV_ERR_ARG, "n_hops must be >= 0");
+    if (n_hops == 0) return APV_OK;
+    BCHK(h, hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    const int H = s->H, K = s->K, V = s->V, n = s->n;
+    const bool runA = s->zones & 1, runB = s->zones & 2;
+    const int first = runA ? 0 : 1, nz = (runA && runB) ? 2 : 1;
+    const size_t nn = (size_t)n * n;
+    // hops per group: as many as keep the block-round launches of the batch within ~3 workgroups per compute unit
+    const int tiles = ((n + 31) / 32) * ((n + 31) / 32 + 1) / 2;
+    static const int forced = getenv("APV_BB_GROUP") ? atoi(getenv("APV_BB_GROUP")) : 0;       // A/B switch
+    int G = forced > 0 ? forced : 768 / (tiles * nz);
+    G = G < 1 ? 1 : (G > 8 && forced <= 0 ? 8 : G);
+    if (G > n_hops) G = n_hops;
+    if (s->grp < G) {
+        double** bufs[] = {&s->g_xin, &s->g_RA, &s->g_RB, &s->g_U, &s->g_lam, &s->g_r, &s->g_w, &s->g_nrm, &s->g_inspec};
+        for (double** b : bufs) {
+            if (*b) (void)hipFree(*b);
+            *b = nullptr;
+        }
+        s->grp = 0;
+        int rc;
+        const size_t gz = (size_t)G * nz;
+        if ((rc = dalloc(h, &s->g_xin, (size_t)G * 2 * H))) return rc;
+        if ((rc = dalloc(h, &s->g_RA, gz * nn))) return rc;
+        if ((rc = dalloc(h, &s->g_RB, gz * nn))) return rc;
+        if ((rc = dalloc(h, &s->g_U, gz * nn))) return rc;
+        if ((rc = dalloc(h, &s->g_lam, gz * n))) return rc;
+        if ((rc = dalloc(h, &s->g_r, gz * n))) return rc;
+        if ((rc = dalloc(h, &s->g_w, gz * V * n))) return rc;
+        if ((rc = dalloc(h, &s->g_nrm, (size_t)G * 4 + gz))) return rc;
+        if ((rc = dalloc(h, &s->g_inspec, (size_t)G * 2 * K * 2))) return rc;
+        s->grp = G;
+    }
+    std::vector<int32_t> status((size_t)G * nz, 0);
+    long bad_hops = 0;
+    for (int h0 = 0; h0 < n_hops; h0 += G) {
+        const int g_n = n_hops - h0 < G ? n_hops - h0 : G;
+        for (int g = 0; g < g_n; ++g) {
+            BCHK(h, hipMemcpyAsync(s->g_xin + (size_t)g * 2 * H, h_in_A + (size_t)(h0 + g) * H, sizeof(double) * H, hipMemcpyHostToDevice, st));
+            BCHK(h, hipMemcpyAsync(s->g_xin + (size_t)g * 2 * H + H, h_in_B + (size_t)(h0 + g) * H, sizeof(double) * H, hipMemcpyHostToDevice, st));
+        }
+        std::vector<BbHop> hops(g_n);
+        for (int g = 0; g < g_n; ++g) {
+            BbHop& q = hops[g];
+            q = BbHop{};
+            q.xin = s->g_xin + (size_t)g * 2 * H;
+            for (int z = 0; z < 2; ++z) {
+                if (!(z ? runB : runA)) continue;
+                const size_t slot = (size_t)g * nz + (z - first);
+                q.Rq[z] = s->g_RA + slot * nn;
+                q.Rq[2 + z] = s->g_RB + slot * nn;
+                q.r[z] = s->g_r + slot * n;
+                q.w[z] = s->g_w + slot * V * n;
+            }
+            q.nrm = s->g_nrm + (size_t)g * 4;
+            q.nrm_dark = s->g_nrm + (size_t)G * 4 + (size_t)g * nz;
+            q.inspec = s->g_inspec + (size_t)g * 2 * K * 2;
+            const int rc = bb_front(h, s, q, nullptr);
+            if (rc != APV_OK) return rc;
+        }
+        int rc = apv_gevd_large(h, n, g_n * nz, s->g_RA, s->g_RB, s->rel_loading ? 0.0 : h->cfg.reg_dark,
+                                s->rel_dark_py ? s->g_nrm + (size_t)G * 4 : nullptr, s->g_U, s->g_lam, s->g_r, h->cfg.mu, V, s->d_ranks, s->g_w,
+                                status.data());
+        if (rc != APV_OK) return rc;
+        for (int g = 0; g < g_n; ++g) {
+            rc = bb_back(h, s, hops[g], h_out + (size_t)(h0 + g) * s->n_out * H);
+            if (rc != APV_OK) return rc;
+            bool bad = false;
+            for (int z = 0; z < nz; ++z) bad = bad || status[(size_t)g * nz + z] == 2;
+            bad_hops += bad;
+        }
+        // the attributes of the handle are those of the last hop (apvast.py:368-403)
+        if (h0 + g_n >= n_hops) {
+            const BbHop& q = hops[g_n - 1];
+            for (int z = 0; z < 2; ++z) {
+                if (!(z ? runB : runA)) continue;
+                const size_t slot = (size_t)(g_n - 1) * nz + (z - first);
+                BCHK(h, hipMemcpyAsync(s->R + (size_t)z * nn, q.Rq[z], sizeof(double) * nn, hipMemcpyDeviceToDevice, st));
+                BCHK(h, hipMemcpyAsync(s->R + (size_t)(2 + z) * nn, q.Rq[2 + z], sizeof(double) * nn, hipMemcpyDeviceToDevice, st));
+                BCHK(h, hipMemcpyAsync(s->r + (size_t)z * n, q.r[z], sizeof(double) * n, hipMemcpyDeviceToDevice, st));
+                BCHK(h, hipMemcpyAsync(s->w + (size_t)z * V * n, q.w[z], sizeof(double) * V * n, hipMemcpyDeviceToDevice, st));
+                BCHK(h, hipMemcpyAsync(s->U + (size_t)z * nn, s->g_U + slot * nn, sizeof(double) * nn, hipMemcpyDeviceToDevice, st));
+                BCHK(h, hipMemcpyAsync(s->lam + (size_t)z * n, s->g_lam + slot * n, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
+            }
+            BCHK(h, hipMemcpyAsync(s->nrm, q.nrm, sizeof(double) * 4, hipMemcpyDeviceToDevice, st));
+            BCHK(h, hipMemcpyAsync(s->inspec, q.inspec, sizeof(double) * 2 * K * 2, hipMemcpyDeviceToDevice, st));
+        }
+        BCHK(h, hipStreamSynchronize(st));       // the group's input staging is rewritten by the next group
+    }
+    BCHK(h, hipGetLastError());
+    if (bad_hops) {
+        s->not_converged += bad_hops;
+        return apv_fail(h, APV_ERR_NO_CONVERGE, "eigen-iteration did not converge (Jacobi sweep cap reached) in some hop; the outputs were written");
     }
     return APV_OK;
 }

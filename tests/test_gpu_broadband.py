@@ -105,6 +105,68 @@ def test_broadband_perceptual_vs_oracle(golden):
     ap.close()
 
 
+@pytest.mark.parametrize("zones", [(True, True), (True, False), (False, True)])
+def test_broadband_process_signal_vs_reference_and_hop_loop(golden, zones):
+    """apv_bb_process_signal: the hop loop of make_python_test.m:44-51 in one call, the joint diagonalisations of consecutive
+    hops solved as one batch.  (1) G1's eight hops through it: the reference's outputs at 1e-9, the last hop's attributes
+    (lambda, w, r, R) as after the per-hop calls; (2) against this library's own hop loop on 11 hops (a group of 8 and a
+    ragged one of 3), one zone or two: outputs 1e-10 of the largest sample, every state buffer equal afterwards."""
+    g = golden("g1_broadband_cfg1")
+    rirs = golden("rirs_cfg1")
+    H = 128
+    if zones == (True, True):
+        ap = make(g, rirs)
+        x = g["x"]
+        out = ap.process_signal(x[0], x[1])
+        ranks = g["ranks"]
+        for q in range(4):
+            got = np.stack(out[q])[ranks]                              # (3, samples, L)
+            exp = g["outputs"][:, q]                                    # (hops, 3, H, L)
+            exp = exp.transpose(1, 0, 2, 3).reshape(len(ranks), -1, exp.shape[-1])
+            assert np.abs(got - exp).max() < 1e-9 * np.abs(exp).max(), q
+        last = x.shape[1] // H - 1
+        for z, (lam, w, r) in enumerate(((ap.lambda_A, ap.w_A, ap.r_A), (ap.lambda_B, ap.w_B, ap.r_B))):
+            assert np.abs(lam[:8] / g["lam"][last, z, :8] - 1).max() < 1e-9
+            assert np.abs(r[:, 0] - g["r"][last, z]).max() < 1e-12 * np.abs(g["r"][last, z]).max()
+            for i in range(8):
+                e = g["w"][last, z, i]
+                assert np.linalg.norm(w[i, :, 0] - e) < 1e-8 * np.linalg.norm(e)
+        iu = np.triu_indices(256)
+        assert np.abs(ap.R_A_to_A[iu] - g["R_AA_triu"]).max() < 1e-11 * np.abs(g["R_AA_triu"]).max()
+        assert np.abs(ap.R_A_to_B[iu] - g["R_AB_triu"]).max() < 1e-11 * np.abs(g["R_AB_triu"]).max()
+    hops = 11
+    x = np.random.default_rng(17).standard_normal((2, hops * H))
+    a = make(g, rirs, run_A=zones[0], run_B=zones[1])
+    b = make(g, rirs, run_A=zones[0], run_B=zones[1])
+    whole = a.process_signal(x[0], x[1])
+    per_hop = [b.process_input_buffers(x[0, h * H:(h + 1) * H], x[1, h * H:(h + 1) * H]) for h in range(hops)]
+    for q in range(4):
+        if whole[q] is None:
+            assert per_hop[0][q] is None
+            continue
+        for v in range(len(whole[q])):
+            ref = np.concatenate([per_hop[h][q][v] for h in range(hops)])
+            assert whole[q][v].shape == ref.shape
+            assert np.abs(whole[q][v] - ref).max() <= 1e-10 * max(np.abs(ref).max(), 1e-30), (q, v)
+    sa, sb = a.get_state(), b.get_state()
+    assert sa.keys() == sb.keys()
+    for k in sa:
+        if isinstance(sa[k], np.ndarray) and sa[k].dtype.kind == "f":
+            assert np.abs(sa[k] - sb[k]).max() <= 1e-10 * max(np.abs(sb[k]).max(), 1e-30), k
+    for name in ("lambda_A", "lambda_B", "w_A", "w_B"):
+        va, vb = getattr(a, name), getattr(b, name)
+        if vb is None:
+            assert va is None
+        else:
+            assert np.abs(va - vb).max() <= 1e-8 * np.abs(vb).max(), name
+    # a per-hop call after the whole-signal call continues the same stream
+    y = np.random.default_rng(18).standard_normal((2, H))
+    oa, ob = a.process_input_buffers(y[0], y[1]), b.process_input_buffers(y[0], y[1])
+    for q in range(4):
+        if oa[q] is not None:
+            assert np.abs(np.stack(oa[q]) - np.stack(ob[q])).max() <= 1e-10 * np.abs(np.stack(ob[q])).max()
+
+
 @pytest.mark.parametrize("J,S,L,M", [(24, 1664, 3, 2), (5, 700, 4, 3), (40, 300, 2, 2)])
 def test_broadband_statistics_shapes(golden, J, S, L, M):
     """Implicit-Hankel statistics (apvast.py:329-364) where a 32-row tile spans several loudspeakers (J not a
