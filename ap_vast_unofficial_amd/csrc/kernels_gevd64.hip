@@ -25,7 +25,8 @@
 // Two kernels share the stages.  gevd64_kernel: one bin per workgroup.  gevd64x2_kernel: TWO bins per workgroup; the
 // float64 stages run for one bin after the other, but the float32 sweeps of the two bins (66 KB each: both fit) are
 // interleaved: while four waves solve the pair problems of one bin (latency bound, one wave per SIMD), the other twelve
-// apply the previous round's factors of the other bin on the matrix cores (the Hermitian half of C only, mirrored).
+// apply the previous round's factors of the other bin on the matrix cores (the six tiles of C above the diagonal of the pair
+// grid, mirrored; the four diagonal tiles come rotated out of the pair solves themselves).
 #include "apv_internal.h"
 
 #include "gevd16_common.h"
@@ -272,64 +273,99 @@ __device__ __forceinline__ int front64(const GevdParams& p, const Sh& sh, bool z
     if (tid < N64) RB[tid * LDD + tid] = mk<double>(RB[tid * LDD + tid].x + p.reg_dark, 0);
     __syncthreads();
     {
-        // Right-looking, ONE barrier per step: the trailing update takes the unscaled column, R_ij -= R_ik conj(R_jk) / d_k, so
-        // nothing has to be scaled before it; column k gets its 1/sqrt(d_k) during step k + 1, when nobody reads it any more.
-        const int ty = tid >> 5, tx = tid & 31;
+        // Right-looking with the matrix in REGISTERS: thread (a, b) owns the 2 x 2 block rows {2a, 2a+1} x columns {2b, 2b+1}
+        // (blocks on or below the diagonal) and keeps it there through all 64 steps.  A step publishes its pivot column (64
+        // numbers, by the 32 threads that own it, into one of two alternating LDS buffers), one barrier, and every thread takes
+        // its two row and two column entries of that column: R_ij -= R_ik conj(R_jk) / d_k on the UNSCALED column, so nothing
+        // is scaled on the way; column k gets its 1/sqrt(d_k) when the factor is written back.  (Round 2 kept the matrix in
+        // LDS: every step read, updated and rewrote the trailing block there between two barriers, 0.6 us a step.)
+        C128* const sCol = reinterpret_cast<C128*>(&sh.sPartI[0][0]);          // [2][64]
+        const int a = tid >> 5, b = tid & 31, i0 = 2 * a, j0 = 2 * b;
+        const bool mine = b <= a;
+        C128 v00 = RB[i0 * LDD + j0], v01 = RB[i0 * LDD + j0 + 1], v10 = RB[(i0 + 1) * LDD + j0], v11 = RB[(i0 + 1) * LDD + j0 + 1];
         for (int kk = 0; kk < N64; ++kk) {
-            const double dkk = RB[kk * LDD + kk].x;
+            C128* const col = sCol + (kk & 1) * N64;
+            if (b == (kk >> 1)) {                                               // the 32 owners of column kk
+                const bool odd = kk & 1;            // (component by component: a select between two structs would put all four in memory)
+                col[i0] = mk<double>(odd ? v01.x : v00.x, odd ? v01.y : v00.y);
+                col[i0 + 1] = mk<double>(odd ? v11.x : v10.x, odd ? v11.y : v10.y);
+            }
+            __syncthreads();
+            const double dkk = col[kk].x;
             if (!(dkk > 0.0) || !(dkk < 1e300)) {           // uniform: every thread reads the same word
                 status = 1;
                 break;
             }
-            const double inv = rcp_full(dkk);
             if (tid == 0) sDinv[kk] = rsq_full(dkk);
-            for (int i = kk + 1 + ty; i < N64; i += 32) {
-                const C128 li = RB[i * LDD + kk];
-                const double lix = li.x * inv, liy = li.y * inv;
-                for (int j = kk + 1 + tx; j <= i; j += 32) {
-                    const C128 lj = RB[j * LDD + kk];
-                    C128 v = RB[i * LDD + j];
-                    v.x = fma_t(-liy, lj.y, fma_t(-lix, lj.x, v.x));            // -= (l_i / d) conj(l_j), as chained FMAs
-                    v.y = fma_t(lix, lj.y, fma_t(-liy, lj.x, v.y));
-                    RB[i * LDD + j] = v;
-                }
+            if (mine && i0 + 1 > kk && j0 + 1 > kk) {        // something of this block lies beyond the pivot
+                const double inv = rcp_full(dkk);
+                const double f0 = (i0 > kk) ? inv : 0.0;     // a row or column at the pivot itself is left alone: multiplier 0
+                const bool c0 = j0 > kk;
+                const C128 l0 = col[i0], l1 = col[i0 + 1], q0 = col[j0], q1 = col[j0 + 1];
+                const double l0x = l0.x * f0, l0y = l0.y * f0, l1x = l1.x * inv, l1y = l1.y * inv;
+                const double m0x = c0 ? q0.x : 0.0, m0y = c0 ? q0.y : 0.0;
+                v00.x = fma_t(-l0y, m0y, fma_t(-l0x, m0x, v00.x));              // -= l conj(m), as chained FMAs
+                v00.y = fma_t(l0x, m0y, fma_t(-l0y, m0x, v00.y));
+                v01.x = fma_t(-l0y, q1.y, fma_t(-l0x, q1.x, v01.x));
+                v01.y = fma_t(l0x, q1.y, fma_t(-l0y, q1.x, v01.y));
+                v10.x = fma_t(-l1y, m0y, fma_t(-l1x, m0x, v10.x));
+                v10.y = fma_t(l1x, m0y, fma_t(-l1y, m0x, v10.y));
+                v11.x = fma_t(-l1y, q1.y, fma_t(-l1x, q1.x, v11.x));
+                v11.y = fma_t(l1x, q1.y, fma_t(-l1y, q1.x, v11.y));
             }
-            if (kk > 0 && tid >= 960) {                      // the previous column, by the wave with the least to do above
-                const double sc = sDinv[kk - 1];
-                const int i = kk + (tid - 960);
-                if (i < N64) {
-                    const C128 v = RB[i * LDD + kk - 1];
-                    RB[i * LDD + kk - 1] = mk<double>(v.x * sc, v.y * sc);
-                }
-            }
-            __syncthreads();
         }
+        __syncthreads();                                     // sDinv is complete
+        if (status == 0 && mine) {                           // L below the diagonal, scaled by column
+            const double s0 = sDinv[j0], s1 = sDinv[j0 + 1];
+            if (j0 < i0) RB[i0 * LDD + j0] = mk<double>(v00.x * s0, v00.y * s0);
+            if (j0 + 1 < i0) RB[i0 * LDD + j0 + 1] = mk<double>(v01.x * s1, v01.y * s1);
+            RB[(i0 + 1) * LDD + j0] = mk<double>(v10.x * s0, v10.y * s0);         // j0 <= i0 < i0 + 1
+            if (j0 + 1 < i0 + 1) RB[(i0 + 1) * LDD + j0 + 1] = mk<double>(v11.x * s1, v11.y * s1);
+        }
+        __syncthreads();
     }
     stamp64(p, z1, k, 9);
     if (p.debug_stop == 2) return -1;
     if (status == 0) {
         // W = L^-1 in 16 x 16 blocks; W^H goes to the UPPER triangle of the region with its diagonal (W_ij at [j][i], conjugated);
         // nothing below reads L's diagonal.  L stays where it is until the last block is done.
-        //   (1) the four diagonal blocks at once, one wave: lane 16 a + c solves L_aa w = e_c by forward substitution
-        if (wave == 0) {
-            const int a = lane >> 4, c = lane & 15, o = 16 * a;
-            double wx[16], wy[16];
+        //   (1) the four diagonal blocks, one wave each: Gauss-Jordan on [L_aa | I] with the rows of the right half in registers
+        //       (lane = row i + 16 x column group; a lane holds W[i][4 cq .. 4 cq + 3]); step k scales row k by 1 / L_kk, hands it
+        //       to the rows below through 256 bytes of LDS and those subtract L_ik times it.  Sixteen short steps, no barrier
+        //       (the LDS executes a wave's accesses in order).
+        if (wave < 4) {
+            const int o = 16 * wave, i = lane & 15, cq = lane >> 4;
+            C128* const rowbuf = reinterpret_cast<C128*>(&sh.sPartI[0][0]) + 16 * wave;      // the Cholesky's column buffers are spent
+            double wx[4], wy[4];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                double sx = (i == c) ? 1.0 : 0.0, sy = 0.0;
+            for (int u = 0; u < 4; ++u) {
+                wx[u] = (4 * cq + u == i) ? 1.0 : 0.0;
+                wy[u] = 0.0;
+            }
+#pragma unroll 4
+            for (int kq2 = 0; kq2 < 16; ++kq2) {
+                if (i == kq2) {
+                    const double dk = sDinv[o + kq2];
 #pragma unroll
-                for (int q = 0; q < i; ++q) {
-                    const C128 l = RB[(o + i) * LDD + o + q];                   // the same word for the 16 lanes of a block
-                    sx = fma_t(l.y, wy[q], fma_t(-l.x, wx[q], sx));
-                    sy = fma_t(-l.y, wx[q], fma_t(-l.x, wy[q], sy));
+                    for (int u = 0; u < 4; ++u) {
+                        wx[u] *= dk;
+                        wy[u] *= dk;
+                        rowbuf[4 * cq + u] = mk<double>(wx[u], wy[u]);
+                    }
                 }
-                const double di = sDinv[o + i];
-                wx[i] = (i < c) ? 0.0 : sx * di;
-                wy[i] = (i < c) ? 0.0 : sy * di;
+                if (i > kq2) {
+                    const C128 l = RB[(o + i) * LDD + o + kq2];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const C128 rk = rowbuf[4 * cq + u];
+                        wx[u] = fma_t(l.y, rk.y, fma_t(-l.x, rk.x, wx[u]));
+                        wy[u] = fma_t(-l.y, rk.x, fma_t(-l.x, rk.y, wy[u]));
+                    }
+                }
             }
 #pragma unroll
-            for (int i = 0; i < 16; ++i)
-                if (i >= c) RB[(o + c) * LDD + o + i] = mk<double>(wx[i], -wy[i]);  // conj(W[o + i][o + c]) at the mirrored place
+            for (int u = 0; u < 4; ++u)
+                if (4 * cq + u <= i) RB[(o + 4 * cq + u) * LDD + o + i] = mk<double>(wx[u], -wy[u]);  // conj(W[o + i][o + 4 cq + u]) at the mirrored place
         }
         __syncthreads();
         //   (2) the blocks below the diagonal, one block diagonal after the other: W_ba = -W_bb (sum_{a <= k < b} L_bk W_ka).  The
@@ -402,8 +438,11 @@ __device__ __forceinline__ int front64(const GevdParams& p, const Sh& sh, bool z
 }
 
 // ---- float32 block Jacobi: the tasks of a round ------------------------------------------------------------------------
-// pair problem w of round r, solved by one wave: reads its 16 x 16 sub-matrix of Cf, leaves the unitary factor in U
-__device__ __forceinline__ void inner_solve(const C64* Cf, C64* U, int r, int w, int lane) {
+// pair problem w of round r, solved by one wave: reads its 16 x 16 sub-matrix of Cf, leaves the unitary factor in U and writes
+// the ROTATED sub-matrix back (the diagonal tile of the pair grid: the wave holds U_w^H C_ww U_w in its registers when the
+// rotations are done, so the matrix cores never see those four tiles: 448 instead of 576 MFMAs per round).  Returns this
+// lane's share of the off-diagonal weight of what it wrote.
+__device__ __forceinline__ float inner_solve(C64* Cf, C64* U, int r, int w, int lane) {
     const int ua = lane >> 3, ub = lane & 7;                      // the 8 x 8 grid of 2 x 2 blocks of a pair problem
     int P, Q;
     rr_pair8(r, w, P, Q);
@@ -412,20 +451,31 @@ __device__ __forceinline__ void inner_solve(const C64* Cf, C64* U, int r, int w,
     C64 tt = Cf[r0 * LDF + c0], tb = Cf[r0 * LDF + c1], bt = Cf[r1 * LDF + c0], bb = Cf[r1 * LDF + c1];
     C64 v0t = mk<float>((2 * ua == ub) ? 1.f : 0.f, 0.f), v0b = mk<float>((2 * ua == 8 + ub) ? 1.f : 0.f, 0.f);
     C64 v1t = mk<float>((2 * ua + 1 == ub) ? 1.f : 0.f, 0.f), v1b = mk<float>((2 * ua + 1 == 8 + ub) ? 1.f : 0.f, 0.f);
-    bool conv = false;
     // Round 0 of an outer sweep pairs every block once: a full inner sweep there covers the pairs INSIDE all eight
     // blocks; the other rounds rotate only the 64 pairs between their two blocks (the first 8 rounds of the
     // schedule, which leave the slots as they were).  Together: every one of the 2016 index pairs once per sweep.
     const bool full = (r == 0);
     if (full) jacobi16_sweep0<float, 15>(tt, tb, bt, bb, v0t, v0b, v1t, v1b, (float (*)[4]) nullptr, lane);
     else jacobi16_sweep0<float, 8>(tt, tb, bt, bb, v0t, v0b, v1t, v1b, (float (*)[4]) nullptr, lane);
-    (void)conv;
+    // where the slots ended up: after the full sweep top / bottom of slot u are the local indices 2 u, 2 u + 1; after the
+    // eight cross rounds they are back at u, 8 + u
     const bool nat = full;
     const int it_b = nat ? 2 * ub : ub, ib_b = nat ? 2 * ub + 1 : 8 + ub;
     U[(2 * ua) * 17 + it_b] = v0t;
     U[(2 * ua) * 17 + ib_b] = v0b;
     U[(2 * ua + 1) * 17 + it_b] = v1t;
     U[(2 * ua + 1) * 17 + ib_b] = v1b;
+    const int gt = idx(nat ? 2 * ua : ua), gb = idx(nat ? 2 * ua + 1 : 8 + ua), ht = idx(it_b), hb = idx(ib_b);
+    if (gt == ht) tt.y = 0.f;                                     // the global diagonal stays real
+    if (gb == hb) bb.y = 0.f;
+    Cf[gt * LDF + ht] = tt;
+    Cf[gt * LDF + hb] = tb;
+    Cf[gb * LDF + ht] = bt;
+    Cf[gb * LDF + hb] = bb;
+    float off = tb.x * tb.x + tb.y * tb.y + bt.x * bt.x + bt.y * bt.y;
+    if (gt != ht) off += tt.x * tt.x + tt.y * tt.y;
+    if (gb != hb) off += bb.x * bb.x + bb.y * bb.y;
+    return off;
 }
 
 // tile (a, b) of the pair grid of round r: C_ab <- U_a^H C_ab U_b on v_mfma_f32_16x16x4_f32; with `mirror` the Hermitian
@@ -737,12 +787,14 @@ __global__ void __launch_bounds__(1024) gevd64_kernel(const GevdParams p) {
             ++n_sweeps;
             float offw = 0.f;
             for (int r = 0; r < NBLK - 1; ++r) {
-                if (wave < 4 && p.debug_stop != 7) inner_solve(Cf, sU[wave], r, wave, lane);   // debug_stop 7 / 8: timing aids
+                float od = 0.f;
+                if (wave < 4 && p.debug_stop != 7) od = inner_solve(Cf, sU[wave], r, wave, lane);   // debug_stop 7 / 8: timing aids
                 __syncthreads();
                 if (p.debug_stop != 8) {
-                    const float o = outer_ctile(Cf, sU, r, ti, tj, lane, false);
+                    float o = 0.f;
+                    if (ti != tj) o = outer_ctile(Cf, sU, r, ti, tj, lane, false);      // the diagonal tiles are the pair solves' own
                     outer_vtile(Vf, sU, r, ti, tj, lane);
-                    if (r == NBLK - 2) offw = o;           // the last round of the sweep rewrites all of C: its off-diagonal weight
+                    if (r == NBLK - 2) offw = o + od;      // the last round of the sweep rewrites all of C: its off-diagonal weight
                 }
                 __syncthreads();
             }
@@ -760,8 +812,8 @@ __global__ void __launch_bounds__(1024) gevd64_kernel(const GevdParams p) {
 }
 
 // ---- two bins per workgroup: float32 sweeps of the two bins interleaved ----------------------------------------------
-__constant__ signed char kUpperA[10] = {0, 0, 0, 0, 1, 1, 1, 2, 2, 3};
-__constant__ signed char kUpperB[10] = {0, 1, 2, 3, 1, 2, 3, 2, 3, 3};
+__constant__ signed char kUpperA[6] = {0, 0, 0, 1, 1, 2};          // the six tiles above the diagonal of the 4 x 4 pair grid
+__constant__ signed char kUpperB[6] = {1, 2, 3, 2, 3, 3};
 
 template <bool FUSED, typename XT>
 __global__ void __launch_bounds__(1024) gevd64x2_kernel(const GevdParams p) {
@@ -773,6 +825,7 @@ __global__ void __launch_bounds__(1024) gevd64x2_kernel(const GevdParams p) {
     __shared__ int sFlag[2];
     __shared__ C64 sU[2][4][16 * 17];                  // per bin: the four unitary factors of its round in flight
     __shared__ float sOffW[2][16];
+    __shared__ float sOffD[2][4];                      // per bin: off-diagonal weight inside the four diagonal tiles (from the pair solves)
     const Sh sh{sRegA, sRegB, sr, scoef, sDinv, sLam, sPart, sPartI, sRed, sOrder, sFlag};
     const bool z1 = (blockIdx.y == 1);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -815,8 +868,8 @@ __global__ void __launch_bounds__(1024) gevd64x2_kernel(const GevdParams p) {
     __syncthreads();
     stamp64(p, z1, k0, 2);
     // ---------------- stage 3a for both bins: in every step four waves solve the pair problems of one bin's next round
-    // while the other twelve apply the factors of the other bin's current round (10 Hermitian tiles of C with their mirrors
-    // + 16 tiles of V = 36 products of 16^3, three per wave); the bins swap roles from step to step
+    // (and write the rotated diagonal tiles back) while the other twelve apply the factors of the other bin's current round (the 6
+    // tiles of C above the diagonal with their mirrors + 16 tiles of V = 28 products of 16^3); the bins swap roles from step to step
     enum { INNER = 0, OUTER = 1, DONE = 2 };
     int st0 = status0 == 0 ? INNER : DONE, st1 = (nb == 2 && status1 == 0) ? INNER : DONE;
     int rnd0 = 0, rnd1 = 0, swp0 = 0, swp1 = 0;
@@ -827,6 +880,9 @@ __global__ void __launch_bounds__(1024) gevd64x2_kernel(const GevdParams p) {
     // the steps' whole length with the barrier: slots 12 / 13 / 14 of the first bin's row, the latter in slot 15
     const bool dbg_t = (p.stamps != nullptr) && lane == 0 && (wave == 0 || wave == 4 || wave == 15);
     unsigned long long t_work = 0, t_all = 0;
+    // the pair solves are one long dependent chain per step and every other wave of the step waits for them at the barrier:
+    // their waves go first whenever they can issue
+    if (wave < 4) __builtin_amdgcn_s_setprio(3);
     for (int step = 0; step < 2 * (NBLK - 1) * max_sweeps + 4 && !(st0 == DONE && st1 == DONE); ++step) {
         const int bS = step & 1, bU = bS ^ 1;
         const int stS = bS ? st1 : st0, stU = bU ? st1 : st0;
@@ -836,19 +892,26 @@ __global__ void __launch_bounds__(1024) gevd64x2_kernel(const GevdParams p) {
         float offw = 0.f;
         const unsigned long long tw0 = dbg_t ? __builtin_amdgcn_s_memtime() : 0ull;
         if (wave < 4) {
-            if (do_inner) inner_solve(Cfb(bS), sU[bS][wave], rS, wave, lane);
+            if (do_inner) {
+                const float od = inner_solve(Cfb(bS), sU[bS][wave], rS, wave, lane);
+                if (rS == NBLK - 2) {                            // the sweep's last round: what it leaves inside the diagonal tiles
+                    const float w = wave_sum(od);
+                    if (lane == 0) sOffD[bS][wave] = w;
+                }
+            }
         } else if (do_outer) {
+            // 6 tiles of C above the diagonal (two products each, mirrored) + 16 tiles of V (one product) = 28 products on twelve
+            // waves, seven per SIMD: waves 4-7 a C tile and a V tile, 8-9 a C tile, 10-15 two V tiles
             const int u = wave - 4;
             C64* const Cf = Cfb(bU);
             C64* const Vf = Vfb(bU);
-            if (u < 10) {
-                const int a = kUpperA[u], b = kUpperB[u];
-                offw = outer_ctile(Cf, sU[bU], rU, a, b, lane, a != b);
-                outer_vtile(Vf, sU[bU], rU, u >> 2, u & 3, lane);
+            if (u < 6) {
+                offw = outer_ctile(Cf, sU[bU], rU, kUpperA[u], kUpperB[u], lane, true);
+                if (u < 4) outer_vtile(Vf, sU[bU], rU, 0, u, lane);
             } else {
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    const int vt = 10 + 3 * (u - 10) + q;
+                for (int q = 0; q < 2; ++q) {
+                    const int vt = 4 + 2 * (u - 6) + q;
                     outer_vtile(Vf, sU[bU], rU, vt >> 2, vt & 3, lane);
                 }
             }
@@ -871,7 +934,9 @@ __global__ void __launch_bounds__(1024) gevd64x2_kernel(const GevdParams p) {
             if (sweep_end) {
                 double off = 0;
 #pragma unroll
-                for (int w = 4; w < 14; ++w) off += (double)sOffW[step & 1][w];
+                for (int w = 4; w < 10; ++w) off += (double)sOffW[step & 1][w];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) off += (double)sOffD[bU][w];
                 const int sw = (bU ? swp1 : swp0) + 1;
                 const double nrm_s = bU ? normF2_1 * scl1 * scl1 : normF2_0 * scl0 * scl0;
                 nst = (presolve_done(off, bU ? offp1 : offp0, nrm_s, kPreTol) || sw >= max_sweeps) ? DONE : INNER;
@@ -881,6 +946,7 @@ __global__ void __launch_bounds__(1024) gevd64x2_kernel(const GevdParams p) {
             if (bU) { st1 = nst; rnd1 = nr; } else { st0 = nst; rnd0 = nr; }
         }
     }
+    if (wave < 4) __builtin_amdgcn_s_setprio(0);
     __syncthreads();
     if (dbg_t) {
         unsigned long long* row = p.stamps + ((size_t)(z1 ? 1 : 0) * p.K + k0) * 16;

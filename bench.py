@@ -284,6 +284,41 @@ def also_cfg3(device, hops=468):
     return rec
 
 
+def also_cfg1(device, hops=40, signal_hops=128):
+    """BASELINE config 1 in the reference's own (broadband, time-domain) formulation through class apvast: the bundled
+    rirs.mat (8 loudspeakers x 8 microphones), N = 256, H = 128, J = 32 (n = J L = 256), S = 512, V = 8, both zone
+    programs, float64.  Timed: `hops` calls of process_input_buffers, then ONE process_signal call (the joint
+    diagonalisations of up to 8 consecutive hops solved as one batch).  A hop is 2.667 ms of audio at 48 kHz."""
+    from ap_vast_unofficial_amd.apvast import apvast
+    g = np.load(os.path.join(ROOT, "tests", "golden", "rirs_cfg1.npz"))
+    N, H = 256, 128
+    obj = apvast(N, g["rirA"], g["rirB"], 32, 16, 0, 0, 8, 1.0, 512, hop_size=H, perceptual=False, mode="broadband",
+                 seed=0, device=device)
+    rec = {"workload": "cfg1: broadband (reference formulation), rirs.mat 8x8, N=256 H=128 J=32 (n=256) S=512 V=8, both zone "
+                       "programs, white noise, through class apvast", "dtype": "f64", "hop_ms_of_audio": H / 48.0}
+    try:
+        x = np.random.default_rng(7).standard_normal((2, (hops + 4) * H))
+        for h in range(4):
+            obj.process_input_buffers(x[0, h * H:(h + 1) * H], x[1, h * H:(h + 1) * H])
+        t0 = time.perf_counter()
+        for h in range(4, hops + 4):
+            obj.process_input_buffers(x[0, h * H:(h + 1) * H], x[1, h * H:(h + 1) * H])
+        dt = time.perf_counter() - t0
+        rec["process_input_buffers"] = {"ms_per_hop": dt / hops * 1e3, "hops": hops, "realtime_factor": (hops * H / 48000.0) / dt}
+        xs = np.random.default_rng(8).standard_normal((2, signal_hops * H))
+        obj.process_signal(xs[0, :16 * H], xs[1, :16 * H])       # allocates the group buffers, captures the batch's sweep graph
+        t0 = time.perf_counter()
+        res = obj.process_signal(xs[0], xs[1])
+        dt = time.perf_counter() - t0
+        assert res[0][0].shape == (signal_hops * H, 8)
+        rec["process_signal"] = {"ms_per_hop": dt / signal_hops * 1e3, "hops": signal_hops,
+                                 "realtime_factor": (signal_hops * H / 48000.0) / dt}
+        rec["not_converged_hops"] = obj.not_converged
+    finally:
+        obj.close()
+    return rec
+
+
 def load_traffic(tag, K, dtype):
     """HBM bytes per launch of the dominant kernel from the committed counter passes (profiles/traffic*.json: rocprofv3
     --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, corrected as MI355X_MICROARCH.md prescribes); None unless the
@@ -585,7 +620,8 @@ def main():
     if rank == 0:
         if world == 1 and not multi and not args.no_also:
             also = {}
-            for name, fn in (("cfg3", lambda: also_cfg3(local_rank)), ("cfg5", lambda: also_cfg5(Engine, local_rank))):
+            for name, fn in (("cfg3", lambda: also_cfg3(local_rank)), ("cfg5", lambda: also_cfg5(Engine, local_rank)),
+                             ("cfg1", lambda: also_cfg1(local_rank))):
                 try:
                     also[name] = fn()
                 except Exception as ex:  # the headline stands on its own: a failing sub-record is reported, not fatal
