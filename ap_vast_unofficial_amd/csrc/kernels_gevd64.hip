@@ -132,7 +132,6 @@ __device__ __forceinline__ int front64(const GevdParams& p, const Sh& sh, bool z
     C128* const RA = reinterpret_cast<C128*>(sh.regA);
     C128* const RB = reinterpret_cast<C128*>(sh.regB);
     C128* const sr = sh.sr;
-    double* const sDinv = sh.sDinv;
     double* const sRed = sh.sRed;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int il = lane & 15, kq = lane >> 4;
@@ -271,103 +270,112 @@ __device__ __forceinline__ int front64(const GevdParams& p, const Sh& sh, bool z
 
     // ---------------- stage 1: Cholesky of B + reg I (lower, in place), then W = L^-1 ----------------
     if (tid < N64) RB[tid * LDD + tid] = mk<double>(RB[tid * LDD + tid].x + p.reg_dark, 0);
+    if (tid == 0) sh.sFlag[1] = 0;
     __syncthreads();
+    // Blocked right-looking factorisation in 16 x 16 tiles.  The diagonal factor L_kk itself is never needed: the panel is
+    // L_ik = R_ik W_kk^H with W_kk = L_kk^-1, the trailing update R_ij -= L_ik L_jk^H, the inverse below takes W_kk and the
+    // off-diagonal tiles of L, and the whitening takes W only.  Per tile column:
+    //   (a) ONE wave turns [D_kk | I] into [. | L1^-1] by elimination (rows in registers: lane = row i + 16 x column group holds
+    //       D[i][4cq..] and the right half's [i][4cq..]; a step hands its pivot column and the pivot row of the right half round
+    //       through 512 bytes of LDS -- no barrier, the LDS executes a wave's accesses in order) and scales row i by 1/sqrt(d_i):
+    //       that IS W_kk (apvast.py:24: B = L L^H).  Its conjugate transpose goes to the UPPER triangle of the tile (the mirrored
+    //       place, diagonal included): nothing reads the upper triangle of the region otherwise.
+    //   (b) panel tiles and (c) trailing tiles on the f64 matrix cores, one tile per wave.
+    // (Rounds 2-3a eliminated column by column over the whole matrix: 64 steps of 0.6 us, bound by the f64 vector ALU issuing
+    // every wave's share of every step.)
     {
-        // Right-looking with the matrix in REGISTERS: thread (a, b) owns the 2 x 2 block rows {2a, 2a+1} x columns {2b, 2b+1}
-        // (blocks on or below the diagonal) and keeps it there through all 64 steps.  A step publishes its pivot column (64
-        // numbers, by the 32 threads that own it, into one of two alternating LDS buffers), one barrier, and every thread takes
-        // its two row and two column entries of that column: R_ij -= R_ik conj(R_jk) / d_k on the UNSCALED column, so nothing
-        // is scaled on the way; column k gets its 1/sqrt(d_k) when the factor is written back.  (Round 2 kept the matrix in
-        // LDS: every step read, updated and rewrote the trailing block there between two barriers, 0.6 us a step.)
-        C128* const sCol = reinterpret_cast<C128*>(&sh.sPartI[0][0]);          // [2][64]
-        const int a = tid >> 5, b = tid & 31, i0 = 2 * a, j0 = 2 * b;
-        const bool mine = b <= a;
-        C128 v00 = RB[i0 * LDD + j0], v01 = RB[i0 * LDD + j0 + 1], v10 = RB[(i0 + 1) * LDD + j0], v11 = RB[(i0 + 1) * LDD + j0 + 1];
-        for (int kk = 0; kk < N64; ++kk) {
-            C128* const col = sCol + (kk & 1) * N64;
-            if (b == (kk >> 1)) {                                               // the 32 owners of column kk
-                const bool odd = kk & 1;            // (component by component: a select between two structs would put all four in memory)
-                col[i0] = mk<double>(odd ? v01.x : v00.x, odd ? v01.y : v00.y);
-                col[i0 + 1] = mk<double>(odd ? v11.x : v10.x, odd ? v11.y : v10.y);
+        C128* const gjbuf = reinterpret_cast<C128*>(&sh.sPartI[0][0]);          // [16] pivot column, [16] pivot row of the right half
+        for (int kb = 0; kb < 4; ++kb) {
+            const int o = 16 * kb;
+            if (wave == 0) {
+                const int i = lane & 15, cq = lane >> 4;
+                double bx[4], by[4], wx[4], wy[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = 4 * cq + u;
+                    const C128 v = (j <= i) ? RB[(o + i) * LDD + o + j] : cj(RB[(o + j) * LDD + o + i]);     // the lower triangle is current
+                    bx[u] = v.x;
+                    by[u] = (j == i) ? 0.0 : v.y;
+                    wx[u] = (j == i) ? 1.0 : 0.0;
+                    wy[u] = 0.0;
+                }
+                double dsc = 1.0;
+                bool bad = false;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int qc = q >> 2, qu = q & 3;
+                    if (cq == qc) gjbuf[i] = mk<double>(bx[qu], by[qu]);          // column q of the left half
+                    if (i == q) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) gjbuf[16 + 4 * cq + u] = mk<double>(wx[u], wy[u]);      // row q of the right half
+                    }
+                    const double dq = gjbuf[q].x;
+                    bad = bad || !(dq > 0.0) || !(dq < 1e300);
+                    const double inv = rcp_full(dq);
+                    if (i == q) dsc = rsq_full(dq);
+                    if (i > q) {
+                        const C128 ci = gjbuf[i];
+                        const double mx = ci.x * inv, my = ci.y * inv;          // multiplier m = B[i][q] / d_q
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const C128 cjv = gjbuf[4 * cq + u], rw = gjbuf[16 + 4 * cq + u];
+                            // left half: -= m conj(B[j][q]) (row q of the Hermitian left half); right half: -= m W[q][j]
+                            bx[u] = fma_t(-my, cjv.y, fma_t(-mx, cjv.x, bx[u]));
+                            by[u] = fma_t(mx, cjv.y, fma_t(-my, cjv.x, by[u]));
+                            wx[u] = fma_t(my, rw.y, fma_t(-mx, rw.x, wx[u]));
+                            wy[u] = fma_t(-my, rw.x, fma_t(-mx, rw.y, wy[u]));
+                        }
+                    }
+                }
+                if (bad && lane == 0) sh.sFlag[1] = 1;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (4 * cq + u <= i) RB[(o + 4 * cq + u) * LDD + o + i] = mk<double>(wx[u] * dsc, -(wy[u] * dsc));   // conj(W[o+i][o+j]) at [o+j][o+i]
             }
             __syncthreads();
-            const double dkk = col[kk].x;
-            if (!(dkk > 0.0) || !(dkk < 1e300)) {           // uniform: every thread reads the same word
+            if (sh.sFlag[1] != 0) {                          // uniform
                 status = 1;
                 break;
             }
-            if (tid == 0) sDinv[kk] = rsq_full(dkk);
-            if (mine && i0 + 1 > kk && j0 + 1 > kk) {        // something of this block lies beyond the pivot
-                const double inv = rcp_full(dkk);
-                const double f0 = (i0 > kk) ? inv : 0.0;     // a row or column at the pivot itself is left alone: multiplier 0
-                const bool c0 = j0 > kk;
-                const C128 l0 = col[i0], l1 = col[i0 + 1], q0 = col[j0], q1 = col[j0 + 1];
-                const double l0x = l0.x * f0, l0y = l0.y * f0, l1x = l1.x * inv, l1y = l1.y * inv;
-                const double m0x = c0 ? q0.x : 0.0, m0y = c0 ? q0.y : 0.0;
-                v00.x = fma_t(-l0y, m0y, fma_t(-l0x, m0x, v00.x));              // -= l conj(m), as chained FMAs
-                v00.y = fma_t(l0x, m0y, fma_t(-l0y, m0x, v00.y));
-                v01.x = fma_t(-l0y, q1.y, fma_t(-l0x, q1.x, v01.x));
-                v01.y = fma_t(l0x, q1.y, fma_t(-l0y, q1.x, v01.y));
-                v10.x = fma_t(-l1y, m0y, fma_t(-l1x, m0x, v10.x));
-                v10.y = fma_t(l1x, m0y, fma_t(-l1y, m0x, v10.y));
-                v11.x = fma_t(-l1y, q1.y, fma_t(-l1x, q1.x, v11.x));
-                v11.y = fma_t(l1x, q1.y, fma_t(-l1y, q1.x, v11.y));
+            if (kb == 3) break;
+            // (b) panel: L_ik = R_ik W_kk^H for the tiles below; B operand W_kk^H[k'][j] = conj(W[j][k']) = RB[o + k'][o + j], k' <= j
+            if (wave < 3 - kb) {
+                const int ib = kb + 1 + wave;
+                C128 lacc[4];
+                cmm64_tile([&](int i, int kk) { return RB[i * LDD + kk]; },
+                           [&](int kk, int j) { return kk <= j ? RB[kk * LDD + j] : mk<double>(0, 0); }, ib, kb, lane, o, o + 16, lacc);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) RB[(16 * ib + kq + 4 * t) * LDD + o + il] = lacc[t];          // only this wave reads this tile
             }
+            __syncthreads();
+            // (c) trailing update of the tiles (i, j), kb < j <= i: R_ij -= L_ik L_jk^H
+            {
+                const int rem = 3 - kb, ntile = rem * (rem + 1) / 2;
+                if (wave < ntile) {
+                    int ib = kb + 1, w2 = wave;
+                    while (w2 > ib - kb - 1) {                // tiles (kb+1,kb+1), (kb+2,kb+1), (kb+2,kb+2), ...
+                        w2 -= ib - kb;
+                        ++ib;
+                    }
+                    const int jb = kb + 1 + w2;
+                    C128 uacc[4];
+                    cmm64_tile([&](int i, int kk) { return RB[i * LDD + kk]; }, [&](int kk, int j) { return cj(RB[j * LDD + kk]); }, ib, jb,
+                               lane, o, o + 16, uacc);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        C128* e = &RB[(16 * ib + kq + 4 * t) * LDD + 16 * jb + il];
+                        const C128 v = *e;
+                        *e = mk<double>(v.x - uacc[t].x, v.y - uacc[t].y);
+                    }
+                }
+            }
+            __syncthreads();
         }
-        __syncthreads();                                     // sDinv is complete
-        if (status == 0 && mine) {                           // L below the diagonal, scaled by column
-            const double s0 = sDinv[j0], s1 = sDinv[j0 + 1];
-            if (j0 < i0) RB[i0 * LDD + j0] = mk<double>(v00.x * s0, v00.y * s0);
-            if (j0 + 1 < i0) RB[i0 * LDD + j0 + 1] = mk<double>(v01.x * s1, v01.y * s1);
-            RB[(i0 + 1) * LDD + j0] = mk<double>(v10.x * s0, v10.y * s0);         // j0 <= i0 < i0 + 1
-            if (j0 + 1 < i0 + 1) RB[(i0 + 1) * LDD + j0 + 1] = mk<double>(v11.x * s1, v11.y * s1);
-        }
-        __syncthreads();
     }
     stamp64(p, z1, k, 9);
     if (p.debug_stop == 2) return -1;
     if (status == 0) {
-        // W = L^-1 in 16 x 16 blocks; W^H goes to the UPPER triangle of the region with its diagonal (W_ij at [j][i], conjugated);
-        // nothing below reads L's diagonal.  L stays where it is until the last block is done.
-        //   (1) the four diagonal blocks, one wave each: Gauss-Jordan on [L_aa | I] with the rows of the right half in registers
-        //       (lane = row i + 16 x column group; a lane holds W[i][4 cq .. 4 cq + 3]); step k scales row k by 1 / L_kk, hands it
-        //       to the rows below through 256 bytes of LDS and those subtract L_ik times it.  Sixteen short steps, no barrier
-        //       (the LDS executes a wave's accesses in order).
-        if (wave < 4) {
-            const int o = 16 * wave, i = lane & 15, cq = lane >> 4;
-            C128* const rowbuf = reinterpret_cast<C128*>(&sh.sPartI[0][0]) + 16 * wave;      // the Cholesky's column buffers are spent
-            double wx[4], wy[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                wx[u] = (4 * cq + u == i) ? 1.0 : 0.0;
-                wy[u] = 0.0;
-            }
-#pragma unroll 4
-            for (int kq2 = 0; kq2 < 16; ++kq2) {
-                if (i == kq2) {
-                    const double dk = sDinv[o + kq2];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        wx[u] *= dk;
-                        wy[u] *= dk;
-                        rowbuf[4 * cq + u] = mk<double>(wx[u], wy[u]);
-                    }
-                }
-                if (i > kq2) {
-                    const C128 l = RB[(o + i) * LDD + o + kq2];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const C128 rk = rowbuf[4 * cq + u];
-                        wx[u] = fma_t(l.y, rk.y, fma_t(-l.x, rk.x, wx[u]));
-                        wy[u] = fma_t(-l.y, rk.x, fma_t(-l.x, rk.y, wy[u]));
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (4 * cq + u <= i) RB[(o + 4 * cq + u) * LDD + o + i] = mk<double>(wx[u], -wy[u]);  // conj(W[o + i][o + 4 cq + u]) at the mirrored place
-        }
-        __syncthreads();
+        // W = L^-1: the diagonal tiles are done (mirrored, conjugated).
         //   (2) the blocks below the diagonal, one block diagonal after the other: W_ba = -W_bb (sum_{a <= k < b} L_bk W_ka).  The
         //       accumulator of the inner sum is the B operand of the second product as it stands (register t is row 4 t + kq).
         auto Wel = [&](int i, int kk) { return cj(RB[kk * LDD + i]); };          // W[i][kk], kk <= i (the diagonal is real)
@@ -717,28 +725,47 @@ __device__ __forceinline__ void back64(const GevdParams& p, const Sh& sh, bool z
 
 
     // ---------------- outputs ----------------
-    if (tid < N64) {
+    // w_V = sum over the V leading columns (descending order) of coef_c x_c: running sums over the sorted columns, in segments
+    // of four held by sixteen threads per row (region B is free by now: V has gone into X); a rank's filter is then the totals of
+    // the segments in front of its last column plus the running sum inside that segment.  (Rounds 2-3a walked the sorted
+    // columns one after the other in 64 threads, every step an index read and two dependent reads behind it: 8 us.)
+    C128* const Tp = RB;
+    if (status != 1) {
+        const int l = tid & 63, part = tid >> 6;
         double ax = 0, ay = 0;
-        int done = 0;
-        for (int t = 0; t < p.nV; ++t) {
-            const int V = p.ranks[t];
-            if (status != 1) {
-                for (; done < V; ++done) {
-                    const int c = sOrder[done];
-                    const C128 cf = scoef[c], v = RA[tid * LDD + c];
-                    ax += cf.x * v.x - cf.y * v.y;
-                    ay += cf.x * v.y + cf.y * v.x;
-                }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = sOrder[4 * part + u];
+            const C128 cf = scoef[c], v = RA[l * LDD + c];
+            ax += cf.x * v.x - cf.y * v.y;
+            ay += cf.x * v.y + cf.y * v.x;
+            Tp[l * LDD + 4 * part + u] = mk<double>(ax, ay);
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < p.nV * N64; idx += 1024) {
+        const int t = idx >> 6, l = idx & 63;
+        const int V = p.ranks[t];
+        double ax = 0, ay = 0;
+        if (status != 1 && V > 0) {
+            const int seg = (V - 1) >> 2;
+            for (int q = 0; q < seg; ++q) {
+                const C128 v = Tp[l * LDD + 4 * q + 3];
+                ax += v.x;
+                ay += v.y;
             }
-            const size_t o = ((size_t)k * p.nV + t) * N64 + tid;
-            if (p.out_c128) reinterpret_cast<double2*>(pw)[o] = make_double2(ax, ay);
-            else reinterpret_cast<float2*>(pw)[o] = make_float2((float)ax, (float)ay);
+            const C128 v = Tp[l * LDD + V - 1];
+            ax += v.x;
+            ay += v.y;
         }
-        if (plam != nullptr) {
-            const double lv = (status != 1) ? sLam[sOrder[tid]] : 0.0;
-            if (p.out_c128) reinterpret_cast<double*>(plam)[(size_t)k * N64 + tid] = lv;
-            else reinterpret_cast<float*>(plam)[(size_t)k * N64 + tid] = (float)lv;
-        }
+        const size_t o = ((size_t)k * p.nV + t) * N64 + l;
+        if (p.out_c128) reinterpret_cast<double2*>(pw)[o] = make_double2(ax, ay);
+        else reinterpret_cast<float2*>(pw)[o] = make_float2((float)ax, (float)ay);
+    }
+    if (tid < N64 && plam != nullptr) {
+        const double lv = (status != 1) ? sLam[sOrder[tid]] : 0.0;
+        if (p.out_c128) reinterpret_cast<double*>(plam)[(size_t)k * N64 + tid] = lv;
+        else reinterpret_cast<float*>(plam)[(size_t)k * N64 + tid] = (float)lv;
     }
     if (p.U != nullptr) {
         C128* U = reinterpret_cast<C128*>(p.U) + (size_t)k * N64 * N64;
