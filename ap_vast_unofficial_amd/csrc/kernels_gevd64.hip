@@ -607,15 +607,20 @@ __device__ __forceinline__ void back64(const GevdParams& p, const Sh& sh, bool z
         for (int it = 0; it < max_ref && !converged; ++it) {
             ++n_ref;
             C128 accT[4], accG[4], accS[4];
+            // (the lane index goes through an empty asm once per step: the 64 global addresses of C's operands are loop invariant
+            // otherwise, and the compiler computes them in front of the loop and parks them in scratch memory -- 28 of the
+            // kernel's spilled registers)
+            int lane_l = lane;
+            asm volatile("" : "+v"(lane_l));
             // C is Hermitian: C[i][k] = conj(C[k][i]) read along a row of the scratch copy (coalesced)
-            cmm64_tile([&](int i, int kk) { return cj(gC[kk * N64 + i]); }, [&](int kk, int j) { return RB[kk * LDD + j]; }, ti, tj, lane, 0,
+            cmm64_tile([&](int i, int kk) { return cj(gC[kk * N64 + i]); }, [&](int kk, int j) { return RB[kk * LDD + j]; }, ti, tj, lane_l, 0,
                        N64, accT);                                                                              // C V
+            // (region A is free: the loop's last barrier ended every read of Z; T leaves the registers before the next product starts)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) RA[(16 * ti + kq + 4 * t) * LDD + 16 * tj + il] = accT[t];
             cmm64_tile([&](int i, int kk) { return cj(RB[kk * LDD + i]); }, [&](int kk, int j) { return RB[kk * LDD + j]; }, ti, tj, lane, 0,
                        N64, accG);                                                                              // V^H V
             if (tid < 2) sFlag[tid] = 0;
-            __syncthreads();
-#pragma unroll
-            for (int t = 0; t < 4; ++t) RA[(16 * ti + kq + 4 * t) * LDD + 16 * tj + il] = accT[t];
             __syncthreads();
             cmm64_tile([&](int i, int kk) { return cj(RB[kk * LDD + i]); }, [&](int kk, int j) { return RA[kk * LDD + j]; }, ti, tj, lane, 0,
                        N64, accS);                                                                              // S = V^H C V
