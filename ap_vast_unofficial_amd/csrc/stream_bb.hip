@@ -859,13 +859,20 @@ int apv_bb_process_signal(apv_handle* h, int32_t n_hops, const double* h_in_A, c
         if ((rc = dalloc(h, &s->g_inspec, (size_t)G * 2 * K * 2))) return rc;
         s->grp = G;
     }
+    // every exit below drains the stream first: copies into the caller's h_out may be in flight
+    auto drained = [&](int rc) { (void)hipStreamSynchronize(st); return rc; };
+#define BDCHK(h, call)                                                                                                     \
+    do {                                                                                                                    \
+        hipError_t _e = (call);                                                                                             \
+        if (_e != hipSuccess) return drained(apv_fail(h, APV_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_e))); \
+    } while (0)
     std::vector<int32_t> status((size_t)G * nz, 0);
     long bad_hops = 0;
     for (int h0 = 0; h0 < n_hops; h0 += G) {
         const int g_n = n_hops - h0 < G ? n_hops - h0 : G;
         for (int g = 0; g < g_n; ++g) {
-            BCHK(h, hipMemcpyAsync(s->g_xin + (size_t)g * 2 * H, h_in_A + (size_t)(h0 + g) * H, sizeof(double) * H, hipMemcpyHostToDevice, st));
-            BCHK(h, hipMemcpyAsync(s->g_xin + (size_t)g * 2 * H + H, h_in_B + (size_t)(h0 + g) * H, sizeof(double) * H, hipMemcpyHostToDevice, st));
+            BDCHK(h, hipMemcpyAsync(s->g_xin + (size_t)g * 2 * H, h_in_A + (size_t)(h0 + g) * H, sizeof(double) * H, hipMemcpyHostToDevice, st));
+            BDCHK(h, hipMemcpyAsync(s->g_xin + (size_t)g * 2 * H + H, h_in_B + (size_t)(h0 + g) * H, sizeof(double) * H, hipMemcpyHostToDevice, st));
         }
         std::vector<BbHop> hops(g_n);
         for (int g = 0; g < g_n; ++g) {
@@ -884,15 +891,15 @@ int apv_bb_process_signal(apv_handle* h, int32_t n_hops, const double* h_in_A, c
             q.nrm_dark = s->g_nrm + (size_t)G * 4 + (size_t)g * nz;
             q.inspec = s->g_inspec + (size_t)g * 2 * K * 2;
             const int rc = bb_front(h, s, q, nullptr);
-            if (rc != APV_OK) return rc;
+            if (rc != APV_OK) return drained(rc);
         }
         int rc = apv_gevd_large(h, n, g_n * nz, s->g_RA, s->g_RB, s->rel_loading ? 0.0 : h->cfg.reg_dark,
                                 s->rel_dark_py ? s->g_nrm + (size_t)G * 4 : nullptr, s->g_U, s->g_lam, s->g_r, h->cfg.mu, V, s->d_ranks, s->g_w,
                                 status.data());
-        if (rc != APV_OK) return rc;
+        if (rc != APV_OK) return drained(rc);
         for (int g = 0; g < g_n; ++g) {
             rc = bb_back(h, s, hops[g], h_out + (size_t)(h0 + g) * s->n_out * H);
-            if (rc != APV_OK) return rc;
+            if (rc != APV_OK) return drained(rc);
             bool bad = false;
             for (int z = 0; z < nz; ++z) bad = bad || status[(size_t)g * nz + z] == 2;
             bad_hops += bad;
@@ -903,25 +910,26 @@ int apv_bb_process_signal(apv_handle* h, int32_t n_hops, const double* h_in_A, c
             for (int z = 0; z < 2; ++z) {
                 if (!(z ? runB : runA)) continue;
                 const size_t slot = (size_t)(g_n - 1) * nz + (z - first);
-                BCHK(h, hipMemcpyAsync(s->R + (size_t)z * nn, q.Rq[z], sizeof(double) * nn, hipMemcpyDeviceToDevice, st));
-                BCHK(h, hipMemcpyAsync(s->R + (size_t)(2 + z) * nn, q.Rq[2 + z], sizeof(double) * nn, hipMemcpyDeviceToDevice, st));
-                BCHK(h, hipMemcpyAsync(s->r + (size_t)z * n, q.r[z], sizeof(double) * n, hipMemcpyDeviceToDevice, st));
-                BCHK(h, hipMemcpyAsync(s->w + (size_t)z * V * n, q.w[z], sizeof(double) * V * n, hipMemcpyDeviceToDevice, st));
-                BCHK(h, hipMemcpyAsync(s->U + (size_t)z * nn, s->g_U + slot * nn, sizeof(double) * nn, hipMemcpyDeviceToDevice, st));
-                BCHK(h, hipMemcpyAsync(s->lam + (size_t)z * n, s->g_lam + slot * n, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
+                BDCHK(h, hipMemcpyAsync(s->R + (size_t)z * nn, q.Rq[z], sizeof(double) * nn, hipMemcpyDeviceToDevice, st));
+                BDCHK(h, hipMemcpyAsync(s->R + (size_t)(2 + z) * nn, q.Rq[2 + z], sizeof(double) * nn, hipMemcpyDeviceToDevice, st));
+                BDCHK(h, hipMemcpyAsync(s->r + (size_t)z * n, q.r[z], sizeof(double) * n, hipMemcpyDeviceToDevice, st));
+                BDCHK(h, hipMemcpyAsync(s->w + (size_t)z * V * n, q.w[z], sizeof(double) * V * n, hipMemcpyDeviceToDevice, st));
+                BDCHK(h, hipMemcpyAsync(s->U + (size_t)z * nn, s->g_U + slot * nn, sizeof(double) * nn, hipMemcpyDeviceToDevice, st));
+                BDCHK(h, hipMemcpyAsync(s->lam + (size_t)z * n, s->g_lam + slot * n, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
             }
-            BCHK(h, hipMemcpyAsync(s->nrm, q.nrm, sizeof(double) * 4, hipMemcpyDeviceToDevice, st));
-            BCHK(h, hipMemcpyAsync(s->inspec, q.inspec, sizeof(double) * 2 * K * 2, hipMemcpyDeviceToDevice, st));
+            BDCHK(h, hipMemcpyAsync(s->nrm, q.nrm, sizeof(double) * 4, hipMemcpyDeviceToDevice, st));
+            BDCHK(h, hipMemcpyAsync(s->inspec, q.inspec, sizeof(double) * 2 * K * 2, hipMemcpyDeviceToDevice, st));
         }
-        BCHK(h, hipStreamSynchronize(st));       // the group's input staging is rewritten by the next group
+        BDCHK(h, hipStreamSynchronize(st));       // the group's input staging is rewritten by the next group
     }
-    BCHK(h, hipGetLastError());
+    BDCHK(h, hipGetLastError());
     if (bad_hops) {
         s->not_converged += bad_hops;
         return apv_fail(h, APV_ERR_NO_CONVERGE, "eigen-iteration did not converge (Jacobi sweep cap reached) in some hop; the outputs were written");
     }
     return APV_OK;
 }
+#undef BDCHK
 
 }  // extern "C"
 

@@ -333,7 +333,7 @@ def load_traffic(tag, K, dtype):
     return None
 
 
-def also_cfg5(Engine, device, steps=10, warmup=3):
+def also_cfg5(Engine, device, steps=20, warmup=8):
     """BASELINE config 5 at kernel level: 64 loudspeakers x 128 control points x 2048 bins, float64, V in {1, 32, 64}."""
     L5, M5, K5 = 64, 128, 2048
     ranks = (1, 32, 64)
@@ -342,7 +342,7 @@ def also_cfg5(Engine, device, steps=10, warmup=3):
         XB, XD, d = synth(K5, 1234, L5, M5)
         dXB, dXD, dd = eng.to_device(XB), eng.to_device(XD), eng.to_device(d)
         dw, ds = eng.alloc(K5 * len(ranks) * L5 * 8), eng.alloc(K5 * 4)
-        for _ in range(warmup):
+        for _ in range(warmup):                    # a GPU that idled runs its first launches ~8 % slower (clock ramp)
             eng.update_dev(dXB, dXD, dd, dw, None, ds)
         eng.sync()
         t0 = time.perf_counter()
