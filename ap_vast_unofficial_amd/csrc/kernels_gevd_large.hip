@@ -331,10 +331,17 @@ __device__ __forceinline__ int tile_index(int I, int J, int t) { return t < BH ?
 // owns are rotated in place.
 // `full`: the inner sweep visits all 496 pairs of the 32 indices (first round of a sweep: that is where the pairs
 // inside one 16-block are annihilated); otherwise only the 256 pairs across the two blocks, in 16 rounds.
+//
+// MODE 0: all of the above in one launch (np (np + 1) / 2 workgroups; rounds 1-2, now the A/B switch APV_LARGE_SPLIT=0).  The
+// redundant inner sweeps cost real time once a launch fills the chip (n = 800: 25 pair problems solved by 650 workgroups), and
+// even below that the off-diagonal workgroups are better off not sweeping.  Round 3 splits the round: MODE 1, np workgroups,
+// solves the pair problems (the diagonal tiles: inner sweep, rotated tile, its X tile) and leaves the rotations V_P in Vbuf;
+// MODE 2, np (np - 1) / 2 workgroups, takes V_P, V_Q from there and applies them to its off-diagonal tile and its two X tiles.
+template <int MODE>
 __global__ void __launch_bounds__(512) block_jacobi_round_kernel(int ld, int nb, int round, int full,
                                                                  const double* __restrict__ Cin, double* __restrict__ Cout,
                                                                  double* __restrict__ X, double* __restrict__ off,
-                                                                 size_t mat_stride) {
+                                                                 size_t mat_stride, double* __restrict__ Vbuf) {
     constexpr int TS = BT * LS;
     __shared__ double sm[6 * TS];
     __shared__ double2 rot[2][BH];
@@ -345,9 +352,16 @@ __global__ void __launch_bounds__(512) block_jacobi_round_kernel(int ld, int nb,
     X += z * mat_stride;
     const int np = nb / 2;
     int P = 0, rem = blockIdx.x;
-    while (rem >= np - P) {
-        rem -= np - P;
-        ++P;
+    if (MODE == 1) {
+        P = blockIdx.x;
+        rem = 0;
+    } else {
+        const int skip = (MODE == 2) ? 1 : 0;                 // MODE 2 enumerates the tiles above the diagonal only
+        while (rem >= np - P - skip) {
+            rem -= np - P - skip;
+            ++P;
+        }
+        rem += skip;
     }
     const int Q = P + rem;
     const bool diag = P == Q;
@@ -355,12 +369,19 @@ __global__ void __launch_bounds__(512) block_jacobi_round_kernel(int ld, int nb,
     rr_pair(nb, round, P, IP, JP);
     rr_pair(nb, round, Q, IQ, JQ);
     const int tid = threadIdx.x, half = tid >> 8, a = (tid >> 4) & 15, b = tid & 15;
+    double* const Vz = Vbuf + (size_t)z * np * TS;
     for (int e = tid; e < BT * BT; e += 512) {
         const int t = e >> 5, u = e & 31;
         const size_t gr = (size_t)tile_index(IP, JP, t) * ld;
-        SP[t * LS + u] = Cin[gr + tile_index(IP, JP, u)];
-        VP[t * LS + u] = (t == u) ? 1.0 : 0.0;
-        if (!diag) {
+        if (MODE != 2) {
+            SP[t * LS + u] = Cin[gr + tile_index(IP, JP, u)];
+            VP[t * LS + u] = (t == u) ? 1.0 : 0.0;
+        } else {
+            VP[t * LS + u] = Vz[(size_t)P * TS + t * LS + u];
+            VQ[t * LS + u] = Vz[(size_t)Q * TS + t * LS + u];
+            T[t * LS + u] = Cin[gr + tile_index(IQ, JQ, u)];
+        }
+        if (MODE == 0 && !diag) {
             SQ[t * LS + u] = Cin[(size_t)tile_index(IQ, JQ, t) * ld + tile_index(IQ, JQ, u)];
             T[t * LS + u] = Cin[gr + tile_index(IQ, JQ, u)];
             VQ[t * LS + u] = (t == u) ? 1.0 : 0.0;
@@ -371,7 +392,7 @@ __global__ void __launch_bounds__(512) block_jacobi_round_kernel(int ld, int nb,
     const bool active = half == 0 || !diag;
     double* const S = half ? SQ : SP;
     double* const V = half ? VQ : VP;
-    const int inner_rounds = full ? BT - 1 : BH;
+    const int inner_rounds = (MODE == 2) ? 0 : (full ? BT - 1 : BH);
     // round-robin positions of pair a / pair b, advanced incrementally (rr_pair without the modulo)
     int ua = (a == 0) ? BT - 1 : a, va = (a == 0) ? 0 : BT - 1 - a;
     int ub = (b == 0) ? BT - 1 : b, vb = (b == 0) ? 0 : BT - 1 - b;
@@ -429,6 +450,7 @@ __global__ void __launch_bounds__(512) block_jacobi_round_kernel(int ld, int nb,
             const int t = e >> 5, u = e & 31;
             Cout[(size_t)tile_index(IP, JP, t) * ld + tile_index(IP, JP, u)] = SP[t * LS + u];
             T[t * LS + u] = X[(size_t)(P * BT + t) * ld + tile_index(IP, JP, u)];
+            if (MODE == 1) Vz[(size_t)P * TS + t * LS + u] = VP[t * LS + u];
         }
         __syncthreads();
         if (half) return;
@@ -566,14 +588,14 @@ __global__ void __launch_bounds__(TPB) vast_prefix_kernel(int n, int V, const in
 struct GevdLargeWs {
     int n = 0, batch = 0;
     double *Bw = nullptr, *W = nullptr, *T1 = nullptr, *C0 = nullptr, *C1 = nullptr, *X = nullptr, *Li = nullptr;
-    double *acc = nullptr, *coef = nullptr;
+    double *acc = nullptr, *coef = nullptr, *Vbuf = nullptr;
     int *flag = nullptr, *order = nullptr;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     void release() {
         if (exec) (void)hipGraphExecDestroy(exec);
         if (graph) (void)hipGraphDestroy(graph);
-        void* bufs[] = {Bw, W, T1, C0, C1, X, Li, acc, coef, flag, order};
+        void* bufs[] = {Bw, W, T1, C0, C1, X, Li, acc, coef, Vbuf, flag, order};
         for (void* b : bufs)
             if (b) (void)hipFree(b);
         *this = GevdLargeWs();
@@ -608,6 +630,11 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
     const size_t mb = sizeof(double) * ms * batch;
     const int gx = (ne + TPB - 1) / TPB;
     const int tiles = np * (np + 1) / 2;
+    // the pair solves and the updates of a round as two launches (see the kernel); APV_LARGE_SPLIT=0 is the A/B switch back to one.
+    // Measured (tools/bench_broadband.py): n = 256 two pairs 4.43 -> 4.29 ms per hop, sixteen pairs 1.24 -> 0.95 ms per hop,
+    // n = 800 two pairs 32.6 -> 24.9 ms per hop -- the split wins even where the chip is far from full.
+    static const int split_env = getenv("APV_LARGE_SPLIT") ? atoi(getenv("APV_LARGE_SPLIT")) : -1;
+    const bool split = split_env != 0;
     if (ws.n != n || ws.batch != batch) {
         ws.release();
         ws.n = n;
@@ -617,6 +644,7 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
         LCHK(hipMalloc((void**)&ws.Li, sizeof(double) * BT * BT * nbk * batch));
         LCHK(hipMalloc((void**)&ws.acc, sizeof(double) * 3 * batch));         // [sweep a | sweep b | ||C||_F^2]
         LCHK(hipMalloc((void**)&ws.coef, sizeof(double) * vs * batch));
+        LCHK(hipMalloc((void**)&ws.Vbuf, sizeof(double) * (size_t)BT * LS * np * batch));
         LCHK(hipMalloc((void**)&ws.flag, sizeof(int) * batch));
         LCHK(hipMalloc((void**)&ws.order, sizeof(int) * vs * batch));
     }
@@ -628,8 +656,16 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
         double *Cc = ws.C0, *Cn = ws.C1;
         for (int sw = 0; sw < 2; ++sw)
             for (int r = 0; r < rounds; ++r) {
-                hipLaunchKernelGGL(block_jacobi_round_kernel, dim3(tiles, 1, batch), dim3(512), 0, st, ld, nb, r, r == 0 ? 1 : 0,
-                                   Cc, Cn, ws.X, ws.acc + (size_t)sw * batch, ms);
+                if (!split) {
+                    hipLaunchKernelGGL(block_jacobi_round_kernel<0>, dim3(tiles, 1, batch), dim3(512), 0, st, ld, nb, r, r == 0 ? 1 : 0,
+                                       Cc, Cn, ws.X, ws.acc + (size_t)sw * batch, ms, ws.Vbuf);
+                } else {
+                    hipLaunchKernelGGL(block_jacobi_round_kernel<1>, dim3(np, 1, batch), dim3(512), 0, st, ld, nb, r, r == 0 ? 1 : 0,
+                                       Cc, Cn, ws.X, ws.acc + (size_t)sw * batch, ms, ws.Vbuf);
+                    if (np > 1)
+                        hipLaunchKernelGGL(block_jacobi_round_kernel<2>, dim3(tiles - np, 1, batch), dim3(512), 0, st, ld, nb, r, 0,
+                                           Cc, Cn, ws.X, ws.acc + (size_t)sw * batch, ms, ws.Vbuf);
+                }
                 double* t = Cc; Cc = Cn; Cn = t;
             }
     };
