@@ -338,22 +338,22 @@ __device__ __forceinline__ int tile_index(int I, int J, int t) { return t < BH ?
 // solves the pair problems (the diagonal tiles: inner sweep, rotated tile, its X tile) and leaves the rotations V_P in Vbuf;
 // MODE 2, np (np - 1) / 2 workgroups, takes V_P, V_Q from there and applies them to its off-diagonal tile and its two X tiles.
 template <int MODE>
-__global__ void __launch_bounds__(512) block_jacobi_round_kernel(int ld, int nb, int round, int full,
-                                                                 const double* __restrict__ Cin, double* __restrict__ Cout,
-                                                                 double* __restrict__ X, double* __restrict__ off,
-                                                                 size_t mat_stride, double* __restrict__ Vbuf) {
+__device__ __forceinline__ void block_jacobi_round_body(double* sm, double2 (*rot)[BH], int blk, int ld, int nb, int round, int full,
+                                                        const double* __restrict__ Cin, double* __restrict__ Cout,
+                                                        double* __restrict__ X, double* __restrict__ off, size_t mat_stride,
+                                                        double* __restrict__ Vbuf, const double* __restrict__ Dbuf) {
     constexpr int TS = BT * LS;
-    __shared__ double sm[6 * TS];
-    __shared__ double2 rot[2][BH];
     double *SP = sm, *SQ = sm + TS, *VP = sm + 2 * TS, *VQ = sm + 3 * TS, *T = sm + 4 * TS, *U = sm + 5 * TS;
     const int z = blockIdx.z;
     Cin += z * mat_stride;
     Cout += z * mat_stride;
     X += z * mat_stride;
     const int np = nb / 2;
-    int P = 0, rem = blockIdx.x;
+    int P = 0, rem = blk;
+    // MODE 5 (look-ahead, see la_solve_kernel): the update half of a round for ALL tiles -- diagonal workgroups copy the rotated
+    // tile from Dbuf and rotate their X tile, the others are MODE 2
     if (MODE == 1) {
-        P = blockIdx.x;
+        P = blk;
         rem = 0;
     } else {
         const int skip = (MODE == 2) ? 1 : 0;                 // MODE 2 enumerates the tiles above the diagonal only
@@ -373,7 +373,10 @@ __global__ void __launch_bounds__(512) block_jacobi_round_kernel(int ld, int nb,
     for (int e = tid; e < BT * BT; e += 512) {
         const int t = e >> 5, u = e & 31;
         const size_t gr = (size_t)tile_index(IP, JP, t) * ld;
-        if (MODE != 2) {
+        if (MODE == 5 && diag) {                              // look-ahead: the pair solve has left the rotated tile and V_P behind
+            SP[t * LS + u] = Dbuf[((size_t)z * np + P) * TS + t * LS + u];
+            VP[t * LS + u] = Vz[(size_t)P * TS + t * LS + u];
+        } else if (MODE != 2 && MODE != 5) {
             SP[t * LS + u] = Cin[gr + tile_index(IP, JP, u)];
             VP[t * LS + u] = (t == u) ? 1.0 : 0.0;
         } else {
@@ -392,7 +395,7 @@ __global__ void __launch_bounds__(512) block_jacobi_round_kernel(int ld, int nb,
     const bool active = half == 0 || !diag;
     double* const S = half ? SQ : SP;
     double* const V = half ? VQ : VP;
-    const int inner_rounds = (MODE == 2) ? 0 : (full ? BT - 1 : BH);
+    const int inner_rounds = (MODE == 2 || MODE == 5) ? 0 : (full ? BT - 1 : BH);
     // round-robin positions of pair a / pair b, advanced incrementally (rr_pair without the modulo)
     int ua = (a == 0) ? BT - 1 : a, va = (a == 0) ? 0 : BT - 1 - a;
     int ub = (b == 0) ? BT - 1 : b, vb = (b == 0) ? 0 : BT - 1 - b;
@@ -585,17 +588,216 @@ __global__ void __launch_bounds__(TPB) vast_prefix_kernel(int n, int V, const in
 }  // namespace
 
 // Workspace + captured two-sweep graph, cached on the handle (sizes rarely change between hops).
+template <int MODE>
+__global__ void __launch_bounds__(512) block_jacobi_round_kernel(int ld, int nb, int round, int full,
+                                                                 const double* __restrict__ Cin, double* __restrict__ Cout,
+                                                                 double* __restrict__ X, double* __restrict__ off,
+                                                                 size_t mat_stride, double* __restrict__ Vbuf,
+                                                                 const double* __restrict__ Dbuf) {
+    __shared__ double sm[6 * BT * LS];
+    __shared__ double2 rot[2][BH];
+    block_jacobi_round_body<MODE>(sm, rot, blockIdx.x, ld, nb, round, full, Cin, Cout, X, off, mat_stride, Vbuf, Dbuf);
+}
+
+// ---- look-ahead (round 3) -----------------------------------------------------------------------------------
+// The pair problems of round r + 1 do not need the whole matrix after round r: the diagonal tile of the pair (I', J') is made of
+// the blocks (I', I'), (J', J') -- sub-blocks of round r's ROTATED diagonal tiles, which the pair solves of round r leave in Dbuf --
+// and (I', J'), a sub-block of V_a^T C_r[tile (a, b)] V_b for the two round-r pairs a, b that held I' and J' (never the same pair
+// two rounds running).  la_solve_kernel forms that one tile itself (two 32^3 products) and solves, so that the update of round
+// r (la: block_jacobi_round_kernel<5>, the whole chip) runs BESIDE the pair solves of round r + 1 (np workgroups, one long
+// dependent chain each) on a second stream: a round costs the longer of the two instead of their sum.
+
+// pair index and position (0: first, 1: second block) of block A in round r of the tournament
+__device__ __forceinline__ void rr_locate(int ne, int r, int A, int& pair, int& half) {
+    const int m1 = ne - 1;
+    int a = 0;
+    if (A != m1 && A != r) {
+        a = (A - r + m1) % m1;
+        if (a >= ne / 2) a = m1 - a;
+    }
+    int p, q;
+    rr_pair(ne, r, a, p, q);
+    pair = a;
+    half = (A == p) ? 0 : 1;
+}
+
+// FIRST: the matrix Csrc is complete (first round of a graph launch): the tile is read as it stands.  Otherwise Csrc is the
+// matrix BEFORE round `prev_round`, Vprev / Dprev that round's rotations and rotated diagonal tiles.
+template <bool FIRST>
+__device__ __forceinline__ void la_solve_body(double* sm, double2 (*rot)[BH], int blk, int ld, int nb, int round, int prev_round, int full,
+                                              const double* __restrict__ Csrc, const double* __restrict__ Vprev,
+                                              const double* __restrict__ Dprev, double* __restrict__ Vcur,
+                                              double* __restrict__ Dcur, double* __restrict__ off, size_t mat_stride) {
+    constexpr int TS = BT * LS;
+    double *SP = sm, *VP = sm + TS, *T = sm + 2 * TS, *U = sm + 3 * TS, *VA = sm + 4 * TS, *VB = sm + 5 * TS;
+    const int z = blockIdx.z, np = nb / 2, P = blk;
+    __builtin_amdgcn_s_setprio(3);          // the launch lasts as long as this chain: its waves go first beside the update's
+    Csrc += z * mat_stride;
+    int IP, JP;
+    rr_pair(nb, round, P, IP, JP);
+    const int tid = threadIdx.x, half = tid >> 8, a = (tid >> 4) & 15, b = tid & 15;
+    const int w = (tid >> 6) & 3, lane = tid & 63;
+    const int orow = (w >> 1) * 16 + (lane >> 4), ocol = (w & 1) * 16 + (lane & 15);     // + 4 t on the row
+    if (FIRST) {
+        for (int e = tid; e < BT * BT; e += 512) {
+            const int t = e >> 5, u = e & 31;
+            SP[t * LS + u] = Csrc[(size_t)tile_index(IP, JP, t) * ld + tile_index(IP, JP, u)];
+            VP[t * LS + u] = (t == u) ? 1.0 : 0.0;
+        }
+        __syncthreads();
+    } else {
+        int pa, ha, pb, hb, Ia, Ja, Ib, Jb;
+        rr_locate(nb, prev_round, IP, pa, ha);
+        rr_locate(nb, prev_round, JP, pb, hb);
+        rr_pair(nb, prev_round, pa, Ia, Ja);
+        rr_pair(nb, prev_round, pb, Ib, Jb);
+        const double* Va = Vprev + ((size_t)z * np + pa) * TS;
+        const double* Vb = Vprev + ((size_t)z * np + pb) * TS;
+        const double* Da = Dprev + ((size_t)z * np + pa) * TS;
+        const double* Db = Dprev + ((size_t)z * np + pb) * TS;
+        for (int e = tid; e < BT * BT; e += 512) {
+            const int t = e >> 5, u = e & 31;
+            T[t * LS + u] = Csrc[(size_t)tile_index(Ia, Ja, t) * ld + tile_index(Ib, Jb, u)];
+            VA[t * LS + u] = Va[t * LS + u];
+            VB[t * LS + u] = Vb[t * LS + u];
+            VP[t * LS + u] = (t == u) ? 1.0 : 0.0;
+            if (t < BH && u < BH) {                            // the two diagonal blocks, from the rotated tiles of the last round
+                SP[t * LS + u] = Da[(ha * BH + t) * LS + ha * BH + u];
+                SP[(BH + t) * LS + BH + u] = Db[(hb * BH + t) * LS + hb * BH + u];
+            }
+        }
+        __syncthreads();
+        if (half == 0) {
+            const d4 o = mm32_mfma<false>(T, VB, w, lane);
+            for (int t = 0; t < 4; ++t) U[(orow + 4 * t) * LS + ocol] = o[t];
+        }
+        __syncthreads();
+        if (half == 0) {
+            const d4 o = mm32_mfma<true>(VA, U, w, lane);       // V_a^T (C V_b)
+            for (int t = 0; t < 4; ++t) T[(orow + 4 * t) * LS + ocol] = o[t];
+        }
+        __syncthreads();
+        for (int e = tid; e < BH * BH; e += 512) {
+            const int t = e >> 4, u = e & 15;
+            const double v = T[(ha * BH + t) * LS + hb * BH + u];
+            SP[t * LS + BH + u] = v;
+            SP[(BH + u) * LS + t] = v;
+        }
+        __syncthreads();
+    }
+    // ---- inner sweep (the first half of the workgroup; see block_jacobi_round_kernel) ----
+    // the first half of the workgroup rotates the tile, the second the accumulated rotation V (both take the round's rotations
+    // from `rot`): half the reads and flops per thread in the part of an inner round that all threads share
+    const int inner_rounds = full ? BT - 1 : BH;
+    int ua = (a == 0) ? BT - 1 : a, va = (a == 0) ? 0 : BT - 1 - a;
+    int ub = (b == 0) ? BT - 1 : b, vb = (b == 0) ? 0 : BT - 1 - b;
+    double offacc = 0.0;
+    for (int t = 0; t < inner_rounds; ++t) {
+        int pa, qa, pb, qb;
+        if (full) {
+            pa = min(ua, va); qa = max(ua, va);
+            pb = min(ub, vb); qb = max(ub, vb);
+            if (a != 0) ua = (ua + 1 == BT - 1) ? 0 : ua + 1;
+            va = (va + 1 == BT - 1) ? 0 : va + 1;
+            if (b != 0) ub = (ub + 1 == BT - 1) ? 0 : ub + 1;
+            vb = (vb + 1 == BT - 1) ? 0 : vb + 1;
+        } else {
+            pa = a;
+            qa = BH + ((a + t) & 15);
+            pb = b;
+            qb = BH + ((b + t) & 15);
+        }
+        if (half == 0 && a == 0) {
+            const double beta = SP[pb * LS + qb];
+            double c, s;
+            sym_rotation(SP[pb * LS + pb], SP[qb * LS + qb], beta, c, s);
+            rot[0][b] = make_double2(c, s);
+            offacc += beta * beta;
+        }
+        __syncthreads();
+        if (half == 0) {
+            const double2 ra = rot[0][a], rb = rot[0][b];
+            const double ca = ra.x, sa = ra.y, cb = rb.x, sb = rb.y;
+            const double xpp = SP[pa * LS + pb], xpq = SP[pa * LS + qb], xqp = SP[qa * LS + pb], xqq = SP[qa * LS + qb];
+            const double ypp = cb * xpp - sb * xpq, ypq = sb * xpp + cb * xpq;
+            const double yqp = cb * xqp - sb * xqq, yqq = sb * xqp + cb * xqq;
+            const double zpq = ca * ypq - sa * yqq;
+            SP[pa * LS + pb] = ca * ypp - sa * yqp;
+            SP[pa * LS + qb] = zpq;
+            SP[qa * LS + pb] = (a == b) ? zpq : sa * ypp + ca * yqp;
+            SP[qa * LS + qb] = sa * ypq + ca * yqq;
+        } else {
+            const double2 rb = rot[0][b];
+            const double cb = rb.x, sb = rb.y;
+            const int r0 = 2 * a, r1 = 2 * a + 1;
+            const double v0p = VP[r0 * LS + pb], v0q = VP[r0 * LS + qb], v1p = VP[r1 * LS + pb], v1q = VP[r1 * LS + qb];
+            VP[r0 * LS + pb] = cb * v0p - sb * v0q;
+            VP[r0 * LS + qb] = sb * v0p + cb * v0q;
+            VP[r1 * LS + pb] = cb * v1p - sb * v1q;
+            VP[r1 * LS + qb] = sb * v1p + cb * v1q;
+        }
+        __syncthreads();
+    }
+    if (tid < 16 && offacc != 0.0) atomicAdd(off + z, offacc);
+    double* Dc = Dcur + ((size_t)z * np + P) * TS;
+    double* Vc = Vcur + ((size_t)z * np + P) * TS;
+    for (int e = tid; e < BT * BT; e += 512) {
+        const int t = e >> 5, u = e & 31;
+        Dc[t * LS + u] = SP[t * LS + u];
+        Vc[t * LS + u] = VP[t * LS + u];
+    }
+}
+
+template <bool FIRST>
+__global__ void __launch_bounds__(512) la_solve_kernel(int ld, int nb, int round, int prev_round, int full,
+                                                       const double* __restrict__ Csrc, const double* __restrict__ Vprev,
+                                                       const double* __restrict__ Dprev, double* __restrict__ Vcur,
+                                                       double* __restrict__ Dcur, double* __restrict__ off, size_t mat_stride) {
+    __shared__ double sm[6 * BT * LS];
+    __shared__ double2 rot[2][BH];
+    la_solve_body<FIRST>(sm, rot, blockIdx.x, ld, nb, round, prev_round, full, Csrc, Vprev, Dprev, Vcur, Dcur, off, mat_stride);
+}
+
+// One launch = the update of round r (workgroups np ..) AND the pair solves of round r + 1 (workgroups 0 .. np - 1: dispatched
+// first, they are the long chain).  Both read the matrix before round r and round r's rotations; the solves write only the next
+// round's V / D buffers, the updates only the next matrix and X: no dependency inside the launch, and consecutive launches are
+// ordered by the stream.  (A first version ran the two on separate streams joined by events, in the captured graph and out of
+// it: the cross-stream edges cost ~10 us a round, most of what the overlap buys.)
+struct LaRound {
+    int round, full;               // the round being updated / whether the NEXT round's inner sweep is a full one
+    int next_round;
+    const double* Cin;             // matrix before `round`
+    double* Cout;                  // matrix after it
+    double* V;                     // rotations of `round` (read by both halves)
+    const double* D;               // rotated diagonal tiles of `round`
+    double* Vnext;
+    double* Dnext;
+    double* off_next;              // pivot weight accumulator of the sweep the next round belongs to
+};
+__global__ void __launch_bounds__(512) la_fused_kernel(int ld, int nb, LaRound q, double* __restrict__ X, size_t mat_stride) {
+    __shared__ double sm[6 * BT * LS];
+    __shared__ double2 rot[2][BH];
+    const int np = nb / 2;
+    if ((int)blockIdx.x < np)
+        la_solve_body<false>(sm, rot, blockIdx.x, ld, nb, q.next_round, q.round, q.full, q.Cin, q.V, q.D, q.Vnext, q.Dnext, q.off_next,
+                             mat_stride);
+    else
+        block_jacobi_round_body<5>(sm, rot, (int)blockIdx.x - np, ld, nb, q.round, 0, q.Cin, q.Cout, X, q.off_next, mat_stride, q.V, q.D);
+}
+
 struct GevdLargeWs {
     int n = 0, batch = 0;
     double *Bw = nullptr, *W = nullptr, *T1 = nullptr, *C0 = nullptr, *C1 = nullptr, *X = nullptr, *Li = nullptr;
-    double *acc = nullptr, *coef = nullptr, *Vbuf = nullptr;
+    double *acc = nullptr, *coef = nullptr, *Vbuf = nullptr, *Vbuf2 = nullptr, *Dbuf = nullptr, *Dbuf2 = nullptr;
+
     int *flag = nullptr, *order = nullptr;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     void release() {
         if (exec) (void)hipGraphExecDestroy(exec);
         if (graph) (void)hipGraphDestroy(graph);
-        void* bufs[] = {Bw, W, T1, C0, C1, X, Li, acc, coef, Vbuf, flag, order};
+        void* bufs[] = {Bw, W, T1, C0, C1, X, Li, acc, coef, Vbuf, Vbuf2, Dbuf, Dbuf2, flag, order};
+
         for (void* b : bufs)
             if (b) (void)hipFree(b);
         *this = GevdLargeWs();
@@ -645,12 +847,44 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
         LCHK(hipMalloc((void**)&ws.acc, sizeof(double) * 3 * batch));         // [sweep a | sweep b | ||C||_F^2]
         LCHK(hipMalloc((void**)&ws.coef, sizeof(double) * vs * batch));
         LCHK(hipMalloc((void**)&ws.Vbuf, sizeof(double) * (size_t)BT * LS * np * batch));
+        LCHK(hipMalloc((void**)&ws.Vbuf2, sizeof(double) * (size_t)BT * LS * np * batch));
+        LCHK(hipMalloc((void**)&ws.Dbuf, sizeof(double) * (size_t)BT * LS * np * batch));
+        LCHK(hipMalloc((void**)&ws.Dbuf2, sizeof(double) * (size_t)BT * LS * np * batch));
+
         LCHK(hipMalloc((void**)&ws.flag, sizeof(int) * batch));
         LCHK(hipMalloc((void**)&ws.order, sizeof(int) * vs * batch));
     }
     // two sweeps: 2 (nb - 1) block rounds bring the ping-pong buffers back to where they started
     static const bool memset_node = getenv("APV_GRAPH_MEMSET") != nullptr;      // A/B switch: a memset node instead (see zero_f64_kernel)
+    // look-ahead (see la_solve_kernel): APV_LARGE_LOOKAHEAD=0 is the A/B switch back to solve-then-update on one stream
+    static const bool la_off = getenv("APV_LARGE_LOOKAHEAD") && atoi(getenv("APV_LARGE_LOOKAHEAD")) == 0;
+    const bool lookahead = split && !la_off && np >= 2;
+    auto two_sweeps_la = [&]() {
+        hipLaunchKernelGGL(zero_f64_kernel, dim3((2 * batch + 63) / 64), dim3(64), 0, st, 2 * batch, ws.acc);
+        double *Cc = ws.C0, *Cn = ws.C1;
+        const int total = 2 * rounds;
+        // the pair solves of the very first round read the matrix as it stands
+        hipLaunchKernelGGL(la_solve_kernel<true>, dim3(np, 1, batch), dim3(512), 0, st, ld, nb, 0, 0, 1, Cc, (const double*)ws.Vbuf2,
+                           (const double*)ws.Dbuf2, ws.Vbuf, ws.Dbuf, ws.acc, ms);
+        for (int gr = 0; gr < total; ++gr) {
+            const int r = gr % rounds;
+            double* Vcur = (gr & 1) ? ws.Vbuf2 : ws.Vbuf;
+            double* Dcur = (gr & 1) ? ws.Dbuf2 : ws.Dbuf;
+            double* Vnext = (gr & 1) ? ws.Vbuf : ws.Vbuf2;
+            double* Dnext = (gr & 1) ? ws.Dbuf : ws.Dbuf2;
+            if (gr + 1 < total) {
+                const int rn = (gr + 1) % rounds, swn = (gr + 1) / rounds;
+                LaRound q{r, rn == 0 ? 1 : 0, rn, Cc, Cn, Vcur, Dcur, Vnext, Dnext, ws.acc + (size_t)swn * batch};
+                hipLaunchKernelGGL(la_fused_kernel, dim3(np + tiles, 1, batch), dim3(512), 0, st, ld, nb, q, ws.X, ms);
+            } else {
+                hipLaunchKernelGGL(block_jacobi_round_kernel<5>, dim3(tiles, 1, batch), dim3(512), 0, st, ld, nb, r, 0, Cc, Cn, ws.X,
+                                   ws.acc, ms, Vcur, (const double*)Dcur);
+            }
+            double* t = Cc; Cc = Cn; Cn = t;
+        }
+    };
     auto two_sweeps = [&]() {
+        if (lookahead) return two_sweeps_la();
         if (memset_node) (void)hipMemsetAsync(ws.acc, 0, sizeof(double) * 2 * batch, st);
         else hipLaunchKernelGGL(zero_f64_kernel, dim3((2 * batch + 63) / 64), dim3(64), 0, st, 2 * batch, ws.acc);
         double *Cc = ws.C0, *Cn = ws.C1;
@@ -658,13 +892,13 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
             for (int r = 0; r < rounds; ++r) {
                 if (!split) {
                     hipLaunchKernelGGL(block_jacobi_round_kernel<0>, dim3(tiles, 1, batch), dim3(512), 0, st, ld, nb, r, r == 0 ? 1 : 0,
-                                       Cc, Cn, ws.X, ws.acc + (size_t)sw * batch, ms, ws.Vbuf);
+                                       Cc, Cn, ws.X, ws.acc + (size_t)sw * batch, ms, ws.Vbuf, (const double*)nullptr);
                 } else {
                     hipLaunchKernelGGL(block_jacobi_round_kernel<1>, dim3(np, 1, batch), dim3(512), 0, st, ld, nb, r, r == 0 ? 1 : 0,
-                                       Cc, Cn, ws.X, ws.acc + (size_t)sw * batch, ms, ws.Vbuf);
+                                       Cc, Cn, ws.X, ws.acc + (size_t)sw * batch, ms, ws.Vbuf, (const double*)nullptr);
                     if (np > 1)
                         hipLaunchKernelGGL(block_jacobi_round_kernel<2>, dim3(tiles - np, 1, batch), dim3(512), 0, st, ld, nb, r, 0,
-                                           Cc, Cn, ws.X, ws.acc + (size_t)sw * batch, ms, ws.Vbuf);
+                                           Cc, Cn, ws.X, ws.acc + (size_t)sw * batch, ms, ws.Vbuf, (const double*)nullptr);
                 }
                 double* t = Cc; Cc = Cn; Cn = t;
             }
