@@ -71,6 +71,10 @@ struct apv_bb {
     double* g_w;           // [grp * nz][V][n]
     double* g_nrm;         // [grp][4] + [grp * nz] dark norms in batch order
     double* g_inspec;      // [grp][2][K] c128
+    // (each of the above twice: the front stages of group g + 1 fill one set while the batched solve of group g reads the other)
+    double* spec_out;      // [n_out][K] c128: the output stage's own spectra (the front stages use `spec` at the same time)
+    hipStream_t front;     // the front stages of apv_bb_process_signal
+    hipEvent_t ev_front[2], ev_back[2];      // group set filled / group set read for the last time
 };
 
 namespace {
@@ -447,10 +451,15 @@ void apv_bb_free(apv_handle* h) {
                       s->inblk, s->spec, s->ov[0], s->ov[1], s->ov[2], s->ov[3], s->tov[0], s->tov[1], s->stats[0],
                       s->stats[1], s->stats[2], s->stats[3], s->tstats[0], s->tstats[1], s->R, s->r, s->U, s->lam, s->w,
                       s->fspec, s->inspec, s->outov, s->out, s->G2, s->G2T, s->tspec[0], s->tspec[1], s->Wgt[0], s->Wgt[1], s->nrm,
-                      s->g_xin, s->g_RA, s->g_RB, s->g_U, s->g_lam, s->g_r, s->g_w, s->g_nrm, s->g_inspec};
+                      s->g_xin, s->g_RA, s->g_RB, s->g_U, s->g_lam, s->g_r, s->g_w, s->g_nrm, s->g_inspec, s->spec_out};
     for (double* b : bufs)
         if (b) (void)hipFree(b);
     if (s->d_ranks) (void)hipFree(s->d_ranks);
+    if (s->front) (void)hipStreamDestroy(s->front);
+    for (int i = 0; i < 2; ++i) {
+        if (s->ev_front[i]) (void)hipEventDestroy(s->ev_front[i]);
+        if (s->ev_back[i]) (void)hipEventDestroy(s->ev_back[i]);
+    }
     delete s;
     h->bb = nullptr;
 }
@@ -612,8 +621,7 @@ static BbHop bb_own_hop(apv_bb* s) {
 
 // stages 1-3 of a hop (and the input spectra of stage 6, which depend on the input ring as it stands now): everything in front
 // of the joint diagonalisation.  t_stage: optional wall times of the stages (APV_BB_TIMING).
-static int bb_front(apv_handle* h, apv_bb* s, const BbHop& q, double* t_stage) {
-    hipStream_t st = h->stream;
+static int bb_front(apv_handle* h, apv_bb* s, const BbHop& q, double* t_stage, hipStream_t st) {
     const int N = s->N, H = s->H, K = s->K, L = s->L, M = s->M, C = s->C, P = s->P, J = s->J, S = s->S, n = s->n;
     std::string why;
     int n_stage = 0;
@@ -733,7 +741,7 @@ static int bb_front(apv_handle* h, apv_bb* s, const BbHop& q, double* t_stage) {
 }
 
 // stages 5-6 of a hop: filter spectra, outputs, overlap-add; h_out [n_out][H] (the copy is queued on the handle's stream)
-static int bb_back(apv_handle* h, apv_bb* s, const BbHop& q, double* h_out) {
+static int bb_back(apv_handle* h, apv_bb* s, const BbHop& q, double* h_out, double* spec) {
     hipStream_t st = h->stream;
     const int N = s->N, H = s->H, K = s->K, L = s->L, J = s->J, V = s->V;
     std::string why;
@@ -751,16 +759,16 @@ static int bb_back(apv_handle* h, apv_bb* s, const BbHop& q, double* h_out) {
         if (!(z ? runB : runA)) continue;
         hipLaunchKernelGGL(apply_f64_kernel, dim3((K + 255) / 256, V * L), dim3(256), 0, st, K, V * L,
                            (const double2*)q.inspec + (size_t)z * K, (const double2*)s->fspec + (size_t)oc * K,
-                           (double2*)s->spec + (size_t)oc * K);
+                           (double2*)spec + (size_t)oc * K);
         oc += V * L;
     }
     for (int z = 0; z < 2; ++z) {
         hipLaunchKernelGGL(apply_f64_kernel, dim3((K + 255) / 256, L), dim3(256), 0, st, K, L,
                            (const double2*)q.inspec + (size_t)z * K, (const double2*)s->fspec + (size_t)oc * K,
-                           (double2*)s->spec + (size_t)oc * K);
+                           (double2*)spec + (size_t)oc * K);
         oc += L;
     }
-    BCHK(h, apv_launch_synthesis(1, N, H, s->n_out, s->spec, K, 1, s->outov, s->out, st, &why));
+    BCHK(h, apv_launch_synthesis(1, N, H, s->n_out, spec, K, 1, s->outov, s->out, st, &why));
     BCHK(h, hipMemcpyAsync(h_out, s->out, sizeof(double) * (size_t)s->n_out * H, hipMemcpyDeviceToHost, st));
     return APV_OK;
 }
@@ -779,7 +787,7 @@ int apv_bb_process_block(apv_handle* h, const double* h_in_A, const double* h_in
     BCHK(h, hipMemcpyAsync(s->xin, h_in_A, sizeof(double) * H, hipMemcpyHostToDevice, st));
     BCHK(h, hipMemcpyAsync(s->xin + H, h_in_B, sizeof(double) * H, hipMemcpyHostToDevice, st));
     const BbHop q = bb_own_hop(s);
-    int rc = bb_front(h, s, q, timing ? t_stage : nullptr);
+    int rc = bb_front(h, s, q, timing ? t_stage : nullptr, st);
     if (rc != APV_OK) return rc;
     const bool runA = s->zones & 1, runB = s->zones & 2;
     const size_t nn = (size_t)n * n;
@@ -800,7 +808,7 @@ int apv_bb_process_block(apv_handle* h, const double* h_in_A, const double* h_in
         t_stage[3] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_prev).count();
         t_prev = std::chrono::steady_clock::now();
     }
-    rc = bb_back(h, s, q, h_out);
+    rc = bb_back(h, s, q, h_out, s->spec);
     if (rc != APV_OK) return rc;
     BCHK(h, hipStreamSynchronize(st));
     BCHK(h, hipGetLastError());
@@ -839,6 +847,10 @@ int apv_bb_process_signal(apv_handle* h, int32_t n_hops, const double* h_in_A, c
     int G = forced > 0 ? forced : 768 / (tiles * nz);
     G = G < 1 ? 1 : (G > 8 && forced <= 0 ? 8 : G);
     if (G > n_hops) G = n_hops;
+    const size_t gz = (size_t)G * nz;
+    // sizes of one buffer set
+    const size_t z_xin = (size_t)G * 2 * H, z_mat = gz * nn, z_vec = gz * n, z_w = gz * V * n, z_nrm = (size_t)G * 4 + gz,
+                 z_insp = (size_t)G * 2 * K * 2;
     if (s->grp < G) {
         double** bufs[] = {&s->g_xin, &s->g_RA, &s->g_RB, &s->g_U, &s->g_lam, &s->g_r, &s->g_w, &s->g_nrm, &s->g_inspec};
         for (double** b : bufs) {
@@ -847,66 +859,95 @@ int apv_bb_process_signal(apv_handle* h, int32_t n_hops, const double* h_in_A, c
         }
         s->grp = 0;
         int rc;
-        const size_t gz = (size_t)G * nz;
-        if ((rc = dalloc(h, &s->g_xin, (size_t)G * 2 * H))) return rc;
-        if ((rc = dalloc(h, &s->g_RA, gz * nn))) return rc;
-        if ((rc = dalloc(h, &s->g_RB, gz * nn))) return rc;
-        if ((rc = dalloc(h, &s->g_U, gz * nn))) return rc;
-        if ((rc = dalloc(h, &s->g_lam, gz * n))) return rc;
-        if ((rc = dalloc(h, &s->g_r, gz * n))) return rc;
-        if ((rc = dalloc(h, &s->g_w, gz * V * n))) return rc;
-        if ((rc = dalloc(h, &s->g_nrm, (size_t)G * 4 + gz))) return rc;
-        if ((rc = dalloc(h, &s->g_inspec, (size_t)G * 2 * K * 2))) return rc;
+        if ((rc = dalloc(h, &s->g_xin, 2 * z_xin))) return rc;
+        if ((rc = dalloc(h, &s->g_RA, 2 * z_mat))) return rc;
+        if ((rc = dalloc(h, &s->g_RB, 2 * z_mat))) return rc;
+        if ((rc = dalloc(h, &s->g_U, z_mat))) return rc;                  // U, lam: written and read by the back half only
+        if ((rc = dalloc(h, &s->g_lam, z_vec))) return rc;
+        if ((rc = dalloc(h, &s->g_r, 2 * z_vec))) return rc;
+        if ((rc = dalloc(h, &s->g_w, z_w))) return rc;
+        if ((rc = dalloc(h, &s->g_nrm, 2 * z_nrm))) return rc;
+        if ((rc = dalloc(h, &s->g_inspec, 2 * z_insp))) return rc;
+        if (!s->spec_out && (rc = dalloc(h, &s->spec_out, (size_t)s->n_out * K * 2))) return rc;
+        if (!s->front) {
+            BCHK(h, hipStreamCreateWithFlags(&s->front, hipStreamNonBlocking));
+            for (int i = 0; i < 2; ++i) {
+                BCHK(h, hipEventCreateWithFlags(&s->ev_front[i], hipEventDisableTiming));
+                BCHK(h, hipEventCreateWithFlags(&s->ev_back[i], hipEventDisableTiming));
+            }
+        }
+        BCHK(h, hipStreamSynchronize(st));            // the zero fills
         s->grp = G;
     }
-    // every exit below drains the stream first: copies into the caller's h_out may be in flight
-    auto drained = [&](int rc) { (void)hipStreamSynchronize(st); return rc; };
+    // (a handle whose group buffers were sized for a larger G keeps them: the set offsets below follow the CURRENT G)
+    hipStream_t fs = s->front;
+    // every exit below drains both streams first: copies into the caller's h_out may be in flight
+    auto drained = [&](int rc) { (void)hipStreamSynchronize(fs); (void)hipStreamSynchronize(st); return rc; };
 #define BDCHK(h, call)                                                                                                     \
     do {                                                                                                                    \
         hipError_t _e = (call);                                                                                             \
         if (_e != hipSuccess) return drained(apv_fail(h, APV_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_e))); \
     } while (0)
-    std::vector<int32_t> status((size_t)G * nz, 0);
-    long bad_hops = 0;
-    for (int h0 = 0; h0 < n_hops; h0 += G) {
-        const int g_n = n_hops - h0 < G ? n_hops - h0 : G;
-        for (int g = 0; g < g_n; ++g) {
-            BDCHK(h, hipMemcpyAsync(s->g_xin + (size_t)g * 2 * H, h_in_A + (size_t)(h0 + g) * H, sizeof(double) * H, hipMemcpyHostToDevice, st));
-            BDCHK(h, hipMemcpyAsync(s->g_xin + (size_t)g * 2 * H + H, h_in_B + (size_t)(h0 + g) * H, sizeof(double) * H, hipMemcpyHostToDevice, st));
+    const int n_groups = (n_hops + G - 1) / G;
+    std::vector<BbHop> hops[2];
+    // the front stages of group g, all on the front stream (rings, histories and overlap buffers are sequential state)
+    auto enqueue_front = [&](int g) -> int {
+        const int set = g & 1, h0 = g * G, g_n = n_hops - h0 < G ? n_hops - h0 : G;
+        double* xin = s->g_xin + set * z_xin;
+        for (int i = 0; i < g_n; ++i) {
+            BDCHK(h, hipMemcpyAsync(xin + (size_t)i * 2 * H, h_in_A + (size_t)(h0 + i) * H, sizeof(double) * H, hipMemcpyHostToDevice, fs));
+            BDCHK(h, hipMemcpyAsync(xin + (size_t)i * 2 * H + H, h_in_B + (size_t)(h0 + i) * H, sizeof(double) * H, hipMemcpyHostToDevice, fs));
         }
-        std::vector<BbHop> hops(g_n);
-        for (int g = 0; g < g_n; ++g) {
-            BbHop& q = hops[g];
-            q = BbHop{};
-            q.xin = s->g_xin + (size_t)g * 2 * H;
+        hops[set].assign(g_n, BbHop{});
+        for (int i = 0; i < g_n; ++i) {
+            BbHop& q = hops[set][i];
+            q.xin = xin + (size_t)i * 2 * H;
             for (int z = 0; z < 2; ++z) {
                 if (!(z ? runB : runA)) continue;
-                const size_t slot = (size_t)g * nz + (z - first);
-                q.Rq[z] = s->g_RA + slot * nn;
-                q.Rq[2 + z] = s->g_RB + slot * nn;
-                q.r[z] = s->g_r + slot * n;
+                const size_t slot = (size_t)i * nz + (z - first);
+                q.Rq[z] = s->g_RA + set * z_mat + slot * nn;
+                q.Rq[2 + z] = s->g_RB + set * z_mat + slot * nn;
+                q.r[z] = s->g_r + set * z_vec + slot * n;
                 q.w[z] = s->g_w + slot * V * n;
             }
-            q.nrm = s->g_nrm + (size_t)g * 4;
-            q.nrm_dark = s->g_nrm + (size_t)G * 4 + (size_t)g * nz;
-            q.inspec = s->g_inspec + (size_t)g * 2 * K * 2;
-            const int rc = bb_front(h, s, q, nullptr);
+            q.nrm = s->g_nrm + set * z_nrm + (size_t)i * 4;
+            q.nrm_dark = s->g_nrm + set * z_nrm + (size_t)G * 4 + (size_t)i * nz;
+            q.inspec = s->g_inspec + set * z_insp + (size_t)i * 2 * K * 2;
+            const int rc = bb_front(h, s, q, nullptr, fs);
             if (rc != APV_OK) return drained(rc);
         }
-        int rc = apv_gevd_large(h, n, g_n * nz, s->g_RA, s->g_RB, s->rel_loading ? 0.0 : h->cfg.reg_dark,
-                                s->rel_dark_py ? s->g_nrm + (size_t)G * 4 : nullptr, s->g_U, s->g_lam, s->g_r, h->cfg.mu, V, s->d_ranks, s->g_w,
-                                status.data());
+        BDCHK(h, hipEventRecord(s->ev_front[set], fs));
+        return APV_OK;
+    };
+    std::vector<int32_t> status((size_t)G * nz, 0);
+    long bad_hops = 0;
+    // per-hop calls before this one ran on the handle's stream: the front stream starts behind them
+    BDCHK(h, hipEventRecord(s->ev_back[0], st));
+    BDCHK(h, hipStreamWaitEvent(fs, s->ev_back[0], 0));
+    int rc = enqueue_front(0);
+    if (rc != APV_OK) return rc;
+    for (int g = 0; g < n_groups; ++g) {
+        const int set = g & 1, h0 = g * G, g_n = n_hops - h0 < G ? n_hops - h0 : G;
+        if (g + 1 < n_groups) {
+            // group g + 1 fills the other set, which the back half of group g - 1 has read (its event is on the handle's stream)
+            if (g >= 1) BDCHK(h, hipStreamWaitEvent(fs, s->ev_back[set ^ 1], 0));
+            if ((rc = enqueue_front(g + 1)) != APV_OK) return rc;
+        }
+        BDCHK(h, hipStreamWaitEvent(st, s->ev_front[set], 0));
+        rc = apv_gevd_large(h, n, g_n * nz, s->g_RA + set * z_mat, s->g_RB + set * z_mat, s->rel_loading ? 0.0 : h->cfg.reg_dark,
+                            s->rel_dark_py ? s->g_nrm + set * z_nrm + (size_t)G * 4 : nullptr, s->g_U, s->g_lam, s->g_r + set * z_vec,
+                            h->cfg.mu, V, s->d_ranks, s->g_w, status.data());
         if (rc != APV_OK) return drained(rc);
-        for (int g = 0; g < g_n; ++g) {
-            rc = bb_back(h, s, hops[g], h_out + (size_t)(h0 + g) * s->n_out * H);
+        for (int i = 0; i < g_n; ++i) {
+            rc = bb_back(h, s, hops[set][i], h_out + (size_t)(h0 + i) * s->n_out * H, s->spec_out);
             if (rc != APV_OK) return drained(rc);
             bool bad = false;
-            for (int z = 0; z < nz; ++z) bad = bad || status[(size_t)g * nz + z] == 2;
+            for (int z = 0; z < nz; ++z) bad = bad || status[(size_t)i * nz + z] == 2;
             bad_hops += bad;
         }
         // the attributes of the handle are those of the last hop (apvast.py:368-403)
-        if (h0 + g_n >= n_hops) {
-            const BbHop& q = hops[g_n - 1];
+        if (g + 1 == n_groups) {
+            const BbHop& q = hops[set][g_n - 1];
             for (int z = 0; z < 2; ++z) {
                 if (!(z ? runB : runA)) continue;
                 const size_t slot = (size_t)(g_n - 1) * nz + (z - first);
@@ -920,8 +961,10 @@ int apv_bb_process_signal(apv_handle* h, int32_t n_hops, const double* h_in_A, c
             BDCHK(h, hipMemcpyAsync(s->nrm, q.nrm, sizeof(double) * 4, hipMemcpyDeviceToDevice, st));
             BDCHK(h, hipMemcpyAsync(s->inspec, q.inspec, sizeof(double) * 2 * K * 2, hipMemcpyDeviceToDevice, st));
         }
-        BDCHK(h, hipStreamSynchronize(st));       // the group's input staging is rewritten by the next group
+        BDCHK(h, hipEventRecord(s->ev_back[set], st));
     }
+    BDCHK(h, hipStreamSynchronize(fs));
+    BDCHK(h, hipStreamSynchronize(st));
     BDCHK(h, hipGetLastError());
     if (bad_hops) {
         s->not_converged += bad_hops;
