@@ -91,7 +91,9 @@ template <> struct Mfma16<float> {
 
 struct NoStamp { __device__ __forceinline__ void operator()(int) const {} };
 // `stamp(i)`: diagnostic hook (stage stamps of the diagnostic kernel instantiation; NoStamp in the product)
-template <typename T, typename XT, typename ST = NoStamp>
+// WITH_D: also r = X^H d (a compile-time flag: tested at run time, `dvec != nullptr` put every d load into a basic block of its own
+// that ended in `s_waitcnt vmcnt(0)`, i.e. waited for the x loads before it as well)
+template <typename T, typename XT, bool WITH_D, typename ST = NoStamp>
 __device__ __forceinline__ void correlate16(const XT* __restrict__ X, const XT* __restrict__ dvec, int M,
                                             Cx<T>* dst, Cx<T>* sr, int lane, ST stamp = ST(), int stamp_base = 0) {
     using MM = Mfma16<T>;
@@ -106,10 +108,23 @@ __device__ __forceinline__ void correlate16(const XT* __restrict__ X, const XT* 
         XT xv[8], dv[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
+            // UNCONDITIONAL loads from a clamped row, then a select: written as `ok ? X[...] : zero` every load sat in a branch of
+            // its own (the address might be out of bounds), the compiler split it into two dword loads and put an
+            // `s_waitcnt vmcnt(0)` behind each -- 48 memory round trips one after the other per bin, a quarter of a wave's life
+            // (profiles/r03/stage_stamps_32768.md: 24 k + 12 k cycles "waiting for the slabs")
             const int m = mc + 4 * q + msub;
             const bool ok = m < M;
-            xv[q] = ok ? X[(size_t)(mc + 4 * q) * N + lane] : zero;
-            dv[q] = (ok && dvec != nullptr) ? dvec[m] : zero;
+            const int mcl = ok ? m : M - 1;
+            const XT xl = X[(size_t)mcl * N + (lane & 15)];
+            xv[q].x = ok ? xl.x : zero.x;
+            xv[q].y = ok ? xl.y : zero.y;
+            if constexpr (WITH_D) {
+                const XT dl = dvec[mcl];
+                dv[q].x = ok ? dl.x : zero.x;
+                dv[q].y = ok ? dl.y : zero.y;
+            } else {
+                dv[q] = zero;
+            }
         }
         if constexpr (!__is_same(ST, NoStamp)) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -121,7 +136,7 @@ __device__ __forceinline__ void correlate16(const XT* __restrict__ X, const XT* 
             re = MM::mac(xr, xr, re);
             re = MM::mac(xi, xi, re);
             im = MM::mac(xr, xi, im);                            // P = sum xr (x) xi; Im R = P - P^T, formed below
-            if (dvec != nullptr) {
+            if constexpr (WITH_D) {
                 rx = fma_t(xi, (T)dv[q].y, fma_t(xr, (T)dv[q].x, rx));        // conj(x) * d, as chained FMAs
                 ry = fma_t(-xi, (T)dv[q].x, fma_t(xr, (T)dv[q].y, ry));
             }
@@ -140,7 +155,7 @@ __device__ __forceinline__ void correlate16(const XT* __restrict__ X, const XT* 
     wsync();
 #pragma unroll
     for (int t = 0; t < 4; ++t) dst[MM::row(lane, t) * LD + col].y = im[t] - pt[t];
-    if (dvec != nullptr) {
+    if constexpr (WITH_D) {
         rx += __shfl_xor(rx, 16, 64); ry += __shfl_xor(ry, 16, 64);
         rx += __shfl_xor(rx, 32, 64); ry += __shfl_xor(ry, 32, 64);
         if (lane < N) sr[lane] = mk<T>(rx, ry);

@@ -73,12 +73,12 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p, const int k, c
     if constexpr (FUSED) {
         const size_t slab = (size_t)k * p.M * N;
         if constexpr (DBG) {
-            correlate16<T, XT>(pXB + slab, pd + (size_t)k * p.M, p.M, sA, sr, lane, stamp, 8);
+            correlate16<T, XT, true>(pXB + slab, pd + (size_t)k * p.M, p.M, sA, sr, lane, stamp, 8);
             stamp(10);
-            correlate16<T, XT>(pXD + slab, (const XT*)nullptr, p.M, sB, sr, lane, stamp, 11);
+            correlate16<T, XT, false>(pXD + slab, (const XT*)nullptr, p.M, sB, sr, lane, stamp, 11);
         } else {
-            correlate16<T, XT>(pXB + slab, pd + (size_t)k * p.M, p.M, sA, sr, lane);
-            correlate16<T, XT>(pXD + slab, (const XT*)nullptr, p.M, sB, sr, lane);
+            correlate16<T, XT, true>(pXB + slab, pd + (size_t)k * p.M, p.M, sA, sr, lane);
+            correlate16<T, XT, false>(pXD + slab, (const XT*)nullptr, p.M, sB, sr, lane);
         }
     } else {
         const C* RB = reinterpret_cast<const C*>(p.RB) + (size_t)k * N * N;

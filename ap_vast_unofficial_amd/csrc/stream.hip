@@ -553,7 +553,9 @@ static int signal_prepare(apv_handle* h) {
     apv_stream* s = h->st;
     if (s->sig_chunk > 0) return APV_OK;
     const size_t K = s->K, C = s->C, M = s->M, H = s->H, e1 = s->esz, e2 = 2 * s->esz;
-    const int chunk = 16;
+    // hops per chunk of the whole-signal path (APV_SIGNAL_CHUNK: tuning aid, 4..64)
+    static const int chunk_env = getenv("APV_SIGNAL_CHUNK") ? atoi(getenv("APV_SIGNAL_CHUNK")) : 0;
+    const int chunk = (chunk_env >= 4 && chunk_env <= 64) ? chunk_env : 16;
     int rc;
     for (int p = 0; p < 4; ++p)
         if (!s->X1[p] && (rc = dalloc(h, &s->X1[p], K * C, e2))) return rc;
