@@ -1,5 +1,6 @@
 // Device helpers of the order-16 kernel (kernels_gevd16m.hip).
 #pragma once
+#include <type_traits>
 #include "apv_internal.h"
 
 namespace {
@@ -103,18 +104,20 @@ __device__ __forceinline__ void correlate16(const XT* __restrict__ X, const XT* 
     XT zero;
     zero.x = 0;
     zero.y = 0;
-    // 32 control points (8 k-steps) at a time: all the loads of a chunk are in flight before its first MFMA
-    for (int mc = 0; mc < M; mc += 32) {
+    // 32 control points (8 k-steps) at a time: all the loads of a chunk are in flight before its first MFMA.  `full` (uniform):
+    // M is a multiple of 32, no row needs clamping and no value masking -- 90 selects and 30 address instructions less per bin
+    auto chunk = [&](int mc, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
         XT xv[8], dv[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            // UNCONDITIONAL loads from a clamped row, then a select: written as `ok ? X[...] : zero` every load sat in a branch of
-            // its own (the address might be out of bounds), the compiler split it into two dword loads and put an
-            // `s_waitcnt vmcnt(0)` behind each -- 48 memory round trips one after the other per bin, a quarter of a wave's life
-            // (profiles/r03/stage_stamps_32768.md: 24 k + 12 k cycles "waiting for the slabs")
+            // UNCONDITIONAL loads (from a clamped row when the chunk is ragged), then a select: written as `ok ? X[...] : zero`
+            // every load sat in a branch of its own (the address might be out of bounds), the compiler split it into two dword
+            // loads and put an `s_waitcnt vmcnt(0)` behind each -- 48 memory round trips one after the other per bin, a quarter
+            // of a wave's life (profiles/r03/stage_stamps_32768.md: 24 k + 12 k cycles "waiting for the slabs")
             const int m = mc + 4 * q + msub;
-            const bool ok = m < M;
-            const int mcl = ok ? m : M - 1;
+            const bool ok = FULL || m < M;
+            const int mcl = (FULL || ok) ? m : M - 1;
             const XT xl = X[(size_t)mcl * N + (lane & 15)];
             xv[q].x = ok ? xl.x : zero.x;
             xv[q].y = ok ? xl.y : zero.y;
@@ -141,6 +144,11 @@ __device__ __forceinline__ void correlate16(const XT* __restrict__ X, const XT* 
                 ry = fma_t(-xi, (T)dv[q].x, fma_t(xr, (T)dv[q].y, ry));
             }
         }
+    };
+    if ((M & 31) == 0) {
+        for (int mc = 0; mc < M; mc += 32) chunk(mc, std::true_type{});
+    } else {
+        for (int mc = 0; mc < M; mc += 32) chunk(mc, std::false_type{});
     }
     // Im R = P - P^T: three MFMAs per k-step instead of four (the f64 matrix pipe is busy half of this kernel's time at the rate
     // the instruction sustains, profiles/r02/mfma_issue_rate.md); the transpose goes through the destination tile
