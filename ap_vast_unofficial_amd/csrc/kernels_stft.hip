@@ -29,6 +29,7 @@ struct FftPlan {
     int nstages;
     int radix[MAX_STAGES];
     int inplace;           // every stage is radix 4 or 2 and short enough for stockham_stage_inplace: ONE LDS buffer of Nh
+    int max_it;            // butterflies per thread of the widest in-place stage (kernels are instantiated for 1 and for INPLACE_MAX_IT)
 };
 constexpr int INPLACE_MAX_IT = 4;      // butterflies per thread and stage the in-place form holds in registers
 
@@ -153,15 +154,18 @@ __device__ __forceinline__ void stockham_stage(const C2<T>* __restrict__ src, C2
 // go back to the same array.  Two barriers per stage instead of one, half the LDS: at 16 KB instead of 32 KB per
 // 2048-point double-precision transform eight workgroups fit a CU instead of five -- and five instead of two beside
 // the streaming pipeline's joint diagonalisation, which holds 80 KB of every CU while the next hop's transforms run.
-template <typename T, int R>
+template <typename T, int R, int MI = INPLACE_MAX_IT>
 __device__ __forceinline__ void stockham_stage_inplace(C2<T>* __restrict__ buf, int Nh, int Ns, const C2<T>* __restrict__ tw) {
+    // MI: butterflies per thread held in registers across the barrier.  The array below is sized by it, whatever the plan needs at run
+    // time: with MI = 4 the float64 transforms carried 64 VGPRs of it (101 in all: five workgroups per CU) although a 2048-point
+    // block needs ONE butterfly per thread and stage; the hot kernels are therefore instantiated for MI = 1 as well (plan.max_it).
     static_assert(R == 2 || R == 4, "in-place stages are radix 2 or 4");
     const int m = Nh / R;
     const int tstep = 2 * (Nh / (Ns * R));
     const int sh = __ffs(Ns) - 1;                      // Ns is a power of two here
-    C2<T> v[INPLACE_MAX_IT][R];
+    C2<T> v[MI][R];
 #pragma unroll
-    for (int it = 0; it < INPLACE_MAX_IT; ++it) {
+    for (int it = 0; it < MI; ++it) {
         const int j = threadIdx.x + it * STFT_TPB;
         if (j >= m) break;
         const int k = j & (Ns - 1);
@@ -190,7 +194,7 @@ __device__ __forceinline__ void stockham_stage_inplace(C2<T>* __restrict__ buf, 
     }
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < INPLACE_MAX_IT; ++it) {
+    for (int it = 0; it < MI; ++it) {
         const int j = threadIdx.x + it * STFT_TPB;
         if (j >= m) break;
         const int q = j >> sh, k = j & (Ns - 1);
@@ -203,13 +207,13 @@ __device__ __forceinline__ void stockham_stage_inplace(C2<T>* __restrict__ buf, 
 
 // forward complex FFT of length plan.Nh on natural-order data in `a`; returns the buffer holding the result (`b` is not
 // touched, and need not exist, when plan.inplace is set)
-template <typename T>
+template <typename T, int MI = INPLACE_MAX_IT>
 __device__ __forceinline__ C2<T>* fft_forward(const FftPlan& plan, C2<T>* a, C2<T>* b, const C2<T>* __restrict__ tw) {
     if (plan.inplace) {
         int Ns = 1;
         for (int s = 0; s < plan.nstages; ++s) {
-            if (plan.radix[s] == 4) stockham_stage_inplace<T, 4>(a, plan.Nh, Ns, tw);
-            else stockham_stage_inplace<T, 2>(a, plan.Nh, Ns, tw);
+            if (plan.radix[s] == 4) stockham_stage_inplace<T, 4, MI>(a, plan.Nh, Ns, tw);
+            else stockham_stage_inplace<T, 2, MI>(a, plan.Nh, Ns, tw);
             Ns *= plan.radix[s];
         }
         return a;
@@ -233,11 +237,11 @@ __device__ __forceinline__ C2<T>* fft_forward(const FftPlan& plan, C2<T>* a, C2<
     return src;
 }
 
-template <typename T>
+template <typename T, int MI = INPLACE_MAX_IT>
 __device__ __forceinline__ void rfft_from_lds(const FftPlan& plan, C2<T>* za, C2<T>* zb, C2<T>* __restrict__ out, long stride_k,
                                               const C2<T>* __restrict__ tw);
 
-template <typename T>
+template <typename T, int MI = INPLACE_MAX_IT>
 __device__ __forceinline__ void stft_analysis_body(const FftPlan& plan, const T* __restrict__ xin, int in_len, int ring_off,
                                                    int use_win, C2<T>* __restrict__ out, long stride_k,
                                                    const C2<T>* __restrict__ tw, const T* __restrict__ win) {
@@ -258,16 +262,19 @@ __device__ __forceinline__ void stft_analysis_body(const FftPlan& plan, const T*
         za[n] = c2<T>(v0, v1);
     }
     __syncthreads();
-    rfft_from_lds<T>(plan, za, zb, out, stride_k, tw);
+    rfft_from_lds<T, MI>(plan, za, zb, out, stride_k, tw);
 }
 
 // the real series x[2n], x[2n+1] sits in za[n] (and the workgroup has met): spectrum to out[k * stride_k], k <= N/2
-template <typename T>
+template <typename T, int MI>
 __device__ __forceinline__ void rfft_from_lds(const FftPlan& plan, C2<T>* za, C2<T>* zb, C2<T>* __restrict__ out, long stride_k,
                                               const C2<T>* __restrict__ tw) {
     const int Nh = plan.Nh, tid = threadIdx.x;
-    const C2<T>* z = fft_forward<T>(plan, za, zb, tw);
+    const C2<T>* z = fft_forward<T, MI>(plan, za, zb, tw);
     // even/odd split: X[k] = E[k] + e^{-2 pi i k/N} O[k]
+    // (unrolling this loop and the input loop above so that all of a thread's loads go out together was tried in round 3 after the
+    // order-16 kernel's slab loads: 65 -> 97 VGPRs and no change in the kernel's 437 us per chunk -- the transforms of a chunk move
+    // 1.1 GB, half of it as 16-byte pieces of bin-major lines, in that time)
     for (int k = tid; k <= Nh; k += STFT_TPB) {
         const C2<T> a = z[k == Nh ? 0 : k];
         const C2<T> bq = z[k == 0 ? 0 : Nh - k];
@@ -306,7 +313,7 @@ struct StftJobs {
     long x_stride, x_hop;
     long spec_hop[STFT_MAX_JOBS];
 };
-template <typename T>
+template <typename T, int MI>
 __global__ void __launch_bounds__(STFT_TPB) stft_analysis_jobs_kernel(FftPlan plan, StftJobs<T> jobs, int ring_off,
                                                                       const C2<T>* __restrict__ tw,
                                                                       const T* __restrict__ win) {
@@ -321,7 +328,7 @@ __global__ void __launch_bounds__(STFT_TPB) stft_analysis_jobs_kernel(FftPlan pl
     while (j + 1 < jobs.n && wg >= jobs.ch0[j + 1]) ++j;
     const int c = wg - jobs.ch0[j];
     const size_t hop = blockIdx.y;
-    stft_analysis_body<T>(plan, jobs.x[j] + (size_t)c * jobs.x_stride + hop * jobs.x_hop, plan.N, ring_off, 1,
+    stft_analysis_body<T, MI>(plan, jobs.x[j] + (size_t)c * jobs.x_stride + hop * jobs.x_hop, plan.N, ring_off, 1,
                           jobs.spec[j] + hop * jobs.spec_hop[j] + (size_t)c * jobs.stride_c[j], jobs.stride_k[j], tw, win);
 }
 
@@ -329,7 +336,7 @@ __global__ void __launch_bounds__(STFT_TPB) stft_analysis_jobs_kernel(FftPlan pl
 // 16-byte pieces, was tried for the chunk launches and lost: 470 us against 440 us per chunk of 16 hops at cfg3.  The transforms are
 // bound by their LDS round trips and barriers, not by the partial-line writes, and sixteen waves in step hide less of them than four
 // independent workgroups.)
-template <typename T>
+template <typename T, int MI>
 __global__ void __launch_bounds__(STFT_TPB) istft_ola_kernel(FftPlan plan, int H, const C2<T>* __restrict__ spec,
                                                              long stride_c, long stride_k, T* __restrict__ overlap,
                                                              T* __restrict__ out, const C2<T>* __restrict__ tw,
@@ -356,7 +363,7 @@ __global__ void __launch_bounds__(STFT_TPB) istft_ola_kernel(FftPlan plan, int H
         za[k] = c2<T>(e.x - o.y, -(e.y + o.x));                          // conj(E + i O)
     }
     __syncthreads();
-    C2<T>* z = fft_forward<T>(plan, za, zb, tw);
+    C2<T>* z = fft_forward<T, MI>(plan, za, zb, tw);
     const T scale = (T)1 / (T)Nh;
     T* ov = overlap + (size_t)c * N;
     T* zf = reinterpret_cast<T*>(z);
@@ -467,7 +474,7 @@ __global__ void __launch_bounds__(STFT_TPB) fir_chunk_spectra_kernel(FftPlan pla
 // (Four hops of a channel per 1024-thread workgroup, so that the channel's response spectrum comes from L2 once per four hops, was
 // tried for the chunk launches and lost: 430 us against 300 us per chunk of 16 hops at cfg3 -- sixteen waves meeting at the same
 // barriers hide less than eight independent workgroups of four.)
-template <typename T>
+template <typename T, int MI>
 __global__ void __launch_bounds__(STFT_TPB) fir_fft_kernel(FftPlan plan, FirFftJobs<T> jobs, int P, int H, int N, int ring_off,
                                                            const C2<T>* __restrict__ tw) {
     extern __shared__ unsigned char smem_raw[];
@@ -495,9 +502,7 @@ __global__ void __launch_bounds__(STFT_TPB) fir_fft_kernel(FftPlan plan, FirFftJ
     // product spectrum (summed over the partitions), packed for the half-length inverse transform exactly as in istft_ola_kernel
     const int n_part = jobs.n_part;
     const long hps = jobs.h_part_stride[j], xps = jobs.x_part_stride;
-    for (int k = tid; k < Fh; k += STFT_TPB) {
-        Z a = cmul(X[k], Hc[k]);
-        Z bq = cmul(X[Fh - k], Hc[Fh - k]);
+    auto pack = [&](int k, Z a, Z bq, Z wk) {
         for (int q = 1; q < n_part; ++q) {
             a = cadd(a, cmul(X[q * xps + k], Hc[q * hps + k]));
             bq = cadd(bq, cmul(X[q * xps + Fh - k], Hc[q * hps + Fh - k]));
@@ -509,12 +514,26 @@ __global__ void __launch_bounds__(STFT_TPB) fir_fft_kernel(FftPlan plan, FirFftJ
         const Z b = c2<T>(bq.x, -bq.y);
         const Z e = c2<T>((T)0.5 * (a.x + b.x), (T)0.5 * (a.y + b.y));
         const Z dm = c2<T>((T)0.5 * (a.x - b.x), (T)0.5 * (a.y - b.y));
-        const Z wk = tw[k];
         const Z o = cmul(dm, c2<T>(wk.x, -wk.y));
         za[k] = c2<T>(e.x - o.y, -(e.y + o.x));
+    };
+    // two bins and their mirrors per thread and pass, all ten loads issued before the first product (a one-bin loop made every
+    // pass a memory round trip of its own: the response spectra come from the Infinity Cache)
+    for (int k0 = tid; k0 < Fh; k0 += 2 * STFT_TPB) {
+        Z xa[2], ha[2], xb[2], hb[2], wk[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int k = k0 + u * STFT_TPB, kk = k < Fh ? k : 0;
+            xa[u] = X[kk]; ha[u] = Hc[kk]; xb[u] = X[Fh - kk]; hb[u] = Hc[Fh - kk]; wk[u] = tw[kk];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int k = k0 + u * STFT_TPB;
+            if (k < Fh) pack(k, cmul(xa[u], ha[u]), cmul(xb[u], hb[u]), wk[u]);
+        }
     }
     __syncthreads();
-    const Z* z = fft_forward<T>(plan, za, zb, tw);
+    const Z* z = fft_forward<T, MI>(plan, za, zb, tw);
     const T scale = (T)1 / (T)Fh;
     T* __restrict__ dst = jobs.resp[j] + (size_t)c * jobs.row_stride;
     const int p0 = jobs.pos0 + hop * H;
@@ -547,10 +566,15 @@ bool make_plan(int N, FftPlan* plan, std::string* why) {
     }
     static const bool pingpong = getenv("APV_FFT_PINGPONG") != nullptr;      // A/B switch: two-buffer stages everywhere
     plan->inplace = pingpong ? 0 : 1;
+    plan->max_it = 1;
     for (int s = 0; s < plan->nstages; ++s) {
         const int r = plan->radix[s];
         if ((r != 2 && r != 4) || plan->Nh / r > INPLACE_MAX_IT * STFT_TPB) plan->inplace = 0;
+        const int it = (plan->Nh / r + STFT_TPB - 1) / STFT_TPB;
+        if (it > plan->max_it) plan->max_it = it;
     }
+    static const bool mi4 = getenv("APV_FFT_MI4") != nullptr;                // A/B switch: the four-butterfly instantiations everywhere
+    if (!plan->inplace || mi4) plan->max_it = INPLACE_MAX_IT;
     return true;
 }
 
@@ -589,7 +613,7 @@ hipError_t launch_synthesis(int N, int H, int n_ch, const void* spec, long strid
     hipError_t e = get_tables<T>(N, &t);
     if (e != hipSuccess) return e;
     const size_t lds = plan_lds<T>(plan);
-    hipLaunchKernelGGL(istft_ola_kernel<T>, dim3(n_ch), dim3(STFT_TPB), lds, s, plan, H, (const C2<T>*)spec, stride_c,
+    hipLaunchKernelGGL((plan.max_it == 1 ? istft_ola_kernel<T, 1> : istft_ola_kernel<T, INPLACE_MAX_IT>), dim3(n_ch), dim3(STFT_TPB), lds, s, plan, H, (const C2<T>*)spec, stride_c,
                        stride_k, (T*)overlap, (T*)out, t.tw, t.win, (out_group > 0 && n_ch % out_group == 0) ? out_group : 0);
     return hipGetLastError();
 }
@@ -622,7 +646,7 @@ hipError_t launch_analysis_jobs(const FftPlan& plan, int n_jobs, const void* con
     if (total <= 0 || n_hops <= 0) return hipSuccess;
     int off = ring_off % plan.N;
     if (off < 0) off += plan.N;
-    hipLaunchKernelGGL(stft_analysis_jobs_kernel<T>, dim3(total, n_hops), dim3(STFT_TPB), plan_lds<T>(plan), s, plan, jobs, off,
+    hipLaunchKernelGGL((plan.max_it == 1 ? stft_analysis_jobs_kernel<T, 1> : stft_analysis_jobs_kernel<T, INPLACE_MAX_IT>), dim3(total, n_hops), dim3(STFT_TPB), plan_lds<T>(plan), s, plan, jobs, off,
                        t.tw, t.win);
     return hipGetLastError();
 }
@@ -806,7 +830,7 @@ hipError_t launch_fir_fft_jobs(int F, int n_jobs, const void* const* Hf, const v
         jobs.inblk = (T*)upd->inblk;
         total += 2 * jobs.upd_wgs;
     }
-    hipLaunchKernelGGL(fir_fft_kernel<T>, dim3(total, n_hops), dim3(STFT_TPB), plan_lds<T>(plan), s, plan, jobs, P, H, N, off, t.tw);
+    hipLaunchKernelGGL((plan.max_it == 1 ? fir_fft_kernel<T, 1> : fir_fft_kernel<T, INPLACE_MAX_IT>), dim3(total, n_hops), dim3(STFT_TPB), plan_lds<T>(plan), s, plan, jobs, P, H, N, off, t.tw);
     return hipGetLastError();
 }
 }  // namespace
