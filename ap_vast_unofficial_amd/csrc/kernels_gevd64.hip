@@ -59,19 +59,32 @@ __device__ __forceinline__ void rr_pair8(int r, int a, int& P, int& Q) {
 
 // one 16 x 16 tile (ti, tj) of a complex 64 x 64 x 64 product on the f64 MFMA; fa(i, k), fb(k, j) fetch operand elements;
 // k runs over [k_begin, k_end) in steps of 4.  out element t is (16 ti + (lane >> 4) + 4 t, 16 tj + (lane & 15)).
-template <typename FA, typename FB>
+// PREFETCH_A: the A operands of the NEXT group of sixteen k are fetched before this group's MFMAs (for A operands that come from
+// global memory -- C and W in the scratch slot: one L2 round trip per product instead of one per group)
+template <bool PREFETCH_A = false, typename FA, typename FB>
 __device__ __forceinline__ void cmm64_tile(FA fa, FB fb, int ti, int tj, int lane, int k_begin, int k_end, C128 out[4]) {
     // three real products per k-step (Karatsuba): P1 = sum ar br, P2 = sum ai bi, P3 = sum (ar + ai)(br + bi);
     // re = P1 - P2, im = P3 - P1 - P2.  These phases are bound by the f64 matrix pipe: 12 MFMAs and two adds beat 16 MFMAs.
     d4 p1 = {0, 0, 0, 0}, p2 = {0, 0, 0, 0}, p3 = {0, 0, 0, 0};
     const int il = lane & 15, kq = lane >> 4;
     const int i = 16 * ti + il, j = 16 * tj + il;
+    C128 an[4];
+    if constexpr (PREFETCH_A) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) an[u] = fa(i, k_begin + 4 * u + kq);
+    }
     for (int k0 = k_begin; k0 < k_end; k0 += 16) {
         C128 a[4], b[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            a[u] = fa(i, k0 + 4 * u + kq);
+            if constexpr (PREFETCH_A) a[u] = an[u];
+            else a[u] = fa(i, k0 + 4 * u + kq);
             b[u] = fb(k0 + 4 * u + kq, j);
+        }
+        if constexpr (PREFETCH_A) {
+            const int kn = (k0 + 16 < k_end) ? k0 + 16 : k0;          // (the last group fetches its own operands again: no branch)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) an[u] = fa(i, kn + 4 * u + kq);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -256,7 +269,9 @@ __device__ __forceinline__ int front64(const GevdParams& p, const Sh& sh, bool z
     } else {
         const C128* gRB = reinterpret_cast<const C128*>(p.RB) + (size_t)k * N64 * N64;
         const C128* gRD = reinterpret_cast<const C128*>(p.RD) + (size_t)k * N64 * N64;
-        for (int idx = tid; idx < N64 * N64; idx += 1024) {
+        #pragma unroll
+        for (int idx4 = 0; idx4 < 4; ++idx4) {
+            const int idx = tid + 1024 * idx4;
             const int i = idx >> 6, j = idx & 63;
             RA[i * LDD + j] = gRB[idx];
             RB[i * LDD + j] = gRD[idx];
@@ -426,7 +441,9 @@ __device__ __forceinline__ int front64(const GevdParams& p, const Sh& sh, bool z
             gC[row * N64 + col] = acc[t];
         }
         // W to the scratch slot, zeros above the diagonal
-        for (int idx = tid; idx < N64 * N64; idx += 1024) {
+        #pragma unroll
+        for (int idx4 = 0; idx4 < 4; ++idx4) {
+            const int idx = tid + 1024 * idx4;
             const int i = idx >> 6, j = idx & 63;
             gW[idx] = j <= i ? Wel(i, j) : mk<double>(0, 0);
         }
@@ -594,7 +611,9 @@ __device__ __forceinline__ void back64(const GevdParams& p, const Sh& sh, bool z
     if (status == 0) {
         C128 acc[4];
         // ---------------- stage 3b: float64 refinement on the matrix cores ----------------
-        for (int idx = tid; idx < N64 * N64; idx += 1024) {
+        #pragma unroll
+        for (int idx4 = 0; idx4 < 4; ++idx4) {
+            const int idx = tid + 1024 * idx4;
             const int i = idx >> 6, j = idx & 63;
             const C64 v = vf_src[i * vf_ld + j];
             RB[i * LDD + j] = mk<double>((double)v.x, (double)v.y);
@@ -613,7 +632,7 @@ __device__ __forceinline__ void back64(const GevdParams& p, const Sh& sh, bool z
             int lane_l = lane;
             asm volatile("" : "+v"(lane_l));
             // C is Hermitian: C[i][k] = conj(C[k][i]) read along a row of the scratch copy (coalesced)
-            cmm64_tile([&](int i, int kk) { return cj(gC[kk * N64 + i]); }, [&](int kk, int j) { return RB[kk * LDD + j]; }, ti, tj, lane_l, 0,
+            cmm64_tile<true>([&](int i, int kk) { return cj(gC[kk * N64 + i]); }, [&](int kk, int j) { return RB[kk * LDD + j]; }, ti, tj, lane_l, 0,
                        N64, accT);                                                                              // C V
             // (region A is free: the loop's last barrier ended every read of Z; T leaves the registers before the next product starts)
 #pragma unroll
@@ -708,7 +727,7 @@ __device__ __forceinline__ void back64(const GevdParams& p, const Sh& sh, bool z
             sOrder[rank] = tid;
         }
         // ---------------- stage 5: X = W^H Q   (W[k][i] = 0 for k < i) ----------------
-        cmm64_tile([&](int i, int kk) { return cj(gW[kk * N64 + i]); }, [&](int kk, int j) { return RB[kk * LDD + j]; }, ti, tj, lane, 16 * ti,
+        cmm64_tile<true>([&](int i, int kk) { return cj(gW[kk * N64 + i]); }, [&](int kk, int j) { return RB[kk * LDD + j]; }, ti, tj, lane, 16 * ti,
                    N64, acc);
         __syncthreads();
 #pragma unroll
@@ -774,7 +793,9 @@ __device__ __forceinline__ void back64(const GevdParams& p, const Sh& sh, bool z
     }
     if (p.U != nullptr) {
         C128* U = reinterpret_cast<C128*>(p.U) + (size_t)k * N64 * N64;
-        for (int idx = tid; idx < N64 * N64; idx += 1024) {
+        #pragma unroll
+        for (int idx4 = 0; idx4 < 4; ++idx4) {
+            const int idx = tid + 1024 * idx4;
             const int i = idx >> 6, j = idx & 63;
             U[idx] = (status != 1) ? RA[i * LDD + sOrder[j]] : mk<double>(0, 0);
         }
@@ -891,7 +912,9 @@ __global__ void __launch_bounds__(1024) gevd64x2_kernel(const GevdParams p) {
         C64* const Cf = Cfb(b);
         C64* const Vf = Vfb(b);
         const C64* const src = gFb(b);
-        for (int idx = tid; idx < N64 * N64; idx += 1024) {
+        #pragma unroll
+        for (int idx4 = 0; idx4 < 4; ++idx4) {
+            const int idx = tid + 1024 * idx4;
             const int i = idx >> 6, j = idx & 63;
             Cf[i * LDF + j] = src[idx];
             Vf[i * LDF + j] = mk<float>(i == j ? 1.f : 0.f, 0.f);
@@ -991,7 +1014,11 @@ __global__ void __launch_bounds__(1024) gevd64x2_kernel(const GevdParams p) {
         if ((b ? status1 : status0) != 0) continue;
         const C64* const Vf = Vfb(b);
         C64* const dst = gFb(b);
-        for (int idx = tid; idx < N64 * N64; idx += 1024) dst[idx] = Vf[(idx >> 6) * LDF + (idx & 63)];
+        #pragma unroll
+        for (int idx4 = 0; idx4 < 4; ++idx4) {
+            const int idx = tid + 1024 * idx4;
+            dst[idx] = Vf[(idx >> 6) * LDF + (idx & 63)];
+        }
     }
     __syncthreads();
     if (p.debug_stop == 5) {

@@ -368,7 +368,9 @@ __device__ __forceinline__ void block_jacobi_round_body(double* sm, double2 (*ro
     rr_pair(nb, round, Q, IQ, JQ);
     const int tid = threadIdx.x, half = tid >> 8, a = (tid >> 4) & 15, b = tid & 15;
     double* const Vz = Vbuf + (size_t)z * np * TS;
-    for (int e = tid; e < BT * BT; e += 512) {
+    #pragma unroll
+    for (int e2 = 0; e2 < BT * BT / 512; ++e2) {
+        const int e = tid + 512 * e2;             // (all of a thread's loads go out before the first is used)
         const int t = e >> 5, u = e & 31;
         const size_t gr = (size_t)tile_index(IP, JP, t) * ld;
         if (MODE == 5 && diag) {                              // look-ahead: the pair solve has left the rotated tile and V_P behind
@@ -447,7 +449,9 @@ __device__ __forceinline__ void block_jacobi_round_body(double* sm, double2 (*ro
     const int orow = (w >> 1) * 16 + (lane >> 4), ocol = (w & 1) * 16 + (lane & 15);     // + 4 t on the row
     if (diag) {
         if (tid < 16 && offacc != 0.0) atomicAdd(off + z, offacc);
-        for (int e = tid; e < BT * BT; e += 512) {
+        #pragma unroll
+        for (int e2 = 0; e2 < BT * BT / 512; ++e2) {
+            const int e = tid + 512 * e2;             // (all of a thread's loads go out before the first is used)
             const int t = e >> 5, u = e & 31;
             Cout[(size_t)tile_index(IP, JP, t) * ld + tile_index(IP, JP, u)] = SP[t * LS + u];
             T[t * LS + u] = X[(size_t)(P * BT + t) * ld + tile_index(IP, JP, u)];
@@ -465,7 +469,9 @@ __device__ __forceinline__ void block_jacobi_round_body(double* sm, double2 (*ro
         const d4 o = mm32_mfma<false>(T, VQ, w, lane);
         for (int t = 0; t < 4; ++t) U[(orow + 4 * t) * LS + ocol] = o[t];
     }
-    for (int e = tid; e < BT * BT; e += 512) {
+    #pragma unroll
+    for (int e2 = 0; e2 < BT * BT / 512; ++e2) {
+        const int e = tid + 512 * e2;             // (all of a thread's loads go out before the first is used)
         const int t = e >> 5, u = e & 31;
         SP[t * LS + u] = X[(size_t)(Q * BT + t) * ld + tile_index(IP, JP, u)];
         SQ[t * LS + u] = X[(size_t)(P * BT + t) * ld + tile_index(IQ, JQ, u)];
@@ -485,7 +491,9 @@ __device__ __forceinline__ void block_jacobi_round_body(double* sm, double2 (*ro
         }
     }
     __syncthreads();
-    for (int e = tid; e < BT * BT; e += 512) {                     // the mirrored tile, coalesced
+    #pragma unroll
+    for (int e2 = 0; e2 < BT * BT / 512; ++e2) {                     // the mirrored tile, coalesced
+        const int e = tid + 512 * e2;             // (all of a thread's loads go out before the first is used)
         const int t = e >> 5, u = e & 31;
         Cout[(size_t)tile_index(IQ, JQ, t) * ld + tile_index(IP, JP, u)] = T[u * LS + t];
     }
@@ -637,7 +645,9 @@ __device__ __forceinline__ void la_solve_body(double* sm, double2 (*rot)[BH], in
     const int w = (tid >> 6) & 3, lane = tid & 63;
     const int orow = (w >> 1) * 16 + (lane >> 4), ocol = (w & 1) * 16 + (lane & 15);     // + 4 t on the row
     if (FIRST) {
-        for (int e = tid; e < BT * BT; e += 512) {
+        #pragma unroll
+        for (int e2 = 0; e2 < BT * BT / 512; ++e2) {
+            const int e = tid + 512 * e2;             // (all of a thread's loads go out before the first is used)
             const int t = e >> 5, u = e & 31;
             SP[t * LS + u] = Csrc[(size_t)tile_index(IP, JP, t) * ld + tile_index(IP, JP, u)];
             VP[t * LS + u] = (t == u) ? 1.0 : 0.0;
@@ -653,7 +663,9 @@ __device__ __forceinline__ void la_solve_body(double* sm, double2 (*rot)[BH], in
         const double* Vb = Vprev + ((size_t)z * np + pb) * TS;
         const double* Da = Dprev + ((size_t)z * np + pa) * TS;
         const double* Db = Dprev + ((size_t)z * np + pb) * TS;
-        for (int e = tid; e < BT * BT; e += 512) {
+        #pragma unroll
+        for (int e2 = 0; e2 < BT * BT / 512; ++e2) {
+            const int e = tid + 512 * e2;             // (all of a thread's loads go out before the first is used)
             const int t = e >> 5, u = e & 31;
             T[t * LS + u] = Csrc[(size_t)tile_index(Ia, Ja, t) * ld + tile_index(Ib, Jb, u)];
             VA[t * LS + u] = Va[t * LS + u];
@@ -739,7 +751,9 @@ __device__ __forceinline__ void la_solve_body(double* sm, double2 (*rot)[BH], in
     if (tid < 16 && offacc != 0.0) atomicAdd(off + z, offacc);
     double* Dc = Dcur + ((size_t)z * np + P) * TS;
     double* Vc = Vcur + ((size_t)z * np + P) * TS;
-    for (int e = tid; e < BT * BT; e += 512) {
+    #pragma unroll
+    for (int e2 = 0; e2 < BT * BT / 512; ++e2) {
+        const int e = tid + 512 * e2;             // (all of a thread's loads go out before the first is used)
         const int t = e >> 5, u = e & 31;
         Dc[t * LS + u] = SP[t * LS + u];
         Vc[t * LS + u] = VP[t * LS + u];
