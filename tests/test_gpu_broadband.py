@@ -229,6 +229,39 @@ def test_broadband_matlab_dialect_vs_oracle(golden, perceptual):
     ap.close()
 
 
+@pytest.mark.parametrize("perceptual", [False, True])
+def test_broadband_process_signal_matlab_dialect_and_weighting(golden, perceptual):
+    """The batched whole-signal call in the MATLAB dialect (relative loading in place: the norms travel with the batch; rank list;
+    normalised statistics) and with the perceptual weighting on (curves from the hop's target spectra inside the front stages):
+    nine hops through process_signal against the same object class driven hop by hop."""
+    from ap_vast_unofficial_amd.apvast import apvast
+    rirs = golden("rirs_cfg1")
+    rA, rB = rirs["rirA"][:, :4, :6], rirs["rirB"][:, :4, :6]
+    N, H, J, S, ranks = 256, 128, 16, 384, [1, 3, 8, 20]
+    def mk():
+        o = apvast(N, rA, rB, J, 8, 1, 2, ranks, 1.0, S, sampling_rate=16000, perceptual=perceptual, mode="broadband",
+                   dialect="matlab", fullscale_db_spl=100.0)
+        rng = np.random.default_rng(21)
+        st = o.get_state()
+        o.set_state({"response": 1e-3 * rng.standard_normal(st["response"].shape),
+                     "target_response": 1e-3 * rng.standard_normal(st["target_response"].shape)})
+        return o
+    a, b = mk(), mk()
+    hops = 9
+    x = np.random.default_rng(8).standard_normal((2, hops * H))
+    whole = a.process_signal(x[0], x[1])
+    per_hop = [b.process_input_buffers(x[0, h * H:(h + 1) * H], x[1, h * H:(h + 1) * H]) for h in range(hops)]
+    for q in range(4):
+        for v in range(len(whole[q])):
+            ref = np.concatenate([per_hop[h][q][v] for h in range(hops)])
+            assert np.abs(whole[q][v] - ref).max() <= 1e-9 * max(np.abs(ref).max(), 1e-30), (q, v)
+    for name in ("lambda_A", "lambda_B", "w_A", "w_B", "R_A_to_A", "R_B_to_A"):
+        va, vb = getattr(a, name), getattr(b, name)
+        assert np.abs(va - vb).max() <= 1e-8 * np.abs(vb).max(), name
+    a.close()
+    b.close()
+
+
 def test_broadband_rank_list_validation(golden):
     """apVast.m:527-549 takes an ascending vector of ranks: a descending or out-of-range list is refused."""
     from ap_vast_unofficial_amd.apvast import apvast
