@@ -109,6 +109,8 @@ __device__ __forceinline__ void correlate16(const XT* __restrict__ X, const XT* 
     auto chunk = [&](int mc, auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
         XT xv[8], dv[8];
+        const XT* const xrow0 = X + (size_t)(mc + msub) * N + (lane & 15);
+        const XT* const drow0 = WITH_D ? dvec + mc + msub : nullptr;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             // UNCONDITIONAL loads (from a clamped row when the chunk is ragged), then a select: written as `ok ? X[...] : zero`
@@ -117,17 +119,21 @@ __device__ __forceinline__ void correlate16(const XT* __restrict__ X, const XT* 
             // of a wave's life (profiles/r03/stage_stamps_32768.md: 24 k + 12 k cycles "waiting for the slabs")
             const int m = mc + 4 * q + msub;
             const bool ok = FULL || m < M;
-            const int mcl = (FULL || ok) ? m : M - 1;
-            const XT xl = X[(size_t)mcl * N + (lane & 15)];
+            XT xl, dl = zero;
+            if constexpr (FULL) {
+                // one base address per chunk, the eight rows at constant offsets (512 q bytes: immediate offsets of the loads;
+                // indexed per load the compiler spent three 64-bit address instructions on each)
+                xl = xrow0[(size_t)(4 * q) * N];
+                if constexpr (WITH_D) dl = drow0[4 * q];
+            } else {
+                const int mcl = ok ? m : M - 1;
+                xl = X[(size_t)mcl * N + (lane & 15)];
+                if constexpr (WITH_D) dl = dvec[mcl];
+            }
             xv[q].x = ok ? xl.x : zero.x;
             xv[q].y = ok ? xl.y : zero.y;
-            if constexpr (WITH_D) {
-                const XT dl = dvec[mcl];
-                dv[q].x = ok ? dl.x : zero.x;
-                dv[q].y = ok ? dl.y : zero.y;
-            } else {
-                dv[q] = zero;
-            }
+            dv[q].x = ok ? dl.x : zero.x;
+            dv[q].y = ok ? dl.y : zero.y;
         }
         if constexpr (!__is_same(ST, NoStamp)) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
