@@ -794,8 +794,9 @@ __device__ __forceinline__ void cmm16(FA fa, FB fb, int lane, Cx<double> out[4])
     for (int t = 0; t < 4; ++t) {
         const double u = p1[t], v = p2[t];
         p1[t] = u - v;                                           // re
-        im[t] = -(u + v);                                        // (written -u - v it saves four sign flips per product and costs
-                                                                 //  a register spill on the common path: 8 -> 55 MB written per launch)
+        im[t] = -u - v;                                          // (two sign modifiers on one add; as -(u + v) it is an add and four
+                                                                 //  sign flips.  Which of the two forms spills more has changed with
+                                                                 //  the code around it: check WRITE_SIZE after touching this kernel)
     }
     // (the operands are fetched again -- the compiler barrier keeps it from holding the eight complex numbers of the first two
     // passes in registers, which the kernel does not have)
