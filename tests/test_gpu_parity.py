@@ -46,12 +46,15 @@ def test_update_vs_reference_golden(Engine, golden, name, dtype):
         assert np.abs(lam / g["lam"] - 1).max() < TOL[dtype]["lam"]
         assert w_err(w, g["w"]) < TOL[dtype]["w"]
     else:
-        # fp32: eigenvalues are accurate relative to the largest one; the error of w grows with the
-        # conditioning of the loaded dark matrix (square 8x8 slabs reach kappa ~ 1e4)
+        # fp32 arithmetic: the perturbation bound of a whitened eigenproblem solved in float32, per bin:
+        # |d lam| / lam_max <= 4 eps32 cond(R_D + reg I), ||d w|| / ||w|| <= 16 eps32 cond (floor 1e-6: the c64 outputs).  Measured
+        # (tools/probes/f32_error_vs_cond.py): 0.6 and 2.9 eps32 cond at 16 x 32 (cond 31), 0.3 and 1.3 at 8 x 8 (cond 5e3).
         RD = subband.correlate(XB, XD, d)[1] + float(g["reg"]) * np.eye(L)
-        amp = max(1.0, np.linalg.cond(RD).max() / 1e2) * (4 if L >= 32 else 1)
-        assert (np.abs(lam - g["lam"]) / g["lam"][:, :1]).max() < TOL[dtype]["lam"] * amp
-        assert w_err(w, g["w"]) < TOL[dtype]["w"] * amp
+        bound = np.finfo(np.float32).eps * np.linalg.cond(RD)                      # per bin
+        e_lam = (np.abs(lam - g["lam"]) / g["lam"][:, :1]).max(axis=1)
+        e_w = (np.linalg.norm(w - g["w"], axis=-1) / np.linalg.norm(g["w"], axis=-1)).max(axis=1)
+        assert (e_lam <= np.maximum(4 * bound, 1e-6)).all(), (e_lam / bound).max()
+        assert (e_w <= np.maximum(16 * bound, 1e-6)).all(), (e_w / bound).max()
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
