@@ -738,14 +738,19 @@ __device__ __forceinline__ int jacobi16_onesided(Cx<float>& g0t_, Cx<float>& g0b
             // rotation for [[nt, beta], [conj(beta), nb]]: with zeta = (nb - nt)/2 and D = |zeta| + sqrt(zeta^2 + |beta|^2),
             // t = sign(zeta) beta / D (|t| <= 1; no division by |beta|), c = 1/sqrt(1 + |t|^2), s = t c; the diagonal moves by
             // Re(conj(t) beta) = sign(zeta) |beta|^2 / D.  Three transcendental instructions, no branch: zeta = beta = 0 gives t = 0.
+            // (round 3: TWO transcendental instructions.  With h = sqrt(zeta^2 + |beta|^2): D^2 + |beta|^2 = 2 h D, so
+            // c = 1/sqrt(1 + |t|^2) = D r and s = sign(zeta) beta r with r = 1/sqrt(2 h D), and 1/D = 2 h r^2 gives the diagonal
+            // shift without a reciprocal.  The floor on |zeta| makes zeta = beta = 0 come out as c = 1, s = 0.)
             const float zeta = 0.5f * (nb - nt);
             const float x = fmaxf(__builtin_fmaf(zeta, zeta, b2), 1e-36f);
-            const float D = fabsf(zeta) + x * __builtin_amdgcn_rsqf(x);
-            const float tsgn = copysignf(__builtin_amdgcn_rcpf(D), zeta);
-            const float tx = bx * tsgn, ty = by * tsgn;
-            const float c = __builtin_amdgcn_rsqf(__builtin_fmaf(tx, tx, __builtin_fmaf(ty, ty, 1.0f)));
-            const CC s = mk<float>(tx * c, ty * c);
-            const float shift = b2 * tsgn;
+            const float hh = x * __builtin_amdgcn_rsqf(x);
+            const float D = fmaxf(fabsf(zeta), 1e-18f) + hh;
+            const float h2 = hh + hh;
+            const float rr = __builtin_amdgcn_rsqf(h2 * D);
+            const float c = D * rr;
+            const float rs = copysignf(rr, zeta);
+            const CC s = mk<float>(bx * rs, by * rs);
+            const float shift = b2 * h2 * rr * rs;
             nt -= shift;
             nb += shift;
             CC w0p, w0q, w1p, w1q;
