@@ -421,6 +421,13 @@ __device__ __forceinline__ int front64(const GevdParams& p, const Sh& sh, bool z
         stamp64(p, z1, k, 10);
         if (p.debug_stop == 3) return -1;
         // ---------------- stage 2: C = W A W^H ----------------
+        // W to the scratch slot first (zeros above the diagonal): the stores drain while the products below run
+#pragma unroll
+        for (int idx4 = 0; idx4 < 4; ++idx4) {
+            const int idx = tid + 1024 * idx4;
+            const int i = idx >> 6, j = idx & 63;
+            gW[idx] = j <= i ? Wel(i, j) : mk<double>(0, 0);
+        }
         C128 acc[4];
         // W is lower triangular: W[i][k] = 0 for k > i (the upper triangle of the region still holds R_D)
         cmm64_tile([&](int i, int kk) { return kk <= i ? Wel(i, kk) : mk<double>(0, 0); },
@@ -439,13 +446,6 @@ __device__ __forceinline__ int front64(const GevdParams& p, const Sh& sh, bool z
             if (row == col) acc[t].y = 0;
             nrm += acc[t].x * acc[t].x + acc[t].y * acc[t].y;
             gC[row * N64 + col] = acc[t];
-        }
-        // W to the scratch slot, zeros above the diagonal
-        #pragma unroll
-        for (int idx4 = 0; idx4 < 4; ++idx4) {
-            const int idx = tid + 1024 * idx4;
-            const int i = idx >> 6, j = idx & 63;
-            gW[idx] = j <= i ? Wel(i, j) : mk<double>(0, 0);
         }
         normF2 = block_sum(nrm, sRed, tid);          // (its barriers also end every read of T in region A)
         const int sexp = (normF2 > 0.0) ? -(ilogb(normF2) / 2) : 0;
