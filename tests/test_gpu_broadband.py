@@ -229,6 +229,23 @@ def test_broadband_matlab_dialect_vs_oracle(golden, perceptual):
     ap.close()
 
 
+@pytest.mark.parametrize("hops", [1, 17])
+def test_broadband_process_signal_group_edges(golden, hops):
+    """One hop (a group of one) and seventeen (two full groups of eight and a group of one) through the batched call."""
+    g = golden("g1_broadband_cfg1")
+    rirs = golden("rirs_cfg1")
+    H = 128
+    x = np.random.default_rng(40 + hops).standard_normal((2, hops * H))
+    a, b = make(g, rirs), make(g, rirs)
+    whole = a.process_signal(x[0], x[1])
+    per_hop = [b.process_input_buffers(x[0, h * H:(h + 1) * H], x[1, h * H:(h + 1) * H]) for h in range(hops)]
+    for q in range(4):
+        for v in range(len(whole[q])):
+            ref = np.concatenate([per_hop[h][q][v] for h in range(hops)])
+            assert np.abs(whole[q][v] - ref).max() <= 1e-10 * max(np.abs(ref).max(), 1e-30), (q, v)
+    assert np.abs(a.lambda_A - b.lambda_A).max() <= 1e-9 * np.abs(b.lambda_A).max()
+
+
 @pytest.mark.parametrize("perceptual", [False, True])
 def test_broadband_process_signal_matlab_dialect_and_weighting(golden, perceptual):
     """The batched whole-signal call in the MATLAB dialect (relative loading in place: the norms travel with the batch; rank list;

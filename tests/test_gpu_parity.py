@@ -336,6 +336,26 @@ def test_jdiag_large_complex_vs_oracle(Engine, n, batch):
         eng2.jdiag_large_complex(np.eye(70, dtype=complex)[None], -np.eye(70, dtype=complex)[None])
 
 
+def test_jdiag_large_complex_relative_loading_batch(Engine):
+    """Complex pairs of order 70 in a batch of three with the relative loading of apvast.py:26-27 (the spectral norm of the
+    embedding is the norm of the complex matrix)."""
+    from ap_vast_unofficial_amd import _capi
+    rng = np.random.default_rng(70)
+    n, batch = 70, 3
+    Y = rng.standard_normal((batch, 2 * n, n)) + 1j * rng.standard_normal((batch, 2 * n, n))
+    Z = rng.standard_normal((batch, 2 * n, n)) + 1j * rng.standard_normal((batch, 2 * n, n))
+    A = np.einsum("kmi,kmj->kij", Y.conj(), Y)
+    B = np.einsum("kmi,kmj->kij", Z.conj(), Z)
+    eng = Engine(1, 4, 4, reg_mode=_capi.REG_REL, reg_dark=1e-8)
+    U, lam = eng.jdiag_large_complex(A, B)
+    eng.close()
+    for k in range(batch):
+        _, lam_ref = gevd.jdiag(A[k], B[k], reg_mode=gevd.REG_MODE_REL)
+        assert np.abs(lam[k] / lam_ref - 1).max() < 1e-9
+        Bl = B[k] + 1e-8 * np.linalg.norm(B[k], 2) * np.eye(n)
+        assert np.abs(U[k].conj().T @ Bl @ U[k] - np.eye(n)).max() < 1e-10
+
+
 def test_jdiag_large_complex_repeated_eigenvalues(Engine):
     """Eigenvalue clusters: the real embedding returns an arbitrary real basis of each eigenspace; the selection must still
     hand back n vectors that are independent over C and meet jdiag's contract.  A = B Hermitian-congruent to
