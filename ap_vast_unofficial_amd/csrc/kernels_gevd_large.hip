@@ -56,14 +56,14 @@ using d4 = __attribute__((ext_vector_type(4))) double;
 
 // The same product on v_mfma_f64_16x16x4_f64: four waves, wave w owns the 16 x 16 tile (w >> 1, w & 1).
 // acc[t] is element (row0 + (lane >> 4) + 4 t, col0 + (lane & 15)).
-template <bool TA>
+template <bool TA, bool TB = false>
 __device__ __forceinline__ d4 mm32_mfma(const double* A, const double* B, int w, int lane) {
     const int row0 = (w >> 1) * 16, col0 = (w & 1) * 16, il = lane & 15, kq = lane >> 4;
     d4 acc = {0, 0, 0, 0};
 #pragma unroll
     for (int k0 = 0; k0 < BT; k0 += 4) {
         const double av = TA ? A[(k0 + kq) * LS + row0 + il] : A[(row0 + il) * LS + k0 + kq];
-        const double bv = B[(k0 + kq) * LS + col0 + il];
+        const double bv = TB ? B[(col0 + il) * LS + k0 + kq] : B[(k0 + kq) * LS + col0 + il];
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
     }
     return acc;
@@ -88,25 +88,29 @@ __global__ void __launch_bounds__(256) chol_panel_kernel(int ld, int k, int nbk,
     LiBuf += (size_t)z * nbk * BT * BT;
     const int I = k + blockIdx.x;
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
-    double accT[4] = {0.0, 0.0, 0.0, 0.0}, accD[4] = {0.0, 0.0, 0.0, 0.0};
+    // the products of the left-looking update on the f64 matrix cores, one 16 x 16 quadrant per wave (round 3: they ran on the
+    // vector ALU with four LDS reads per four multiply-adds, 3 us per product; the late panels of n = 800 took 100-200 us)
+    const int wq = tid >> 6, lq = tid & 63;
+    d4 accT = {0.0, 0.0, 0.0, 0.0}, accD = {0.0, 0.0, 0.0, 0.0};
     for (int J = 0; J < k; ++J) {
-        for (int e = tid; e < BT * BT; e += 256) {
+#pragma unroll
+        for (int e4 = 0; e4 < BT * BT / 256; ++e4) {
+            const int e = tid + 256 * e4;
             const int t = e >> 5, u = e & 31;
             La[t * LS + u] = B[(size_t)(I * BT + t) * ld + J * BT + u];
             Lb[t * LS + u] = B[(size_t)(k * BT + t) * ld + J * BT + u];
         }
         __syncthreads();
-        double o[4];
-        mm32<false, true>(Lb, Lb, ty, tx, o);
-        for (int i = 0; i < 4; ++i) accD[i] -= o[i];
+        const d4 oD = mm32_mfma<false, true>(Lb, Lb, wq, lq);
+        for (int i = 0; i < 4; ++i) accD[i] -= oD[i];
         if (I != k) {
-            mm32<false, true>(La, Lb, ty, tx, o);
-            for (int i = 0; i < 4; ++i) accT[i] -= o[i];
+            const d4 oT = mm32_mfma<false, true>(La, Lb, wq, lq);
+            for (int i = 0; i < 4; ++i) accT[i] -= oT[i];
         }
         __syncthreads();
     }
-    for (int i = 0; i < 4; ++i) {
-        const int r = ty + ((i >> 1) << 4), c = tx + ((i & 1) << 4);
+    for (int i = 0; i < 4; ++i) {                      // accumulator element i of wave wq: row (wq >> 1) 16 + (lane >> 4) + 4 i
+        const int r = (wq >> 1) * 16 + (lq >> 4) + 4 * i, c = (wq & 1) * 16 + (lq & 15);
         Dm[r * LS + c] = B[(size_t)(k * BT + r) * ld + k * BT + c] + accD[i];
         if (I != k) La[r * LS + c] = B[(size_t)(I * BT + r) * ld + k * BT + c] + accT[i];
         Wp[r * LS + c] = (r == c) ? 1.0 : 0.0;
