@@ -819,16 +819,19 @@ __global__ void __launch_bounds__(512) la_fused_kernel(int ld, int nb, LaRound q
 
 struct GevdLargeWs {
     int n = 0, batch = 0;
-    int last_pairs = 0;      // pairs of sweeps the last converged call of this shape took
+    int last_sweeps = 0;     // sweeps the last converged call of this shape took
     double *Bw = nullptr, *W = nullptr, *T1 = nullptr, *C0 = nullptr, *C1 = nullptr, *X = nullptr, *Li = nullptr;
     double *acc = nullptr, *coef = nullptr, *Vbuf = nullptr, *Vbuf2 = nullptr, *Dbuf = nullptr, *Dbuf2 = nullptr;
 
     int *flag = nullptr, *order = nullptr;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
+    // captured sweeps: [0] two sweeps C0 -> C0 (the stretch nobody tests), [1] one sweep C0 -> C1, [2] one sweep C1 -> C0
+    hipGraph_t graph[3] = {nullptr, nullptr, nullptr};
+    hipGraphExec_t exec[3] = {nullptr, nullptr, nullptr};
     void release() {
-        if (exec) (void)hipGraphExecDestroy(exec);
-        if (graph) (void)hipGraphDestroy(graph);
+        for (int g = 0; g < 3; ++g) {
+            if (exec[g]) (void)hipGraphExecDestroy(exec[g]);
+            if (graph[g]) (void)hipGraphDestroy(graph[g]);
+        }
         void* bufs[] = {Bw, W, T1, C0, C1, X, Li, acc, coef, Vbuf, Vbuf2, Dbuf, Dbuf2, flag, order};
 
         for (void* b : bufs)
@@ -892,13 +895,16 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
     // look-ahead (see la_solve_kernel): APV_LARGE_LOOKAHEAD=0 is the A/B switch back to solve-then-update on one stream
     static const bool la_off = getenv("APV_LARGE_LOOKAHEAD") && atoi(getenv("APV_LARGE_LOOKAHEAD")) == 0;
     const bool lookahead = split && !la_off && np >= 2;
-    auto two_sweeps_la = [&]() {
-        hipLaunchKernelGGL(zero_f64_kernel, dim3((2 * batch + 63) / 64), dim3(64), 0, st, 2 * batch, ws.acc);
-        double *Cc = ws.C0, *Cn = ws.C1;
-        const int total = 2 * rounds;
+    // nsweeps = 2: both accumulators, C0 -> C0.  nsweeps = 1: one sweep from C0 (odd = false, accumulator a) or from C1 (odd = true,
+    // accumulator b) into the other buffer -- rounds = nb - 1 is odd, so a sweep leaves the matrix in the buffer it did not start in.
+    auto sweeps_la = [&](int nsweeps, bool odd) {
+        double* const acc0 = ws.acc + (odd ? (size_t)batch : 0);
+        hipLaunchKernelGGL(zero_f64_kernel, dim3((nsweeps * batch + 63) / 64), dim3(64), 0, st, nsweeps * batch, acc0);
+        double *Cc = odd ? ws.C1 : ws.C0, *Cn = odd ? ws.C0 : ws.C1;
+        const int total = nsweeps * rounds;
         // the pair solves of the very first round read the matrix as it stands
         hipLaunchKernelGGL(la_solve_kernel<true>, dim3(np, 1, batch), dim3(512), 0, st, ld, nb, 0, 0, 1, Cc, (const double*)ws.Vbuf2,
-                           (const double*)ws.Dbuf2, ws.Vbuf, ws.Dbuf, ws.acc, ms);
+                           (const double*)ws.Dbuf2, ws.Vbuf, ws.Dbuf, acc0, ms);
         for (int gr = 0; gr < total; ++gr) {
             const int r = gr % rounds;
             double* Vcur = (gr & 1) ? ws.Vbuf2 : ws.Vbuf;
@@ -907,48 +913,50 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
             double* Dnext = (gr & 1) ? ws.Dbuf : ws.Dbuf2;
             if (gr + 1 < total) {
                 const int rn = (gr + 1) % rounds, swn = (gr + 1) / rounds;
-                LaRound q{r, rn == 0 ? 1 : 0, rn, Cc, Cn, Vcur, Dcur, Vnext, Dnext, ws.acc + (size_t)swn * batch};
+                LaRound q{r, rn == 0 ? 1 : 0, rn, Cc, Cn, Vcur, Dcur, Vnext, Dnext, acc0 + (size_t)swn * batch};
                 hipLaunchKernelGGL(la_fused_kernel, dim3(np + tiles, 1, batch), dim3(512), 0, st, ld, nb, q, ws.X, ms);
             } else {
                 hipLaunchKernelGGL(block_jacobi_round_kernel<5>, dim3(tiles, 1, batch), dim3(512), 0, st, ld, nb, r, 0, Cc, Cn, ws.X,
-                                   ws.acc, ms, Vcur, (const double*)Dcur);
+                                   acc0, ms, Vcur, (const double*)Dcur);
             }
             double* t = Cc; Cc = Cn; Cn = t;
         }
     };
-    auto two_sweeps = [&]() {
-        if (lookahead) return two_sweeps_la();
-        if (memset_node) (void)hipMemsetAsync(ws.acc, 0, sizeof(double) * 2 * batch, st);
-        else hipLaunchKernelGGL(zero_f64_kernel, dim3((2 * batch + 63) / 64), dim3(64), 0, st, 2 * batch, ws.acc);
-        double *Cc = ws.C0, *Cn = ws.C1;
-        for (int sw = 0; sw < 2; ++sw)
+    auto sweeps = [&](int nsweeps, bool odd) {
+        if (lookahead) return sweeps_la(nsweeps, odd);
+        double* const acc0 = ws.acc + (odd ? (size_t)batch : 0);
+        if (memset_node) (void)hipMemsetAsync(acc0, 0, sizeof(double) * nsweeps * batch, st);
+        else hipLaunchKernelGGL(zero_f64_kernel, dim3((nsweeps * batch + 63) / 64), dim3(64), 0, st, nsweeps * batch, acc0);
+        double *Cc = odd ? ws.C1 : ws.C0, *Cn = odd ? ws.C0 : ws.C1;
+        for (int sw = 0; sw < nsweeps; ++sw)
             for (int r = 0; r < rounds; ++r) {
                 if (!split) {
                     hipLaunchKernelGGL(block_jacobi_round_kernel<0>, dim3(tiles, 1, batch), dim3(512), 0, st, ld, nb, r, r == 0 ? 1 : 0,
-                                       Cc, Cn, ws.X, ws.acc + (size_t)sw * batch, ms, ws.Vbuf, (const double*)nullptr);
+                                       Cc, Cn, ws.X, acc0 + (size_t)sw * batch, ms, ws.Vbuf, (const double*)nullptr);
                 } else {
                     hipLaunchKernelGGL(block_jacobi_round_kernel<1>, dim3(np, 1, batch), dim3(512), 0, st, ld, nb, r, r == 0 ? 1 : 0,
-                                       Cc, Cn, ws.X, ws.acc + (size_t)sw * batch, ms, ws.Vbuf, (const double*)nullptr);
+                                       Cc, Cn, ws.X, acc0 + (size_t)sw * batch, ms, ws.Vbuf, (const double*)nullptr);
                     if (np > 1)
                         hipLaunchKernelGGL(block_jacobi_round_kernel<2>, dim3(tiles - np, 1, batch), dim3(512), 0, st, ld, nb, r, 0,
-                                           Cc, Cn, ws.X, ws.acc + (size_t)sw * batch, ms, ws.Vbuf, (const double*)nullptr);
+                                           Cc, Cn, ws.X, acc0 + (size_t)sw * batch, ms, ws.Vbuf, (const double*)nullptr);
                 }
                 double* t = Cc; Cc = Cn; Cn = t;
             }
     };
     static const bool no_graph = getenv("APV_NO_GRAPH") != nullptr;      // plain launches: rocprofv3 can then trace the rounds
-    if (!ws.exec && !no_graph) {
-        LCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-        two_sweeps();
-        // the capture is always closed, whatever was recorded: a stream left in capture mode fails every later call
-        const hipError_t ce = hipStreamEndCapture(st, &ws.graph);
-        const hipError_t le = hipGetLastError();
-        if (ce != hipSuccess || le != hipSuccess || !ws.graph) {
-            if (ws.graph) (void)hipGraphDestroy(ws.graph);
-            ws.graph = nullptr;
-            return apv_fail(h, APV_ERR_HIP, std::string("capturing the Jacobi sweeps: ") + hipGetErrorString(ce != hipSuccess ? ce : le));
+    if (!ws.exec[0] && !no_graph) {
+        for (int g = 0; g < 3; ++g) {
+            LCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            sweeps(g == 0 ? 2 : 1, g == 2);
+            // the capture is always closed, whatever was recorded: a stream left in capture mode fails every later call
+            const hipError_t ce = hipStreamEndCapture(st, &ws.graph[g]);
+            const hipError_t le = hipGetLastError();
+            if (ce != hipSuccess || le != hipSuccess || !ws.graph[g]) {
+                ws.release();
+                return apv_fail(h, APV_ERR_HIP, std::string("capturing the Jacobi sweeps: ") + hipGetErrorString(ce != hipSuccess ? ce : le));
+            }
+            LCHK(hipGraphInstantiate(&ws.exec[g], ws.graph[g], nullptr, nullptr, 0));
         }
-        LCHK(hipGraphInstantiate(&ws.exec, ws.graph, nullptr, nullptr, 0));
     }
     LCHK(hipMemsetAsync(ws.W, 0, mb, st));
     LCHK(hipMemsetAsync(ws.X, 0, mb, st));
@@ -981,33 +989,43 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
     }
     static const bool timing = getenv("APV_BB_TIMING") != nullptr;       // profiling aid, see stream_bb.hip
     const auto t_pre = std::chrono::steady_clock::now();
-    int n_graphs = 0;
+    int n_sweeps = 0;
     std::vector<double> norm2(hacc.begin() + 2 * batch, hacc.end());
-    const int max_pairs = (h->cfg.max_sweeps > 0 ? h->cfg.max_sweeps : 30) / 2 + 1;
+    const int max_sweeps = ((h->cfg.max_sweeps > 0 ? h->cfg.max_sweeps : 30) / 2 + 1) * 2;
     // a sweep whose pivots weigh <= tol ||C||^2 leaves ~tol^2 behind (quadratic convergence); APV_LARGE_TOL2 is a tuning aid
     static const double kLargeTol2 = getenv("APV_LARGE_TOL2") ? atof(getenv("APV_LARGE_TOL2")) : 1e-16;   // 1e-20 (round 1) cost two more sweeps for the same G1 errors
+    // APV_LARGE_PAIRS=1: the stop test after every second sweep only, as before round 3's last change (A/B switch)
+    static const bool pairs_only = getenv("APV_LARGE_PAIRS") && atoi(getenv("APV_LARGE_PAIRS")) != 0;
     bool converged = false;
-    // The stop test costs a copy and a host synchronisation per pair of sweeps.  Consecutive calls of a stream solve problems of
-    // the same kind: the pairs of sweeps the LAST call of this shape needed, less two, are launched back to back before the first
-    // test (two tests instead of six at cfg1; the count can still go down from call to call as well as up).
-    const int untested = (ws.last_pairs > 2 && h->gl_tol2 <= 0.0) ? ws.last_pairs - 2 : 0;
-    for (int it = 0; it < max_pairs && !converged; ++it) {
-        if (ws.exec) LCHK(hipGraphLaunch(ws.exec, st));
-        else two_sweeps();
-        ++n_graphs;
-        if (it < untested && it + 1 < max_pairs) continue;
+    // The stop test costs a copy and a host synchronisation.  Consecutive calls of a stream solve problems of the same kind: of
+    // the sweeps the LAST call of this shape needed, all but the last three (an even count: they go as captured pairs) are
+    // launched back to back before the first test; from there every sweep is tested, so that the sweep found to be the last one
+    // IS the last one (tested in pairs, half the calls ran a sixteenth sweep after a fifteenth that had already met the bound).
+    const int untested = (ws.last_sweeps > 4 && h->gl_tol2 <= 0.0 && !timing) ? ((ws.last_sweeps - 3) & ~1) : 0;
+    const double tol2 = h->gl_tol2 > 0.0 ? h->gl_tol2 : kLargeTol2;
+    while (n_sweeps < max_sweeps && !converged) {
+        const bool odd = n_sweeps & 1;
+        const bool pair = !odd && (n_sweeps < untested || pairs_only);
+        if (ws.exec[0]) LCHK(hipGraphLaunch(ws.exec[pair ? 0 : (odd ? 2 : 1)], st));
+        else sweeps(pair ? 2 : 1, odd);
+        n_sweeps += pair ? 2 : 1;
+        if (n_sweeps <= untested && n_sweeps < max_sweeps) continue;
         LCHK(hipMemcpyAsync(hacc.data(), ws.acc, sizeof(double) * 2 * batch, hipMemcpyDeviceToHost, st));
         LCHK(hipStreamSynchronize(st));
-        converged = true;                     // judged on the second sweep of the pair
+        const double* const wt = hacc.data() + ((pair || odd) ? batch : 0);      // the pivot weights of the sweep just run
+        if (timing)
+            for (int z = 0; z < batch; ++z)
+                fprintf(stderr, "[apv gevd_large] sweep %d matrix %d: pivot weight / ||C||^2 %.2e\n", n_sweeps, z, wt[z] / norm2[z]);
+        converged = true;
         for (int z = 0; z < batch; ++z)
-            if (!(hacc[batch + z] <= (h->gl_tol2 > 0.0 ? h->gl_tol2 : kLargeTol2) * norm2[z])) converged = false;
+            if (!(wt[z] <= tol2 * norm2[z])) converged = false;
     }
+    double* const Cfin = (n_sweeps & 1) ? ws.C1 : ws.C0;
     const auto t_sweeps = std::chrono::steady_clock::now();
-    if (converged && h->gl_tol2 <= 0.0) ws.last_pairs = n_graphs;
+    if (converged && h->gl_tol2 <= 0.0) ws.last_sweeps = n_sweeps;
     if (!converged)
         for (int z = 0; z < batch; ++z) h_status[z] = 2;
-    // after an even number of sweeps the current matrix is back in C0
-    hipLaunchKernelGGL(rank_kernel, dim3(gx, 1, batch), dim3(TPB), 0, st, n, ld, ws.C0, d_lam, ws.order, ms, vs);
+    hipLaunchKernelGGL(rank_kernel, dim3(gx, 1, batch), dim3(TPB), 0, st, n, ld, Cfin, d_lam, ws.order, ms, vs);
     hipLaunchKernelGGL(gather_cols_kernel, dim3(gx, n, batch), dim3(TPB), 0, st, n, ld, ws.X, ws.order, d_U, ms, vs,
                        (size_t)n * n);
     if (d_r != nullptr && d_w != nullptr && V > 0) {
@@ -1019,7 +1037,7 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
     LCHK(hipGetLastError());
     if (timing)
         fprintf(stderr, "[apv gevd_large] n=%d batch=%d: factor+whiten %.3f ms, %d sweeps %.3f ms, sort+filter %.3f ms\n", n, batch,
-                std::chrono::duration<double, std::milli>(t_pre - t_begin).count(), 2 * n_graphs,
+                std::chrono::duration<double, std::milli>(t_pre - t_begin).count(), n_sweeps,
                 std::chrono::duration<double, std::milli>(t_sweeps - t_pre).count(),
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_sweeps).count());
 #undef LCHK

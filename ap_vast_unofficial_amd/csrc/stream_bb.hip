@@ -841,10 +841,14 @@ int apv_bb_process_signal(apv_handle* h, int32_t n_hops, const double* h_in_A, c
     const bool runA = s->zones & 1, runB = s->zones & 2;
     const int first = runA ? 0 : 1, nz = (runA && runB) ? 2 : 1;
     const size_t nn = (size_t)n * n;
-    // hops per group: as many as keep the block-round launches of the batch within ~3 workgroups per compute unit
-    const int tiles = ((n + 31) / 32) * ((n + 31) / 32 + 1) / 2;
+    // hops per group: eight, or as many as keep the group's matrices (two buffer sets here, the solver's workspace: ~19 arrays of
+    // n x n doubles per hop and zone) within 8 GB.  (Rounds 2-3 capped the group where the block-round launches of the batch
+    // reached ~3 workgroups per compute unit, which left n = 800 at one hop per group: but a round there is its pair-solve chain,
+    // not the chip -- tools/probes/large_batch_scaling.py: 7.5 / 4.9 / 4.1 ms per matrix at batch 2 / 4 / 8 -- and the whole
+    // signal went 21.2 -> 15.2 / 13.0 / 11.9 ms per hop with groups of 2 / 4 / 8, under the 16.7 ms a hop of audio lasts.)
     static const int forced = getenv("APV_BB_GROUP") ? atoi(getenv("APV_BB_GROUP")) : 0;       // A/B switch
-    int G = forced > 0 ? forced : 768 / (tiles * nz);
+    const size_t per_hop_bytes = (size_t)19 * nn * sizeof(double) * nz;
+    int G = forced > 0 ? forced : (int)(((size_t)8 << 30) / per_hop_bytes);
     G = G < 1 ? 1 : (G > 8 && forced <= 0 ? 8 : G);
     if (G > n_hops) G = n_hops;
     const size_t gz = (size_t)G * nz;

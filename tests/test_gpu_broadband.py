@@ -246,6 +246,36 @@ def test_broadband_process_signal_group_edges(golden, hops):
     assert np.abs(a.lambda_A - b.lambda_A).max() <= 1e-9 * np.abs(b.lambda_A).max()
 
 
+def test_broadband_process_signal_order_400(golden):
+    """The whole-signal call at an order whose block rounds fill the chip (n = 8 x 50 = 400, padded to 416: 91 tiles per matrix):
+    ten hops go as a group of eight (sixteen pairs in one batch) and one of two; samples and attributes as the hop loop leaves
+    them, and the last hop's eigenvalues against numpy on the statistics the object reports."""
+    from ap_vast_unofficial_amd.apvast import apvast
+    import scipy.linalg
+    rirs = golden("rirs_cfg1")
+    N, H, J, S, V = 512, 256, 50, 640, 12
+    def mk():
+        return apvast(N, rirs["rirA"], rirs["rirB"], J, 12, 2, 5, V, 1.0, S, hop_size=H, perceptual=False, mode="broadband", seed=5)
+    a, b = mk(), mk()
+    hops = 10
+    x = np.random.default_rng(77).standard_normal((2, hops * H))
+    whole = a.process_signal(x[0], x[1])
+    per_hop = [b.process_input_buffers(x[0, h * H:(h + 1) * H], x[1, h * H:(h + 1) * H]) for h in range(hops)]
+    for q in range(4):
+        for v in range(len(whole[q])):
+            ref = np.concatenate([per_hop[h][q][v] for h in range(hops)])
+            assert np.abs(whole[q][v] - ref).max() <= 1e-9 * max(np.abs(ref).max(), 1e-30), (q, v)
+    for name in ("lambda_A", "lambda_B", "r_A", "R_A_to_A", "R_A_to_B"):
+        va, vb = getattr(a, name), getattr(b, name)
+        assert np.abs(va - vb).max() <= 1e-9 * np.abs(vb).max(), name
+    n = 8 * J
+    lam_ref = scipy.linalg.eigh(a.R_A_to_A, a.R_A_to_B + 1e-7 * np.eye(n), eigvals_only=True)[::-1]
+    lam = np.diag(a.lambda_A) if a.lambda_A.ndim == 2 else a.lambda_A
+    assert np.abs(lam[:V] / lam_ref[:V] - 1).max() < 1e-8
+    a.close()
+    b.close()
+
+
 @pytest.mark.parametrize("perceptual", [False, True])
 def test_broadband_process_signal_matlab_dialect_and_weighting(golden, perceptual):
     """The batched whole-signal call in the MATLAB dialect (relative loading in place: the norms travel with the batch; rank list;
