@@ -24,6 +24,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <vector>
 
 namespace {
@@ -817,21 +818,48 @@ __global__ void __launch_bounds__(512) la_fused_kernel(int ld, int nb, LaRound q
         block_jacobi_round_body<5>(sm, rot, (int)blockIdx.x - np, ld, nb, q.round, 0, q.Cin, q.Cout, X, q.off_next, mat_stride, q.V, q.D);
 }
 
+// The captured sweeps of one batch size.  A stream alternates between sizes (a whole signal: groups of eight hops, a ragged last
+// group, then single hops again), and a capture is ~100 launches at n = 800: the workspace keeps the sets of the last few sizes.
+struct GevdLargeGraphs {
+    int batch = 0;
+    int last_sweeps = 0;     // sweeps the last converged call of this size took
+    // [0] two sweeps C0 -> C0 (the stretch nobody tests), [1] one sweep C0 -> C1, [2] one sweep C1 -> C0
+    hipGraph_t graph[3] = {nullptr, nullptr, nullptr};
+    hipGraphExec_t exec[3] = {nullptr, nullptr, nullptr};
+    void destroy() {
+        for (int g = 0; g < 3; ++g) {
+            if (exec[g]) (void)hipGraphExecDestroy(exec[g]);
+            if (graph[g]) (void)hipGraphDestroy(graph[g]);
+            exec[g] = nullptr;
+            graph[g] = nullptr;
+        }
+    }
+};
+
 struct GevdLargeWs {
-    int n = 0, batch = 0;
-    int last_sweeps = 0;     // sweeps the last converged call of this shape took
+    int n = 0, cap = 0;      // order, and the batch the buffers were sized for (smaller batches use their head)
     double *Bw = nullptr, *W = nullptr, *T1 = nullptr, *C0 = nullptr, *C1 = nullptr, *X = nullptr, *Li = nullptr;
     double *acc = nullptr, *coef = nullptr, *Vbuf = nullptr, *Vbuf2 = nullptr, *Dbuf = nullptr, *Dbuf2 = nullptr;
 
     int *flag = nullptr, *order = nullptr;
-    // captured sweeps: [0] two sweeps C0 -> C0 (the stretch nobody tests), [1] one sweep C0 -> C1, [2] one sweep C1 -> C0
-    hipGraph_t graph[3] = {nullptr, nullptr, nullptr};
-    hipGraphExec_t exec[3] = {nullptr, nullptr, nullptr};
-    void release() {
-        for (int g = 0; g < 3; ++g) {
-            if (exec[g]) (void)hipGraphExecDestroy(exec[g]);
-            if (graph[g]) (void)hipGraphDestroy(graph[g]);
+    std::vector<GevdLargeGraphs> sets;       // most recently used last; at most kMaxSets
+    static constexpr size_t kMaxSets = 4;
+    GevdLargeGraphs& set_for(int batch) {
+        for (size_t i = 0; i < sets.size(); ++i)
+            if (sets[i].batch == batch) {
+                std::rotate(sets.begin() + i, sets.begin() + i + 1, sets.end());
+                return sets.back();
+            }
+        if (sets.size() == kMaxSets) {
+            sets.front().destroy();
+            sets.erase(sets.begin());
         }
+        sets.emplace_back();
+        sets.back().batch = batch;
+        return sets.back();
+    }
+    void release() {
+        for (GevdLargeGraphs& g : sets) g.destroy();
         void* bufs[] = {Bw, W, T1, C0, C1, X, Li, acc, coef, Vbuf, Vbuf2, Dbuf, Dbuf2, flag, order};
 
         for (void* b : bufs)
@@ -873,10 +901,10 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
     // n = 800 two pairs 32.6 -> 24.9 ms per hop -- the split wins even where the chip is far from full.
     static const int split_env = getenv("APV_LARGE_SPLIT") ? atoi(getenv("APV_LARGE_SPLIT")) : -1;
     const bool split = split_env != 0;
-    if (ws.n != n || ws.batch != batch) {
+    if (ws.n != n || ws.cap < batch) {
         ws.release();
         ws.n = n;
-        ws.batch = batch;
+        ws.cap = batch;
         LCHK(hipMalloc((void**)&ws.Bw, mb)); LCHK(hipMalloc((void**)&ws.W, mb)); LCHK(hipMalloc((void**)&ws.T1, mb));
         LCHK(hipMalloc((void**)&ws.C0, mb)); LCHK(hipMalloc((void**)&ws.C1, mb)); LCHK(hipMalloc((void**)&ws.X, mb));
         LCHK(hipMalloc((void**)&ws.Li, sizeof(double) * BT * BT * nbk * batch));
@@ -890,6 +918,7 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
         LCHK(hipMalloc((void**)&ws.flag, sizeof(int) * batch));
         LCHK(hipMalloc((void**)&ws.order, sizeof(int) * vs * batch));
     }
+    GevdLargeGraphs& gs = ws.set_for(batch);
     // two sweeps: 2 (nb - 1) block rounds bring the ping-pong buffers back to where they started
     static const bool memset_node = getenv("APV_GRAPH_MEMSET") != nullptr;      // A/B switch: a memset node instead (see zero_f64_kernel)
     // look-ahead (see la_solve_kernel): APV_LARGE_LOOKAHEAD=0 is the A/B switch back to solve-then-update on one stream
@@ -944,18 +973,18 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
             }
     };
     static const bool no_graph = getenv("APV_NO_GRAPH") != nullptr;      // plain launches: rocprofv3 can then trace the rounds
-    if (!ws.exec[0] && !no_graph) {
+    if (!gs.exec[0] && !no_graph) {
         for (int g = 0; g < 3; ++g) {
             LCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
             sweeps(g == 0 ? 2 : 1, g == 2);
             // the capture is always closed, whatever was recorded: a stream left in capture mode fails every later call
-            const hipError_t ce = hipStreamEndCapture(st, &ws.graph[g]);
+            const hipError_t ce = hipStreamEndCapture(st, &gs.graph[g]);
             const hipError_t le = hipGetLastError();
-            if (ce != hipSuccess || le != hipSuccess || !ws.graph[g]) {
-                ws.release();
+            if (ce != hipSuccess || le != hipSuccess || !gs.graph[g]) {
+                gs.destroy();
                 return apv_fail(h, APV_ERR_HIP, std::string("capturing the Jacobi sweeps: ") + hipGetErrorString(ce != hipSuccess ? ce : le));
             }
-            LCHK(hipGraphInstantiate(&ws.exec[g], ws.graph[g], nullptr, nullptr, 0));
+            LCHK(hipGraphInstantiate(&gs.exec[g], gs.graph[g], nullptr, nullptr, 0));
         }
     }
     LCHK(hipMemsetAsync(ws.W, 0, mb, st));
@@ -1001,12 +1030,12 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
     // the sweeps the LAST call of this shape needed, all but the last three (an even count: they go as captured pairs) are
     // launched back to back before the first test; from there every sweep is tested, so that the sweep found to be the last one
     // IS the last one (tested in pairs, half the calls ran a sixteenth sweep after a fifteenth that had already met the bound).
-    const int untested = (ws.last_sweeps > 4 && h->gl_tol2 <= 0.0 && !timing) ? ((ws.last_sweeps - 3) & ~1) : 0;
+    const int untested = (gs.last_sweeps > 4 && h->gl_tol2 <= 0.0 && !timing) ? ((gs.last_sweeps - 3) & ~1) : 0;
     const double tol2 = h->gl_tol2 > 0.0 ? h->gl_tol2 : kLargeTol2;
     while (n_sweeps < max_sweeps && !converged) {
         const bool odd = n_sweeps & 1;
         const bool pair = !odd && (n_sweeps < untested || pairs_only);
-        if (ws.exec[0]) LCHK(hipGraphLaunch(ws.exec[pair ? 0 : (odd ? 2 : 1)], st));
+        if (gs.exec[0]) LCHK(hipGraphLaunch(gs.exec[pair ? 0 : (odd ? 2 : 1)], st));
         else sweeps(pair ? 2 : 1, odd);
         n_sweeps += pair ? 2 : 1;
         if (n_sweeps <= untested && n_sweeps < max_sweeps) continue;
@@ -1022,7 +1051,7 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
     }
     double* const Cfin = (n_sweeps & 1) ? ws.C1 : ws.C0;
     const auto t_sweeps = std::chrono::steady_clock::now();
-    if (converged && h->gl_tol2 <= 0.0) ws.last_sweeps = n_sweeps;
+    if (converged && h->gl_tol2 <= 0.0) gs.last_sweeps = n_sweeps;
     if (!converged)
         for (int z = 0; z < batch; ++z) h_status[z] = 2;
     hipLaunchKernelGGL(rank_kernel, dim3(gx, 1, batch), dim3(TPB), 0, st, n, ld, Cfin, d_lam, ws.order, ms, vs);

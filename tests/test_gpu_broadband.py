@@ -244,6 +244,18 @@ def test_broadband_process_signal_group_edges(golden, hops):
             ref = np.concatenate([per_hop[h][q][v] for h in range(hops)])
             assert np.abs(whole[q][v] - ref).max() <= 1e-10 * max(np.abs(ref).max(), 1e-30), (q, v)
     assert np.abs(a.lambda_A - b.lambda_A).max() <= 1e-9 * np.abs(b.lambda_A).max()
+    # the same handle goes on: a single hop, then another signal (the solver keeps the captured sweeps of each batch size it has
+    # seen -- sixteen pairs, a ragged group, two -- and must come back to each with the right buffers)
+    y = np.random.default_rng(90 + hops).standard_normal((2, 10 * H))
+    one_a = a.process_input_buffers(y[0, :H], y[1, :H])
+    one_b = b.process_input_buffers(y[0, :H], y[1, :H])
+    whole = a.process_signal(y[0, H:], y[1, H:])
+    per_hop = [b.process_input_buffers(y[0, h * H:(h + 1) * H], y[1, h * H:(h + 1) * H]) for h in range(1, 10)]
+    for q in range(4):
+        for v in range(len(whole[q])):
+            assert np.abs(one_a[q][v] - one_b[q][v]).max() <= 1e-10 * max(np.abs(one_b[q][v]).max(), 1e-30), (q, v)
+            ref = np.concatenate([per_hop[h][q][v] for h in range(9)])
+            assert np.abs(whole[q][v] - ref).max() <= 1e-10 * max(np.abs(ref).max(), 1e-30), (q, v)
 
 
 def test_broadband_process_signal_order_400(golden):
