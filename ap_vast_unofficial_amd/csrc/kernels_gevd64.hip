@@ -160,8 +160,15 @@ __device__ __forceinline__ int front64(const GevdParams& p, const Sh& sh, bool z
         // of the chunk (whole lines, each slab element read from memory ONCE) while the matrix cores work on the chunk before, and
         // the sixteen waves take their operands from LDS.  (Round 2 had every wave fetch its own operands from L2: each element
         // eight times, in 128-byte pieces, and the loop waited for memory M / 16 times: 85 us per bin against 28 us of MFMA time.)
-        // Per k-step THREE real products: Re R = sum xr (x) xr + xi (x) xi, and P = sum xr (x) xi with Im R = P - P^T, the transpose
-        // taken through the LDS tile of the mirrored wave when R is written (as in the order-16 kernel).
+        // R is Hermitian: only the ten tiles on and above the diagonal are formed (round 3; sixteen before).  Waves 0-3 take the
+        // diagonal tiles of BOTH matrices, three real products each per k-step (Re R = sum xr (x) xr + xi (x) xi, P = sum xr (x) xi,
+        // Im R = P - P^T inside the tile); waves 4-15 one tile above the diagonal of ONE matrix, four products.  A SIMD hosts one
+        // wave of the first kind and three of the second: 18 matrix instructions per k-step where the full matrices took 24 --
+        // the stage is bound by the f64 matrix pipe (65 cycles an instruction, nothing co-issues with it).
+        const bool dwave = wave < 4;
+        const int oj = dwave ? 0 : wave - 4, om = oj >= 6 ? 1 : 0, ou = oj - 6 * om;        // off-diagonal job: matrix, tile 0..5
+        const int ci = dwave ? wave : (ou >= 3) + (ou >= 5);                                  // (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)
+        const int cj_ = dwave ? wave : (ou < 3 ? ou + 1 : (ou < 5 ? ou - 1 : 3));
         const XT* XBk = pXB + (size_t)k * M * N64;
         const XT* XDk = pXD + (size_t)k * M * N64;
         const XT* dvk = pd + (size_t)k * M;
@@ -207,19 +214,32 @@ __device__ __forceinline__ int front64(const GevdParams& p, const Sh& sh, bool z
             if (c + 1 < n_chunks) fetch(c + 1);                             // in flight while the MFMAs below run
             const XT* cb = sX + (size_t)buf * 2 * CHUNK_ELEMS;
             const XT* cd = cb + CHUNK_ELEMS;
+            if (dwave) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int row = (4 * u + kq) * N64;
-                const XT ba = cb[row + 16 * ti + il], bb_ = cb[row + 16 * tj + il];
-                const XT da = cd[row + 16 * ti + il], db = cd[row + 16 * tj + il];
-                double ar = ba.x, ai = ba.y, br = bb_.x, bi = bb_.y;
-                bre = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, bre, 0, 0, 0);
-                bre = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bi, bre, 0, 0, 0);
-                bp = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, bp, 0, 0, 0);          // P = sum xr (x) xi
-                ar = da.x; ai = da.y; br = db.x; bi = db.y;
-                dre = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, dre, 0, 0, 0);
-                dre = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bi, dre, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, dp, 0, 0, 0);
+                for (int u = 0; u < 4; ++u) {
+                    const int row = (4 * u + kq) * N64;
+                    const XT ba = cb[row + 16 * ci + il], da = cd[row + 16 * ci + il];
+                    double ar = ba.x, ai = ba.y;
+                    bre = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, ar, bre, 0, 0, 0);
+                    bre = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, ai, bre, 0, 0, 0);
+                    bp = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, ai, bp, 0, 0, 0);          // P = sum xr (x) xi
+                    ar = da.x; ai = da.y;
+                    dre = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, ar, dre, 0, 0, 0);
+                    dre = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, ai, dre, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, ai, dp, 0, 0, 0);
+                }
+            } else {
+                const XT* cs = om ? cd : cb;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int row = (4 * u + kq) * N64;
+                    const XT xa = cs[row + 16 * ci + il], xb = cs[row + 16 * cj_ + il];
+                    const double ar = xa.x, ai = xa.y, br = xb.x, bi = xb.y;
+                    bre = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, bre, 0, 0, 0);
+                    bre = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bi, bre, 0, 0, 0);
+                    bp = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, bp, 0, 0, 0);          // Im R = xr (x) xi - xi (x) xr
+                    bp = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, br, bp, 0, 0, 0);
+                }
             }
             // r = X_B^H d: wave w takes control point w of the chunk, lane l loudspeaker l; the sixteen partial sums meet below
             {
@@ -247,24 +267,38 @@ __device__ __forceinline__ int front64(const GevdParams& p, const Sh& sh, bool z
             }
             __syncthreads();
         }
-        // R with Im R = P - P^T: P to LDS first (imaginary slot), the transposed element read back from the mirrored tile
+        // Diagonal tiles: Im R = P - P^T, P to LDS first (imaginary slot), the transposed element read back from the same tile.
+        // The other waves hold a finished tile above the diagonal and write it twice: as it is, and conjugated to its mirror.
+        if (dwave) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            RA[(16 * ti + kq + 4 * t) * LDD + 16 * tj + il] = mk<double>(bre[t], bp[t]);
-            RB[(16 * ti + kq + 4 * t) * LDD + 16 * tj + il] = mk<double>(dre[t], dp[t]);
+            for (int t = 0; t < 4; ++t) {
+                RA[(16 * ci + kq + 4 * t) * LDD + 16 * ci + il] = mk<double>(bre[t], bp[t]);
+                RB[(16 * ci + kq + 4 * t) * LDD + 16 * ci + il] = mk<double>(dre[t], dp[t]);
+            }
+        } else {
+            C128* const R = om ? RB : RA;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                R[(16 * ci + kq + 4 * t) * LDD + 16 * cj_ + il] = mk<double>(bre[t], bp[t]);
+                R[(16 * cj_ + il) * LDD + 16 * ci + kq + 4 * t] = mk<double>(bre[t], -bp[t]);
+            }
         }
         __syncthreads();
-        double pbt[4], pdt[4];
+        double pbt[4] = {0, 0, 0, 0}, pdt[4] = {0, 0, 0, 0};
+        if (dwave) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            pbt[t] = RA[(16 * tj + il) * LDD + 16 * ti + kq + 4 * t].y;                   // P[col][row]
-            pdt[t] = RB[(16 * tj + il) * LDD + 16 * ti + kq + 4 * t].y;
+            for (int t = 0; t < 4; ++t) {
+                pbt[t] = RA[(16 * ci + il) * LDD + 16 * ci + kq + 4 * t].y;                   // P[col][row]
+                pdt[t] = RB[(16 * ci + il) * LDD + 16 * ci + kq + 4 * t].y;
+            }
         }
         __syncthreads();
+        if (dwave) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            RA[(16 * ti + kq + 4 * t) * LDD + 16 * tj + il].y = bp[t] - pbt[t];
-            RB[(16 * ti + kq + 4 * t) * LDD + 16 * tj + il].y = dp[t] - pdt[t];
+            for (int t = 0; t < 4; ++t) {
+                RA[(16 * ci + kq + 4 * t) * LDD + 16 * ci + il].y = bp[t] - pbt[t];
+                RB[(16 * ci + kq + 4 * t) * LDD + 16 * ci + il].y = dp[t] - pdt[t];
+            }
         }
     } else {
         const C128* gRB = reinterpret_cast<const C128*>(p.RB) + (size_t)k * N64 * N64;

@@ -9,7 +9,7 @@ def main():
     rng = np.random.default_rng(3)
     eng = Engine(1, 4, 4)
     for n in (256, 800):
-        for batch in (1, 2, 4, 8):
+        for batch in (1, 2, 4, 8, 16):
             Y = rng.standard_normal((2, batch, n, 2 * n))
             A = Y[0] @ Y[0].transpose(0, 2, 1)
             B = Y[1] @ Y[1].transpose(0, 2, 1)
