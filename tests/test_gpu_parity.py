@@ -263,7 +263,7 @@ def test_jdiag_large_broadband_golden(Engine, golden):
     print(f"jdiag_large n=256: {dt * 1e3:.1f} ms")
 
 
-@pytest.mark.parametrize("n,batch", [(65, 1), (100, 2), (257, 1), (800, 1)])
+@pytest.mark.parametrize("n,batch", [(65, 1), (100, 2), (257, 1), (800, 1), (2048, 1)])      # 2048: the largest order the entry point takes
 def test_jdiag_large_vs_oracle(Engine, n, batch):
     rng = np.random.default_rng(n)
     Y = rng.standard_normal((batch, 3 * n, n))
@@ -314,7 +314,7 @@ def test_jdiag_complex_beyond_64_golden(golden, tag):
         assert np.linalg.norm(w - g["w_" + tag][t]) < 1e-7 * np.linalg.norm(g["w_" + tag][t])
 
 
-@pytest.mark.parametrize("n,batch", [(65, 2), (200, 1), (512, 1)])
+@pytest.mark.parametrize("n,batch", [(65, 2), (200, 1), (512, 1), (1024, 1)])       # 1024: the largest (its embedding is of order 2048)
 def test_jdiag_large_complex_vs_oracle(Engine, n, batch):
     rng = np.random.default_rng(n)
     Y = rng.standard_normal((batch, 2 * n, n)) + 1j * rng.standard_normal((batch, 2 * n, n))
