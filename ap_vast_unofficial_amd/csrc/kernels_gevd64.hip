@@ -470,13 +470,18 @@ __device__ __forceinline__ int front64(const GevdParams& p, const Sh& sh, bool z
 #pragma unroll
         for (int t = 0; t < 4; ++t) RA[(16 * ti + kq + 4 * t) * LDD + 16 * tj + il] = acc[t];
         __syncthreads();
+        // The length of this product's k-range goes with the COLUMN tile, and a SIMD hosts the waves of one value of wave & 3: with
+        // the kernel's usual (ti, tj) = (wave >> 2, wave & 3) one SIMD would run four full-length tiles and another four of a quarter
+        // the length.  Here the wave takes tile (wave & 3, wave >> 2): every SIMD gets one tile of each length (16 -> 10 k-blocks on
+        // the busiest matrix pipe).
+        const int ti2 = wave & 3, tj2 = wave >> 2;
         cmm64_tile([&](int i, int kk) { return RA[i * LDD + kk]; },
-                   [&](int kk, int j) { return kk <= j ? cj(Wel(j, kk)) : mk<double>(0, 0); }, ti, tj, lane, 0, 16 * (tj + 1),
+                   [&](int kk, int j) { return kk <= j ? cj(Wel(j, kk)) : mk<double>(0, 0); }, ti2, tj2, lane, 0, 16 * (tj2 + 1),
                    acc);                                                                                          // C = T W^H
         double nrm = 0;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int row = 16 * ti + kq + 4 * t, col = 16 * tj + il;
+            const int row = 16 * ti2 + kq + 4 * t, col = 16 * tj2 + il;
             if (row == col) acc[t].y = 0;
             nrm += acc[t].x * acc[t].x + acc[t].y * acc[t].y;
             gC[row * N64 + col] = acc[t];
@@ -487,7 +492,7 @@ __device__ __forceinline__ int front64(const GevdParams& p, const Sh& sh, bool z
         // float32 working copy: C scaled to ||C||_F ~ 1 (and V = I beside it)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int row = 16 * ti + kq + 4 * t, col = 16 * tj + il;
+            const int row = 16 * ti2 + kq + 4 * t, col = 16 * tj2 + il;
             cf_dst[row * cf_ld + col] = mk<float>((float)(acc[t].x * scl), (float)(acc[t].y * scl));
             if (vf_dst != nullptr) vf_dst[row * cf_ld + col] = mk<float>(row == col ? 1.f : 0.f, 0.f);
         }
