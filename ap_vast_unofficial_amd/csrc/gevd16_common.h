@@ -613,14 +613,36 @@ template <typename TS, int LDA, int LDF>
 __device__ __forceinline__ void chol16_f32(const Cx<TS>* sA, int sexp, float delta, Cx<float>* fG, Cx<float> (*fcol)[16],
                                            int lane) {
     const int i = lane >> 2, jq = lane & 3;
+    // Symmetric permutation first: the indices in ASCENDING order of the diagonal, so that the reversed elimination below takes
+    // the largest diagonal element first (round 3; NumPy model of the sweeps, tools/probes/onesided_schedule_model.py: 4.58 ->
+    // 4.35 sweeps on the bench workload; pivoting on the CURRENT diagonal at every step gives 4.12 but costs more than it
+    // saves: a wave-wide argmax per step and no statically known spent column groups).  Row i counts the diagonal elements
+    // below its own, a quarter per lane; G = P U keeps its rows at their own indices, so nothing downstream sees the order.
+    int* const sperm = reinterpret_cast<int*>(&fcol[1][0]);           // 16 ints; the staging buffer is first written in step 1
+    {
+        const TS di = sA[i * LDA + i].x;
+        int below = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int j = jq + 4 * t;
+            const TS dj = sA[j * LDA + j].x;
+            below += (dj < di || (dj == di && j < i)) ? 1 : 0;
+        }
+        below += __builtin_amdgcn_update_dpp(0, below, 0xB1, 0xf, 0xf, true);       // over the four lanes of the row
+        below += __builtin_amdgcn_update_dpp(0, below, 0x4E, 0xf, 0xf, true);
+        if (jq == 0) sperm[below] = i;
+    }
+    wsync();
+    const int pi = sperm[15 - i];                                     // the index that sits at (reversed) position i
     f2v brow[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int j = jq + 4 * t;
-        const Cx<TS> v = sA[(15 - i) * LDA + (15 - j)];           // the matrix with its indices reversed: see fG below
+        const Cx<TS> v = sA[pi * LDA + sperm[15 - j]];             // the matrix sorted and with its indices reversed: see fG below
         brow[t] = (f2v){scale_to_f32(v.x, sexp), scale_to_f32(v.y, sexp)};
         if (j == i) brow[t] = (f2v){brow[t].x + delta, 0.f};
     }
+    wsync();                                                           // sperm is read: the staging buffer may be written
     // The outer-product update runs on the WHOLE Hermitian matrix, without the triangle tests: rows and columns already
     // eliminated only cancel to rounding level and are never read again, and a wave-wide unconditional update is cheaper than
     // its predicates.  The column goes through LDS permuted (element j = jq + 4t at jq*4 + t) so that the four partners of a
@@ -637,7 +659,7 @@ __device__ __forceinline__ void chol16_f32(const Cx<TS>* sA, int sexp, float del
             Cx<float> g = mk<float>(lic.x * inv, lic.y * inv);
             if (i == kk) g = mk<float>(dkk * inv, 0.f);
             if (i < kk) g = mk<float>(0.f, 0.f);
-            fG[(15 - i) * LDF + (15 - kk)] = g;
+            fG[pi * LDF + (15 - kk)] = g;
         }
         const f2v li2 = {lic.x * inv2, lic.y * inv2};
         const f4v* const part = reinterpret_cast<const f4v*>(&fcol[buf][jq * 4]);

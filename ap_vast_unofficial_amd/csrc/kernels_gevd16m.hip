@@ -241,7 +241,7 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p, const int k, c
                     f0t = fG[(2 * va) * LDF + vb]; f0b = fG[(2 * va) * LDF + 8 + vb];
                     f1t = fG[(2 * va + 1) * LDF + vb]; f1b = fG[(2 * va + 1) * LDF + 8 + vb];
                     float n2t, n2b;
-                    fs = jacobi16_onesided<LDF>(f0t, f0b, f1t, f1b, lane, (dstop >= 20 && dstop <= 27) ? __builtin_powif(10.f, 20 - dstop) : kPresolveTol2, (float)normS2, Prec<float>::max_sweeps, fconv, n2t, n2b, fG);
+                    fs = jacobi16_onesided<LDF>(f0t, f0b, f1t, f1b, lane, (dstop >= 20 && dstop <= 27) ? __builtin_powif(10.f, 20 - dstop) : (dstop >= 30 && dstop <= 49) ? 0.5e-6f * (float)(dstop - 29) : kPresolveTol2, (float)normS2, Prec<float>::max_sweeps, fconv, n2t, n2b, fG);
                     trust = fconv && spectrum_ok(n2t, n2b);
                     stamp(5);
                     if (dstop == 13) {
