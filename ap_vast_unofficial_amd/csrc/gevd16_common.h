@@ -633,12 +633,13 @@ __device__ __forceinline__ void chol16_f32(const Cx<TS>* sA, int sexp, float del
         if (jq == 0) sperm[below] = i;
     }
     wsync();
-    const int pi = sperm[15 - i];                                     // the index that sits at (reversed) position i
+    // (& 15: a NaN on the diagonal leaves slots of sperm unwritten -- the result is NaN either way, the indices stay inside the matrix)
+    const int pi = sperm[15 - i] & 15;                                // the index that sits at (reversed) position i
     f2v brow[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int j = jq + 4 * t;
-        const Cx<TS> v = sA[pi * LDA + sperm[15 - j]];             // the matrix sorted and with its indices reversed: see fG below
+        const Cx<TS> v = sA[pi * LDA + (sperm[15 - j] & 15)];             // the matrix sorted and with its indices reversed: see fG below
         brow[t] = (f2v){scale_to_f32(v.x, sexp), scale_to_f32(v.y, sexp)};
         if (j == i) brow[t] = (f2v){brow[t].x + delta, 0.f};
     }

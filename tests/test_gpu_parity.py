@@ -506,6 +506,29 @@ def test_degenerate_spectra(Engine, dtype):
     assert w_err(w[2:, :], w_ref[2:, :]) < TOL[dtype]["w"] * 10
 
 
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_nan_bin_is_contained(Engine, dtype):
+    """A NaN in one bin's slab (a dead sensor, an overflow upstream) must stay in that bin: the launch completes, the other
+    bins come out as the oracle's, and the poisoned bin reports itself (status != 0 or non-finite filters) instead of
+    returning finite numbers.  (The float factor's index permutation is built from comparisons of the diagonal: with NaN
+    they are all false, and the indices must still stay inside the matrix.)"""
+    L, M, K = 16, 32, 8
+    rng = np.random.default_rng(91)
+    XB, XD, d = cn(rng, K, M, L), cn(rng, K, M, L), cn(rng, K, M)
+    XB[3, 5, 7] = np.nan
+    XD[6, 0, :] = np.nan
+    eng = Engine(K, L, M, ranks=(1, 8, 16), mu=1.0, compute_dtype=dtype)
+    w, lam, status = eng.update(XB, XD, d, raise_on_status=False)
+    eng.close()
+    good = [k for k in range(K) if k not in (3, 6)]
+    w_ref, lam_ref, _ = subband.update(XB[good], XD[good], d[good], 1.0, [1, 8, 16])
+    assert not status[good].any()
+    assert w_err(w[good], w_ref) < TOL[dtype]["w"] * 10
+    assert np.abs(lam[good] / lam_ref - 1).max() < TOL[dtype]["lam"] * 10
+    for k in (3, 6):
+        assert status[k] != 0 or not np.isfinite(w[k]).all() or not np.isfinite(lam[k]).all(), k
+
+
 @pytest.mark.parametrize("scale", [1e-8, 1e8])
 def test_input_scale_robustness(Engine, scale):
     """The float32 pre-solve works on a copy of C brought to unit norm by a power of two: inputs far from unit scale
