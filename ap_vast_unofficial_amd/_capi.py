@@ -536,7 +536,7 @@ class Engine:
         return out
 
     def bb_process_signal(self, in_A, in_B, n_out):
-        """n_hops hops in one call: (n_hops, n_out, H) float64; the joint diagonalisations of up to 8 consecutive hops are one batch."""
+        """n_hops hops in one call: (n_hops, n_out, H) float64; the joint diagonalisations of up to 16 consecutive hops are one batch."""
         in_A = np.ascontiguousarray(in_A, dtype=np.float64).ravel()
         in_B = np.ascontiguousarray(in_B, dtype=np.float64).ravel()
         H = self.cfg.hop_size

@@ -299,7 +299,7 @@ class apvast:
         if input_A.size == 0:
             raise RuntimeError("invalid input size")
         if self.mode == "broadband":
-            # the joint diagonalisations of up to 8 consecutive hops are solved as one batch (apv_bb_process_signal)
+            # the joint diagonalisations of up to 16 consecutive hops are solved as one batch (apv_bb_process_signal)
             blocks = self._eng.bb_process_signal(input_A, input_B, self._n_out)          # (hops, n_out, H)
             L, V = self.number_of_srcs, len(self._ranks)
             sig = np.ascontiguousarray(blocks.transpose(1, 0, 2)).reshape(self._n_out, -1)      # (n_out, samples)

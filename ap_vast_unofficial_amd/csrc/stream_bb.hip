@@ -841,15 +841,23 @@ int apv_bb_process_signal(apv_handle* h, int32_t n_hops, const double* h_in_A, c
     const bool runA = s->zones & 1, runB = s->zones & 2;
     const int first = runA ? 0 : 1, nz = (runA && runB) ? 2 : 1;
     const size_t nn = (size_t)n * n;
-    // hops per group: eight, or as many as keep the group's matrices (two buffer sets here, the solver's workspace: ~19 arrays of
+    // hops per group: eight or sixteen, or as many as keep the group's matrices (two buffer sets here, the solver's workspace: ~19 arrays of
     // n x n doubles per hop and zone) within 8 GB.  (Rounds 2-3 capped the group where the block-round launches of the batch
     // reached ~3 workgroups per compute unit, which left n = 800 at one hop per group: but a round there is its pair-solve chain,
     // not the chip -- tools/probes/large_batch_scaling.py: 7.5 / 4.9 / 4.1 ms per matrix at batch 2 / 4 / 8 -- and the whole
     // signal went 21.2 -> 15.2 / 13.0 / 11.9 ms per hop with groups of 2 / 4 / 8, under the 16.7 ms a hop of audio lasts.)
     static const int forced = getenv("APV_BB_GROUP") ? atoi(getenv("APV_BB_GROUP")) : 0;       // A/B switch
     const size_t per_hop_bytes = (size_t)19 * nn * sizeof(double) * nz;
-    int G = forced > 0 ? forced : (int)(((size_t)8 << 30) / per_hop_bytes);
-    G = G < 1 ? 1 : (G > 8 && forced <= 0 ? 8 : G);
+    // sixteen while the group stays within 1 GiB (cfg1: 0.78 / 0.68 / 0.61 / 0.62 / 0.61 ms per hop with 8 / 12 / 16 / 24 / 32 hops
+    // a group), eight beyond (n = 800: 11.0 ms per hop with eight, 12.0 with sixteen: 3 GB of matrices no longer sit in the
+    // Infinity Cache and the batch sweeps until its slowest member is done), fewer only to stay within 8 GiB
+    int G;
+    if (forced > 0) G = forced;
+    else if (16 * per_hop_bytes <= ((size_t)1 << 30)) G = 16;
+    else {
+        G = (int)(((size_t)8 << 30) / per_hop_bytes);
+        G = G < 1 ? 1 : (G > 8 ? 8 : G);
+    }
     if (G > n_hops) G = n_hops;
     const size_t gz = (size_t)G * nz;
     // sizes of one buffer set

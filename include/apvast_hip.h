@@ -255,7 +255,7 @@ int  apv_bb_init(apv_handle* h, int32_t rir_len, const double* h_rir_A, const do
 int  apv_bb_process_block(apv_handle* h, const double* h_in_A, const double* h_in_B, double* h_out);
 /* n_hops consecutive hops in one call: h_in_A / h_in_B hold n_hops * H samples, h_out is [n_hops][n_out][H] with the channel
  * order of apv_bb_process_block.  A hop's statistics never depend on an earlier hop's filters, so the joint diagonalisations
- * of up to 8 consecutive hops are solved as ONE batch (the dependent launches of a single n = 256 pair leave most of the chip
+ * of up to 16 consecutive hops (8 at large orders) are solved as ONE batch (the dependent launches of a single n = 256 pair leave most of the chip
  * idle); rings, overlap buffers and outputs advance hop by hop as in the per-hop call.  Outputs equal those of n_hops calls
  * of apv_bb_process_block up to the rounding of the eigen-iteration (a batch sweeps until its slowest member has converged).
  *                        replaces the hop loop of main.m:52-62 / make_python_test.m:44-51 around apvast.py:153-165 */

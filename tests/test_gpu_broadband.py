@@ -109,8 +109,8 @@ def test_broadband_perceptual_vs_oracle(golden):
 def test_broadband_process_signal_vs_reference_and_hop_loop(golden, zones):
     """apv_bb_process_signal: the hop loop of make_python_test.m:44-51 in one call, the joint diagonalisations of consecutive
     hops solved as one batch.  (1) G1's eight hops through it: the reference's outputs at 1e-9, the last hop's attributes
-    (lambda, w, r, R) as after the per-hop calls; (2) against this library's own hop loop on 11 hops (a group of 8 and a
-    ragged one of 3), one zone or two: outputs 1e-10 of the largest sample, every state buffer equal afterwards."""
+    (lambda, w, r, R) as after the per-hop calls; (2) against this library's own hop loop on 11 hops (one ragged group; the
+    group edges have a test of their own below), one zone or two: outputs 1e-10 of the largest sample, every state buffer equal afterwards."""
     g = golden("g1_broadband_cfg1")
     rirs = golden("rirs_cfg1")
     H = 128
@@ -229,9 +229,10 @@ def test_broadband_matlab_dialect_vs_oracle(golden, perceptual):
     ap.close()
 
 
-@pytest.mark.parametrize("hops", [1, 17])
+@pytest.mark.parametrize("hops", [1, 17, 35])
 def test_broadband_process_signal_group_edges(golden, hops):
-    """One hop (a group of one) and seventeen (two full groups of eight and a group of one) through the batched call."""
+    """One hop (a group of one), seventeen (a full group of sixteen and a group of one) and thirty-five (two full groups, whose
+    front and back halves overlap on two streams, and a ragged one of three) through the batched call."""
     g = golden("g1_broadband_cfg1")
     rirs = golden("rirs_cfg1")
     H = 128
@@ -260,7 +261,7 @@ def test_broadband_process_signal_group_edges(golden, hops):
 
 def test_broadband_process_signal_order_400(golden):
     """The whole-signal call at an order whose block rounds fill the chip (n = 8 x 50 = 400, padded to 416: 91 tiles per matrix):
-    ten hops go as a group of eight (sixteen pairs in one batch) and one of two; samples and attributes as the hop loop leaves
+    ten hops go as one group (twenty pairs in one batch); samples and attributes as the hop loop leaves
     them, and the last hop's eigenvalues against numpy on the statistics the object reports."""
     from ap_vast_unofficial_amd.apvast import apvast
     import scipy.linalg
