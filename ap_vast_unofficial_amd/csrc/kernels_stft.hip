@@ -10,6 +10,7 @@
 // (mixed radix 4/2/3/5/7, so the reference's own N = 1600 works) plus the even/odd split step.  Twiddles and
 // the window come from tables computed once per (device, N, dtype) on the host in double precision.
 #include "apv_internal.h"
+#include <cstdlib>
 
 #include <cmath>
 #include <map>
@@ -30,10 +31,15 @@ struct FftPlan {
     int radix[MAX_STAGES];
     int inplace;           // every stage is radix 4 or 2 and short enough for stockham_stage_inplace: ONE LDS buffer of Nh
     int max_it;            // butterflies per thread of the widest in-place stage (kernels are instantiated for 1 and for INPLACE_MAX_IT)
+    int debug;             // timing aids of the analysis transforms (APV_STFT_DEBUG; results are wrong): 1 no spectrum stores, 2 no sample loads, 4 no stages
 };
 constexpr int INPLACE_MAX_IT = 4;      // butterflies per thread and stage the in-place form holds in registers
 
-template <typename T> struct C2 { T x, y; };
+// 16-byte alignment for the double-precision pair: the compiler then moves it as ONE ds_read_b128 / ds_write_b128 / dwordx4
+// (4 LDS cycles per wave-instruction where the two ds_read2_b64 halves of an 8-byte-aligned pair cost 16, and sixteen lanes a
+// group at a 16-byte stride are a 2-way bank conflict on top: SQ_LDS_BANK_CONFLICT was 61 % of the LDS-active cycles of every
+// transform kernel, profiles/r03/analysis_counters.md)
+template <typename T> struct alignas(2 * sizeof(T)) C2 { T x, y; };
 template <typename T> __device__ __forceinline__ C2<T> c2(T a, T b) { C2<T> r; r.x = a; r.y = b; return r; }
 template <typename T> __device__ __forceinline__ C2<T> cadd(C2<T> a, C2<T> b) { return c2<T>(a.x + b.x, a.y + b.y); }
 template <typename T> __device__ __forceinline__ C2<T> csub(C2<T> a, C2<T> b) { return c2<T>(a.x - b.x, a.y - b.y); }
@@ -245,7 +251,7 @@ template <typename T, int MI = INPLACE_MAX_IT>
 __device__ __forceinline__ void stft_analysis_body(const FftPlan& plan, const T* __restrict__ xin, int in_len, int ring_off,
                                                    int use_win, C2<T>* __restrict__ out, long stride_k,
                                                    const C2<T>* __restrict__ tw, const T* __restrict__ win) {
-    extern __shared__ unsigned char smem_raw[];
+    extern __shared__ __align__(16) unsigned char smem_raw[];
     C2<T>* za = reinterpret_cast<C2<T>*>(smem_raw);
     const int N = plan.N, Nh = plan.Nh;
     C2<T>* zb = za + Nh;
@@ -254,7 +260,14 @@ __device__ __forceinline__ void stft_analysis_body(const FftPlan& plan, const T*
         int i0 = 2 * n + ring_off, i1 = i0 + 1;
         if (i0 >= N) i0 -= N;
         if (i1 >= N) i1 -= N;
-        T v0 = (2 * n < in_len) ? xin[i0] : (T)0, v1 = (2 * n + 1 < in_len) ? xin[i1] : (T)0;
+        T v0, v1;
+        if (plan.debug & 2) {
+            v0 = (T)i0;
+            v1 = (T)i1;
+        } else {
+            v0 = (2 * n < in_len) ? xin[i0] : (T)0;
+            v1 = (2 * n + 1 < in_len) ? xin[i1] : (T)0;
+        }
         if (use_win) {
             v0 *= win[2 * n];
             v1 *= win[2 * n + 1];
@@ -270,7 +283,7 @@ template <typename T, int MI>
 __device__ __forceinline__ void rfft_from_lds(const FftPlan& plan, C2<T>* za, C2<T>* zb, C2<T>* __restrict__ out, long stride_k,
                                               const C2<T>* __restrict__ tw) {
     const int Nh = plan.Nh, tid = threadIdx.x;
-    const C2<T>* z = fft_forward<T, MI>(plan, za, zb, tw);
+    const C2<T>* z = (plan.debug & 4) ? za : fft_forward<T, MI>(plan, za, zb, tw);
     // even/odd split: X[k] = E[k] + e^{-2 pi i k/N} O[k]
     // (unrolling this loop and the input loop above so that all of a thread's loads go out together was tried in round 3 after the
     // order-16 kernel's slab loads: 65 -> 97 VGPRs and no change in the kernel's 437 us per chunk -- the transforms of a chunk move
@@ -283,7 +296,7 @@ __device__ __forceinline__ void rfft_from_lds(const FftPlan& plan, C2<T>* za, C2
         const C2<T> dm = c2<T>((T)0.5 * (a.x - b.x), (T)0.5 * (a.y - b.y));
         const C2<T> o = c2<T>(dm.y, -dm.x);                              // -i * dm
         const C2<T> ow = cmul(o, tw[k]);                                 // tw[Nh] = -1
-        out[(size_t)k * stride_k] = c2<T>(e.x + ow.x, e.y + ow.y);
+        if (!(plan.debug & 1) || e.x == (T)12345.678) out[(size_t)k * stride_k] = c2<T>(e.x + ow.x, e.y + ow.y);
     }
 }
 
@@ -341,7 +354,7 @@ __global__ void __launch_bounds__(STFT_TPB) istft_ola_kernel(FftPlan plan, int H
                                                              long stride_c, long stride_k, T* __restrict__ overlap,
                                                              T* __restrict__ out, const C2<T>* __restrict__ tw,
                                                              const T* __restrict__ win, int out_group) {
-    extern __shared__ unsigned char smem_raw[];
+    extern __shared__ __align__(16) unsigned char smem_raw[];
     C2<T>* za = reinterpret_cast<C2<T>*>(smem_raw);
     const int N = plan.N, Nh = plan.Nh;
     C2<T>* zb = za + Nh;
@@ -454,7 +467,7 @@ template <typename T>
 __global__ void __launch_bounds__(STFT_TPB) fir_chunk_spectra_kernel(FftPlan plan, int P, int H, const T* __restrict__ hist0,
                                                                      const T* __restrict__ hist1, const T* __restrict__ pin,
                                                                      C2<T>* __restrict__ spec, const C2<T>* __restrict__ tw) {
-    extern __shared__ unsigned char smem_raw[];
+    extern __shared__ __align__(16) unsigned char smem_raw[];
     C2<T>* za = reinterpret_cast<C2<T>*>(smem_raw);
     C2<T>* zb = za + plan.Nh;
     const int g = blockIdx.x, hop = blockIdx.y, keep = P - 1, len = keep + H;
@@ -477,7 +490,7 @@ __global__ void __launch_bounds__(STFT_TPB) fir_chunk_spectra_kernel(FftPlan pla
 template <typename T, int MI>
 __global__ void __launch_bounds__(STFT_TPB) fir_fft_kernel(FftPlan plan, FirFftJobs<T> jobs, int P, int H, int N, int ring_off,
                                                            const C2<T>* __restrict__ tw) {
-    extern __shared__ unsigned char smem_raw[];
+    extern __shared__ __align__(16) unsigned char smem_raw[];
     using Z = C2<T>;
     Z* za = reinterpret_cast<Z*>(smem_raw);
     const int Fh = plan.Nh;
@@ -567,6 +580,7 @@ bool make_plan(int N, FftPlan* plan, std::string* why) {
     static const bool pingpong = getenv("APV_FFT_PINGPONG") != nullptr;      // A/B switch: two-buffer stages everywhere
     plan->inplace = pingpong ? 0 : 1;
     plan->max_it = 1;
+    plan->debug = getenv("APV_STFT_DEBUG") ? atoi(getenv("APV_STFT_DEBUG")) : 0;
     for (int s = 0; s < plan->nstages; ++s) {
         const int r = plan->radix[s];
         if ((r != 2 && r != 4) || plan->Nh / r > INPLACE_MAX_IT * STFT_TPB) plan->inplace = 0;
