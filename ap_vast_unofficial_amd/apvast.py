@@ -290,7 +290,7 @@ class apvast:
         zone that does not run; sample for sample what the per-hop calls return, concatenated.  The attributes
         afterwards are those of the last hop.
         `out`: optional C-contiguous array of shape signal_output_shape(n_samples) and dtype signal_output_dtype to receive
-        the samples (the returned arrays are then slices of it).  A 10 s signal returns 184 MB; a caller that processes many
+        the samples (the returned arrays are then slices of it, in its dtype: float32 for dtype="f32" / "mixed").  A 10 s signal returns 184 MB; a caller that processes many
         signals saves the first-touch cost of that much fresh memory by passing the same array again."""
         input_A = np.asarray(input_A).ravel()
         input_B = np.asarray(input_B).ravel()
@@ -308,8 +308,11 @@ class apvast:
             self._hops += blocks.shape[0] - 1
             self._refresh_broadband()
             return res
+        given = out is not None
         out = self._eng.process_signal(input_A, input_B, self._n_out, out=out)   # (groups, n_samples, L), written in place by the library
-        if out.dtype != np.float64:
+        # float32 / mixed arithmetic produce float32 samples: a fresh result is widened to the float64 the reference returns; a
+        # caller's own `out` is handed back as it is (its slices), without a second copy of the whole signal on the host
+        if out.dtype != np.float64 and not given:
             out = out.astype(np.float64)
         res = self._split_groups(out)
         self._refresh_attributes()

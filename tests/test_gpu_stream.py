@@ -433,6 +433,34 @@ def test_process_signal_equals_hop_loop(dtype, run_A, run_B, perceptual, P):
     b.close()
 
 
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_process_signal_into_callers_array(dtype):
+    """`out=`: the samples land in the caller's array (shape / dtype as the object says) and the returned lists are slices of
+    it, in its own dtype -- float32 arithmetic hands float32 back without a second copy of the signal; without `out` the
+    result is float64 as the reference's; the values are the same either way.  A wrong shape or dtype is refused."""
+    from ap_vast_unofficial_amd.apvast import apvast
+    rirA, rirB = synth_rirs(70, 4, 8, 11)
+    N, H = 128, 64
+    mk = lambda: apvast(N, rirA, rirB, 16, 5, 1, 2, 2, 1.0, 4 * N, hop_size=H, seed=3, dtype=dtype, perceptual=False, sampling_rate=16000)
+    a, b = mk(), mk()
+    x = np.random.default_rng(9).standard_normal((2, 20 * H))
+    buf = np.full(a.signal_output_shape(x.shape[1]), np.nan, dtype=a.signal_output_dtype)
+    assert buf.dtype == (np.float64 if dtype == "f64" else np.float32)
+    got = a.process_signal(x[0], x[1], out=buf)
+    ref = b.process_signal(x[0], x[1])
+    assert np.isfinite(buf).all()
+    for q in range(4):
+        for v in range(len(ref[q])):
+            assert ref[q][v].dtype == np.float64
+            assert got[q][v].dtype == buf.dtype
+            assert np.array_equal(got[q][v].astype(np.float64), ref[q][v]), (q, v)
+    assert np.shares_memory(got[0][0], buf) and np.shares_memory(got[1][1], buf)
+    with pytest.raises((ValueError, RuntimeError, TypeError)):
+        a.process_signal(x[0], x[1], out=np.empty((1, 2, 3), dtype=buf.dtype))
+    a.close()
+    b.close()
+
+
 def test_process_signal_vs_oracle_cfg3_shape():
     """The pipelined path against the oracle at BASELINE configs[2]'s shape (16 loudspeakers, 32 control points,
     block 2048, 800-tap RIRs), float64 end to end."""
