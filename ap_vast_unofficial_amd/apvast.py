@@ -301,10 +301,11 @@ class apvast:
         if self.mode == "broadband":
             # the joint diagonalisations of up to 16 consecutive hops are solved as one batch (apv_bb_process_signal)
             blocks = self._eng.bb_process_signal(input_A, input_B, self._n_out)          # (hops, n_out, H)
-            L, V = self.number_of_srcs, len(self._ranks)
-            sig = np.ascontiguousarray(blocks.transpose(1, 0, 2)).reshape(self._n_out, -1)      # (n_out, samples)
-            grp = sig.reshape(self._n_out // L, L, -1).transpose(0, 2, 1)                 # (groups, samples, L)
-            res = self._split_groups(np.ascontiguousarray(grp))
+            L = self.number_of_srcs
+            hops, H = blocks.shape[0], blocks.shape[2]
+            # (hops, groups x L, H) -> (groups, samples, L) in one pass over the samples
+            grp = np.ascontiguousarray(blocks.reshape(hops, self._n_out // L, L, H).transpose(1, 0, 3, 2))
+            res = self._split_groups(grp.reshape(self._n_out // L, hops * H, L))
             self._hops += blocks.shape[0] - 1
             self._refresh_broadband()
             return res
