@@ -470,6 +470,7 @@ def main():
     if os.environ.get("APV_BENCH_DRYRUN"):
         return dryrun_rank()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL needs it); before HIP starts
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
