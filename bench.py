@@ -471,6 +471,11 @@ def main():
         return dryrun_rank()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL needs it); before HIP starts
+    # ONE JSON line on stdout: libraries write there too (librccl prints a version banner when a communicator is made), so file
+    # descriptor 1 is pointed at stderr for the life of the rank and the line goes out through a private copy of the original.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -630,7 +635,8 @@ def main():
             out["also"] = also
         if not args.no_cpu_baseline and world == 1 and not multi:
             out["cpu_baseline"] = cpu_baseline(ranks, mu)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":
