@@ -341,8 +341,12 @@ __global__ void __launch_bounds__(STFT_TPB) stft_analysis_jobs_kernel(FftPlan pl
     while (j + 1 < jobs.n && wg >= jobs.ch0[j + 1]) ++j;
     const int c = wg - jobs.ch0[j];
     const size_t hop = blockIdx.y;
+    // timing aid (APV_STFT_DEBUG & 64; the spectra come out in the wrong places): every channel writes its bins as ONE contiguous run
+    // inside the set's region -- what a channel-major spectra layout would cost this kernel
+    const bool cm = (plan.debug & 64) && jobs.stride_c[j] == 1;
     stft_analysis_body<T, MI>(plan, jobs.x[j] + (size_t)c * jobs.x_stride + hop * jobs.x_hop, plan.N, ring_off, 1,
-                          jobs.spec[j] + hop * jobs.spec_hop[j] + (size_t)c * jobs.stride_c[j], jobs.stride_k[j], tw, win);
+                          jobs.spec[j] + hop * jobs.spec_hop[j] + (cm ? (size_t)c * (plan.Nh + 1) : (size_t)c * jobs.stride_c[j]),
+                          cm ? 1 : jobs.stride_k[j], tw, win);
 }
 
 // (Four neighbouring channels per 1024-thread workgroup, so that every bin's four values go out as one 64-byte line instead of four
