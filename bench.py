@@ -26,6 +26,8 @@ Rank 0 prints ONE JSON line.  At N = 1 it also carries:
   also.cfg3   BASELINE config 3 through the drop-in class: 468 hops of 10 s pink noise, 16 x 32, N = 2048, float64, once
               through apvast.process_input_buffers (one call per hop) and once through apvast.process_signal
   also.cfg5   BASELINE config 5 at kernel level: 64 x 128 x 2048 bins in float64, with its own roofline
+  also.cfg1   BASELINE config 1 in the reference's own broadband formulation through the class (per-hop calls and process_signal)
+  also.reference_test_parameters   the same at the reference's own test parameters (make_python_test.m: n = 800)
   cpu_baseline  the oracle's per-bin loop on the host cores (one single-threaded process per core)
 """
 import argparse
@@ -288,7 +290,7 @@ def also_cfg1(device, hops=40, signal_hops=128):
     """BASELINE config 1 in the reference's own (broadband, time-domain) formulation through class apvast: the bundled
     rirs.mat (8 loudspeakers x 8 microphones), N = 256, H = 128, J = 32 (n = J L = 256), S = 512, V = 8, both zone
     programs, float64.  Timed: `hops` calls of process_input_buffers, then ONE process_signal call (the joint
-    diagonalisations of up to 8 consecutive hops solved as one batch).  A hop is 2.667 ms of audio at 48 kHz."""
+    diagonalisations of up to 16 consecutive hops solved as one batch).  A hop is 2.667 ms of audio at 48 kHz."""
     from ap_vast_unofficial_amd.apvast import apvast
     g = np.load(os.path.join(ROOT, "tests", "golden", "rirs_cfg1.npz"))
     N, H = 256, 128
@@ -307,6 +309,40 @@ def also_cfg1(device, hops=40, signal_hops=128):
         rec["process_input_buffers"] = {"ms_per_hop": dt / hops * 1e3, "hops": hops, "realtime_factor": (hops * H / 48000.0) / dt}
         xs = np.random.default_rng(8).standard_normal((2, signal_hops * H))
         obj.process_signal(xs[0, :16 * H], xs[1, :16 * H])       # allocates the group buffers, captures the batch's sweep graph
+        t0 = time.perf_counter()
+        res = obj.process_signal(xs[0], xs[1])
+        dt = time.perf_counter() - t0
+        assert res[0][0].shape == (signal_hops * H, 8)
+        rec["process_signal"] = {"ms_per_hop": dt / signal_hops * 1e3, "hops": signal_hops,
+                                 "realtime_factor": (signal_hops * H / 48000.0) / dt}
+        rec["not_converged_hops"] = obj.not_converged
+    finally:
+        obj.close()
+    return rec
+
+
+def also_reftest(device, hops=6, signal_hops=16):
+    """The reference's own test parameters (Python/make_python_test.m:6-15) in its broadband formulation through class apvast:
+    block 1600, hop 800, J = 100 (n = J L = 800), V = 50, S = 1000, the bundled 8 x 8 impulse responses, both zone programs,
+    float64.  Timed: `hops` calls of process_input_buffers, then ONE process_signal call (groups of eight hops: sixteen pairs
+    of order 800 per batch).  A hop is 16.67 ms of audio at 48 kHz."""
+    from ap_vast_unofficial_amd.apvast import apvast
+    g = np.load(os.path.join(ROOT, "tests", "golden", "rirs_cfg1.npz"))
+    N, J, V, S, H = 1600, 100, 50, 1000, 800
+    obj = apvast(N, g["rirA"], g["rirB"], J, 20, 6, 6, V, 1.0, S, perceptual=False, mode="broadband", seed=0, device=device)
+    rec = {"workload": "make_python_test.m parameters: broadband (reference formulation), rirs.mat 8x8, N=1600 H=800 J=100 (n=800) "
+                       "S=1000 V=50, both zone programs, white noise, through class apvast", "dtype": "f64", "hop_ms_of_audio": H / 48.0}
+    try:
+        x = np.random.default_rng(7).standard_normal((2, (hops + 2) * H))
+        for h in range(2):
+            obj.process_input_buffers(x[0, h * H:(h + 1) * H], x[1, h * H:(h + 1) * H])
+        t0 = time.perf_counter()
+        for h in range(2, hops + 2):
+            obj.process_input_buffers(x[0, h * H:(h + 1) * H], x[1, h * H:(h + 1) * H])
+        dt = time.perf_counter() - t0
+        rec["process_input_buffers"] = {"ms_per_hop": dt / hops * 1e3, "hops": hops, "realtime_factor": (hops * H / 48000.0) / dt}
+        xs = np.random.default_rng(8).standard_normal((2, signal_hops * H))
+        obj.process_signal(xs[0, :8 * H], xs[1, :8 * H])         # allocates the group buffers, captures the batch's sweep graphs
         t0 = time.perf_counter()
         res = obj.process_signal(xs[0], xs[1])
         dt = time.perf_counter() - t0
@@ -627,7 +663,8 @@ def main():
         if world == 1 and not multi and not args.no_also:
             also = {}
             for name, fn in (("cfg3", lambda: also_cfg3(local_rank)), ("cfg5", lambda: also_cfg5(Engine, local_rank)),
-                             ("cfg1", lambda: also_cfg1(local_rank))):
+                             ("cfg1", lambda: also_cfg1(local_rank)),
+                             ("reference_test_parameters", lambda: also_reftest(local_rank))):
                 try:
                     also[name] = fn()
                 except Exception as ex:  # the headline stands on its own: a failing sub-record is reported, not fatal
