@@ -73,6 +73,9 @@ struct apv_handle {
     std::vector<int> bb_rank_list;   // apv_bb_set_rank_list: ranks of the next apv_bb_init (empty = 1..V)
     void* gl_ws;             // workspace + captured sweep graph of apv_gevd_large, owned
     double gl_tol2;          // > 0: stop threshold of apv_gevd_large's sweeps for the next call (the complex path asks for accurate eigenVECTORS)
+    int gl_lead_rank;        // > 0: the next apv_gevd_large call needs the leading gl_lead_rank eigenpairs only (kernels_gevd_lead.hip); reset by the call
+    int gl_lead_done;        // set by apv_gevd_large: 1 = only the leading columns of U / entries of lambda were written
+    void* lead_ws;           // workspace of apv_gevd_lead, owned
     void* comm;       // ncclComm_t
     int comm_rank, comm_world;
     hipStream_t comm_stream;      // the all-gather runs here so that it overlaps the next block's kernels
@@ -89,6 +92,7 @@ void apv_stream_free(apv_handle* h);      // stream.hip
 void apv_bb_free(apv_handle* h);          // stream_bb.hip
 long apv_bb_not_converged(const apv_handle* h);   // stream_bb.hip: hops of the broadband stream that hit the sweep cap
 void apv_gevd_large_free(apv_handle* h);  // kernels_gevd_large.hip
+void apv_gevd_lead_free(apv_handle* h);   // kernels_gevd_lead.hip
 int apv_fail(apv_handle* h, int code, const std::string& msg);
 GevdParams apv_base_params(const apv_handle* h);
 
@@ -111,6 +115,11 @@ size_t apv_gevd64_slot_bytes();          // scratch per (zone program, bin)
 // kernels_gevd_large.hip: real symmetric pairs of broadband order, f64, device pointers (see the file header)
 int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const double* d_B, double reg,
                    const double* d_reg_scale, double* d_U, double* d_lam, const double* d_r, double mu, int V, const int* d_ranks, double* d_w, int32_t* h_status);
+
+// kernels_gevd_lead.hip: the leading b eigenpairs of whitened matrices by Chebyshev-filtered subspace iteration (see the file header)
+int apv_gevd_lead_block(int n, int rank);
+int apv_gevd_lead(apv_handle* h, int n, int ne, int batch, int b, int rank, const double* C, const double* WT, double* d_U,
+                  double* d_lam, int* done);
 
 // stream_bb.hip: d_out[i] = ||mats[i]||_2 (largest eigenvalue of a symmetric PSD n x n matrix, Lanczos), i < count <= 4
 hipError_t apv_launch_norm2(int n, int count, const double* const* d_mats, double* d_out, hipStream_t s);

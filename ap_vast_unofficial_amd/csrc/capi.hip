@@ -161,6 +161,9 @@ int apv_create(const apv_config* cfg, apv_handle** out) {
     h->bb = nullptr;
     h->gl_ws = nullptr;
     h->gl_tol2 = 0.0;
+    h->gl_lead_rank = 0;
+    h->gl_lead_done = 0;
+    h->lead_ws = nullptr;
     h->comm_stream = nullptr;
     h->ev_ready = nullptr;
     for (auto& g : h->gather_done) { g.ptr = nullptr; g.ev = nullptr; }
@@ -203,6 +206,7 @@ int apv_destroy(apv_handle* h) {
     apv_stream_free(h);
     apv_bb_free(h);
     apv_gevd_large_free(h);
+    apv_gevd_lead_free(h);
     if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
     if (h->comm) ncclCommDestroy((ncclComm_t)h->comm);
     for (auto& g : h->gather_done)

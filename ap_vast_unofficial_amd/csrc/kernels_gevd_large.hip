@@ -904,6 +904,11 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
                    const double* d_reg_scale, double* d_U, double* d_lam, const double* d_r, double mu, int V, const int* d_ranks, double* d_w, int32_t* h_status) {
     hipStream_t st = h->stream;
     const auto t_begin = std::chrono::steady_clock::now();
+    // the caller consumes the leading lead_rank eigenpairs only (apvast.py:406-414): kernels_gevd_lead.hip, with this function's
+    // block Jacobi as the fall-back.  One-shot request, like gl_tol2.
+    const int lead_rank = h->gl_lead_rank;
+    h->gl_lead_rank = 0;
+    h->gl_lead_done = 0;
     const int ne = (n + BT - 1) / BT * BT, ld = ne;          // padded with ghost rows/columns: zero in A and C, unit in B
     const int nbk = ne / BT, nb = ne / BH, np = nb / 2, rounds = nb - 1;
     const size_t ms = (size_t)ne * ne, vs = (size_t)ne;
@@ -1039,6 +1044,28 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
     }
     static const bool timing = getenv("APV_BB_TIMING") != nullptr;       // profiling aid, see stream_bb.hip
     const auto t_pre = std::chrono::steady_clock::now();
+    // (a caller who sets a sweep cap or a sweep tolerance of his own is asking for the Jacobi iteration they belong to)
+    int lead_b = (lead_rank > 0 && h->gl_tol2 <= 0.0 && h->cfg.max_sweeps <= 0) ? apv_gevd_lead_block(n, lead_rank) : 0, lead_done = 0;
+    if (lead_b > 0) {
+        // C0 (whitened, symmetric) and X = W^T are read only; on *done == 0 nothing was written and the sweeps below run
+        const int lrc = apv_gevd_lead(h, n, ne, batch, lead_b, lead_rank, ws.C0, ws.X, d_U, d_lam, &lead_done);
+        if (lrc != APV_OK) return lrc;
+    }
+    if (lead_done) {
+        h->gl_lead_done = 1;
+        if (d_r != nullptr && d_w != nullptr && V > 0) {
+            hipLaunchKernelGGL(coef_kernel, dim3((lead_b + 31) / 32, 1, batch), dim3(TPB), 0, st, n, d_U, d_lam, d_r, mu, ws.coef, (size_t)n * n, vs);
+            hipLaunchKernelGGL(vast_prefix_kernel, dim3(gx, 1, batch), dim3(TPB), 0, st, n, V, d_ranks, d_U, ws.coef, d_w, (size_t)n * n, vs,
+                               (size_t)V * n);
+        }
+        LCHK(hipStreamSynchronize(st));
+        LCHK(hipGetLastError());
+        if (timing)
+            fprintf(stderr, "[apv gevd_large] n=%d batch=%d: factor+whiten %.3f ms, leading %d of block %d %.3f ms\n", n, batch,
+                    std::chrono::duration<double, std::milli>(t_pre - t_begin).count(), lead_rank, lead_b,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_pre).count());
+        return APV_OK;
+    }
     int n_sweeps = 0;
     std::vector<double> norm2(hacc.begin() + 2 * batch, hacc.end());
     const int max_sweeps = ((h->cfg.max_sweeps > 0 ? h->cfg.max_sweeps : 30) / 2 + 1) * 2;

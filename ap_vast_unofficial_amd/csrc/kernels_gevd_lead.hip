@@ -1,0 +1,704 @@
+// Leading eigenpairs of the whitened matrix of a broadband pair: what the per-hop path consumes.
+//
+//   apvast.py:406-414 builds the filters from the first V generalised eigenpairs only (V = 8 of n = 256 at BASELINE config 1,
+//   50 of 800 with the parameters of make_python_test.m:6-15); the full lambda_* / U_* (apvast.py:380-387) are attributes read
+//   after the fact.  apv_gevd_large's block Jacobi diagonalises all of C = W A W^T: 12-15 sweeps x (n/16 - 1) dependent launches.
+//   This file finds the leading b = V + guard eigenpairs of the same C by Chebyshev-filtered subspace iteration:
+//
+//     X0      deterministic pseudo-random block, n x b (no state carried from hop to hop: the statistics windows of consecutive
+//             hops share 75 % of their samples at cfg1 but 20 % at the reference's parameters, and a start that is right to 1e-1
+//             instead of 1e0 saves one filter degree of ~25 -- tools/probes/lead_model.py)
+//     pass    Z = C Y                                         one block product (f64 MFMA, the matrix streams from L2 / HBM)
+//             G = Y^T Y, H = Y^T Z                            b x b Gram matrices, K split over slabs of 128 rows
+//             (H, G) -> T, theta                              ONE workgroup: scale to a unit diagonal, eliminate [G | I] (Cholesky
+//                                                             factor and its inverse in one go), M = L^-1 H L^-T, cyclic Jacobi
+//                                                             in LDS, sort, T = D L^-T Q
+//             X = Y T, CX = Z T, res_j = ||CX_j - theta_j X_j||   Ritz vectors and their residuals
+//             host: converged?  else degree m of the next filter from the Ritz values
+//             Y = p_m(C) X                                    scaled Chebyshev polynomial that damps [0, theta_b] (C is positive
+//                                                             semi-definite): step 1 is elementwise (C X is known), m - 1 products
+//     end     U[:, :b] = W^T X, lambda[:b] = theta            jdiag's contract on the leading columns (apvast.py:31-35)
+//
+//   The degree is capped by the amplification ratio T_m(x(theta_1)) between the largest Ritz value and the damped interval:
+//   1e6 in the first filter, 1e10 in the second, 1e12 from there -- beyond that the guard columns turn into copies of the
+//   leading eigenvector and the Gram matrix loses rank (model: cond 1e16 at degree 16 with lambda_1 / lambda_V = 8).
+//   A pair whose leading V residuals do not reach the bound within kMaxPass passes (a flat spectrum: lambda_{b+1} / lambda_V
+//   close to one), or whose Gram matrix breaks down, hands the whole call back to the block Jacobi of apv_gevd_large.
+#include "apv_internal.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+namespace {
+
+using d4 = __attribute__((ext_vector_type(4))) double;
+
+constexpr int LEAD_MAXB = 32;            // matrices per call
+constexpr int kMaxPass = 12;             // Rayleigh-Ritz passes before the call falls back
+
+struct LeadCoef {                        // Ynew = a C Ycur + b Ycur + g Yprev, per matrix
+    double a[LEAD_MAXB], b[LEAD_MAXB], g[LEAD_MAXB];
+    unsigned active;                     // bit z: matrix z takes part in this launch
+};
+
+__device__ __forceinline__ double lead_rnd(unsigned i) {
+    unsigned x = i * 0x9E3779B9u + 0x7F4A7C15u;
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return (double)(int)x * (1.0 / 2147483648.0);
+}
+
+// X[z][i][j] = pseudo-random in (-1, 1) for i < n, 0 on the ghost rows of the padding
+__global__ void __launch_bounds__(256) lead_init_kernel(int n, int ne, int b, double* __restrict__ X, size_t y_stride) {
+    X += blockIdx.z * y_stride;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= ne * b) return;
+    X[idx] = (idx / b) < n ? lead_rnd((unsigned)idx) : 0.0;
+}
+
+// Yo = a (A Yc) + b Yc + g Yp for the block Yc [ne][b] (row-major).  A workgroup owns 16 rows x 16 NB columns; the K dimension
+// is dealt to its four waves in chunks of 16 (one 32-byte load per lane of A's rows: lane (r, kq) holds A[r][k0 + 4 kq .. + 3],
+// and MFMA j of the chunk contracts the indices k0 + 4 kq + j -- any order of the contraction index serves, as long as the B
+// operand follows it), the four partial tiles meet in LDS in a fixed order.
+template <int NB>
+__global__ void __launch_bounds__(256) lead_mult_kernel(int ne, int lda, size_t a_stride, const double* __restrict__ A, int b,
+                                                        size_t y_stride, const double* __restrict__ Yc,
+                                                        const double* __restrict__ Yp, double* __restrict__ Yo, int rows_out,
+                                                        int ldo, size_t o_stride, LeadCoef cf) {
+    __shared__ double red[4][NB][256];
+    const int z = blockIdx.z;
+    if (!((cf.active >> z) & 1u)) return;
+    const double ca = cf.a[z], cb = cf.b[z], cg = cf.g[z];
+    A += z * a_stride;
+    Yc += z * y_stride;
+    Yo += z * o_stride;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, il = lane & 15, kq = lane >> 4;
+    const int row0 = blockIdx.x * 16, col0 = blockIdx.y * 16 * NB;
+    d4 acc[NB];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) acc[c] = d4{0, 0, 0, 0};
+    if (ca != 0.0) {
+        const double* arow = A + (size_t)(row0 + il) * lda + 4 * kq;
+        for (int k0 = w * 16; k0 < ne; k0 += 64) {
+            const d4 av = *reinterpret_cast<const d4*>(arow + k0);
+            const double* yr = Yc + (size_t)(k0 + 4 * kq) * b + col0 + il;
+            double bv[4][NB];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int c = 0; c < NB; ++c) bv[j][c] = yr[(size_t)j * b + 16 * c];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int c = 0; c < NB; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[j], bv[j][c], acc[c], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NB; ++c)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) red[w][c][t * 64 + lane] = acc[c][t];
+    __syncthreads();
+    // wave w finishes accumulator row t = w: element (row0 + kq + 4 w, col0 + 16 c + il)
+    const int row = row0 + kq + 4 * w;
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+        const int col = col0 + 16 * c + il;
+        const double s = ((red[0][c][w * 64 + lane] + red[1][c][w * 64 + lane]) + red[2][c][w * 64 + lane]) + red[3][c][w * 64 + lane];
+        double v = ca * s;
+        if (cb != 0.0) v = __builtin_fma(cb, Yc[(size_t)row * b + col], v);
+        if (cg != 0.0) v = __builtin_fma(cg, Yp[z * y_stride + (size_t)row * b + col], v);
+        if (row < rows_out) Yo[(size_t)row * ldo + col] = v;
+    }
+}
+
+// Yo = a P + b X, elementwise (the first step of a filter: P = C X is known from the Rayleigh-Ritz pass)
+__global__ void __launch_bounds__(256) lead_axpby_kernel(int count, size_t y_stride, const double* __restrict__ P,
+                                                         const double* __restrict__ X, double* __restrict__ Yo, LeadCoef cf) {
+    const int z = blockIdx.z;
+    if (!((cf.active >> z) & 1u)) return;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= count) return;
+    const size_t o = z * y_stride + idx;
+    Yo[o] = __builtin_fma(cf.a[z], P[o], cf.b[z] * X[o]);
+}
+
+// Partial Gram matrices of one slab of 128 rows: tile (ti, tj), tj <= ti, of G = Y^T Y and H = Y^T Z.  Gp / Hp:
+// [z][slab][pair][256], element (4 t + (lane >> 4), lane & 15) of the tile at t * 64 + lane.
+__global__ void __launch_bounds__(256) lead_gram_kernel(int ne, int b, size_t y_stride, const double* __restrict__ Y,
+                                                        const double* __restrict__ Z, double* __restrict__ Gp,
+                                                        double* __restrict__ Hp, unsigned active) {
+    __shared__ double red[2][4][256];
+    const int z = blockIdx.z, s = blockIdx.y;
+    if (!((active >> z) & 1u)) return;
+    int ti = 0, tj = blockIdx.x;
+    while (tj > ti) { tj -= ti + 1; ++ti; }
+    Y += z * y_stride;
+    Z += z * y_stride;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, il = lane & 15, kq = lane >> 4;
+    d4 ag = {0, 0, 0, 0}, ah = {0, 0, 0, 0};
+    const int r0 = s * 128 + w * 32;
+    if (r0 < ne) {
+#pragma unroll
+        for (int k0 = 0; k0 < 32; k0 += 4) {
+            const size_t ro = (size_t)(r0 + k0 + kq) * b;
+            const double a = Y[ro + 16 * ti + il], bg = Y[ro + 16 * tj + il], bh = Z[ro + 16 * tj + il];
+            ag = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bg, ag, 0, 0, 0);
+            ah = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bh, ah, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        red[0][w][t * 64 + lane] = ag[t];
+        red[1][w][t * 64 + lane] = ah[t];
+    }
+    __syncthreads();
+    const size_t o = (((size_t)z * gridDim.y + s) * gridDim.x + blockIdx.x) * 256 + tid;
+    Gp[o] = ((red[0][0][tid] + red[0][1][tid]) + red[0][2][tid]) + red[0][3][tid];
+    Hp[o] = ((red[1][0][tid] + red[1][1][tid]) + red[1][2][tid]) + red[1][3][tid];
+}
+
+// 1/sqrt(x) to full double precision: v_rsq_f64 and one third-order correction (as in kernels_gevd_large.hip)
+__device__ __forceinline__ double lead_rsq(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = __builtin_fma(-(x * y), y, 1.0);
+    return __builtin_fma(y * e, __builtin_fma(0.375, e, 0.5), y);
+}
+
+// Jacobi rotation J = [[c, s], [-s, c]] that annihilates beta in [[alpha, beta], [beta, gamma]]; tangent in float, (c, s) formed
+// in double from it (orthogonal to 1e-16, leaves ~1e-7 |beta| behind: the sweeps stay quadratic).  See sym_rotation in
+// kernels_gevd_large.hip.
+__device__ __forceinline__ void lead_rotation(double alpha, double gamma, double beta, double& c, double& s) {
+    const double b2 = beta * beta;
+    const bool rotate = b2 > 1e-290 && b2 > 1e-60 * (alpha * alpha + gamma * gamma);
+    const double d = gamma - alpha, tb = 2.0 * beta;
+    const int ex = __builtin_amdgcn_frexp_exp(fabs(d) >= fabs(tb) ? d : tb);
+    const float fd = (float)__builtin_ldexp(d, -ex), fb = (float)__builtin_ldexp(tb, -ex);
+    const float s2 = __builtin_fmaf(fd, fd, fb * fb);
+    const float hyp = s2 * __builtin_amdgcn_rsqf(s2);
+    const float mag = fabsf(fb) * __builtin_amdgcn_rcpf(fabsf(fd) + hyp);
+    const float t = __builtin_copysignf(mag, __builtin_copysignf(1.0f, fd) * fb);
+    const double td = (double)t;
+    const double cc = lead_rsq(__builtin_fma(td, td, 1.0));
+    c = rotate ? cc : 1.0;
+    s = rotate ? td * cc : 0.0;
+}
+
+// 16 x 16 tile of op(A) op(B) with operands in LDS (row stride ld), K deep: acc[t] = element (row0 + (lane >> 4) + 4 t, col0 + (lane & 15))
+template <bool TA, bool TB, int K>
+__device__ __forceinline__ d4 lead_tile(const double* A, const double* Bm, int ld, int row0, int col0, int lane) {
+    const int il = lane & 15, kq = lane >> 4;
+    d4 acc = {0, 0, 0, 0};
+#pragma unroll 4
+    for (int k0 = 0; k0 < K; k0 += 4) {
+        const double av = TA ? A[(k0 + kq) * ld + row0 + il] : A[(row0 + il) * ld + k0 + kq];
+        const double bv = TB ? Bm[(col0 + il) * ld + k0 + kq] : Bm[(k0 + kq) * ld + col0 + il];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// The projected problem of one pass: (H, G) of order B -> T [B][B] (X = Y T has orthonormal columns that diagonalise C on
+// span Y), theta [B] descending.  info[z] = {Gram breakdown, sweeps, Jacobi met its bound, 0}.
+template <int B, int NT>
+__global__ void __launch_bounds__(NT) lead_small_kernel(int nslab, const double* __restrict__ Gp, const double* __restrict__ Hp,
+                                                        int max_sweeps, double tol2, double* __restrict__ T,
+                                                        double* __restrict__ theta, int* __restrict__ info, unsigned active) {
+    constexpr int LD = B + 1, NTL = B / 16, NPAIR = NTL * (NTL + 1) / 2, NP = B / 2, NW = NT / 64;
+    extern __shared__ double sm[];
+    double* S0 = sm;                 // G -> W H -> Q
+    double* S1 = S0 + B * LD;        // H -> M
+    double* S2 = S1 + B * LD;        // W = L^-1
+    double* dsc = S2 + B * LD;       // [B] 1/sqrt(diag G)
+    double* th = dsc + B;            // [B]
+    double* pw = th + B;             // [NP] pivot weights of a sweep
+    double2* cs = reinterpret_cast<double2*>(pw + NP + (NP & 1));    // [NP]
+    int* pq = reinterpret_cast<int*>(cs + NP);                       // [B]: p of pair k, then q of pair k
+    int* rk = pq + B;                                                // [B]
+    __shared__ int fail;
+    __shared__ double scal[2];
+    const int z = blockIdx.x;
+    if (!((active >> z) & 1u)) return;
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    Gp += (size_t)z * nslab * NPAIR * 256;
+    Hp += (size_t)z * nslab * NPAIR * 256;
+    if (tid == 0) fail = 0;
+    // a: the slabs' partial sums, in slab order; strictly lower tiles are mirrored
+    for (int e = tid; e < NPAIR * 256; e += NT) {
+        const int pair = e >> 8, rem = e & 255, t = rem >> 6, ln = rem & 63;
+        int ti = 0, tj = pair;
+        while (tj > ti) { tj -= ti + 1; ++ti; }
+        double g = 0.0, hh = 0.0;
+        for (int s = 0; s < nslab; ++s) {
+            g += Gp[((size_t)s * NPAIR + pair) * 256 + rem];
+            hh += Hp[((size_t)s * NPAIR + pair) * 256 + rem];
+        }
+        const int i = 16 * ti + (ln >> 4) + 4 * t, j = 16 * tj + (ln & 15);
+        S0[i * LD + j] = g;
+        S1[i * LD + j] = hh;
+        if (ti != tj) {
+            S0[j * LD + i] = g;
+            S1[j * LD + i] = hh;
+        }
+    }
+    __syncthreads();
+    // diagonal tiles of H: Y^T Z is symmetric up to rounding only
+    for (int e = tid; e < NTL * 120; e += NT) {
+        const int tl = e / 120;
+        int i = 1, j = e % 120;
+        while (j >= i) { j -= i; ++i; }          // 0 <= j < i < 16
+        const int gi = 16 * tl + i, gj = 16 * tl + j;
+        const double m = 0.5 * (S1[gi * LD + gj] + S1[gj * LD + gi]);
+        S1[gi * LD + gj] = m;
+        S1[gj * LD + gi] = m;
+    }
+    if (tid < B) {
+        const double g = S0[tid * LD + tid];
+        if (!(g > 0.0)) fail = 1;
+        dsc[tid] = g > 0.0 ? lead_rsq(g) : 1.0;
+    }
+    __syncthreads();
+    // b: unit diagonal (the columns of Y differ by the filter's amplification, up to 1e12), W = I
+    for (int e = tid; e < B * B; e += NT) {
+        const int i = e / B, j = e % B;
+        const double sc = dsc[i] * dsc[j];
+        S0[i * LD + j] *= sc;
+        S1[i * LD + j] *= sc;
+        S2[i * LD + j] = i == j ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    // c: eliminate [G | I]: G = Lt D Lt^T, the right half becomes Lt^-1; pivots stay on G's diagonal
+    for (int k = 0; k < B - 1; ++k) {
+        const double piv = S0[k * LD + k];
+        if (!(piv > 1e-13)) {                    // uniform: every thread reads the same word
+            if (tid == 0) fail = 1;
+            break;
+        }
+        const double rp = 1.0 / piv;
+        for (int e = tid; e < (B - 1 - k) * B; e += NT) {
+            const int i = k + 1 + e / B, j = e % B;
+            const double f = S0[i * LD + k] * rp;
+            if (j > k) S0[i * LD + j] = __builtin_fma(-f, S0[k * LD + j], S0[i * LD + j]);
+            else S2[i * LD + j] = __builtin_fma(-f, S2[k * LD + j], S2[i * LD + j]);
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (!(S0[(B - 1) * LD + B - 1] > 1e-13) && tid == 0) fail = 1;
+    __syncthreads();
+    if (fail) {
+        if (tid == 0) {
+            info[4 * z] = 1;
+            info[4 * z + 1] = 0;
+            info[4 * z + 2] = 0;
+        }
+        return;
+    }
+    if (tid < B) th[tid] = lead_rsq(S0[tid * LD + tid]);
+    __syncthreads();
+    for (int e = tid; e < B * B; e += NT) S2[(e / B) * LD + e % B] *= th[e / B];        // W = D^-1/2 Lt^-1
+    __syncthreads();
+    // d: M = W H W^T
+    for (int tile = wv; tile < NTL * NTL; tile += NW) {
+        const int r0 = (tile / NTL) * 16, c0 = (tile % NTL) * 16;
+        const d4 a = lead_tile<false, false, B>(S2, S1, LD, r0, c0, lane);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) S0[(r0 + (lane >> 4) + 4 * t) * LD + c0 + (lane & 15)] = a[t];
+    }
+    __syncthreads();
+    for (int tile = wv; tile < NTL * NTL; tile += NW) {
+        const int r0 = (tile / NTL) * 16, c0 = (tile % NTL) * 16;
+        const d4 a = lead_tile<false, true, B>(S0, S2, LD, r0, c0, lane);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) S1[(r0 + (lane >> 4) + 4 * t) * LD + c0 + (lane & 15)] = a[t];
+    }
+    __syncthreads();
+    double nrm = 0.0;
+    for (int e = tid; e < B * B; e += NT) {
+        const int i = e / B, j = e % B;
+        if (j < i) {
+            const double m = 0.5 * (S1[i * LD + j] + S1[j * LD + i]);
+            S1[i * LD + j] = m;
+            S1[j * LD + i] = m;
+            nrm += 2.0 * m * m;
+        } else if (j == i) {
+            const double m = S1[i * LD + i];
+            nrm += m * m;
+        }
+        S0[i * LD + j] = i == j ? 1.0 : 0.0;        // Q = I (W H is spent)
+    }
+    // ||M||_F^2 (order of the sum fixed: lanes through DPP-free LDS tree)
+    __shared__ double redn[NT];
+    redn[tid] = nrm;
+    __syncthreads();
+    for (int s = NT / 2; s > 0; s >>= 1) {
+        if (tid < s) redn[tid] += redn[tid + s];
+        __syncthreads();
+    }
+    const double norm2 = redn[0];
+    // e: cyclic Jacobi, round-robin pairing (player 0 fixed, the others rotate): slot s holds player s == 0 ? 0 : 1 + (s - 1 - r) mod (B - 1)
+    int sweeps = 0, conv = 0;
+    for (int sw = 0; sw < max_sweeps && !conv; ++sw) {
+        double pwk = 0.0;
+        for (int r = 0; r < B - 1; ++r) {
+            if (tid < NP) {
+                const int s1 = tid, s2 = B - 1 - tid;
+                int a1 = s1 - 1 - r; a1 %= (B - 1); if (a1 < 0) a1 += B - 1;
+                int a2 = s2 - 1 - r; a2 %= (B - 1); if (a2 < 0) a2 += B - 1;
+                const int p = s1 == 0 ? 0 : 1 + a1, q = 1 + a2;
+                const double al = S1[p * LD + p], ga = S1[q * LD + q], be = S1[p * LD + q];
+                double c, s;
+                lead_rotation(al, ga, be, c, s);
+                pwk = __builtin_fma(be, be, pwk);
+                cs[tid] = double2{c, s};
+                pq[tid] = p;
+                pq[NP + tid] = q;
+            }
+            __syncthreads();
+            for (int e = tid; e < NP * NP; e += NT) {
+                const int k = e / NP, l = e % NP;
+                const int pk = pq[k], qk = pq[NP + k], pl = pq[l], ql = pq[NP + l];
+                const double2 rk2 = cs[k], rl = cs[l];
+                const double a = S1[pk * LD + pl], b_ = S1[pk * LD + ql], c_ = S1[qk * LD + pl], d_ = S1[qk * LD + ql];
+                const double a1 = a * rl.x - b_ * rl.y, b1 = a * rl.y + b_ * rl.x;
+                const double c1 = c_ * rl.x - d_ * rl.y, d1 = c_ * rl.y + d_ * rl.x;
+                S1[pk * LD + pl] = rk2.x * a1 - rk2.y * c1;
+                S1[pk * LD + ql] = rk2.x * b1 - rk2.y * d1;
+                S1[qk * LD + pl] = rk2.y * a1 + rk2.x * c1;
+                S1[qk * LD + ql] = rk2.y * b1 + rk2.x * d1;
+            }
+            for (int e = tid; e < B * NP; e += NT) {
+                const int i = e / NP, l = e % NP;
+                const int pl = pq[l], ql = pq[NP + l];
+                const double2 rl = cs[l];
+                const double x = S0[i * LD + pl], y = S0[i * LD + ql];
+                S0[i * LD + pl] = x * rl.x - y * rl.y;
+                S0[i * LD + ql] = x * rl.y + y * rl.x;
+            }
+            __syncthreads();
+        }
+        if (tid < NP) pw[tid] = pwk;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.0;
+            for (int k = 0; k < NP; ++k) t += pw[k];
+            scal[0] = t;
+        }
+        __syncthreads();
+        ++sweeps;
+        conv = scal[0] <= tol2 * norm2;         // a sweep whose pivots weigh <= tol2 ||M||^2 leaves ~tol2^2 behind
+        __syncthreads();
+    }
+    // f: descending order, T = D W^T Q with its columns in that order
+    if (tid < B) th[tid] = S1[tid * LD + tid];
+    __syncthreads();
+    if (tid < B) {
+        const double li = th[tid];
+        int rank = 0;
+        for (int j = 0; j < B; ++j) rank += (th[j] > li) || (th[j] == li && j < tid);
+        rk[tid] = rank;
+        theta[(size_t)z * B + rank] = li;
+    }
+    __syncthreads();
+    T += (size_t)z * B * B;
+    for (int tile = wv; tile < NTL * NTL; tile += NW) {
+        const int r0 = (tile / NTL) * 16, c0 = (tile % NTL) * 16;
+        const d4 a = lead_tile<true, false, B>(S2, S0, LD, r0, c0, lane);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int i = r0 + (lane >> 4) + 4 * t, j = c0 + (lane & 15);
+            T[(size_t)i * B + rk[j]] = dsc[i] * a[t];
+        }
+    }
+    if (tid == 0) {
+        info[4 * z] = 0;
+        info[4 * z + 1] = sweeps;
+        info[4 * z + 2] = conv;
+    }
+}
+
+// X = Y T, CX = Z T; respart[z][row tile][col] = sum over the tile's 16 rows of (CX - theta X)^2
+__global__ void __launch_bounds__(256) lead_rot_kernel(int ne, int b, size_t y_stride, const double* __restrict__ Y,
+                                                       const double* __restrict__ Z, const double* __restrict__ T,
+                                                       const double* __restrict__ theta, double* __restrict__ X,
+                                                       double* __restrict__ CX, double* __restrict__ respart, unsigned active) {
+    __shared__ double red[2][4][256];
+    __shared__ double r2[16][17];
+    const int z = blockIdx.z;
+    if (!((active >> z) & 1u)) return;
+    Y += z * y_stride; Z += z * y_stride; X += z * y_stride; CX += z * y_stride;
+    T += (size_t)z * b * b;
+    theta += (size_t)z * b;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, il = lane & 15, kq = lane >> 4;
+    const int row0 = blockIdx.x * 16, col0 = blockIdx.y * 16;
+    d4 ax = {0, 0, 0, 0}, ac = {0, 0, 0, 0};
+    const int kw = b / 4;
+    for (int k0 = w * kw; k0 < (w + 1) * kw; k0 += 4) {
+        const double ay = Y[(size_t)(row0 + il) * b + k0 + kq], az = Z[(size_t)(row0 + il) * b + k0 + kq];
+        const double bt = T[(size_t)(k0 + kq) * b + col0 + il];
+        ax = __builtin_amdgcn_mfma_f64_16x16x4f64(ay, bt, ax, 0, 0, 0);
+        ac = __builtin_amdgcn_mfma_f64_16x16x4f64(az, bt, ac, 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        red[0][w][t * 64 + lane] = ax[t];
+        red[1][w][t * 64 + lane] = ac[t];
+    }
+    __syncthreads();
+    const int e = w * 64 + lane;
+    const double x = ((red[0][0][e] + red[0][1][e]) + red[0][2][e]) + red[0][3][e];
+    const double cx = ((red[1][0][e] + red[1][1][e]) + red[1][2][e]) + red[1][3][e];
+    const int rl = kq + 4 * w, row = row0 + rl, col = col0 + il;
+    X[(size_t)row * b + col] = x;
+    CX[(size_t)row * b + col] = cx;
+    const double rr = __builtin_fma(-theta[col], x, cx);
+    r2[rl][il] = rr * rr;
+    __syncthreads();
+    if (tid < 16) {
+        double s = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += r2[r][tid];
+        respart[((size_t)z * gridDim.x + blockIdx.x) * b + col0 + tid] = s;
+    }
+}
+
+// out[z] = {theta[b], res[b], info[4] as doubles}: what the host reads after a pass
+__global__ void __launch_bounds__(64) lead_res_kernel(int nrt, int b, const double* __restrict__ respart,
+                                                      const double* __restrict__ theta, const int* __restrict__ info,
+                                                      double* __restrict__ out, unsigned active) {
+    const int z = blockIdx.x, j = threadIdx.x;
+    if (!((active >> z) & 1u)) return;
+    double* o = out + (size_t)z * (2 * b + 4);
+    if (j < b) {
+        double s = 0.0;
+        for (int t = 0; t < nrt; ++t) s += respart[((size_t)z * nrt + t) * b + j];
+        o[j] = theta[(size_t)z * b + j];
+        o[b + j] = sqrt(s);
+    }
+    if (j < 4) o[2 * b + j] = (double)info[4 * z + j];
+}
+
+// lam[z][j] = theta[z][j], j < b (dense [batch][n] eigenvalue array of the caller)
+__global__ void __launch_bounds__(64) lead_lam_kernel(int n, int b, const double* __restrict__ theta, double* __restrict__ lam) {
+    const int z = blockIdx.x, j = threadIdx.x;
+    if (j < b) lam[(size_t)z * n + j] = theta[(size_t)z * b + j];
+}
+
+struct LeadWs {
+    int ne = 0, b = 0, cap = 0;
+    double* P[3] = {nullptr, nullptr, nullptr};
+    double *Zb = nullptr, *Gp = nullptr, *Hp = nullptr, *T = nullptr, *theta = nullptr, *respart = nullptr, *out = nullptr;
+    int* info = nullptr;
+    double* h_out = nullptr;          // pinned
+    void release() {
+        void* bufs[] = {P[0], P[1], P[2], Zb, Gp, Hp, T, theta, respart, out, info};
+        for (void* p : bufs)
+            if (p) (void)hipFree(p);
+        if (h_out) (void)hipHostFree(h_out);
+        *this = LeadWs();
+    }
+};
+
+template <int B, int NT>
+hipError_t launch_small(hipStream_t st, int batch, int nslab, const double* Gp, const double* Hp, int max_sweeps, double tol2,
+                        double* T, double* theta, int* info, unsigned active) {
+    constexpr int LD = B + 1, NP = B / 2;
+    const size_t bytes = sizeof(double) * (3 * (size_t)B * LD + 2 * B + NP + (NP & 1)) + sizeof(double2) * NP + sizeof(int) * 2 * B;
+    static bool once = false;
+    if (!once) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lead_small_kernel<B, NT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return e;
+        once = true;
+    }
+    hipLaunchKernelGGL((lead_small_kernel<B, NT>), dim3(batch), dim3(NT), bytes, st, nslab, Gp, Hp, max_sweeps, tol2, T, theta, info,
+                       active);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+void apv_gevd_lead_free(apv_handle* h) {
+    if (h->lead_ws) {
+        static_cast<LeadWs*>(h->lead_ws)->release();
+        delete static_cast<LeadWs*>(h->lead_ws);
+        h->lead_ws = nullptr;
+    }
+}
+
+// Block width for `rank` wanted eigenpairs of an order-n problem, 0 when the leading solver does not apply
+int apv_gevd_lead_block(int n, int rank) {
+    static const int off = getenv("APV_LEAD") ? atoi(getenv("APV_LEAD")) == 0 : 0;
+    if (off || rank <= 0) return 0;
+    int b = (rank + 16 + 15) / 16 * 16;
+    if (b < 32) b = 32;
+    if (b > 64) b = 64;
+    if (b - rank < 8) return 0;              // too few guard vectors
+    if (3 * b > n) return 0;                 // the block is no small part of the matrix: the full solve is the cheaper one
+    return b;
+}
+
+// C: [batch][ne][ld = ne] whitened matrices (symmetric, zero ghost rows / columns), WT: [batch][ne][ne] = W^T.
+// On success with *done = 1: d_U[z][i][j] (n x n, j < b) and d_lam[z][j] (j < b) hold the leading b eigenpairs.
+// *done = 0: nothing was written, the caller runs the full solve.
+int apv_gevd_lead(apv_handle* h, int n, int ne, int batch, int b, int rank, const double* C, const double* WT, double* d_U,
+                  double* d_lam, int* done) {
+    *done = 0;
+    if (batch > LEAD_MAXB || b % 16 != 0 || b < 32 || b > 64 || ne % 32 != 0) return APV_OK;
+    hipStream_t st = h->stream;
+#define LCHK(call)                                                                                   \
+    do {                                                                                             \
+        hipError_t _e = (call);                                                                      \
+        if (_e != hipSuccess) return apv_fail(h, APV_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+    if (!h->lead_ws) h->lead_ws = new LeadWs();
+    LeadWs& ws = *static_cast<LeadWs*>(h->lead_ws);
+    const size_t ys = (size_t)ne * b, ms = (size_t)ne * ne;
+    const int nrt = ne / 16, nslab = (ne + 127) / 128, ntl = b / 16, npair = ntl * (ntl + 1) / 2;
+    const int ow = 2 * b + 4;
+    if (ws.ne != ne || ws.b != b || ws.cap < batch) {
+        ws.release();
+        ws.ne = ne; ws.b = b; ws.cap = batch;
+        for (int i = 0; i < 3; ++i) LCHK(hipMalloc((void**)&ws.P[i], sizeof(double) * ys * batch));
+        LCHK(hipMalloc((void**)&ws.Zb, sizeof(double) * ys * batch));
+        LCHK(hipMalloc((void**)&ws.Gp, sizeof(double) * (size_t)batch * nslab * npair * 256));
+        LCHK(hipMalloc((void**)&ws.Hp, sizeof(double) * (size_t)batch * nslab * npair * 256));
+        LCHK(hipMalloc((void**)&ws.T, sizeof(double) * (size_t)batch * b * b));
+        LCHK(hipMalloc((void**)&ws.theta, sizeof(double) * (size_t)batch * b));
+        LCHK(hipMalloc((void**)&ws.respart, sizeof(double) * (size_t)batch * nrt * b));
+        LCHK(hipMalloc((void**)&ws.out, sizeof(double) * (size_t)batch * ow));
+        LCHK(hipMalloc((void**)&ws.info, sizeof(int) * 4 * batch));
+        LCHK(hipHostMalloc((void**)&ws.h_out, sizeof(double) * (size_t)batch * ow));
+    }
+    static const bool dbg = getenv("APV_LEAD_DEBUG") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned active = batch >= 32 ? 0xFFFFFFFFu : ((1u << batch) - 1u);
+    LeadCoef one{};
+    one.active = active;
+    for (int z = 0; z < batch; ++z) { one.a[z] = 1.0; one.b[z] = 0.0; one.g[z] = 0.0; }
+    auto mult = [&](const double* A, const double* Yc, const double* Yp, double* Yo, int rows_out, int ldo, size_t os, const LeadCoef& cf) {
+        // 16 x 16 outputs per workgroup while that fills the chip, 16 x 32 beyond
+        const long wgs = (long)nrt * (b / 16) * batch;
+        if (wgs > 2048 && b % 32 == 0)
+            hipLaunchKernelGGL((lead_mult_kernel<2>), dim3(nrt, b / 32, batch), dim3(256), 0, st, ne, ne, ms, A, b, ys, Yc, Yp, Yo, rows_out, ldo, os, cf);
+        else
+            hipLaunchKernelGGL((lead_mult_kernel<1>), dim3(nrt, b / 16, batch), dim3(256), 0, st, ne, ne, ms, A, b, ys, Yc, Yp, Yo, rows_out, ldo, os, cf);
+    };
+    int ic = 0, ix = 1, iy = 2;
+    int final_buf[LEAD_MAXB];
+    for (int z = 0; z < batch; ++z) final_buf[z] = -1;
+    hipLaunchKernelGGL(lead_init_kernel, dim3((unsigned)((ys + 255) / 256), 1, batch), dim3(256), 0, st, n, ne, b, ws.P[ic], ys);
+    static const double kLimits[3] = {1e6, 1e10, 1e12};
+    int total_mv = 0, pass = 0;
+    bool fallback = false;
+    for (;; ++pass) {
+        // Rayleigh-Ritz on span P[ic]
+        one.active = active;
+        mult(C, ws.P[ic], nullptr, ws.Zb, ne, b, ys, one);
+        ++total_mv;
+        hipLaunchKernelGGL(lead_gram_kernel, dim3(npair, nslab, batch), dim3(256), 0, st, ne, b, ys, ws.P[ic], ws.Zb, ws.Gp, ws.Hp, active);
+        hipError_t se;
+        const int msw = pass == 0 ? 4 : 20;      // the first block is random: its Ritz values only set the filter's bounds
+        if (b == 32) se = launch_small<32, 256>(st, batch, nslab, ws.Gp, ws.Hp, msw, 1e-18, ws.T, ws.theta, ws.info, active);
+        else if (b == 48) se = launch_small<48, 256>(st, batch, nslab, ws.Gp, ws.Hp, msw, 1e-18, ws.T, ws.theta, ws.info, active);
+        else se = launch_small<64, 512>(st, batch, nslab, ws.Gp, ws.Hp, msw, 1e-18, ws.T, ws.theta, ws.info, active);
+        LCHK(se);
+        hipLaunchKernelGGL(lead_rot_kernel, dim3(nrt, b / 16, batch), dim3(256), 0, st, ne, b, ys, ws.P[ic], ws.Zb, ws.T, ws.theta, ws.P[ix],
+                           ws.P[iy], ws.respart, active);
+        hipLaunchKernelGGL(lead_res_kernel, dim3(batch), dim3(64), 0, st, nrt, b, ws.respart, ws.theta, ws.info, ws.out, active);
+        LCHK(hipMemcpyAsync(ws.h_out, ws.out, sizeof(double) * (size_t)batch * ow, hipMemcpyDeviceToHost, st));
+        LCHK(hipStreamSynchronize(st));
+        LeadCoef step[16];
+        int deg[LEAD_MAXB], mdeg = 0;
+        for (int z = 0; z < batch; ++z) {
+            deg[z] = 0;
+            if (!((active >> z) & 1u)) continue;
+            const double* th = ws.h_out + (size_t)z * ow;
+            const double* rs = th + b;
+            const double* inf = rs + b;
+            if (inf[0] != 0.0 || !(th[0] > 0.0)) { fallback = true; break; }
+            double rmax = 0.0;
+            for (int j = 0; j < rank; ++j) rmax = rs[j] > rmax ? rs[j] : rmax;
+            // The leading `rank` vectors span the invariant subspace to rmax / gap; the bound asks for 1e-10 there and 1e-12 of the
+            // largest eigenvalue on every residual, but never for less than float64 gives (a cluster that straddles the cut has no
+            // gap: any orthonormal basis of it is as good as the one LAPACK's rounding picks for the reference)
+            const double gap = th[rank - 1] - th[rank];
+            double target = 1e-12 * th[0];
+            if (1e-10 * gap < target) target = 1e-10 * gap;
+            const double floor_ = 3e-14 * sqrt((double)n) * th[0];
+            if (target < floor_) target = floor_;
+            const bool conv = rmax <= target && inf[2] != 0.0;
+            if (dbg)
+                fprintf(stderr, "[apv lead] pass %d matrix %d: theta1 %.4e theta_V/theta1 %.3f theta_b/theta_V %.3f gap %.2e res %.2e target %.2e jacobi %d sweeps%s\n",
+                        pass, z, th[0], th[rank - 1] / th[0], th[b - 1] / th[rank - 1], gap / th[0], rmax / th[0], target / th[0], (int)inf[1], conv ? " converged" : "");
+            if (conv) {
+                active &= ~(1u << z);
+                final_buf[z] = ix;
+                continue;
+            }
+            if (pass + 1 >= kMaxPass) { fallback = true; break; }
+            // degree of the next filter
+            double c = th[b - 1];
+            if (!(c > 1e-12 * th[0])) c = 1e-12 * th[0];
+            const double x1 = 2.0 * th[0] / c - 1.0;
+            const double lim = kLimits[pass < 2 ? pass : 2];
+            int m = (int)floor(acosh(lim) / acosh(x1 > 1.0 + 1e-12 ? x1 : 1.0 + 1e-12));
+            const double xv = 2.0 * th[rank - 1] / c - 1.0;
+            if (xv > 1.0 + 1e-9 && rmax > 0.0) {
+                const int need = (int)ceil(log(10.0 * rmax / target) / acosh(xv));
+                if (need >= 1 && need < m) m = need;
+            }
+            m = m < 1 ? 1 : (m > 16 ? 16 : m);
+            deg[z] = m;
+            mdeg = m > mdeg ? m : mdeg;
+        }
+        if (fallback || active == 0) break;
+        // coefficients of the scaled three-term recurrence (Zhou & Saad 2007): damped interval [0, c], sigma_1 = e / (theta_1 - e)
+        for (int i = 0; i < mdeg; ++i) step[i].active = active;
+        for (int z = 0; z < batch; ++z) {
+            if (!((active >> z) & 1u)) continue;
+            const double* th = ws.h_out + (size_t)z * ow;
+            double c = th[b - 1];
+            if (!(c > 1e-12 * th[0])) c = 1e-12 * th[0];
+            const double e = 0.5 * c, ctr = 0.5 * c, sigma1 = e / (th[0] - ctr);
+            double sigma = sigma1;
+            for (int i = 0; i < mdeg; ++i) {
+                if (i >= deg[z]) { step[i].a[z] = 0.0; step[i].b[z] = 1.0; step[i].g[z] = 0.0; continue; }
+                if (i == 0) { step[i].a[z] = sigma1 / e; step[i].b[z] = -ctr * sigma1 / e; step[i].g[z] = 0.0; continue; }
+                const double sn = 1.0 / (2.0 / sigma1 - sigma);
+                step[i].a[z] = 2.0 * sn / e;
+                step[i].b[z] = -ctr * 2.0 * sn / e;
+                step[i].g[z] = -sigma * sn;
+                sigma = sn;
+            }
+        }
+        // step 1 from the known product: Y1 = a CX + b X
+        hipLaunchKernelGGL(lead_axpby_kernel, dim3((unsigned)((ys + 255) / 256), 1, batch), dim3(256), 0, st, (int)ys, ys, ws.P[iy], ws.P[ix], ws.P[ic], step[0]);
+        int prev = ix, cur = ic, fre = iy;
+        for (int i = 1; i < mdeg; ++i) {
+            mult(C, ws.P[cur], ws.P[prev], ws.P[fre], ne, b, ys, step[i]);
+            ++total_mv;
+            const int t = prev; prev = cur; cur = fre; fre = t;
+        }
+        ic = cur; ix = prev; iy = fre;
+    }
+    LCHK(hipGetLastError());
+    if (dbg)
+        fprintf(stderr, "[apv lead] n=%d b=%d rank=%d batch=%d: %d passes, %d block products, %.3f ms%s\n", n, b, rank, batch, pass + 1, total_mv,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), fallback ? " -> full solve" : "");
+    if (fallback) return APV_OK;
+    // U[:, :b] = W^T X, one launch per buffer that holds finished blocks
+    for (int buf = 0; buf < 3; ++buf) {
+        LeadCoef cf = one;
+        cf.active = 0;
+        for (int z = 0; z < batch; ++z)
+            if (final_buf[z] == buf) cf.active |= 1u << z;
+        if (cf.active) mult(WT, ws.P[buf], nullptr, d_U, n, n, (size_t)n * n, cf);
+    }
+    hipLaunchKernelGGL(lead_lam_kernel, dim3(batch), dim3(64), 0, st, n, b, ws.theta, d_lam);
+    LCHK(hipGetLastError());
+#undef LCHK
+    *done = 1;
+    return APV_OK;
+}

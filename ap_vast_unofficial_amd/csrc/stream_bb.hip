@@ -29,6 +29,8 @@ struct apv_bb {
     int dialect, skip, ncols, toff, rel_loading, rel_dark_py;          // statistics conventions of the dialect
     long not_converged;    // hops whose joint diagonalisation hit the sweep cap
     int* d_ranks;          // [V] ascending
+    int max_rank;          // the largest of them: the eigenpairs a hop consumes (apvast.py:406-414)
+    int full_valid;        // U / lam hold ALL eigenpairs of the last hop (0: the leading block only; the rest is computed when read)
     double* nrm;           // [4] ||R_q||_2 for the relative loading
     int ring_off, stat_off, cur;
     int n_out;
@@ -521,6 +523,8 @@ int apv_bb_init(apv_handle* h, int32_t rir_len, const double* h_rir_A, const dou
     s->rel_dark_py = c.reg_mode == APV_REG_REL && dialect == APV_DIALECT_PYTHON;      // apvast.py:26-27, inside jdiag
     const int nz = ((s->zones & 1) ? 1 : 0) + ((s->zones & 2) ? 1 : 0);
     s->n_out = nz * nsol * L + 2 * L;
+    s->max_rank = ranks.back();
+    s->full_valid = 1;
     BCHK(h, hipMalloc((void**)&s->d_ranks, sizeof(int) * nsol));
     BCHK(h, hipMemcpyAsync(s->d_ranks, ranks.data(), sizeof(int) * nsol, hipMemcpyHostToDevice, h->stream));
     BCHK(h, hipStreamSynchronize(h->stream));
@@ -798,10 +802,12 @@ int apv_bb_process_block(apv_handle* h, const double* h_in_A, const double* h_in
         const int first = runA ? 0 : 1, batch = (runA && runB) ? 2 : 1;
         // Python dialect, EXPERIMENTAL_REGULARIZATION = False: jdiag loads a copy of the dark matrix with reg_dark ||B||_2
         // (apvast.py:26-27); the R_* attributes stay as accumulated
+        h->gl_lead_rank = s->max_rank;
         rc = apv_gevd_large(h, n, batch, s->R + first * nn, s->R + (2 + first) * nn, s->rel_loading ? 0.0 : h->cfg.reg_dark,
                             s->rel_dark_py ? s->nrm + 2 + first : nullptr, s->U + first * nn, s->lam + (size_t)first * n, s->r + (size_t)first * n, h->cfg.mu, V, s->d_ranks,
                             s->w + (size_t)first * V * n, status);
         if (rc != APV_OK) return rc;
+        s->full_valid = !h->gl_lead_done;
     }
     if (timing) {
         (void)hipStreamSynchronize(st);
@@ -946,10 +952,12 @@ int apv_bb_process_signal(apv_handle* h, int32_t n_hops, const double* h_in_A, c
             if ((rc = enqueue_front(g + 1)) != APV_OK) return rc;
         }
         BDCHK(h, hipStreamWaitEvent(st, s->ev_front[set], 0));
+        h->gl_lead_rank = s->max_rank;
         rc = apv_gevd_large(h, n, g_n * nz, s->g_RA + set * z_mat, s->g_RB + set * z_mat, s->rel_loading ? 0.0 : h->cfg.reg_dark,
                             s->rel_dark_py ? s->g_nrm + set * z_nrm + (size_t)G * 4 : nullptr, s->g_U, s->g_lam, s->g_r + set * z_vec,
                             h->cfg.mu, V, s->d_ranks, s->g_w, status.data());
         if (rc != APV_OK) return drained(rc);
+        if (g + 1 == n_groups) s->full_valid = !h->gl_lead_done;
         for (int i = 0; i < g_n; ++i) {
             rc = bb_back(h, s, hops[set][i], h_out + (size_t)(h0 + i) * s->n_out * H, s->spec_out);
             if (rc != APV_OK) return drained(rc);
@@ -1155,11 +1163,36 @@ static int bb_lookup(apv_handle* h, const char* name, double** d, size_t* count,
     return apv_fail(h, APV_ERR_STATE, std::string("unknown broadband state name: ") + name);
 }
 
+// The per-hop path solves for the eigenpairs the filters use (kernels_gevd_lead.hip).  lambda_* / U_* in full (apvast.py:380-387)
+// are attributes somebody may read afterwards: the first read after such a hop runs the complete joint diagonalisation on
+// the hop's matrices, which are still there (R is never modified by the solver).
+static int bb_complete_eigenpairs(apv_handle* h) {
+    apv_bb* s = h->bb;
+    if (s->full_valid) return APV_OK;
+    BCHK(h, hipSetDevice(h->device));
+    const bool runA = s->zones & 1, runB = s->zones & 2;
+    const int first = runA ? 0 : 1, batch = (runA && runB) ? 2 : 1, n = s->n;
+    const size_t nn = (size_t)n * n;
+    int32_t status[2] = {0, 0};
+    h->gl_lead_rank = 0;
+    const int rc = apv_gevd_large(h, n, batch, s->R + first * nn, s->R + (2 + first) * nn, s->rel_loading ? 0.0 : h->cfg.reg_dark,
+                                  s->rel_dark_py ? s->nrm + 2 + first : nullptr, s->U + first * nn, s->lam + (size_t)first * n,
+                                  nullptr, h->cfg.mu, 0, nullptr, nullptr, status);
+    if (rc != APV_OK) return rc;
+    if (status[0] == 2 || status[1] == 2)
+        return apv_fail(h, APV_ERR_NO_CONVERGE, "eigen-iteration did not converge (Jacobi sweep cap reached) while completing lambda / U");
+    s->full_valid = 1;
+    return APV_OK;
+}
+
 int apv_bb_get_state(apv_handle* h, const char* name, double* h_dst, size_t count) {
     if (!h || !h->bb || !name || !h_dst) return apv_fail(h, APV_ERR_ARG, "null argument / broadband stream not initialised");
     double* d; size_t need; int rows, len, off;
     int rc = bb_lookup(h, name, &d, &need, &rows, &len, &off);
     if (rc != APV_OK) return rc;
+    if (!std::strcmp(name, "lambda") || !std::strcmp(name, "U0") || !std::strcmp(name, "U1")) {
+        if ((rc = bb_complete_eigenpairs(h)) != APV_OK) return rc;
+    }
     if (count != need) return apv_fail(h, APV_ERR_STATE, "state size mismatch");
     BCHK(h, hipSetDevice(h->device));
     if (rows == 0) {

@@ -87,7 +87,7 @@ typedef struct apv_config {
     double  reg_dark;         /* 1e-7 in the Python dialect (apvast.py:23) */
     double  reg_bright;       /* relative bright loading (apVast.m:552-569); 0 in the Python dialect */
     double  mu;               /* trade-off parameter (apvast.py:49, 410) */
-    int32_t max_sweeps;       /* Jacobi sweep cap; 0 = default */
+    int32_t max_sweeps;       /* Jacobi sweep cap; 0 = default.  Broadband mode: a value > 0 also selects the complete block-Jacobi solve for every hop (0: the per-hop path computes the leading eigenpairs the filters use, the rest when lambda / U are read) */
     int32_t block_size;       /* N : STFT length for the streaming entry points (0 = kernel-level use only) */
     int32_t hop_size;         /* H */
     int32_t n_zones;          /* streaming: bit mask of zone programs, 1 = A, 2 = B (run_A/run_B, apvast.py:53-54) */
