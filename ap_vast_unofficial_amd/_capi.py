@@ -25,7 +25,7 @@ EXPORTS = (
     "apv_create", "apv_destroy", "apv_last_error", "apv_abi_version",
     "apv_dev_alloc", "apv_dev_free", "apv_memcpy_h2d", "apv_memcpy_d2h", "apv_sync",
     "apv_timer_start", "apv_timer_stop",
-    "apv_update_dev", "apv_update", "apv_corr_dev", "apv_corr_bf16_dev", "apv_to_bf16_dev", "apv_gevd_vast_dev", "apv_jdiag_batched", "apv_jdiag_large", "apv_jdiag_large_c128",
+    "apv_update_dev", "apv_update", "apv_corr_dev", "apv_corr_bf16_dev", "apv_to_bf16_dev", "apv_gevd_vast_dev", "apv_jdiag_batched", "apv_jdiag_large", "apv_jdiag_leading", "apv_jdiag_large_c128",
     "apv_stft_analysis_dev", "apv_istft_ola_dev",
     "apv_stream_init", "apv_stream_set_perceptual", "apv_process_block", "apv_process_block_f64", "apv_process_signal", "apv_process_signal_f64", "apv_stream_is_f64", "apv_stream_get_statistics", "apv_stream_not_converged", "apv_state_bytes", "apv_get_state", "apv_set_state",
     "apv_bb_set_rank_list", "apv_bb_init", "apv_bb_set_perceptual", "apv_bb_process_block", "apv_bb_process_signal", "apv_bb_get_state", "apv_bb_set_state",
@@ -99,6 +99,7 @@ def load():
     lib.apv_gevd_vast_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     lib.apv_jdiag_batched.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
     lib.apv_jdiag_large.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
+    lib.apv_jdiag_leading.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.apv_jdiag_large_c128.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
     lib.apv_stft_analysis_dev.argtypes = [vp, i32, vp, vp]
     lib.apv_istft_ola_dev.argtypes = [vp, i32, vp, vp, vp]
@@ -383,6 +384,20 @@ class Engine:
         status = np.empty(batch, dtype=np.int32)
         self._chk(self.lib.apv_jdiag_large(self.h, n, batch, _ptr(A), _ptr(B), _ptr(U), _ptr(lam), _ptr(status)))
         return U, lam
+
+    def jdiag_leading(self, A, B, rank):
+        """The leading `rank` eigenpairs of real symmetric pairs (what apvast.py:406-414 consumes of jdiag's result):
+        U (batch, n, rank), lam (batch, rank), info (batch,) -- 0: subspace iteration, 1: fell back to the complete solve."""
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        B = np.ascontiguousarray(B, dtype=np.float64)
+        if A.ndim != 3 or A.shape != B.shape or A.shape[1] != A.shape[2]:
+            raise ValueError("A, B must be (batch, n, n)")
+        batch, n, _ = A.shape
+        U = np.empty((batch, n, int(rank)))
+        lam = np.empty((batch, int(rank)))
+        info = np.empty(batch, dtype=np.int32)
+        self._chk(self.lib.apv_jdiag_leading(self.h, n, batch, int(rank), _ptr(A), _ptr(B), _ptr(U), _ptr(lam), _ptr(info)))
+        return U, lam, info
 
     def jdiag_large_complex(self, A, B):
         """Complex Hermitian pairs of order 65..1024: U (batch, n, n) complex128, lam (batch, n) float64."""

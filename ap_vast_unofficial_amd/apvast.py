@@ -242,6 +242,14 @@ class apvast:
         if name in c:
             return c[name]
         e, V, n = self._eng, len(self._ranks), self.filter_length * self.number_of_srcs
+        if name.startswith("R_"):
+            # R_X_to_Y belongs to the zone program of its SIGNAL X (apvast.py:333-347, 369-371): R_A_to_B exists whenever run_A is set
+            path = {"R_A_to_A": 0, "R_A_to_B": 2, "R_B_to_B": 1, "R_B_to_A": 3}[name]
+            if not (self.run_A, self.run_B)[path & 1]:
+                return None
+            v = e.bb_get_state(f"R{path}", (n, n))
+            c[name] = v
+            return v
         zone = {"A": 0, "B": 1}.get(name[-1])
         if zone is not None and not (self.run_A, self.run_B)[zone] and not name.startswith("input_spectrum"):
             return None
@@ -254,11 +262,6 @@ class apvast:
         elif name.startswith("input_spectrum_"):
             spec = e.bb_get_state("input_spectrum", (2, self._K, 2))
             v = (spec[zone, :, 0] + 1j * spec[zone, :, 1]).reshape(-1, 1)     # apvast.py:430-431
-        elif name.startswith("R_"):
-            path = {"R_A_to_A": 0, "R_A_to_B": 2, "R_B_to_B": 1, "R_B_to_A": 3}[name]
-            if not (self.run_A, self.run_B)[path & 1]:
-                return None
-            v = e.bb_get_state(f"R{path}", (n, n))
         else:
             raise AttributeError(name)
         c[name] = v

@@ -527,6 +527,63 @@ int apv_jdiag_large(apv_handle* h, int32_t n, int32_t batch, const double* h_A, 
     return APV_OK;
 }
 
+// gathers the leading `rank` columns of U [batch][n][n] into [batch][n][rank]
+__global__ void __launch_bounds__(256) lead_cols_kernel(int n, int rank, const double* __restrict__ U, double* __restrict__ out) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t per = (size_t)n * rank;
+    if (idx >= per) return;
+    const int z = blockIdx.y;
+    const int i = (int)(idx / rank), j = (int)(idx % rank);
+    out[z * per + idx] = U[(size_t)z * n * n + (size_t)i * n + j];
+}
+
+int apv_jdiag_leading(apv_handle* h, int32_t n, int32_t batch, int32_t rank, const double* h_A, const double* h_B, double* h_U,
+                      double* h_lam, int32_t* h_info) {
+    if (!h || !h_A || !h_B || !h_U || !h_lam) return fail(h, APV_ERR_ARG, "null host pointer");
+    if (n < 1 || n > 2048 || batch < 0) return fail(h, APV_ERR_ARG, "apv_jdiag_leading: n must be in 1..2048");
+    if (rank < 1 || rank > n) return fail(h, APV_ERR_ARG, "apv_jdiag_leading: rank must be in 1..n");
+    if (batch == 0) return APV_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t mat = (size_t)batch * n * n * sizeof(double);
+    struct Tmp {
+        double* p[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        ~Tmp() { for (double* q : p) if (q) (void)hipFree(q); }
+    } t;
+    double*& dA = t.p[0]; double*& dB = t.p[1]; double*& dU = t.p[2]; double*& dl = t.p[3]; double*& dn = t.p[4]; double*& dV = t.p[5];
+    HIPCHK(h, hipMalloc((void**)&dA, mat));
+    HIPCHK(h, hipMalloc((void**)&dB, mat));
+    HIPCHK(h, hipMalloc((void**)&dU, mat));
+    HIPCHK(h, hipMalloc((void**)&dl, (size_t)batch * n * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&dV, (size_t)batch * n * rank * sizeof(double)));
+    HIPCHK(h, hipMemcpyAsync(dA, h_A, mat, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(dB, h_B, mat, hipMemcpyHostToDevice, h->stream));
+    if (h->cfg.reg_mode == APV_REG_REL) {
+        HIPCHK(h, hipMalloc((void**)&dn, (size_t)batch * sizeof(double)));
+        for (int z0 = 0; z0 < batch; z0 += 4) {
+            const double* mats[4];
+            const int cnt = batch - z0 < 4 ? batch - z0 : 4;
+            for (int q = 0; q < cnt; ++q) mats[q] = dB + (size_t)(z0 + q) * n * n;
+            HIPCHK(h, apv_launch_norm2(n, cnt, mats, dn + z0, h->stream));
+        }
+    }
+    std::vector<int32_t> st(batch, 0);
+    h->gl_lead_rank = rank;
+    int rc = apv_gevd_large(h, n, batch, dA, dB, h->cfg.reg_dark, dn, dU, dl, nullptr, 0.0, 0, nullptr, nullptr, st.data());
+    const int lead_done = h->gl_lead_done;
+    if (rc != APV_OK) return rc;
+    const size_t per = (size_t)n * rank;
+    hipLaunchKernelGGL(lead_cols_kernel, dim3((unsigned)((per + 255) / 256), batch), dim3(256), 0, h->stream, n, rank, dU, dV);
+    HIPCHK(h, hipMemcpyAsync(h_U, dV, (size_t)batch * per * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    for (int z = 0; z < batch; ++z)
+        HIPCHK(h, hipMemcpyAsync(h_lam + (size_t)z * rank, dl + (size_t)z * n, sizeof(double) * rank, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int z = 0; z < batch; ++z) {
+        if (h_info) h_info[z] = lead_done ? 0 : 1;
+        if (st[z] == 2) return fail(h, APV_ERR_NO_CONVERGE, "eigen-iteration did not converge");
+    }
+    return APV_OK;
+}
+
 int apv_stft_analysis_dev(apv_handle* h, int32_t n_ch, const float* d_x, void* d_spec) {
     if (!h || !d_x || !d_spec) return fail(h, APV_ERR_ARG, "null device pointer");
     if (h->cfg.block_size <= 0) return fail(h, APV_ERR_ARG, "handle was created without an STFT geometry");

@@ -590,8 +590,9 @@ int apv_gevd_lead(apv_handle* h, int n, int ne, int batch, int b, int rank, cons
     for (int z = 0; z < batch; ++z) final_buf[z] = -1;
     hipLaunchKernelGGL(lead_init_kernel, dim3((unsigned)((ys + 255) / 256), 1, batch), dim3(256), 0, st, n, ne, b, ws.P[ic], ys);
     static const double kLimits[3] = {1e6, 1e10, 1e12};
+    static const int kPartialSweeps = getenv("APV_LEAD_SWEEPS") ? atoi(getenv("APV_LEAD_SWEEPS")) : 3;     // tuning aid
     int total_mv = 0, pass = 0;
-    bool fallback = false;
+    bool fallback = false, finishing = false;
     for (;; ++pass) {
         // Rayleigh-Ritz on span P[ic]
         one.active = active;
@@ -599,7 +600,9 @@ int apv_gevd_lead(apv_handle* h, int n, int ne, int batch, int b, int rank, cons
         ++total_mv;
         hipLaunchKernelGGL(lead_gram_kernel, dim3(npair, nslab, batch), dim3(256), 0, st, ne, b, ys, ws.P[ic], ws.Zb, ws.Gp, ws.Hp, active);
         hipError_t se;
-        const int msw = pass == 0 ? 4 : 20;      // the first block is random: its Ritz values only set the filter's bounds
+        // Any orthogonal Q serves a pass that is followed by another filter: the sweeps only have to sharpen the Ritz values that
+        // set its bounds.  A pass that may be the last one (`finishing`) sweeps until the Jacobi bound is met.
+        const int msw = finishing ? 20 : kPartialSweeps;
         if (b == 32) se = launch_small<32, 256>(st, batch, nslab, ws.Gp, ws.Hp, msw, 1e-18, ws.T, ws.theta, ws.info, active);
         else if (b == 48) se = launch_small<48, 256>(st, batch, nslab, ws.Gp, ws.Hp, msw, 1e-18, ws.T, ws.theta, ws.info, active);
         else se = launch_small<64, 512>(st, batch, nslab, ws.Gp, ws.Hp, msw, 1e-18, ws.T, ws.theta, ws.info, active);
@@ -611,6 +614,7 @@ int apv_gevd_lead(apv_handle* h, int n, int ne, int batch, int b, int rank, cons
         LCHK(hipStreamSynchronize(st));
         LeadCoef step[16];
         int deg[LEAD_MAXB], mdeg = 0;
+        bool next_finishing = false;
         for (int z = 0; z < batch; ++z) {
             deg[z] = 0;
             if (!((active >> z) & 1u)) continue;
@@ -647,13 +651,17 @@ int apv_gevd_lead(apv_handle* h, int n, int ne, int batch, int b, int rank, cons
             const double xv = 2.0 * th[rank - 1] / c - 1.0;
             if (xv > 1.0 + 1e-9 && rmax > 0.0) {
                 const int need = (int)ceil(log(10.0 * rmax / target) / acosh(xv));
+                // the filter is as long as the bound asks, not as long as the cap allows: the next pass is expected to end the solve
+                if (need <= m) next_finishing = true;
                 if (need >= 1 && need < m) m = need;
             }
+            if (rmax <= target) next_finishing = true;      // only the partial sweeps stand between this pass and the bound
             m = m < 1 ? 1 : (m > 16 ? 16 : m);
             deg[z] = m;
             mdeg = m > mdeg ? m : mdeg;
         }
         if (fallback || active == 0) break;
+        finishing = next_finishing;
         // coefficients of the scaled three-term recurrence (Zhou & Saad 2007): damped interval [0, c], sigma_1 = e / (theta_1 - e)
         for (int i = 0; i < mdeg; ++i) step[i].active = active;
         for (int z = 0; z < batch; ++z) {

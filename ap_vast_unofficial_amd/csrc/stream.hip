@@ -98,6 +98,8 @@ struct apv_stream {
     void* ck_inspec;              // [2 sig_chunk][2][K]
     void* ck_w[CK_NB - 1][2];     // [K][nV][L] per zone: filters of back streams 1 ... (back stream 0 uses w, lam)
     void* ck_lam[CK_NB - 1][2];
+    void* ck_spill[CK_NB - 1];    // per-bin scratch of the joint diagonalisation (orders 33..64) for back streams 1 ...: two hops' workgroups for
+                                  // the same bin run at once, each parks its state in its own stream's slot (back stream 0 uses d_Lspill)
     hipStream_t ck_back[CK_NB - 1];
     void* ck_pin_in;              // pinned [CK_NS][sig_chunk][2][H]: the host stages chunk c + 1 while chunks c - 1 and c are in flight
     void* ck_pin_out;             // pinned [CK_NS][sig_chunk] hop results
@@ -213,6 +215,7 @@ void apv_stream_free(apv_handle* h) {
             if (s->ck_w[b][z]) (void)hipFree(s->ck_w[b][z]);
             if (s->ck_lam[b][z]) (void)hipFree(s->ck_lam[b][z]);
         }
+        if (s->ck_spill[b]) (void)hipFree(s->ck_spill[b]);
         if (s->ck_back[b]) (void)hipStreamDestroy(s->ck_back[b]);
     }
     for (int q = 0; q < CK_NS; ++q)
@@ -366,6 +369,7 @@ struct BackSchedule {
     void* result = nullptr;
     void* ospec = nullptr;
     bool no_copy = false;
+    void* lspill = nullptr;   // GevdParams::Lspill of this launch (nullptr: the handle's d_Lspill)
 };
 
 // Back half of a hop on stream `st`: spectra of set `set` -> per-bin filters (K5'-K10), output spectra (K3), synthesis
@@ -396,6 +400,7 @@ static int enqueue_back(apv_handle* h, hipStream_t st, const HopSpectra& q, void
         p.status = ostatus[first];
         p.n_zones = (runA && runB) ? 2 : 1;
         p.yield_issue = sch.yield_issue;
+        if (sch.lspill) p.Lspill = sch.lspill;
         if (p.n_zones == 2) {
             p.XB1 = q.X[3]; p.XD1 = q.X[2]; p.d1 = q.tspec[1];
             p.w1 = wz[1]; p.lam1 = lamz[1]; p.status1 = ostatus[1];
@@ -778,6 +783,11 @@ static int chunk_prepare(apv_handle* h) {
             if ((rc = dalloc(h, &s->ck_w[b][z], K * s->nV * L, wsz(h)))) return rc;
             if ((rc = dalloc(h, &s->ck_lam[b][z], K * L, lsz(h)))) return rc;
         }
+        {
+            const apv_config& c = h->cfg;
+            const size_t spill = apv_gevd_spill_bytes((int)L, (int)K, c.compute_dtype, c.reg_mode, c.reg_bright, c.sweep_tol2, c.n_zones == 3 ? 2 : 1);
+            if (spill > 0 && (rc = dalloc(h, &s->ck_spill[b], spill, 1))) return rc;
+        }
         SCHK(h, hipStreamCreateWithFlags(&s->ck_back[b], hipStreamNonBlocking));
     }
     for (int q = 0; q < CK_NS; ++q) SCHK(h, hipEventCreateWithFlags(&s->ck_done[q], hipEventDisableTiming));
@@ -1008,6 +1018,7 @@ static int process_signal_chunked_t(apv_handle* h, int n_hops, const TI* h_in_A,
             sch.no_copy = true;
             static const bool no_yield = getenv("APV_SIGNAL_NO_YIELD") != nullptr;       // A/B switch
             sch.yield_issue = no_yield ? 0 : 1;
+            sch.lspill = b > 0 ? s->ck_spill[b - 1] : nullptr;
             rc = enqueue_back(h, bs[b], set_of(par, i), wset[b], lset[b], nullptr, sch);
             if (rc != APV_OK) return bail(rc, h->err);
             if (i + CK_NB >= nc) CK(hipEventRecord(s->ck_backdone[par][b], bs[b]));   // this stream's last hop of the chunk

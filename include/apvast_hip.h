@@ -166,6 +166,14 @@ int  apv_jdiag_batched(apv_handle* h, int32_t n, int32_t batch, const double* h_
  * the sizes of its call sites apvast.py:380, 382 */
 int  apv_jdiag_large(apv_handle* h, int32_t n, int32_t batch, const double* h_A, const double* h_B,
                      double* h_U, double* h_lam, int32_t* h_status);
+/* The leading `rank` eigenpairs of real symmetric pairs of broadband order -- what the filters consume: apvast.py:406-414 uses
+ * U[:, :V] and diag(D)[:V] of the jdiag call at apvast.py:380, 382.  U: [batch][n][rank] (columns = eigenvectors, descending,
+ * U^T (B + reg I) U = I), lam: [batch][rank].  Chebyshev-filtered subspace iteration on the whitened matrix
+ * (kernels_gevd_lead.hip); h_info[z] = 0: that solver converged, 1: the call fell back to the complete block-Jacobi solve of
+ * apv_jdiag_large (flat spectrum beyond the cut, rank too large for a block of 64, Gram breakdown) -- the results are
+ * valid either way.  h_info may be NULL.                      replaces apvast.py:20-36 + the slices of 406-414 */
+int  apv_jdiag_leading(apv_handle* h, int32_t n, int32_t batch, int32_t rank, const double* h_A, const double* h_B,
+                       double* h_U, double* h_lam, int32_t* h_info);
 /* Complex Hermitian pairs beyond the per-bin orders, n <= 1024 (apvast.py:20-36 takes any order; apv_jdiag_batched stops at
  * 64): A, B, U are [batch][n][n] complex128 row-major, lam [batch][n] f64.  Runs the real symmetric solver above on the
  * embedding [Re -Im; Im Re] of order 2n and keeps n of its 2n eigenvectors that are independent over C

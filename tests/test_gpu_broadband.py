@@ -75,6 +75,13 @@ def test_g1b_single_zone_on_gpu(golden):
         assert np.abs(np.stack(out[0]) - g["out_A"][h]).max() <= 1e-9 * np.abs(g["out_A"][h]).max()
         assert np.abs(np.stack(out[3]) - g["out_Bt"][h]).max() <= 1e-9 * np.abs(g["out_Bt"][h]).max()
     assert np.abs(ap.lambda_A[:4] / g["lam"][:4] - 1).max() < 1e-8
+    # zone program A owns both of its matrices (apvast.py:333-347, 369-371): R_A_to_B is built whenever run_A is set, although its
+    # name ends in the zone that does not run; zone B's are absent
+    assert ap.R_B_to_B is None and ap.R_B_to_A is None
+    RD = ap.R_A_to_B
+    assert RD is not None and RD.shape == (256, 256) and np.array_equal(RD, RD.T)
+    U = ap.U_A
+    assert np.abs(U.T @ (RD + 1e-7 * np.eye(256)) @ U - np.eye(256)).max() < 1e-9
     ap.close()
 
 

@@ -379,6 +379,33 @@ def _hop_loop(ap, x, h0, h1):
             for q in range(4)]
 
 
+@pytest.mark.parametrize("dtype,L", [("f64", 64), ("f32", 64), ("f64", 40)])
+def test_process_signal_equals_hop_loop_orders_33_to_64(dtype, L):
+    """Orders 33..64 park per-bin state of the joint diagonalisation in HBM scratch (the order-64 kernel's slots, the LDS
+    kernel's Cholesky factor).  The chunked whole-signal path runs the diagonalisations of consecutive hops on three streams at
+    once: each back stream must park in scratch of its own, or two hops overwrite each other's bins.  Bit for bit
+    against the hop loop, over a chunk boundary."""
+    from ap_vast_unofficial_amd.apvast import apvast
+    M = L + 8
+    rirA, rirB = synth_rirs(70, L, M, 21)
+    N, H = 128, 64
+    mk = lambda: apvast(N, rirA, rirB, 16, 5, 1, 2, 2, 1.0, 4 * N, hop_size=H, seed=3, dtype=dtype, perceptual=False,
+                        sampling_rate=16000)
+    a, b = mk(), mk()
+    n_hops = 21
+    x = np.random.default_rng(9).standard_normal((2, n_hops * H))
+    ref = _hop_loop(a, x, 0, n_hops)
+    got = list(b.process_signal(x[0], x[1]))
+    for q in range(4):
+        for v in range(len(ref[q])):
+            assert got[q][v].shape == ref[q][v].shape == (n_hops * H, L)
+            assert np.array_equal(got[q][v], ref[q][v]), (q, v)
+    for z in "AB":
+        assert np.array_equal(getattr(a, "w_" + z), getattr(b, "w_" + z))
+    a.close()
+    b.close()
+
+
 @pytest.mark.parametrize("dtype,run_A,run_B,perceptual,P", [("f64", True, True, False, 70), ("mixed", True, True, False, 70),
                                                             ("f32", True, False, False, 70), ("f64", False, True, True, 70),
                                                             ("f64", True, True, False, 20), ("f32", True, True, False, 20)])
