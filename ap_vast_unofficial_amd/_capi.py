@@ -30,7 +30,7 @@ EXPORTS = (
     "apv_stream_init", "apv_stream_set_perceptual", "apv_process_block", "apv_process_block_f64", "apv_process_signal", "apv_process_signal_f64", "apv_stream_is_f64", "apv_stream_get_statistics", "apv_stream_not_converged", "apv_state_bytes", "apv_get_state", "apv_set_state",
     "apv_bb_set_rank_list", "apv_bb_init", "apv_bb_set_perceptual", "apv_bb_process_block", "apv_bb_process_signal", "apv_bb_get_state", "apv_bb_set_state",
     "apv_predict_pressure", "apv_vast_static",
-    "apv_comm_unique_id", "apv_comm_init", "apv_allgather_filters_dev", "apv_comm_last_gather", "apv_comm_barrier",
+    "apv_comm_unique_id", "apv_comm_init", "apv_allgather_filters_dev", "apv_comm_count", "apv_comm_last_gather", "apv_comm_barrier",
     "apv_debug_set_stamps", "apv_device_sync", "apv_device_info",
 )
 
@@ -127,6 +127,7 @@ def load():
     lib.apv_comm_unique_id.argtypes = [C.c_char_p]
     lib.apv_comm_init.argtypes = [vp, C.c_char_p, i32, i32]
     lib.apv_allgather_filters_dev.argtypes = [vp, vp, vp]
+    lib.apv_comm_count.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     lib.apv_comm_last_gather.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(sz)]
     lib.apv_comm_barrier.argtypes = [vp]
     lib.apv_debug_set_stamps.argtypes = [vp, vp]
@@ -611,6 +612,12 @@ class Engine:
 
     def allgather_filters_dev(self, dw_shard, dw_all):
         self._chk(self.lib.apv_allgather_filters_dev(self.h, dw_shard.ptr, dw_all.ptr))
+
+    def comm_count(self):
+        """(ranks, this rank) as the RCCL communicator reports them."""
+        n, r = C.c_int32(), C.c_int32()
+        self._chk(self.lib.apv_comm_count(self.h, C.byref(n), C.byref(r)))
+        return n.value, r.value
 
     def comm_last_gather(self):
         """(device milliseconds, bytes contributed by this rank) of the latest all-gather."""

@@ -624,6 +624,14 @@ int apv_comm_init(apv_handle* h, const char id[128], int32_t rank, int32_t world
     ncclComm_t comm;
     ncclResult_t r = ncclCommInitRank(&comm, world, uid, rank);
     if (r != ncclSuccess) return fail(h, APV_ERR_RCCL, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
+    // the communicator must be the one that was asked for: a rank that joined another job's id, or a world of another size,
+    // would gather somebody else's shards without any call failing
+    int count = -1, urank = -1;
+    if (ncclCommCount(comm, &count) != ncclSuccess || ncclCommUserRank(comm, &urank) != ncclSuccess || count != world || urank != rank) {
+        (void)ncclCommDestroy(comm);
+        return fail(h, APV_ERR_RCCL, "communicator reports " + std::to_string(count) + " ranks / rank " + std::to_string(urank) +
+                                         ", expected " + std::to_string(world) + " / " + std::to_string(rank));
+    }
     h->comm = comm;
     h->comm_rank = rank;
     h->comm_world = world;
@@ -668,6 +676,18 @@ int apv_allgather_filters_dev(apv_handle* h, const void* d_w_shard, void* d_w_al
     }
     h->gather_done[slot].ptr = d_w_shard;
     HIPCHK(h, hipEventRecord(h->gather_done[slot].ev, h->comm_stream));
+    return APV_OK;
+}
+
+int apv_comm_count(apv_handle* h, int32_t* n_ranks, int32_t* user_rank) {
+    if (!h || !n_ranks) return fail(h, APV_ERR_ARG, "null argument");
+    if (!h->comm) return fail(h, APV_ERR_RCCL, "communicator not initialised (apv_comm_init)");
+    int count = 0, urank = 0;
+    ncclResult_t r = ncclCommCount((ncclComm_t)h->comm, &count);
+    if (r == ncclSuccess) r = ncclCommUserRank((ncclComm_t)h->comm, &urank);
+    if (r != ncclSuccess) return fail(h, APV_ERR_RCCL, std::string("ncclCommCount: ") + ncclGetErrorString(r));
+    *n_ranks = count;
+    if (user_rank) *user_rank = urank;
     return APV_OK;
 }
 

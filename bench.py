@@ -25,7 +25,10 @@ is exchanged over a TCP hub (ap_vast_unofficial_amd/rendezvous.py) and barriers 
 Rank 0 prints ONE JSON line.  At N = 1 it also carries:
   also.cfg3   BASELINE config 3 through the drop-in class: 468 hops of 10 s pink noise, 16 x 32, N = 2048, float64, once
               through apvast.process_input_buffers (one call per hop) and once through apvast.process_signal
-  also.cfg5   BASELINE config 5 at kernel level: 64 x 128 x 2048 bins in float64, with its own roofline
+  also.cfg5   BASELINE config 5 at kernel level: 64 x 128 x 2048 bins in float64, with its own roofline, and
+              also.cfg5.correlation: the correlation stage alone with f32 / bf16 / f64 accumulation on the matrix cores
+  also.cfg4_rehearsal   the multi-rank code path (TCP rendezvous, RCCL communicator, cfg4 shard, all-gather, gather check) at world
+              size 1, run in a child process that is started and has ended before this process touches the GPU
   also.cfg1   BASELINE config 1 in the reference's own broadband formulation through the class (per-hop calls and process_signal)
   also.reference_test_parameters   the same at the reference's own test parameters (make_python_test.m: n = 800)
   cpu_baseline  the oracle's per-bin loop on the host cores (one single-threaded process per core)
@@ -283,6 +286,25 @@ def also_cfg3(device, hops=468):
         rec["not_converged_hops"] = obj.not_converged
     finally:
         obj.close()
+    # outside the timed regions: the whole-signal call must return what the hop loop returns, sample for sample.  Two fresh objects
+    # (same seed, same start buffers), the first `check_hops` hops of the same input: three chunks of the pipelined path.
+    check_hops = 48
+    a = apvast(N, rirA, rirB, 100, 20, 0, 0, 1, 1.0, 4 * N, hop_size=H, sampling_rate=48000, perceptual=False, dtype="f64", seed=0, device=device)
+    b = apvast(N, rirA, rirB, 100, 20, 0, 0, 1, 1.0, 4 * N, hop_size=H, sampling_rate=48000, perceptual=False, dtype="f64", seed=0, device=device)
+    try:
+        loop = [a.process_input_buffers(x[0, h * H:(h + 1) * H], x[1, h * H:(h + 1) * H]) for h in range(check_hops)]
+        sig = b.process_signal(x[0, :check_hops * H], x[1, :check_hops * H])
+        equal = True
+        for q in range(4):
+            for v in range(len(sig[q])):
+                equal = equal and np.array_equal(np.concatenate([o[q][v] for o in loop]), sig[q][v])
+        rec["values_checked"] = {"hops": check_hops, "process_signal_equals_hop_loop": bool(equal),
+                                 "how": "numpy.array_equal on every output sample of both zones and both target paths, fresh objects"}
+        if not equal:
+            raise RuntimeError("cfg3: process_signal differs from the hop loop")
+    finally:
+        a.close()
+        b.close()
     return rec
 
 
@@ -369,6 +391,57 @@ def load_traffic(tag, K, dtype):
     return None
 
 
+def cfg5_correlation(Engine, device, reps=20):
+    """BASELINE config 5's "fp32 vs bf16 correlation accumulation": the correlation stage alone (R_B = X_B^H X_B, R_D = X_D^H X_D,
+    r = X_B^H d) at 64 x 128 x 2048 through apv_corr_dev / apv_corr_bf16_dev: c64 inputs on the f32 matrix cores, bf16 input pairs
+    on the bf16 matrix cores with f32 accumulation, and c64 inputs on the f64 matrix cores.  Bytes are what each variant must move
+    (inputs once, R_B / R_D / r once); errors are relative Frobenius distances to the float64 result, worst bin of the first 32."""
+    L5, M5, K5 = 64, 128, 2048
+    XB, XD, d = synth(K5, 1234, L5, M5)
+    n_in = (K5 * M5 * L5, K5 * M5 * L5, K5 * M5)
+    nbytes = {"f32": sum(n_in) * 8 + (2 * K5 * L5 * L5 + K5 * L5) * 8,
+              "bf16": sum(n_in) * 4 + (2 * K5 * L5 * L5 + K5 * L5) * 8,
+              "f64": sum(n_in) * 8 + (2 * K5 * L5 * L5 + K5 * L5) * 16}
+    flop = 16 * M5 * L5 * L5 + 8 * M5 * L5
+    res, ref = {}, None
+    for mode in ("f64", "f32", "bf16"):
+        eng = Engine(K5, L5, M5, compute_dtype="f64" if mode == "f64" else "f32", device=device)
+        try:
+            src = [eng.to_device(a) for a in (XB, XD, d)]
+            cs = 16 if mode == "f64" else 8
+            dR = [eng.alloc(K5 * L5 * L5 * cs), eng.alloc(K5 * L5 * L5 * cs), eng.alloc(K5 * L5 * cs)]
+            if mode == "bf16":
+                bf = [eng.alloc(n * 4) for n in n_in]
+                for s_, b_, n in zip(src, bf, n_in):
+                    eng._chk(eng.lib.apv_to_bf16_dev(eng.h, n, s_.ptr, b_.ptr))
+                run = lambda: eng._chk(eng.lib.apv_corr_bf16_dev(eng.h, bf[0].ptr, bf[1].ptr, bf[2].ptr, dR[0].ptr, dR[1].ptr, dR[2].ptr))
+            else:
+                run = lambda: eng._chk(eng.lib.apv_corr_dev(eng.h, src[0].ptr, src[1].ptr, src[2].ptr, dR[0].ptr, dR[1].ptr, dR[2].ptr))
+            for _ in range(4):
+                run()
+            eng.sync()
+            eng.timer_start()
+            for _ in range(reps):
+                run()
+            ms = eng.timer_stop() / reps
+            dt = np.complex128 if mode == "f64" else np.complex64
+            got = [dR[0].download((K5, L5, L5), dt)[:32].astype(np.complex128), dR[1].download((K5, L5, L5), dt)[:32].astype(np.complex128),
+                   dR[2].download((K5, L5), dt)[:32].astype(np.complex128)]
+        finally:
+            eng.close()
+        if ref is None:
+            ref = got
+        fro = lambda a, b: float((np.linalg.norm((a - b).reshape(32, -1), axis=1) / np.linalg.norm(b.reshape(32, -1), axis=1)).max())
+        res[mode] = {"ms": ms, "algorithmic_bytes": nbytes[mode], "algorithmic_gbps": nbytes[mode] / (ms * 1e-3) / 1e9,
+                     "hbm_frac": nbytes[mode] / (ms * 1e-3) / HBM_PEAK, "tflops": flop * K5 / (ms * 1e-3) / 1e12,
+                     "bins_per_s": K5 / (ms * 1e-3),
+                     "R_B_rel_fro_err_vs_f64": fro(got[0], ref[0]), "R_D_rel_fro_err_vs_f64": fro(got[1], ref[1]),
+                     "r_rel_err_vs_f64": fro(got[2], ref[2])}
+    res["workload"] = "cfg5 correlation alone: 64 x 128 x 2048, R_B, R_D, r from c64 (bf16: rounded pairs) control-point slabs"
+    res["hbm_peak_gbps"] = HBM_PEAK / 1e9
+    return res
+
+
 def also_cfg5(Engine, device, steps=20, warmup=8):
     """BASELINE config 5 at kernel level: 64 loudspeakers x 128 control points x 2048 bins, float64, V in {1, 32, 64}."""
     L5, M5, K5 = 64, 128, 2048
@@ -395,7 +468,11 @@ def also_cfg5(Engine, device, steps=20, warmup=8):
     fpu = flop_per_update(L5, M5, L5)
     ach = bpu * K5 / (kern_ms * 1e-3)
     alu = K5 / (kern_ms * 1e-3) * fpu
-    return {"workload": "cfg5: 64 loudspeakers x 128 control points x 2048 bins, fused correlate+GEVD+VAST filter, 1 zone "
+    try:
+        corr = cfg5_correlation(Engine, device)
+    except Exception as ex:
+        corr = {"error": f"{type(ex).__name__}: {ex}"}
+    return {"correlation": corr, "workload": "cfg5: 64 loudspeakers x 128 control points x 2048 bins, fused correlate+GEVD+VAST filter, 1 zone "
                         "program, V in {1, 32, 64}, c64 in / c64 out",
             "dtype": "f64", "steps": steps, "value": steps * K5 / wall, "unit": "updates/s", "ms_per_step": wall / steps * 1e3,
             "status_nonzero_bins": int((st != 0).sum()),
@@ -406,6 +483,54 @@ def also_cfg5(Engine, device, steps=20, warmup=8):
                                  "MI355X) with its LAPACK-style flop count; the HBM fraction is reported beside it",
                          "hbm": {"algorithmic_bytes_per_update": bpu, "achieved_gbps": ach / 1e9, "peak_gbps": HBM_PEAK / 1e9,
                                  "frac": ach / HBM_PEAK, "traffic": load_traffic("traffic_cfg5.json", K5, "f64")}}}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# multi-rank self-checks
+# ---------------------------------------------------------------------------------------------------------------------
+def checksum64(buf):
+    """63-bit checksum of a bytes-like object (BLAKE2b, 8-byte digest): fits the rendezvous' int64 value."""
+    import hashlib
+    return int.from_bytes(hashlib.blake2b(bytes(buf), digest_size=8).digest(), "little") & ((1 << 63) - 1)
+
+
+def verify_gather(rz, rank, world, own_shard_bytes, gathered_slice):
+    """Every rank sends the checksum of the shard it contributed over the rendezvous; rank 0 compares them, rank by rank, with
+    the checksums of the slices of ITS gathered bank (`gathered_slice(g)` -> bytes of slice g; only rank 0 calls it).  A
+    mis-ordered, stale or foreign gather cannot pass: every rank's inputs have their own seed.  Returns the verdict on every
+    rank (rank 0 decides, everybody learns it)."""
+    sums = rz.gather(checksum64(own_shard_bytes))
+    bad = -1
+    if rank == 0:
+        for g in range(world):
+            if checksum64(gathered_slice(g)) != sums[g]:
+                bad = g
+                break
+    bad = rz.broadcast(bad if rank == 0 else None)
+    return bad
+
+
+def run_cfg4_rehearsal():
+    """The multi-rank code path at world size 1 in a child of this process: started -- and finished -- before this process has
+    made any GPU call (a process that holds a HIP context must not start another that does).  Returns the child's record."""
+    env = dict(os.environ)
+    env.update({"APV_BENCH_FORCE_DIST": "1", "RANK": "0", "LOCAL_RANK": env.get("LOCAL_RANK", "0"), "WORLD_SIZE": "1",
+                "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port()), "APV_BENCH_CHILD": "1"})
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    t0 = time.perf_counter()
+    p = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "100", "--warmup", "20", "--no-also",
+                        "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    if p.returncode != 0:
+        return {"error": f"child exited with code {p.returncode}: {p.stderr.decode(errors='replace')[-400:]}"}
+    line = json.loads(p.stdout.decode().strip().splitlines()[-1])
+    keep = ("value", "unit", "ms_per_step", "steps", "n_gpus", "collective_us", "collective_bytes_per_rank", "rccl_ranks",
+            "gather_check")
+    rec = {k: line.get(k) for k in keep}
+    rec["workload"] = line["config"]["workload"]
+    rec["collective"] = line["config"]["collective"]
+    rec["kernel_ms"] = line["roofline"]["kernel_ms"]
+    rec["child_wall_s"] = time.perf_counter() - t0
+    return rec
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -480,9 +605,19 @@ def dryrun_rank():
     assert uid == bytes(range(128))
     worst = rz.allreduce(1.0 + rank, max)
     ranks_seen = rz.allreduce(1 << rank, lambda v: sum(v))
+    # the gather check of the real run: every rank's shard has its own seed; rank 0's "gathered bank" is what a correct
+    # all-gather would hold.  APV_BENCH_DRYRUN_SWAP=1 hands rank 0 a bank with two slices exchanged: the check must name it.
+    shard = lambda g: np.random.default_rng(1234 + g).standard_normal(256).astype(np.float32).tobytes()
+    order = list(range(world))
+    if os.environ.get("APV_BENCH_DRYRUN_SWAP") and world > 1:
+        order[0], order[1] = order[1], order[0]
+    bad = verify_gather(rz, rank, world, shard(rank), lambda g: shard(order[g]))
     rz.close()
+    if bad >= 0:
+        print(f"[bench] gather check failed: slice {bad} of the gathered bank is not rank {bad}'s shard", file=sys.stderr, flush=True)
+        raise SystemExit(9)
     if rank == 0:
-        print(json.dumps({"dryrun": True, "n_gpus": world, "max_elapsed": worst, "rank_mask": ranks_seen,
+        print(json.dumps({"dryrun": True, "n_gpus": world, "max_elapsed": worst, "rank_mask": ranks_seen, "gather_check": "ok",
                           "local_rank": int(os.environ.get("LOCAL_RANK", "-1"))}), flush=True)
 
 
@@ -507,6 +642,13 @@ def main():
         return dryrun_rank()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL needs it); before HIP starts
+    rehearsal = None
+    if (args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not os.environ.get("APV_BENCH_FORCE_DIST")
+            and not args.no_also):
+        try:
+            rehearsal = run_cfg4_rehearsal()          # before anything below loads HIP in this process
+        except Exception as ex:
+            rehearsal = {"error": f"{type(ex).__name__}: {ex}"}
     # ONE JSON line on stdout: libraries write there too (librccl prints a version banner when a communicator is made), so file
     # descriptor 1 is pointed at stderr for the life of the rank and the line goes out through a private copy of the original.
     sys.stdout.flush()
@@ -566,9 +708,12 @@ def main():
 
     flip = [0]
 
+    last_out = [dw]
+
     def step():
         out = dw if flip[0] == 0 else dw2
         flip[0] ^= 1
+        last_out[0] = out
         eng.update_dev(dXB, dXD, dd, out, None, dstatus)
         if multi:
             eng.allgather_filters_dev(out, dw_all)
@@ -606,11 +751,23 @@ def main():
     status = dstatus.download((K,), np.int32)      # every launch rewrote it: this is the last step's
     if status.any():
         raise RuntimeError(f"GEVD status != 0 in {int((status != 0).sum())} bins")
-    gather_ms = gather_bytes = None
+    gather_ms = gather_bytes = rccl_ranks = None
+    gather_check = None
     if multi:
         gather_ms, gather_bytes = eng.comm_last_gather()
         elapsed = rz.allreduce(elapsed, max)
         gather_ms = rz.allreduce(gather_ms, max)
+        # what the communicator itself says, and whether the bank rank 0 holds after the last step IS the ranks' shards in rank
+        # order (outside the timed region)
+        rccl_ranks, rccl_rank = eng.comm_count()
+        if rccl_ranks != world or rccl_rank != rank:
+            raise SystemExit(f"[bench] RCCL communicator reports {rccl_ranks} ranks / rank {rccl_rank}, expected {world} / {rank}")
+        own = last_out[0].download((w_bytes,), np.uint8)
+        bank = dw_all.download((w_bytes * world,), np.uint8) if rank == 0 else None
+        bad = verify_gather(rz, rank, world, own, lambda g: bank[g * w_bytes:(g + 1) * w_bytes])
+        if bad >= 0:
+            raise SystemExit(f"[bench] gather check failed: slice {bad} of the gathered filter bank is not rank {bad}'s shard")
+        gather_check = f"ok: {world} slice checksums (BLAKE2b-64 of {w_bytes} bytes each) equal the ranks' own"
 
     out = None
     if rank == 0:
@@ -648,6 +805,8 @@ def main():
             # the all-gather alone: device time of the last one (max over ranks), what each rank sent, and the per-link rate a
             # direct all-gather would need (each rank sends its shard to every one of the world-1 peers in parallel)
             out["collective_us"] = gather_ms * 1e3
+            out["rccl_ranks"] = rccl_ranks
+            out["gather_check"] = gather_check
             out["collective_bytes_per_rank"] = gather_bytes
             out["collective_gbps_per_link"] = gather_bytes / (gather_ms * 1e-3) / 1e9 if gather_ms > 0 else None
 
@@ -669,6 +828,8 @@ def main():
                     also[name] = fn()
                 except Exception as ex:  # the headline stands on its own: a failing sub-record is reported, not fatal
                     also[name] = {"error": f"{type(ex).__name__}: {ex}"}
+            if rehearsal is not None:
+                also["cfg4_rehearsal"] = rehearsal
             out["also"] = also
         if not args.no_cpu_baseline and world == 1 and not multi:
             out["cpu_baseline"] = cpu_baseline(ranks, mu)

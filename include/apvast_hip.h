@@ -294,6 +294,9 @@ int  apv_comm_init(apv_handle* h, const char id[128], int32_t rank, int32_t worl
  * next apv_update_dev (into a different shard buffer) overlaps it; an update into the SAME shard buffer waits
  * for the gather.  apv_sync() waits for both streams. */
 int  apv_allgather_filters_dev(apv_handle* h, const void* d_w_shard, void* d_w_all);
+/* What the communicator itself reports (ncclCommCount / ncclCommUserRank); apv_comm_init already fails when they differ from
+ * what it was given.  user_rank may be NULL. */
+int  apv_comm_count(apv_handle* h, int32_t* n_ranks, int32_t* user_rank);
 /* device time of the latest all-gather (HIP events on the communication stream) and the bytes this rank sent */
 int  apv_comm_last_gather(apv_handle* h, float* elapsed_ms, size_t* bytes_per_rank);
 /* all ranks of the communicator meet here (one-word ncclAllReduce); also drains the handle's compute stream */

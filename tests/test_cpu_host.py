@@ -263,6 +263,14 @@ def test_bench_launches_its_own_ranks():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["rank_mask"] == 0b11 and rec["max_elapsed"] == 2.0 and rec["local_rank"] == 0
     assert "2 ranks started" in r.stderr
+    # the gather check of the N > 1 run: every rank sends the checksum of its shard over the rendezvous, rank 0 compares them
+    # with the checksums of its gathered bank's slices, in rank order -- and names the slice when two are exchanged
+    assert rec["gather_check"] == "ok"
+    env["APV_BENCH_DRYRUN_SWAP"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True,
+                       timeout=120)
+    assert r.returncode != 0 and r.stdout.strip() == "" and "gather check failed: slice 0" in r.stderr
+    env.pop("APV_BENCH_DRYRUN_SWAP")
     # a rank that dies takes the job down with a non-zero exit instead of leaving the others in the rendezvous
     env["APV_BENCH_DRYRUN_FAIL_RANK"] = "1"
     env["APV_BENCH_LAUNCH_TIMEOUT"] = "60"

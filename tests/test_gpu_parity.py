@@ -78,13 +78,18 @@ def test_update_vs_oracle(Engine, K, L, M, ranks, dtype):
     assert not status.any()
     nz = min(L, M)                       # beyond rank(R_B) the eigenvalues are rounding noise
     scale = lam_ref[:, :1]
-    assert (np.abs(lam[:, :nz] - lam_ref[:, :nz]) / scale).max() < TOL[dtype]["lam"] * 10
+    # The plain SURVEY 8(c) bounds (lambda 1e-9 / 1e-5, w 1e-7 / 1e-4) hold in every case but one.  Measured on the device
+    # (tools/probes/parity_margins.py, profiles/r04/parity_margins.md): float64 lambda <= 5.0e-11 relative (order 64; <= 7.5e-14
+    # below it), w <= 4.8e-8 (order 64; 1.0e-10 at 16 x 32); float32 lambda <= 7.4e-6, w <= 4.3e-6.  The exception is float32 with
+    # M < L: the dark matrix is singular and loaded to cond ~ 3e3, and the float32 whitening of it leaves 7.1e-5 on the
+    # eigenvalues and 0.8-1.8e-3 on the filters whichever eigensolver follows (tools/probes/rankdef_f32_probe.py; float64: 8e-14
+    # and 6e-12, inside the plain bounds).
+    loose = dtype == "f32" and M < L
+    assert (np.abs(lam[:, :nz] - lam_ref[:, :nz]) / scale).max() < TOL[dtype]["lam"] * (10 if loose else 1)
     if M >= L:
-        assert np.abs(lam / lam_ref - 1).max() < TOL[dtype]["lam"] * (10 if L >= 32 else 1)
+        assert np.abs(lam / lam_ref - 1).max() < TOL[dtype]["lam"]
     good = [t for t, V in enumerate(ranks) if V <= nz]
-    # M < L in float32: the error is that of the float32 whitening of a dark matrix loaded to cond ~ 3e3 (either eigensolver
-    # gives the same 0.8-1.8e-3 over 64 bins and three seeds, tools/probes/rankdef_f32_probe.py; float64: 3e-12)
-    assert w_err(w[:, good], w_ref[:, good]) < TOL[dtype]["w"] * ((30 if dtype == "f32" else 10) if M < L else 1)
+    assert w_err(w[:, good], w_ref[:, good]) < TOL[dtype]["w"] * (30 if loose else 1)
 
 
 def test_empty_shard(Engine):
