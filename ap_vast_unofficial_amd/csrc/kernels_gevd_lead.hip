@@ -13,10 +13,11 @@
 //             (H, G) -> T, theta                              ONE workgroup: scale to a unit diagonal, eliminate [G | I] (Cholesky
 //                                                             factor and its inverse in one go), M = L^-1 H L^-T, cyclic Jacobi
 //                                                             in LDS, sort, T = D L^-T Q
-//             X = Y T, CX = Z T, res_j = ||CX_j - theta_j X_j||   Ritz vectors and their residuals
+//             X = Y T, res_j = ||Z T_j - theta_j X_j||        Ritz vectors, their residuals (partial sums per row tile; the host
+//                                                             adds them up) and step 1 of the next filter (C X = Z T is known)
 //             host: converged?  else degree m of the next filter from the Ritz values
 //             Y = p_m(C) X                                    scaled Chebyshev polynomial that damps [0, theta_b] (C is positive
-//                                                             semi-definite): step 1 is elementwise (C X is known), m - 1 products
+//                                                             semi-definite): m - 1 products
 //     end     U[:, :b] = W^T X, lambda[:b] = theta            jdiag's contract on the leading columns (apvast.py:31-35)
 //
 //   The degree is capped by the amplification ratio T_m(x(theta_1)) between the largest Ritz value and the damped interval:
@@ -75,24 +76,61 @@ __global__ void __launch_bounds__(256) lead_mult_kernel(int ne, int lda, size_t 
     Yc += z * y_stride;
     Yo += z * o_stride;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, il = lane & 15, kq = lane >> 4;
-    const int row0 = blockIdx.x * 16, col0 = blockIdx.y * 16 * NB;
+    // Workgroups go to the eight XCDs round robin by their linear index, and each XCD has an L2 of its own: the column tiles of one
+    // row tile get indices that are congruent modulo 8, so that A's 16-row strip is fetched into ONE L2, by the first of them --
+    // and, the mapping being the same in every launch, is still there for the next product (two matrices of order 800 are 1.4 MB
+    // per XCD).  blockIdx.x runs over row tiles x column tiles.
+    const int nct = gridDim.y == 1 ? (int)(b / (16 * NB)) : 1;
+    int rt, ct;
+    {
+        const int id = blockIdx.x, nrt8 = (int)(gridDim.x / nct) / 8 * 8, grp = id / (8 * nct);
+        if (grp * 8 < nrt8) { rt = grp * 8 + (id & 7); ct = (id >> 3) % nct; }
+        else { const int rem = id - nrt8 * nct; rt = nrt8 + rem / nct; ct = rem % nct; }       // the ragged last row tiles
+    }
+    const int row0 = rt * 16, col0 = ct * 16 * NB;
     d4 acc[NB];
 #pragma unroll
     for (int c = 0; c < NB; ++c) acc[c] = d4{0, 0, 0, 0};
     if (ca != 0.0) {
         const double* arow = A + (size_t)(row0 + il) * lda + 4 * kq;
-        for (int k0 = w * 16; k0 < ne; k0 += 64) {
-            const d4 av = *reinterpret_cast<const d4*>(arow + k0);
-            const double* yr = Yc + (size_t)(k0 + 4 * kq) * b + col0 + il;
-            double bv[4][NB];
+        const double* ycol = Yc + (size_t)(4 * kq) * b + col0 + il;
+        // two chunks of 16 in flight per wave: the loads of the next pair go out before the MFMAs of this one
+        constexpr int PF = 2;
+        d4 av[PF];
+        double bv[PF][4][NB];
+        auto fetch = [&](int k0, int u) {
+            if (k0 < ne) {
+                av[u] = *reinterpret_cast<const d4*>(arow + k0);
+                const double* yr = ycol + (size_t)k0 * b;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int c = 0; c < NB; ++c) bv[j][c] = yr[(size_t)j * b + 16 * c];
+                    for (int c = 0; c < NB; ++c) bv[u][j][c] = yr[(size_t)j * b + 16 * c];
+            }
+        };
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+        for (int u = 0; u < PF; ++u) fetch(w * 16 + 64 * u, u);
+        for (int k0 = w * 16; k0 < ne; k0 += 64 * PF) {
+            d4 cav[PF];
+            double cbv[PF][4][NB];
 #pragma unroll
-                for (int c = 0; c < NB; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[j], bv[j][c], acc[c], 0, 0, 0);
+            for (int u = 0; u < PF; ++u) {
+                cav[u] = av[u];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int c = 0; c < NB; ++c) cbv[u][j][c] = bv[u][j][c];
+            }
+#pragma unroll
+            for (int u = 0; u < PF; ++u) fetch(k0 + 64 * (PF + u), u);
+#pragma unroll
+            for (int u = 0; u < PF; ++u)
+                if (k0 + 64 * u < ne) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int c = 0; c < NB; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(cav[u][j], cbv[u][j][c], acc[c], 0, 0, 0);
+                }
         }
     }
 #pragma unroll
@@ -111,17 +149,6 @@ __global__ void __launch_bounds__(256) lead_mult_kernel(int ne, int lda, size_t 
         if (cg != 0.0) v = __builtin_fma(cg, Yp[z * y_stride + (size_t)row * b + col], v);
         if (row < rows_out) Yo[(size_t)row * ldo + col] = v;
     }
-}
-
-// Yo = a P + b X, elementwise (the first step of a filter: P = C X is known from the Rayleigh-Ritz pass)
-__global__ void __launch_bounds__(256) lead_axpby_kernel(int count, size_t y_stride, const double* __restrict__ P,
-                                                         const double* __restrict__ X, double* __restrict__ Yo, LeadCoef cf) {
-    const int z = blockIdx.z;
-    if (!((cf.active >> z) & 1u)) return;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= count) return;
-    const size_t o = z * y_stride + idx;
-    Yo[o] = __builtin_fma(cf.a[z], P[o], cf.b[z] * X[o]);
 }
 
 // Partial Gram matrices of one slab of 128 rows: tile (ti, tj), tj <= ti, of G = Y^T Y and H = Y^T Z.  Gp / Hp:
@@ -200,11 +227,11 @@ __device__ __forceinline__ d4 lead_tile(const double* A, const double* Bm, int l
 }
 
 // The projected problem of one pass: (H, G) of order B -> T [B][B] (X = Y T has orthonormal columns that diagonalise C on
-// span Y), theta [B] descending.  info[z] = {Gram breakdown, sweeps, Jacobi met its bound, 0}.
+// span Y), theta [B] descending; hinfo[z] = {theta[B], Gram breakdown, sweeps, Jacobi met its bound, -} is what the host reads.
 template <int B, int NT>
 __global__ void __launch_bounds__(NT) lead_small_kernel(int nslab, const double* __restrict__ Gp, const double* __restrict__ Hp,
                                                         int max_sweeps, double tol2, double* __restrict__ T,
-                                                        double* __restrict__ theta, int* __restrict__ info, unsigned active) {
+                                                        double* __restrict__ theta, double* __restrict__ hinfo, unsigned active) {
     constexpr int LD = B + 1, NTL = B / 16, NPAIR = NTL * (NTL + 1) / 2, NP = B / 2, NW = NT / 64;
     extern __shared__ double sm[];
     double* S0 = sm;                 // G -> W H -> Q
@@ -289,9 +316,9 @@ __global__ void __launch_bounds__(NT) lead_small_kernel(int nslab, const double*
     __syncthreads();
     if (fail) {
         if (tid == 0) {
-            info[4 * z] = 1;
-            info[4 * z + 1] = 0;
-            info[4 * z + 2] = 0;
+            hinfo[(size_t)z * (B + 4) + B] = 1.0;
+            hinfo[(size_t)z * (B + 4) + B + 1] = 0.0;
+            hinfo[(size_t)z * (B + 4) + B + 2] = 0.0;
         }
         return;
     }
@@ -399,6 +426,7 @@ __global__ void __launch_bounds__(NT) lead_small_kernel(int nslab, const double*
         for (int j = 0; j < B; ++j) rank += (th[j] > li) || (th[j] == li && j < tid);
         rk[tid] = rank;
         theta[(size_t)z * B + rank] = li;
+        hinfo[(size_t)z * (B + 4) + rank] = li;           // the host's copy: {theta[B], breakdown, sweeps, Jacobi met its bound, -}
     }
     __syncthreads();
     T += (size_t)z * B * B;
@@ -412,22 +440,24 @@ __global__ void __launch_bounds__(NT) lead_small_kernel(int nslab, const double*
         }
     }
     if (tid == 0) {
-        info[4 * z] = 0;
-        info[4 * z + 1] = sweeps;
-        info[4 * z + 2] = conv;
+        hinfo[(size_t)z * (B + 4) + B] = 0.0;
+        hinfo[(size_t)z * (B + 4) + B + 1] = (double)sweeps;
+        hinfo[(size_t)z * (B + 4) + B + 2] = (double)conv;
     }
 }
 
-// X = Y T, CX = Z T; respart[z][row tile][col] = sum over the tile's 16 rows of (CX - theta X)^2
+// X = Y T and, from CX = Z T, the residual partials respart[z][row tile][col] = sum over the tile's 16 rows of (CX - theta X)^2
+// and the first step of the next filter, Y1 = (sigma_1 / e) (CX - e X) with the damped interval [0, c = theta_b] (e = c / 2,
+// sigma_1 = e / (theta_1 - e)): C X is known here, so that step needs no product with C.
 __global__ void __launch_bounds__(256) lead_rot_kernel(int ne, int b, size_t y_stride, const double* __restrict__ Y,
                                                        const double* __restrict__ Z, const double* __restrict__ T,
                                                        const double* __restrict__ theta, double* __restrict__ X,
-                                                       double* __restrict__ CX, double* __restrict__ respart, unsigned active) {
+                                                       double* __restrict__ Y1, double* __restrict__ respart, unsigned active) {
     __shared__ double red[2][4][256];
     __shared__ double r2[16][17];
     const int z = blockIdx.z;
     if (!((active >> z) & 1u)) return;
-    Y += z * y_stride; Z += z * y_stride; X += z * y_stride; CX += z * y_stride;
+    Y += z * y_stride; Z += z * y_stride; X += z * y_stride; Y1 += z * y_stride;
     T += (size_t)z * b * b;
     theta += (size_t)z * b;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, il = lane & 15, kq = lane >> 4;
@@ -451,7 +481,11 @@ __global__ void __launch_bounds__(256) lead_rot_kernel(int ne, int b, size_t y_s
     const double cx = ((red[1][0][e] + red[1][1][e]) + red[1][2][e]) + red[1][3][e];
     const int rl = kq + 4 * w, row = row0 + rl, col = col0 + il;
     X[(size_t)row * b + col] = x;
-    CX[(size_t)row * b + col] = cx;
+    const double th0 = theta[0];
+    double c = theta[b - 1];
+    if (!(c > 1e-12 * th0)) c = 1e-12 * th0;
+    const double hc = 0.5 * c, a1 = 1.0 / (th0 - hc);            // sigma_1 / e
+    Y1[(size_t)row * b + col] = a1 * (cx - hc * x);
     const double rr = __builtin_fma(-theta[col], x, cx);
     r2[rl][il] = rr * rr;
     __syncthreads();
@@ -463,22 +497,6 @@ __global__ void __launch_bounds__(256) lead_rot_kernel(int ne, int b, size_t y_s
     }
 }
 
-// out[z] = {theta[b], res[b], info[4] as doubles}: what the host reads after a pass
-__global__ void __launch_bounds__(64) lead_res_kernel(int nrt, int b, const double* __restrict__ respart,
-                                                      const double* __restrict__ theta, const int* __restrict__ info,
-                                                      double* __restrict__ out, unsigned active) {
-    const int z = blockIdx.x, j = threadIdx.x;
-    if (!((active >> z) & 1u)) return;
-    double* o = out + (size_t)z * (2 * b + 4);
-    if (j < b) {
-        double s = 0.0;
-        for (int t = 0; t < nrt; ++t) s += respart[((size_t)z * nrt + t) * b + j];
-        o[j] = theta[(size_t)z * b + j];
-        o[b + j] = sqrt(s);
-    }
-    if (j < 4) o[2 * b + j] = (double)info[4 * z + j];
-}
-
 // lam[z][j] = theta[z][j], j < b (dense [batch][n] eigenvalue array of the caller)
 __global__ void __launch_bounds__(64) lead_lam_kernel(int n, int b, const double* __restrict__ theta, double* __restrict__ lam) {
     const int z = blockIdx.x, j = threadIdx.x;
@@ -488,11 +506,11 @@ __global__ void __launch_bounds__(64) lead_lam_kernel(int n, int b, const double
 struct LeadWs {
     int ne = 0, b = 0, cap = 0;
     double* P[3] = {nullptr, nullptr, nullptr};
-    double *Zb = nullptr, *Gp = nullptr, *Hp = nullptr, *T = nullptr, *theta = nullptr, *respart = nullptr, *out = nullptr;
-    int* info = nullptr;
+    double *Zb = nullptr, *Gp = nullptr, *Hp = nullptr, *T = nullptr, *theta = nullptr;
+    double* out = nullptr;            // what the host reads after a pass: [batch][row tiles][b] residual partials, then [batch][b + 4] hinfo
     double* h_out = nullptr;          // pinned
     void release() {
-        void* bufs[] = {P[0], P[1], P[2], Zb, Gp, Hp, T, theta, respart, out, info};
+        void* bufs[] = {P[0], P[1], P[2], Zb, Gp, Hp, T, theta, out};
         for (void* p : bufs)
             if (p) (void)hipFree(p);
         if (h_out) (void)hipHostFree(h_out);
@@ -502,7 +520,7 @@ struct LeadWs {
 
 template <int B, int NT>
 hipError_t launch_small(hipStream_t st, int batch, int nslab, const double* Gp, const double* Hp, int max_sweeps, double tol2,
-                        double* T, double* theta, int* info, unsigned active) {
+                        double* T, double* theta, double* hinfo, unsigned active) {
     constexpr int LD = B + 1, NP = B / 2;
     const size_t bytes = sizeof(double) * (3 * (size_t)B * LD + 2 * B + NP + (NP & 1)) + sizeof(double2) * NP + sizeof(int) * 2 * B;
     static bool once = false;
@@ -512,7 +530,7 @@ hipError_t launch_small(hipStream_t st, int batch, int nslab, const double* Gp, 
         if (e != hipSuccess) return e;
         once = true;
     }
-    hipLaunchKernelGGL((lead_small_kernel<B, NT>), dim3(batch), dim3(NT), bytes, st, nslab, Gp, Hp, max_sweeps, tol2, T, theta, info,
+    hipLaunchKernelGGL((lead_small_kernel<B, NT>), dim3(batch), dim3(NT), bytes, st, nslab, Gp, Hp, max_sweeps, tol2, T, theta, hinfo,
                        active);
     return hipGetLastError();
 }
@@ -556,7 +574,7 @@ int apv_gevd_lead(apv_handle* h, int n, int ne, int batch, int b, int rank, cons
     LeadWs& ws = *static_cast<LeadWs*>(h->lead_ws);
     const size_t ys = (size_t)ne * b, ms = (size_t)ne * ne;
     const int nrt = ne / 16, nslab = (ne + 127) / 128, ntl = b / 16, npair = ntl * (ntl + 1) / 2;
-    const int ow = 2 * b + 4;
+    const size_t n_part = (size_t)batch * nrt * b, ow = n_part + (size_t)batch * (b + 4);
     if (ws.ne != ne || ws.b != b || ws.cap < batch) {
         ws.release();
         ws.ne = ne; ws.b = b; ws.cap = batch;
@@ -566,10 +584,8 @@ int apv_gevd_lead(apv_handle* h, int n, int ne, int batch, int b, int rank, cons
         LCHK(hipMalloc((void**)&ws.Hp, sizeof(double) * (size_t)batch * nslab * npair * 256));
         LCHK(hipMalloc((void**)&ws.T, sizeof(double) * (size_t)batch * b * b));
         LCHK(hipMalloc((void**)&ws.theta, sizeof(double) * (size_t)batch * b));
-        LCHK(hipMalloc((void**)&ws.respart, sizeof(double) * (size_t)batch * nrt * b));
-        LCHK(hipMalloc((void**)&ws.out, sizeof(double) * (size_t)batch * ow));
-        LCHK(hipMalloc((void**)&ws.info, sizeof(int) * 4 * batch));
-        LCHK(hipHostMalloc((void**)&ws.h_out, sizeof(double) * (size_t)batch * ow));
+        LCHK(hipMalloc((void**)&ws.out, sizeof(double) * ow));
+        LCHK(hipHostMalloc((void**)&ws.h_out, sizeof(double) * ow));
     }
     static const bool dbg = getenv("APV_LEAD_DEBUG") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
@@ -581,18 +597,22 @@ int apv_gevd_lead(apv_handle* h, int n, int ne, int batch, int b, int rank, cons
         // 16 x 16 outputs per workgroup while that fills the chip, 16 x 32 beyond
         const long wgs = (long)nrt * (b / 16) * batch;
         if (wgs > 2048 && b % 32 == 0)
-            hipLaunchKernelGGL((lead_mult_kernel<2>), dim3(nrt, b / 32, batch), dim3(256), 0, st, ne, ne, ms, A, b, ys, Yc, Yp, Yo, rows_out, ldo, os, cf);
+            hipLaunchKernelGGL((lead_mult_kernel<2>), dim3(nrt * (b / 32), 1, batch), dim3(256), 0, st, ne, ne, ms, A, b, ys, Yc, Yp, Yo, rows_out, ldo, os, cf);
         else
-            hipLaunchKernelGGL((lead_mult_kernel<1>), dim3(nrt, b / 16, batch), dim3(256), 0, st, ne, ne, ms, A, b, ys, Yc, Yp, Yo, rows_out, ldo, os, cf);
+            hipLaunchKernelGGL((lead_mult_kernel<1>), dim3(nrt * (b / 16), 1, batch), dim3(256), 0, st, ne, ne, ms, A, b, ys, Yc, Yp, Yo, rows_out, ldo, os, cf);
     };
     int ic = 0, ix = 1, iy = 2;
     int final_buf[LEAD_MAXB];
     for (int z = 0; z < batch; ++z) final_buf[z] = -1;
     hipLaunchKernelGGL(lead_init_kernel, dim3((unsigned)((ys + 255) / 256), 1, batch), dim3(256), 0, st, n, ne, b, ws.P[ic], ys);
     static const double kLimits[3] = {1e6, 1e10, 1e12};
-    static const int kPartialSweeps = getenv("APV_LEAD_SWEEPS") ? atoi(getenv("APV_LEAD_SWEEPS")) : 3;     // tuning aid
+    // measured (tools/probes/lead_sweeps_probe.sh, profiles/r04/lead_sweeps_probe.txt): one sweep per non-final pass at b = 64
+    // (n = 800: 1.61 ms for seven passes; two sweeps 1.77 for six, three 2.09, four 2.39), two at b = 32 (n = 256: 0.51 ms, the same
+    // with one or three)
+    static const int kSweepsEnv = getenv("APV_LEAD_SWEEPS") ? atoi(getenv("APV_LEAD_SWEEPS")) : 0;     // tuning aid
+    const int kPartialSweeps = kSweepsEnv > 0 ? kSweepsEnv : (b >= 48 ? 1 : 2);
     int total_mv = 0, pass = 0;
-    bool fallback = false, finishing = false;
+    bool fallback = false;
     for (;; ++pass) {
         // Rayleigh-Ritz on span P[ic]
         one.active = active;
@@ -600,30 +620,37 @@ int apv_gevd_lead(apv_handle* h, int n, int ne, int batch, int b, int rank, cons
         ++total_mv;
         hipLaunchKernelGGL(lead_gram_kernel, dim3(npair, nslab, batch), dim3(256), 0, st, ne, b, ys, ws.P[ic], ws.Zb, ws.Gp, ws.Hp, active);
         hipError_t se;
-        // Any orthogonal Q serves a pass that is followed by another filter: the sweeps only have to sharpen the Ritz values that
-        // set its bounds.  A pass that may be the last one (`finishing`) sweeps until the Jacobi bound is met.
-        const int msw = finishing ? 20 : kPartialSweeps;
-        if (b == 32) se = launch_small<32, 256>(st, batch, nslab, ws.Gp, ws.Hp, msw, 1e-18, ws.T, ws.theta, ws.info, active);
-        else if (b == 48) se = launch_small<48, 256>(st, batch, nslab, ws.Gp, ws.Hp, msw, 1e-18, ws.T, ws.theta, ws.info, active);
-        else se = launch_small<64, 512>(st, batch, nslab, ws.Gp, ws.Hp, msw, 1e-18, ws.T, ws.theta, ws.info, active);
+        // Any orthogonal Q serves: X = Y T has orthonormal columns whatever the sweeps leave undone, theta_j = M_jj is the Rayleigh
+        // quotient of X_j, and the residual ||C X_j - theta_j X_j|| measured below certifies the pair by itself.  The sweeps only
+        // have to keep the columns close to Ritz vectors (the filter's amplification then scales columns instead of making them
+        // parallel) and sharpen the Ritz values that set the next filter's bounds; an off-diagonal element left in the leading
+        // block shows in the residuals and costs another pass.
+        const int msw = kPartialSweeps;
+        double* const hinfo = ws.out + n_part;
+        if (b == 32) se = launch_small<32, 256>(st, batch, nslab, ws.Gp, ws.Hp, msw, 1e-18, ws.T, ws.theta, hinfo, active);
+        else if (b == 48) se = launch_small<48, 256>(st, batch, nslab, ws.Gp, ws.Hp, msw, 1e-18, ws.T, ws.theta, hinfo, active);
+        else se = launch_small<64, 512>(st, batch, nslab, ws.Gp, ws.Hp, msw, 1e-18, ws.T, ws.theta, hinfo, active);
         LCHK(se);
+        // Ritz vectors into P[ix], the next filter's first step into P[iy]; the residual partials are summed by the host (row tiles in order)
         hipLaunchKernelGGL(lead_rot_kernel, dim3(nrt, b / 16, batch), dim3(256), 0, st, ne, b, ys, ws.P[ic], ws.Zb, ws.T, ws.theta, ws.P[ix],
-                           ws.P[iy], ws.respart, active);
-        hipLaunchKernelGGL(lead_res_kernel, dim3(batch), dim3(64), 0, st, nrt, b, ws.respart, ws.theta, ws.info, ws.out, active);
-        LCHK(hipMemcpyAsync(ws.h_out, ws.out, sizeof(double) * (size_t)batch * ow, hipMemcpyDeviceToHost, st));
+                           ws.P[iy], ws.out, active);
+        LCHK(hipMemcpyAsync(ws.h_out, ws.out, sizeof(double) * ow, hipMemcpyDeviceToHost, st));
         LCHK(hipStreamSynchronize(st));
         LeadCoef step[16];
         int deg[LEAD_MAXB], mdeg = 0;
-        bool next_finishing = false;
         for (int z = 0; z < batch; ++z) {
             deg[z] = 0;
             if (!((active >> z) & 1u)) continue;
-            const double* th = ws.h_out + (size_t)z * ow;
-            const double* rs = th + b;
-            const double* inf = rs + b;
+            const double* th = ws.h_out + n_part + (size_t)z * (b + 4);
+            const double* inf = th + b;
             if (inf[0] != 0.0 || !(th[0] > 0.0)) { fallback = true; break; }
             double rmax = 0.0;
-            for (int j = 0; j < rank; ++j) rmax = rs[j] > rmax ? rs[j] : rmax;
+            for (int j = 0; j < rank; ++j) {
+                double s2 = 0.0;
+                for (int t = 0; t < nrt; ++t) s2 += ws.h_out[((size_t)z * nrt + t) * b + j];
+                const double rj = sqrt(s2);
+                rmax = rj > rmax ? rj : rmax;
+            }
             // The leading `rank` vectors span the invariant subspace to rmax / gap; the bound asks for 1e-10 there and 1e-12 of the
             // largest eigenvalue on every residual, but never for less than float64 gives (a cluster that straddles the cut has no
             // gap: any orthonormal basis of it is as good as the one LAPACK's rounding picks for the reference)
@@ -632,7 +659,7 @@ int apv_gevd_lead(apv_handle* h, int n, int ne, int batch, int b, int rank, cons
             if (1e-10 * gap < target) target = 1e-10 * gap;
             const double floor_ = 3e-14 * sqrt((double)n) * th[0];
             if (target < floor_) target = floor_;
-            const bool conv = rmax <= target && inf[2] != 0.0;
+            const bool conv = rmax <= target;
             if (dbg)
                 fprintf(stderr, "[apv lead] pass %d matrix %d: theta1 %.4e theta_V/theta1 %.3f theta_b/theta_V %.3f gap %.2e res %.2e target %.2e jacobi %d sweeps%s\n",
                         pass, z, th[0], th[rank - 1] / th[0], th[b - 1] / th[rank - 1], gap / th[0], rmax / th[0], target / th[0], (int)inf[1], conv ? " converged" : "");
@@ -651,22 +678,19 @@ int apv_gevd_lead(apv_handle* h, int n, int ne, int batch, int b, int rank, cons
             const double xv = 2.0 * th[rank - 1] / c - 1.0;
             if (xv > 1.0 + 1e-9 && rmax > 0.0) {
                 const int need = (int)ceil(log(10.0 * rmax / target) / acosh(xv));
-                // the filter is as long as the bound asks, not as long as the cap allows: the next pass is expected to end the solve
-                if (need <= m) next_finishing = true;
-                if (need >= 1 && need < m) m = need;
+                if (need >= 1 && need < m) m = need;        // as long as the bound asks, not as long as the cap allows
             }
-            if (rmax <= target) next_finishing = true;      // only the partial sweeps stand between this pass and the bound
             m = m < 1 ? 1 : (m > 16 ? 16 : m);
+            if (dbg) fprintf(stderr, "[apv lead]   matrix %d: next filter of degree %d (x_1 = %.2f, x_V = %.3f)\n", z, m, x1, xv);
             deg[z] = m;
             mdeg = m > mdeg ? m : mdeg;
         }
         if (fallback || active == 0) break;
-        finishing = next_finishing;
         // coefficients of the scaled three-term recurrence (Zhou & Saad 2007): damped interval [0, c], sigma_1 = e / (theta_1 - e)
         for (int i = 0; i < mdeg; ++i) step[i].active = active;
         for (int z = 0; z < batch; ++z) {
             if (!((active >> z) & 1u)) continue;
-            const double* th = ws.h_out + (size_t)z * ow;
+            const double* th = ws.h_out + n_part + (size_t)z * (b + 4);
             double c = th[b - 1];
             if (!(c > 1e-12 * th[0])) c = 1e-12 * th[0];
             const double e = 0.5 * c, ctr = 0.5 * c, sigma1 = e / (th[0] - ctr);
@@ -681,9 +705,8 @@ int apv_gevd_lead(apv_handle* h, int n, int ne, int batch, int b, int rank, cons
                 sigma = sn;
             }
         }
-        // step 1 from the known product: Y1 = a CX + b X
-        hipLaunchKernelGGL(lead_axpby_kernel, dim3((unsigned)((ys + 255) / 256), 1, batch), dim3(256), 0, st, (int)ys, ys, ws.P[iy], ws.P[ix], ws.P[ic], step[0]);
-        int prev = ix, cur = ic, fre = iy;
+        // step 1 (Y1 = (sigma_1 / e) (C X - e X)) was written by lead_rot_kernel from the known product
+        int prev = ix, cur = iy, fre = ic;
         for (int i = 1; i < mdeg; ++i) {
             mult(C, ws.P[cur], ws.P[prev], ws.P[fre], ne, b, ys, step[i]);
             ++total_mv;
