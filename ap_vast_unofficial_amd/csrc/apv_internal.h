@@ -119,7 +119,7 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
 // kernels_gevd_lead.hip: the leading b eigenpairs of whitened matrices by Chebyshev-filtered subspace iteration (see the file header)
 int apv_gevd_lead_block(int n, int rank);
 int apv_gevd_lead(apv_handle* h, int n, int ne, int batch, int b, int rank, const double* C, const double* WT, double* d_U,
-                  double* d_lam, int* done);
+                  double* d_lam, const int* h_pd_flags, int* done);
 
 // stream_bb.hip: d_out[i] = ||mats[i]||_2 (largest eigenvalue of a symmetric PSD n x n matrix, Lanczos), i < count <= 4
 hipError_t apv_launch_norm2(int n, int count, const double* const* d_mats, double* d_out, hipStream_t s);

@@ -1026,12 +1026,26 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
     hipLaunchKernelGGL((gemm_kernel<false, true>), gg, dim3(256), 0, st, n, ld, ws.T1, ws.W, ws.C0, ms);      // C = T1 W^T
     hipLaunchKernelGGL(symmetrise_kernel, dim3(gx, n, batch), dim3(TPB), 0, st, n, ld, ws.C0, ms);
     hipLaunchKernelGGL(transpose_kernel, dim3(gx, n, batch), dim3(TPB), 0, st, n, ld, ws.W, ws.X, ms);         // X = W^T Q, Q = I
-    hipLaunchKernelGGL(frob2_kernel, dim3(64, 1, batch), dim3(TPB), 0, st, n, ld, ws.C0, ws.acc + 2 * batch, ms);
     std::vector<int> hflag(batch, 0);
     std::vector<double> hacc(3 * batch, 0.0);
-    LCHK(hipMemcpyAsync(hflag.data(), ws.flag, sizeof(int) * batch, hipMemcpyDeviceToHost, st));
-    LCHK(hipMemcpyAsync(hacc.data(), ws.acc, sizeof(double) * 3 * batch, hipMemcpyDeviceToHost, st));
-    LCHK(hipStreamSynchronize(st));
+    static const bool timing = getenv("APV_BB_TIMING") != nullptr;       // profiling aid, see stream_bb.hip
+    // (a caller who sets a sweep cap or a sweep tolerance of his own is asking for the Jacobi iteration they belong to)
+    int lead_b = (lead_rank > 0 && h->gl_tol2 <= 0.0 && h->cfg.max_sweeps <= 0) ? apv_gevd_lead_block(n, lead_rank) : 0, lead_done = 0;
+    bool flags_read = false;
+    if (lead_b > 0) {
+        // C0 (whitened, symmetric) and X = W^T are read only; on *done == 0 nothing was written and the sweeps below run.  The
+        // factorisation's flags come back with the first pass's results (no synchronisation of their own on this path).
+        LCHK(hipMemcpyAsync(hflag.data(), ws.flag, sizeof(int) * batch, hipMemcpyDeviceToHost, st));
+        const int lrc = apv_gevd_lead(h, n, ne, batch, lead_b, lead_rank, ws.C0, ws.X, d_U, d_lam, hflag.data(), &lead_done);
+        if (lrc != APV_OK && lrc != APV_ERR_NOT_PD) return lrc;
+        flags_read = true;
+    }
+    if (!lead_done) {
+        hipLaunchKernelGGL(frob2_kernel, dim3(64, 1, batch), dim3(TPB), 0, st, n, ld, ws.C0, ws.acc + 2 * batch, ms);
+        if (!flags_read) LCHK(hipMemcpyAsync(hflag.data(), ws.flag, sizeof(int) * batch, hipMemcpyDeviceToHost, st));
+        LCHK(hipMemcpyAsync(hacc.data(), ws.acc, sizeof(double) * 3 * batch, hipMemcpyDeviceToHost, st));
+        LCHK(hipStreamSynchronize(st));
+    }
     bool any_bad = false;
     for (int z = 0; z < batch; ++z) {
         h_status[z] = hflag[z] ? 1 : 0;
@@ -1042,15 +1056,7 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
         (void)hipGetLastError();
         return apv_fail(h, APV_ERR_NOT_PD, "Matrix is not positive definite");
     }
-    static const bool timing = getenv("APV_BB_TIMING") != nullptr;       // profiling aid, see stream_bb.hip
     const auto t_pre = std::chrono::steady_clock::now();
-    // (a caller who sets a sweep cap or a sweep tolerance of his own is asking for the Jacobi iteration they belong to)
-    int lead_b = (lead_rank > 0 && h->gl_tol2 <= 0.0 && h->cfg.max_sweeps <= 0) ? apv_gevd_lead_block(n, lead_rank) : 0, lead_done = 0;
-    if (lead_b > 0) {
-        // C0 (whitened, symmetric) and X = W^T are read only; on *done == 0 nothing was written and the sweeps below run
-        const int lrc = apv_gevd_lead(h, n, ne, batch, lead_b, lead_rank, ws.C0, ws.X, d_U, d_lam, &lead_done);
-        if (lrc != APV_OK) return lrc;
-    }
     if (lead_done) {
         h->gl_lead_done = 1;
         if (d_r != nullptr && d_w != nullptr && V > 0) {

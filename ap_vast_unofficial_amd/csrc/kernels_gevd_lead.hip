@@ -5,9 +5,10 @@
 //   after the fact.  apv_gevd_large's block Jacobi diagonalises all of C = W A W^T: 12-15 sweeps x (n/16 - 1) dependent launches.
 //   This file finds the leading b = V + guard eigenpairs of the same C by Chebyshev-filtered subspace iteration:
 //
-//     X0      deterministic pseudo-random block, n x b (no state carried from hop to hop: the statistics windows of consecutive
-//             hops share 75 % of their samples at cfg1 but 20 % at the reference's parameters, and a start that is right to 1e-1
-//             instead of 1e0 saves one filter degree of ~25 -- tools/probes/lead_model.py)
+//     X0      deterministic pseudo-random block, n x b.  No state is carried from hop to hop: in the NumPy model
+//             (tools/probes/lead_model.py, profiles/r04/lead_model.txt) a start from the previous hop's block saves a pass in
+//             three of fourteen pairs at cfg1 (75 % of the statistics window shared) and nothing at the reference's
+//             parameters (20 % shared), and a stateless solve keeps a resumed stream bit for bit
 //     pass    Z = C Y                                         one block product (f64 MFMA, the matrix streams from L2 / HBM)
 //             G = Y^T Y, H = Y^T Z                            b x b Gram matrices, K split over slabs of 128 rows
 //             (H, G) -> T, theta                              ONE workgroup: scale to a unit diagonal, eliminate [G | I] (Cholesky
@@ -560,8 +561,11 @@ int apv_gevd_lead_block(int n, int rank) {
 // C: [batch][ne][ld = ne] whitened matrices (symmetric, zero ghost rows / columns), WT: [batch][ne][ne] = W^T.
 // On success with *done = 1: d_U[z][i][j] (n x n, j < b) and d_lam[z][j] (j < b) hold the leading b eigenpairs.
 // *done = 0: nothing was written, the caller runs the full solve.
+// h_pd_flags[batch]: host words an asynchronous copy queued BEFORE this call fills with the factorisation's flags (non-zero: the
+// dark matrix was not positive definite and C is garbage); they are valid after the first pass's synchronisation, and the call
+// then returns APV_ERR_NOT_PD with *done = 0.
 int apv_gevd_lead(apv_handle* h, int n, int ne, int batch, int b, int rank, const double* C, const double* WT, double* d_U,
-                  double* d_lam, int* done) {
+                  double* d_lam, const int* h_pd_flags, int* done) {
     *done = 0;
     if (batch > LEAD_MAXB || b % 16 != 0 || b < 32 || b > 64 || ne % 32 != 0) return APV_OK;
     hipStream_t st = h->stream;
@@ -625,7 +629,8 @@ int apv_gevd_lead(apv_handle* h, int n, int ne, int batch, int b, int rank, cons
         // have to keep the columns close to Ritz vectors (the filter's amplification then scales columns instead of making them
         // parallel) and sharpen the Ritz values that set the next filter's bounds; an off-diagonal element left in the leading
         // block shows in the residuals and costs another pass.
-        const int msw = kPartialSweeps;
+        static const int kSweepEvery = getenv("APV_LEAD_SWEEP_EVERY") ? atoi(getenv("APV_LEAD_SWEEP_EVERY")) : 1;      // tuning aid
+        const int msw = (kSweepEvery > 1 && pass > 1 && pass % kSweepEvery != 0) ? 0 : kPartialSweeps;
         double* const hinfo = ws.out + n_part;
         if (b == 32) se = launch_small<32, 256>(st, batch, nslab, ws.Gp, ws.Hp, msw, 1e-18, ws.T, ws.theta, hinfo, active);
         else if (b == 48) se = launch_small<48, 256>(st, batch, nslab, ws.Gp, ws.Hp, msw, 1e-18, ws.T, ws.theta, hinfo, active);
@@ -636,6 +641,9 @@ int apv_gevd_lead(apv_handle* h, int n, int ne, int batch, int b, int rank, cons
                            ws.P[iy], ws.out, active);
         LCHK(hipMemcpyAsync(ws.h_out, ws.out, sizeof(double) * ow, hipMemcpyDeviceToHost, st));
         LCHK(hipStreamSynchronize(st));
+        if (pass == 0 && h_pd_flags)
+            for (int z = 0; z < batch; ++z)
+                if (h_pd_flags[z]) return APV_ERR_NOT_PD;
         LeadCoef step[16];
         int deg[LEAD_MAXB], mdeg = 0;
         for (int z = 0; z < batch; ++z) {
