@@ -121,6 +121,12 @@ def test_leading_falls_back_on_a_flat_spectrum(Engine):
     eng.close()
     assert info2[0] == 1
     _check_pairs(A2, B2, U2[0], lv2[0], lam2)
+    # a dark matrix that is not positive definite raises as the reference's cholesky does (apvast.py:21-24): on this path the
+    # factorisation's flag comes back with the subspace iteration's first pass
+    eng3 = Engine(1, 4, 4)
+    with pytest.raises(np.linalg.LinAlgError):
+        eng3.jdiag_leading(np.eye(128)[None], -np.eye(128)[None], 8)
+    eng3.close()
 
 
 def test_hop_attributes_complete_themselves_when_read(golden):
