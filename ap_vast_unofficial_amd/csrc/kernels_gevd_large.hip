@@ -93,15 +93,29 @@ __global__ void __launch_bounds__(256) chol_panel_kernel(int ld, int k, int nbk,
     // vector ALU with four LDS reads per four multiply-adds, 3 us per product; the late panels of n = 800 took 100-200 us)
     const int wq = tid >> 6, lq = tid & 63;
     d4 accT = {0.0, 0.0, 0.0, 0.0}, accD = {0.0, 0.0, 0.0, 0.0};
+    // the tiles of term J + 1 are fetched into registers while the matrix cores work on term J (round 4: one term was a load, a
+    // barrier, two products and a barrier, ~0.8 us, 300 of them at n = 800)
+    double ra[BT * BT / 256], rb[BT * BT / 256];
+    auto gload = [&](int J) {
+#pragma unroll
+        for (int e4 = 0; e4 < BT * BT / 256; ++e4) {
+            const int e = tid + 256 * e4;
+            const int t = e >> 5, u = e & 31;
+            ra[e4] = B[(size_t)(I * BT + t) * ld + J * BT + u];
+            rb[e4] = B[(size_t)(k * BT + t) * ld + J * BT + u];
+        }
+    };
+    if (k > 0) gload(0);
     for (int J = 0; J < k; ++J) {
 #pragma unroll
         for (int e4 = 0; e4 < BT * BT / 256; ++e4) {
             const int e = tid + 256 * e4;
             const int t = e >> 5, u = e & 31;
-            La[t * LS + u] = B[(size_t)(I * BT + t) * ld + J * BT + u];
-            Lb[t * LS + u] = B[(size_t)(k * BT + t) * ld + J * BT + u];
+            La[t * LS + u] = ra[e4];
+            Lb[t * LS + u] = rb[e4];
         }
         __syncthreads();
+        if (J + 1 < k) gload(J + 1);
         const d4 oD = mm32_mfma<false, true>(Lb, Lb, wq, lq);
         for (int i = 0; i < 4; ++i) accD[i] -= oD[i];
         if (I != k) {
@@ -291,6 +305,109 @@ __global__ void __launch_bounds__(256) gemm_kernel(int n, int ld, const double* 
     const int orow = row0 + (w >> 1) * 16 + (lane >> 4), ocol = col0 + (w & 1) * 16 + (lane & 15);
     for (int t = 0; t < 4; ++t)
         if (orow + 4 * t < n && ocol < n) C[(size_t)(orow + 4 * t) * ld + ocol] = acc[t];
+}
+
+// ---- round 4: a general product for the factor-and-whiten stage --------------------------------------------------------------
+// C = alpha op(A) op(B), 64 x 64 tile per workgroup, each of the four waves a 32 x 32 quarter (2 x 2 MFMA tiles), operands
+// straight from global memory in the MFMA's own layout (no LDS: the two waves that share an operand strip hit the same lines
+// of the CU's L1), K in chunks of 16 with the next chunk's loads in flight during this chunk's sixteen MFMAs.
+//   A operand, element (i, k): A[i lda + k]  (one 32-byte load per lane and chunk: lane (r, kq) holds k0 + 4 kq .. + 3; MFMA j of
+//                                             the chunk contracts k0 + 4 kq + j -- any order of the contraction index serves)
+//   B operand, element (k, j): TB ? B[j ldb + k] (the same 32-byte pattern) : B[k ldb + j] (four 8-byte loads, coalesced over j)
+// Two levels of batch: blockIdx.z = z * n2 + p, pointer = base + z * s?1 + p * s?2 (p: the pairs of a level of tri_invert).
+// klim 1: A is lower triangular, k stops at the tile's last row; klim 2: op(B) = W^T with W lower triangular, k stops at the tile's
+// last column.  lower_only: tiles strictly above the diagonal are not computed (the caller mirrors).
+struct Gemm64 {
+    int M, N, K;
+    const double* A; int lda; size_t sA1, sA2;
+    const double* B; int ldb; size_t sB1, sB2;
+    double* C; int ldc; size_t sC1, sC2;
+    double alpha;
+    int n2, klim, lower_only;
+    const int* flag;        // per matrix z: non-zero = the factorisation failed, leave
+};
+
+template <bool TB>
+__global__ void __launch_bounds__(256) gemm64_kernel(const Gemm64 g) {
+    const int zz = blockIdx.z, z = zz / g.n2, pp = zz % g.n2;
+    if (g.flag && g.flag[z]) return;
+    const int row0 = blockIdx.y * 64, col0 = blockIdx.x * 64;
+    if (g.lower_only && col0 > row0) return;
+    const double* A = g.A + z * g.sA1 + pp * g.sA2;
+    const double* B = g.B + z * g.sB1 + pp * g.sB2;
+    double* C = g.C + z * g.sC1 + pp * g.sC2;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, il = lane & 15, kq = lane >> 4;
+    const int wr = row0 + (w >> 1) * 32, wc = col0 + (w & 1) * 32;
+    int kend = g.K;
+    if (g.klim == 1) kend = min(kend, row0 + 64);
+    if (g.klim == 2) kend = min(kend, col0 + 64);
+    kend = (kend + 15) & ~15;
+    if (kend > g.K) kend = g.K;             // K is a multiple of 16 at every call site
+    // rows / columns beyond M / N are clamped for the loads and masked at the store
+    const int ar0 = min(wr + il, g.M - 1), ar1 = min(wr + 16 + il, g.M - 1);
+    const int bc0 = min(wc + il, g.N - 1), bc1 = min(wc + 16 + il, g.N - 1);
+    const double* a0 = A + (size_t)ar0 * g.lda + 4 * kq;
+    const double* a1 = A + (size_t)ar1 * g.lda + 4 * kq;
+    d4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = d4{0, 0, 0, 0};
+    d4 av[2], bv[2], nav[2], nbv[2];
+    auto fetch = [&](int k0, d4 (&ta)[2], d4 (&tb)[2]) {
+        ta[0] = *reinterpret_cast<const d4*>(a0 + k0);
+        ta[1] = *reinterpret_cast<const d4*>(a1 + k0);
+        if (TB) {
+            tb[0] = *reinterpret_cast<const d4*>(B + (size_t)bc0 * g.ldb + k0 + 4 * kq);
+            tb[1] = *reinterpret_cast<const d4*>(B + (size_t)bc1 * g.ldb + k0 + 4 * kq);
+        } else {
+            const double* br = B + (size_t)(k0 + 4 * kq) * g.ldb;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                tb[0][j] = br[(size_t)j * g.ldb + bc0];
+                tb[1][j] = br[(size_t)j * g.ldb + bc1];
+            }
+        }
+    };
+    if (kend > 0) fetch(0, av, bv);
+    for (int k0 = 0; k0 < kend; k0 += 16) {
+        if (k0 + 16 < kend) fetch(k0 + 16, nav, nbv);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0][j], bv[0][j], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0][j], bv[1][j], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1][j], bv[0][j], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1][j], bv[1][j], acc[1][1], 0, 0, 0);
+        }
+        av[0] = nav[0]; av[1] = nav[1]; bv[0] = nbv[0]; bv[1] = nbv[1];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int r = wr + 16 * i + kq + 4 * t, c = wc + 16 * j + il;
+                if (r < g.M && c < g.N) C[(size_t)r * g.ldc + c] = g.alpha * acc[i][j][t];
+            }
+}
+
+// C[j][i] = C[i][j] for j < i (the whitened matrix was formed on and below the diagonal tiles only)
+__global__ void __launch_bounds__(TPB) mirror_lower_kernel(int n, int ld, double* __restrict__ C, size_t mat_stride, const int* __restrict__ flag) {
+    if (flag[blockIdx.z]) return;
+    C += blockIdx.z * mat_stride;
+    const int i = blockIdx.y;
+    for (int j = blockIdx.x * TPB + threadIdx.x; j < i; j += gridDim.x * TPB) C[(size_t)j * ld + i] = C[(size_t)i * ld + j];
+}
+
+// W's diagonal 32 x 32 blocks = the inverses of L's diagonal blocks that the panel kernel left in LiBuf
+__global__ void __launch_bounds__(256) diag_inverse_scatter_kernel(int ld, int nbk, const double* __restrict__ LiBuf, double* __restrict__ W,
+                                                                   size_t mat_stride, const int* __restrict__ flag) {
+    const int z = blockIdx.z, k = blockIdx.x;
+    if (flag[z]) return;
+    const double* src = LiBuf + ((size_t)z * nbk + k) * BT * BT;
+    double* dst = W + z * mat_stride + (size_t)k * BT * ld + k * BT;
+    for (int e = threadIdx.x; e < BT * BT; e += 256) dst[(size_t)(e >> 5) * ld + (e & 31)] = src[e];
 }
 
 __global__ void __launch_bounds__(TPB) symmetrise_kernel(int n, int ld, double* __restrict__ C, size_t mat_stride) {
@@ -1020,11 +1137,42 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
     hipLaunchKernelGGL(load_pair_kernel, dim3(gx, ne, batch), dim3(TPB), 0, st, n, ne, ld, d_A, d_B, reg, d_reg_scale, ws.C0, ws.Bw, ms);   // C0 holds A for now
     for (int k = 0; k < nbk; ++k)
         hipLaunchKernelGGL(chol_panel_kernel, dim3(nbk - k, 1, batch), dim3(256), 0, st, ld, k, nbk, ws.Bw, ws.Li, ws.flag, ms);
-    hipLaunchKernelGGL(tri_inverse_kernel, dim3(nbk, BT / 8, batch), dim3(256), 0, st, ld, nbk, ws.Bw, ws.Li, ws.W, ws.flag, ms);
-    const dim3 gg((n + BT - 1) / BT, (n + BT - 1) / BT, batch);
-    hipLaunchKernelGGL((gemm_kernel<false, false>), gg, dim3(256), 0, st, n, ld, ws.W, ws.C0, ws.T1, ms);     // T1 = W A
-    hipLaunchKernelGGL((gemm_kernel<false, true>), gg, dim3(256), 0, st, n, ld, ws.T1, ws.W, ws.C0, ms);      // C = T1 W^T
-    hipLaunchKernelGGL(symmetrise_kernel, dim3(gx, n, batch), dim3(TPB), 0, st, n, ld, ws.C0, ms);
+    // APV_LARGE_OLDPRE=1: round 3's tile walk for W = L^-1 and its 32 x 32-tile products (A/B switch)
+    static const bool old_pre = getenv("APV_LARGE_OLDPRE") != nullptr;
+    if (old_pre) {
+        hipLaunchKernelGGL(tri_inverse_kernel, dim3(nbk, BT / 8, batch), dim3(256), 0, st, ld, nbk, ws.Bw, ws.Li, ws.W, ws.flag, ms);
+        const dim3 gg((n + BT - 1) / BT, (n + BT - 1) / BT, batch);
+        hipLaunchKernelGGL((gemm_kernel<false, false>), gg, dim3(256), 0, st, n, ld, ws.W, ws.C0, ws.T1, ms);     // T1 = W A
+        hipLaunchKernelGGL((gemm_kernel<false, true>), gg, dim3(256), 0, st, n, ld, ws.T1, ws.W, ws.C0, ms);      // C = T1 W^T
+        hipLaunchKernelGGL(symmetrise_kernel, dim3(gx, n, batch), dim3(TPB), 0, st, n, ld, ws.C0, ms);
+    } else {
+        // W = L^-1 by recursive halving: with L = [L11 0; L21 L22], L^-1 = [W11 0; -W22 L21 W11  W22].  The diagonal 32 x 32
+        // blocks are the panel kernel's; every level doubles the block (32 -> 64 -> ...): two products per level over all pairs of
+        // the level at once (T1 is the scratch for L21 W11), ~ 2 log2(n / 32) launches instead of a walk of n / 32 dependent
+        // block rows.  Ghost rows: the padded part of L is the identity, so is W's.
+        hipLaunchKernelGGL(diag_inverse_scatter_kernel, dim3(nbk, 1, batch), dim3(256), 0, st, ld, nbk, ws.Li, ws.W, ms, ws.flag);
+        for (int sz = BT; sz < ne; sz *= 2) {
+            const int span = 2 * sz, full = ne / span, rem = ne - full * span;        // `full` complete pairs, then maybe a ragged one
+            for (int part = 0; part < 2; ++part) {
+                const int np_ = part == 0 ? full : (rem > sz ? 1 : 0);
+                if (np_ == 0) continue;
+                const int o0 = part == 0 ? 0 : full * span;                              // first index of the part's first pair
+                const int m2 = part == 0 ? sz : rem - sz;                                 // rows of the second block
+                const size_t off11 = (size_t)o0 * ld + o0, off21 = (size_t)(o0 + sz) * ld + o0, off22 = (size_t)(o0 + sz) * ld + o0 + sz;
+                const size_t ps = (size_t)span * ld + span;
+                Gemm64 g1{m2, sz, sz, ws.Bw + off21, ld, ms, ps, ws.W + off11, ld, ms, ps, ws.T1 + off21, ld, ms, ps, 1.0, np_, 0, 0, ws.flag};
+                hipLaunchKernelGGL((gemm64_kernel<false>), dim3((sz + 63) / 64, (m2 + 63) / 64, batch * np_), dim3(256), 0, st, g1);   // T = L21 W11
+                Gemm64 g2{m2, sz, m2, ws.W + off22, ld, ms, ps, ws.T1 + off21, ld, ms, ps, ws.W + off21, ld, ms, ps, -1.0, np_, 1, 0, ws.flag};
+                hipLaunchKernelGGL((gemm64_kernel<false>), dim3((sz + 63) / 64, (m2 + 63) / 64, batch * np_), dim3(256), 0, st, g2);   // W21 = -W22 T
+            }
+        }
+        const int gt = (ne + 63) / 64;
+        Gemm64 ga{ne, ne, ne, ws.W, ld, ms, 0, ws.C0, ld, ms, 0, ws.T1, ld, ms, 0, 1.0, 1, 1, 0, ws.flag};
+        hipLaunchKernelGGL((gemm64_kernel<false>), dim3(gt, gt, batch), dim3(256), 0, st, ga);                  // T1 = W A (W lower triangular)
+        Gemm64 gb{ne, ne, ne, ws.T1, ld, ms, 0, ws.W, ld, ms, 0, ws.C0, ld, ms, 0, 1.0, 1, 2, 1, ws.flag};
+        hipLaunchKernelGGL((gemm64_kernel<true>), dim3(gt, gt, batch), dim3(256), 0, st, gb);                   // C = T1 W^T, tiles on and below the diagonal
+        hipLaunchKernelGGL(mirror_lower_kernel, dim3(gx, ne, batch), dim3(TPB), 0, st, ne, ld, ws.C0, ms, ws.flag);
+    }
     hipLaunchKernelGGL(transpose_kernel, dim3(gx, n, batch), dim3(TPB), 0, st, n, ld, ws.W, ws.X, ms);         // X = W^T Q, Q = I
     std::vector<int> hflag(batch, 0);
     std::vector<double> hacc(3 * batch, 0.0);
@@ -1032,6 +1180,8 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
     // (a caller who sets a sweep cap or a sweep tolerance of his own is asking for the Jacobi iteration they belong to)
     int lead_b = (lead_rank > 0 && h->gl_tol2 <= 0.0 && h->cfg.max_sweeps <= 0) ? apv_gevd_lead_block(n, lead_rank) : 0, lead_done = 0;
     bool flags_read = false;
+    if (timing) (void)hipStreamSynchronize(st);        // the timer's stage boundary (the product path does not stop here)
+    const auto t_pre = std::chrono::steady_clock::now();
     if (lead_b > 0) {
         // C0 (whitened, symmetric) and X = W^T are read only; on *done == 0 nothing was written and the sweeps below run.  The
         // factorisation's flags come back with the first pass's results (no synchronisation of their own on this path).
@@ -1056,7 +1206,6 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
         (void)hipGetLastError();
         return apv_fail(h, APV_ERR_NOT_PD, "Matrix is not positive definite");
     }
-    const auto t_pre = std::chrono::steady_clock::now();
     if (lead_done) {
         h->gl_lead_done = 1;
         if (d_r != nullptr && d_w != nullptr && V > 0) {
