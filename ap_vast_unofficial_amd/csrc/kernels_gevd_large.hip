@@ -1127,7 +1127,12 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
                 gs.destroy();
                 return apv_fail(h, APV_ERR_HIP, std::string("capturing the Jacobi sweeps: ") + hipGetErrorString(ce != hipSuccess ? ce : le));
             }
-            LCHK(hipGraphInstantiate(&gs.exec[g], gs.graph[g], nullptr, nullptr, 0));
+            const hipError_t ie = hipGraphInstantiate(&gs.exec[g], gs.graph[g], nullptr, nullptr, 0);
+            if (ie != hipSuccess) {
+                // a set with exec[0] alone would skip the capture next time and launch null graphs: all or nothing
+                gs.destroy();
+                return apv_fail(h, APV_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie));
+            }
         }
     }
     LCHK(hipMemsetAsync(ws.W, 0, mb, st));
@@ -1229,6 +1234,7 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
     // APV_LARGE_PAIRS=1: the stop test after every second sweep only, as before round 3's last change (A/B switch)
     static const bool pairs_only = getenv("APV_LARGE_PAIRS") && atoi(getenv("APV_LARGE_PAIRS")) != 0;
     bool converged = false;
+    size_t last_off = 0;          // where in hacc the last tested sweep's pivot weights are
     // The stop test costs a copy and a host synchronisation.  Consecutive calls of a stream solve problems of the same kind: of
     // the sweeps the LAST call of this shape needed, all but the last three (an even count: they go as captured pairs) are
     // launched back to back before the first test; from there every sweep is tested, so that the sweep found to be the last one
@@ -1244,7 +1250,8 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
         if (n_sweeps <= untested && n_sweeps < max_sweeps) continue;
         LCHK(hipMemcpyAsync(hacc.data(), ws.acc, sizeof(double) * 2 * batch, hipMemcpyDeviceToHost, st));
         LCHK(hipStreamSynchronize(st));
-        const double* const wt = hacc.data() + ((pair || odd) ? batch : 0);      // the pivot weights of the sweep just run
+        last_off = (pair || odd) ? (size_t)batch : 0;
+        const double* const wt = hacc.data() + last_off;      // the pivot weights of the sweep just run
         if (timing)
             for (int z = 0; z < batch; ++z)
                 fprintf(stderr, "[apv gevd_large] sweep %d matrix %d: pivot weight / ||C||^2 %.2e\n", n_sweeps, z, wt[z] / norm2[z]);
@@ -1255,8 +1262,12 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
     double* const Cfin = (n_sweeps & 1) ? ws.C1 : ws.C0;
     const auto t_sweeps = std::chrono::steady_clock::now();
     if (converged && h->gl_tol2 <= 0.0) gs.last_sweeps = n_sweeps;
-    if (!converged)
-        for (int z = 0; z < batch; ++z) h_status[z] = 2;
+    if (!converged) {
+        // only the members that are still above the bound carry the sweep-cap status (a batch sweeps until its slowest member is done)
+        const double* const wl = hacc.data() + last_off;
+        for (int z = 0; z < batch; ++z)
+            if (!(wl[z] <= tol2 * norm2[z])) h_status[z] = 2;
+    }
     hipLaunchKernelGGL(rank_kernel, dim3(gx, 1, batch), dim3(TPB), 0, st, n, ld, Cfin, d_lam, ws.order, ms, vs);
     hipLaunchKernelGGL(gather_cols_kernel, dim3(gx, n, batch), dim3(TPB), 0, st, n, ld, ws.X, ws.order, d_U, ms, vs,
                        (size_t)n * n);

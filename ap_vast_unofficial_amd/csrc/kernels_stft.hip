@@ -10,6 +10,7 @@
 // (mixed radix 4/2/3/5/7, so the reference's own N = 1600 works) plus the even/odd split step.  Twiddles and
 // the window come from tables computed once per (device, N, dtype) on the host in double precision.
 #include "apv_internal.h"
+#include <cstdio>
 #include <cstdlib>
 
 #include <cmath>
@@ -584,7 +585,20 @@ bool make_plan(int N, FftPlan* plan, std::string* why) {
     static const bool pingpong = getenv("APV_FFT_PINGPONG") != nullptr;      // A/B switch: two-buffer stages everywhere
     plan->inplace = pingpong ? 0 : 1;
     plan->max_it = 1;
-    plan->debug = getenv("APV_STFT_DEBUG") ? atoi(getenv("APV_STFT_DEBUG")) : 0;
+    // Timing aids of the probes: they make every transform WRONG.  A stray APV_STFT_DEBUG in somebody's environment must not
+    // corrupt a stream silently: the bits are honoured only together with APV_STFT_DEBUG_PROBE=1, which the probe
+    // scripts set; alone, the variable refuses the plan -- no stream can be created with it.
+    plan->debug = 0;
+    if (getenv("APV_STFT_DEBUG") && atoi(getenv("APV_STFT_DEBUG")) != 0) {
+        if (!getenv("APV_STFT_DEBUG_PROBE")) {
+            if (why) *why = "APV_STFT_DEBUG is set (timing aids that make every transform wrong) without APV_STFT_DEBUG_PROBE=1: unset it";
+            return false;
+        }
+        plan->debug = atoi(getenv("APV_STFT_DEBUG"));
+        static bool warned = false;
+        if (!warned) fprintf(stderr, "[apv] APV_STFT_DEBUG=%d: the transforms of this process are timing aids, their results are WRONG\n", plan->debug);
+        warned = true;
+    }
     for (int s = 0; s < plan->nstages; ++s) {
         const int r = plan->radix[s];
         if ((r != 2 && r != 4) || plan->Nh / r > INPLACE_MAX_IT * STFT_TPB) plan->inplace = 0;

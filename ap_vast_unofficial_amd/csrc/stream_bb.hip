@@ -857,9 +857,12 @@ int apv_bb_process_signal(apv_handle* h, int32_t n_hops, const double* h_in_A, c
     // sixteen while the group stays within 1 GiB (cfg1: 0.78 / 0.68 / 0.61 / 0.62 / 0.61 ms per hop with 8 / 12 / 16 / 24 / 32 hops
     // a group), eight beyond (n = 800: 11.0 ms per hop with eight, 12.0 with sixteen: 3 GB of matrices no longer sit in the
     // Infinity Cache and the batch sweeps until its slowest member is done), fewer only to stay within 8 GiB
+    // (round 4: with the leading-eigenpair solver a batch no longer sweeps until its slowest member is done, and sixteen hops a
+    // group are the better choice at n = 800 too: 4.83 ms per hop against 4.98 with eight, tools/probes/bb_group_sweep.sh)
+    const bool lead = h->cfg.max_sweeps <= 0 && apv_gevd_lead_block(n, s->max_rank) > 0;
     int G;
     if (forced > 0) G = forced;
-    else if (16 * per_hop_bytes <= ((size_t)1 << 30)) G = 16;
+    else if (16 * per_hop_bytes <= ((size_t)(lead ? 8 : 1) << 30)) G = 16;
     else {
         G = (int)(((size_t)8 << 30) / per_hop_bytes);
         G = G < 1 ? 1 : (G > 8 ? 8 : G);

@@ -1,10 +1,12 @@
 """GPU parity of the streaming path (class apvast, mode='subband') against the CPU oracle."""
 import os
+import sys
 
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from oracle.subband_stream import SubbandStreamOracle  # noqa: E402  (checker only)
 
@@ -377,6 +379,23 @@ def _hop_loop(ap, x, h0, h1):
     # concatenate like main.m:58-61: per zone a list over the ranks of (n_samples, L)
     return [None if outs[0][q] is None else [np.concatenate([o[q][v] for o in outs]) for v in range(len(outs[0][q]))]
             for q in range(4)]
+
+
+def test_stray_debug_variable_cannot_corrupt_a_stream():
+    """APV_STFT_DEBUG switches timing aids on that make every transform wrong (tools/probes/analysis_bound.sh).  Left over in an
+    environment it must not silently corrupt the outputs: without APV_STFT_DEBUG_PROBE=1 no stream can be created."""
+    import subprocess
+    code = ("import sys, numpy as np; sys.path.insert(0, %r)\n"
+            "from ap_vast_unofficial_amd.apvast import apvast\n"
+            "r = np.random.default_rng(0).standard_normal((20, 4, 8)) * 1e-3\n"
+            "try:\n"
+            "    apvast(128, r, r, 16, 5, 1, 2, 2, 1.0, 512, hop_size=64, perceptual=False, seed=3)\n"
+            "except RuntimeError as e:\n"
+            "    print('REFUSED', e)\n" % ROOT)
+    env = dict(os.environ, APV_STFT_DEBUG="1")
+    env.pop("APV_STFT_DEBUG_PROBE", None)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert "REFUSED" in out.stdout and "APV_STFT_DEBUG" in out.stdout, out.stdout + out.stderr
 
 
 @pytest.mark.parametrize("dtype,L", [("f64", 64), ("f32", 64), ("f64", 40)])
