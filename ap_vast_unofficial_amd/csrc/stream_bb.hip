@@ -61,6 +61,12 @@ struct apv_bb {
     double* G2;            // [K][nch]
     double* G2T;           // [nch][K]
     double* tspec[2];      // [M][K] c128 target spectra (kept: the curves come from both zones before any scaling)
+    // Round 4: the four response sets and the two target sets of a hop are ONE set of 4 C + 2 M channels -- rings, overlap buffers,
+    // statistics rings and spectra are each one allocation, paths first, then the targets (resp[p], tresp[z], ov[p], ... point into
+    // them) -- so that the hop's windowed transforms, its synthesis and its append to the statistics rings are one launch each
+    // instead of six (apvast.py:197-311 runs the same three steps per buffer).
+    double *resp_all, *ov_all, *stats_all, *pspec_all;
+    int n_all;             // 4 C + 2 M
     double* Wgt[2];        // [M][K]
     // apv_bb_process_signal: G consecutive hops share ONE batched joint diagonalisation (allocated on first use)
     int grp;               // hops per group the buffers below are sized for (0: not allocated)
@@ -98,6 +104,21 @@ using d4 = __attribute__((ext_vector_type(4))) double;
 // new_hist = [old_hist[H:], x, zeros(pad)]: the last P-1 inputs, this hop, and the zero tail
 __global__ void __launch_bounds__(256) hist_f64_kernel(int P, int H, int pad, const double* __restrict__ old_hist,
                                                        const double* __restrict__ x, double* __restrict__ new_hist) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int keep = P - 1;
+    if (i < keep) new_hist[i] = old_hist[i + H];
+    else if (i < keep + H) new_hist[i] = x[i - keep];
+    else if (i < keep + H + pad) new_hist[i] = 0.0;
+}
+
+// both input signals' histories in one launch (blockIdx.y = signal)
+__global__ void __launch_bounds__(256) hist2_f64_kernel(int P, int H, int pad, const double* __restrict__ old0,
+                                                        const double* __restrict__ old1, const double* __restrict__ x,
+                                                        double* __restrict__ new0, double* __restrict__ new1) {
+    const int g = blockIdx.y;
+    const double* old_hist = g ? old1 : old0;
+    double* new_hist = g ? new1 : new0;
+    x += (size_t)g * H;
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int keep = P - 1;
     if (i < keep) new_hist[i] = old_hist[i + H];
@@ -410,6 +431,24 @@ __global__ void __launch_bounds__(256) apply_f64_kernel(int K, int n_ch, const d
     out[(size_t)ch * K + k] = make_double2(x.x * f.x - x.y * f.y, x.x * f.y + x.y * f.x);
 }
 
+// the same for up to four channel groups with inputs of their own, one launch (a hop's zone programs and target paths)
+struct ApplyJobsD {
+    const double2* in[4];
+    const double2* filt[4];
+    double2* out[4];
+    int first[5];          // first channel of each job in the launch's channel index; first[n] = total
+    int n;
+};
+__global__ void __launch_bounds__(256) apply_f64_jobs_kernel(int K, ApplyJobsD j) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    int ch = blockIdx.y, q = 0;
+    while (q + 1 < j.n && ch >= j.first[q + 1]) ++q;
+    ch -= j.first[q];
+    if (k >= K) return;
+    const double2 x = j.in[q][k], f = j.filt[q][(size_t)ch * K + k];
+    j.out[q][(size_t)ch * K + k] = make_double2(x.x * f.x - x.y * f.y, x.x * f.y + x.y * f.x);
+}
+
 // p[t][m] = sum_s sum_q rir[q][s][m] x[t-q][s]          (Matlab/ControlMethods/predictPressure.m:12-16)
 __global__ void __launch_bounds__(256) predict_pressure_kernel(int T, int L, int M, int P, const double* __restrict__ x,
                                                                const double* __restrict__ rir, double* __restrict__ out) {
@@ -449,10 +488,9 @@ void apv_bb_free(apv_handle* h) {
     apv_bb* s = h->bb;
     if (!s) return;
     double* bufs[] = {s->rir[0], s->rir[1], s->trir[0], s->trir[1], s->xhist[0][0], s->xhist[0][1], s->xhist[1][0],
-                      s->xhist[1][1], s->xin, s->resp[0], s->resp[1], s->resp[2], s->resp[3], s->tresp[0], s->tresp[1],
-                      s->inblk, s->spec, s->ov[0], s->ov[1], s->ov[2], s->ov[3], s->tov[0], s->tov[1], s->stats[0],
-                      s->stats[1], s->stats[2], s->stats[3], s->tstats[0], s->tstats[1], s->R, s->r, s->U, s->lam, s->w,
-                      s->fspec, s->inspec, s->outov, s->out, s->G2, s->G2T, s->tspec[0], s->tspec[1], s->Wgt[0], s->Wgt[1], s->nrm,
+                      s->xhist[1][1], s->xin, s->resp_all, s->ov_all, s->stats_all, s->pspec_all,
+                      s->inblk, s->spec, s->R, s->r, s->U, s->lam, s->w,
+                      s->fspec, s->inspec, s->outov, s->out, s->G2, s->G2T, s->Wgt[0], s->Wgt[1], s->nrm,
                       s->g_xin, s->g_RA, s->g_RB, s->g_U, s->g_lam, s->g_r, s->g_w, s->g_nrm, s->g_inspec, s->spec_out};
     for (double* b : bufs)
         if (b) (void)hipFree(b);
@@ -552,20 +590,24 @@ int apv_bb_init(apv_handle* h, int32_t rir_len, const double* h_rir_A, const dou
         for (int g = 0; g < 2; ++g)
             if ((rc = dalloc(h, &s->xhist[b][g], hist))) return rc;
     if ((rc = dalloc(h, &s->xin, (size_t)2 * H))) return rc;
+    s->n_all = 4 * C + 2 * M;
+    if ((rc = dalloc(h, &s->resp_all, (size_t)s->n_all * N))) return rc;
+    if ((rc = dalloc(h, &s->ov_all, (size_t)s->n_all * N))) return rc;
+    if ((rc = dalloc(h, &s->stats_all, (size_t)s->n_all * S))) return rc;
+    if ((rc = dalloc(h, &s->pspec_all, (size_t)s->n_all * K * 2))) return rc;
     for (int p = 0; p < 4; ++p) {
-        if ((rc = dalloc(h, &s->resp[p], (size_t)C * N))) return rc;
-        if ((rc = dalloc(h, &s->ov[p], (size_t)C * N))) return rc;
-        if ((rc = dalloc(h, &s->stats[p], (size_t)C * S))) return rc;
+        s->resp[p] = s->resp_all + (size_t)p * C * N;
+        s->ov[p] = s->ov_all + (size_t)p * C * N;
+        s->stats[p] = s->stats_all + (size_t)p * C * S;
     }
     for (int z = 0; z < 2; ++z) {
-        if ((rc = dalloc(h, &s->tresp[z], (size_t)M * N))) return rc;
-        if ((rc = dalloc(h, &s->tov[z], (size_t)M * N))) return rc;
-        if ((rc = dalloc(h, &s->tstats[z], (size_t)M * S))) return rc;
+        s->tresp[z] = s->resp_all + ((size_t)4 * C + (size_t)z * M) * N;
+        s->tov[z] = s->ov_all + ((size_t)4 * C + (size_t)z * M) * N;
+        s->tstats[z] = s->stats_all + ((size_t)4 * C + (size_t)z * M) * S;
+        s->tspec[z] = s->pspec_all + ((size_t)4 * C + (size_t)z * M) * K * 2;
     }
     const size_t spec_ch = (size_t)(C > s->n_out ? C : s->n_out);
     if ((rc = dalloc(h, &s->spec, spec_ch * K * 2))) return rc;
-    for (int z = 0; z < 2; ++z)
-        if ((rc = dalloc(h, &s->tspec[z], (size_t)M * K * 2))) return rc;
     if ((rc = dalloc(h, &s->inblk, (size_t)2 * N))) return rc;
     if ((rc = dalloc(h, &s->R, (size_t)4 * n * n))) return rc;
     if ((rc = dalloc(h, &s->r, (size_t)2 * n))) return rc;
@@ -639,9 +681,8 @@ static int bb_front(apv_handle* h, apv_bb* s, const BbHop& q, double* t_stage, h
     };
     const int nxt = s->cur ^ 1;
     const int hist_total = P - 1 + H + s->pad;
-    for (int g = 0; g < 2; ++g)
-        hipLaunchKernelGGL(hist_f64_kernel, dim3((hist_total + 255) / 256), dim3(256), 0, st, P, H, s->pad,
-                           s->xhist[s->cur][g], q.xin + (size_t)g * H, s->xhist[nxt][g]);
+    hipLaunchKernelGGL(hist2_f64_kernel, dim3((hist_total + 255) / 256, 2), dim3(256), 0, st, P, H, s->pad, s->xhist[s->cur][0],
+                       s->xhist[s->cur][1], q.xin, s->xhist[nxt][0], s->xhist[nxt][1]);
     s->cur = nxt;
     s->ring_off = (s->ring_off + H) % N;
     s->stat_off = (s->stat_off + H) % S;
@@ -662,36 +703,31 @@ static int bb_front(apv_handle* h, apv_bb* s, const BbHop& q, double* t_stage, h
         BCHK(h, apv_launch_fir_jobs_f64(jobs, nj, P, H, N, s->ring_off, st));
     }
     stage_done();
-    // 2: WOLA (unit weights, apvast.py:326-327, or the perceptual curves) and append the finished hop to the statistics rings
+    // 2: WOLA (unit weights, apvast.py:326-327, or the perceptual curves) and append the finished hop to the statistics rings:
+    // all 4 C + 2 M channels of the hop in one launch per step (see resp_all)
     const bool runA = s->zones & 1, runB = s->zones & 2;
-    for (int z = 0; z < 2; ++z)
-        BCHK(h, apv_launch_analysis(1, N, M, s->tresp[z], N, N, s->ring_off, 1, s->tspec[z], K, 1, st, &why));
+    auto pspec = [&](int p) { return s->pspec_all + (size_t)p * C * K * 2; };
+    BCHK(h, apv_launch_analysis(1, N, s->n_all, s->resp_all, N, N, s->ring_off, 1, s->pspec_all, K, 1, st, &why));
+    for (int p = 0; p < 4; ++p) {
+        const bool live = (p == 0 || p == 1) ? runA : runB;      // A->A, A->B belong to zone program A
+        if (!live) BCHK(h, hipMemsetAsync(pspec(p), 0, sizeof(double) * 2 * (size_t)C * K, st));   // apvast.py:239-255: spectra stay 0
+    }
     if (s->nch > 0) {
-        // curves from the unweighted target spectra of both zones (apvast.py:205), then the scaling (208-209)
+        // curves from the unweighted target spectra of both zones (apvast.py:205), then the scaling (208-209);
+        // A->A, B->A x zone A's curve; A->B, B->B x zone B's (apvast.py:258-262)
         for (int z = 0; z < 2; ++z)
             BCHK(h, apv_launch_perceptual_weights_f64(K, M, s->nch, (const double2*)s->tspec[z], s->G2, s->G2T, s->Cs, s->Ca,
                                                       s->Leff, N, s->norm_mode, s->Wgt[z], st));
         for (int z = 0; z < 2; ++z)
             BCHK(h, apv_launch_scale_spectra_cm_f64(K, M, 1, (double2*)s->tspec[z], s->Wgt[z], st));
-    }
-    for (int z = 0; z < 2; ++z) {
-        BCHK(h, apv_launch_synthesis(1, N, H, M, s->tspec[z], K, 1, s->tov[z], nullptr, st, &why));
-        hipLaunchKernelGGL(ring_append_f64_kernel, dim3((H + 255) / 256, M), dim3(256), 0, st, S, H, s->stat_off,
-                           s->tov[z], (long)N, s->tstats[z]);
-    }
-    for (int p = 0; p < 4; ++p) {
-        const bool live = (p == 0 || p == 1) ? runA : runB;      // A->A, A->B belong to zone program A
-        if (live) {
-            BCHK(h, apv_launch_analysis(1, N, C, s->resp[p], N, N, s->ring_off, 1, s->spec, K, 1, st, &why));
-            // A->A, B->A x zone A's curve; A->B, B->B x zone B's (apvast.py:258-262)
-            if (s->nch > 0) BCHK(h, apv_launch_scale_spectra_cm_f64(K, C, L, (double2*)s->spec, s->Wgt[path_zone(p)], st));
-        } else {
-            BCHK(h, hipMemsetAsync(s->spec, 0, sizeof(double) * 2 * (size_t)C * K, st));   // apvast.py:239-255: spectra stay 0
+        for (int p = 0; p < 4; ++p) {
+            const bool live = (p == 0 || p == 1) ? runA : runB;
+            if (live) BCHK(h, apv_launch_scale_spectra_cm_f64(K, C, L, (double2*)pspec(p), s->Wgt[path_zone(p)], st));
         }
-        BCHK(h, apv_launch_synthesis(1, N, H, C, s->spec, K, 1, s->ov[p], nullptr, st, &why));
-        hipLaunchKernelGGL(ring_append_f64_kernel, dim3((H + 255) / 256, C), dim3(256), 0, st, S, H, s->stat_off,
-                           s->ov[p], (long)N, s->stats[p]);
     }
+    BCHK(h, apv_launch_synthesis(1, N, H, s->n_all, s->pspec_all, K, 1, s->ov_all, nullptr, st, &why));
+    hipLaunchKernelGGL(ring_append_f64_kernel, dim3((H + 255) / 256, s->n_all), dim3(256), 0, st, S, H, s->stat_off, s->ov_all, (long)N,
+                       s->stats_all);
     stage_done();
     // 3: statistics.  R order: bright [0] A->A, [1] B->B; dark [2] A->B, [3] B->A
     const int stat_src[4] = {0, 3, 1, 2};
@@ -750,27 +786,40 @@ static int bb_back(apv_handle* h, apv_bb* s, const BbHop& q, double* h_out, doub
     const int N = s->N, H = s->H, K = s->K, L = s->L, J = s->J, V = s->V;
     std::string why;
     const bool runA = s->zones & 1, runB = s->zones & 2;
-    // 5: filter spectra: channel (v, l) = taps w[v][l*J : (l+1)*J] zero-padded to N, no window
-    int oc = 0;
-    for (int z = 0; z < 2; ++z) {
-        if (!(z ? runB : runA)) continue;
-        BCHK(h, apv_launch_analysis(1, N, V * L, q.w[z], J, J, 0, 0, s->fspec + (size_t)oc * K * 2, K, 1, st, &why));
-        oc += V * L;
+    // 5: filter spectra: channel (v, l) = taps w[v][l*J : (l+1)*J] zero-padded to N, no window; both zones' filters in one launch
+    // when they lie one behind the other (they do: [zone][V][n] in the handle's arrays and in a group's slices)
+    const int n = s->n;
+    if (runA && runB && q.w[1] == q.w[0] + (size_t)V * n) {
+        BCHK(h, apv_launch_analysis(1, N, 2 * V * L, q.w[0], J, J, 0, 0, s->fspec, K, 1, st, &why));
+    } else {
+        int oc = 0;
+        for (int z = 0; z < 2; ++z) {
+            if (!(z ? runB : runA)) continue;
+            BCHK(h, apv_launch_analysis(1, N, V * L, q.w[z], J, J, 0, 0, s->fspec + (size_t)oc * K * 2, K, 1, st, &why));
+            oc += V * L;
+        }
     }
-    // 6: outputs
-    oc = 0;
-    for (int z = 0; z < 2; ++z) {
-        if (!(z ? runB : runA)) continue;
-        hipLaunchKernelGGL(apply_f64_kernel, dim3((K + 255) / 256, V * L), dim3(256), 0, st, K, V * L,
-                           (const double2*)q.inspec + (size_t)z * K, (const double2*)s->fspec + (size_t)oc * K,
-                           (double2*)spec + (size_t)oc * K);
-        oc += V * L;
-    }
-    for (int z = 0; z < 2; ++z) {
-        hipLaunchKernelGGL(apply_f64_kernel, dim3((K + 255) / 256, L), dim3(256), 0, st, K, L,
-                           (const double2*)q.inspec + (size_t)z * K, (const double2*)s->fspec + (size_t)oc * K,
-                           (double2*)spec + (size_t)oc * K);
-        oc += L;
+    // 6: outputs: the live zone programs' V L channels each, then the target paths A_t, B_t, in one launch
+    {
+        ApplyJobsD aj{};
+        int oc = 0;
+        for (int z = 0; z < 2; ++z) {
+            if (!(z ? runB : runA)) continue;
+            aj.in[aj.n] = (const double2*)q.inspec + (size_t)z * K;
+            aj.filt[aj.n] = (const double2*)s->fspec + (size_t)oc * K;
+            aj.out[aj.n] = (double2*)spec + (size_t)oc * K;
+            aj.first[aj.n++] = oc;
+            oc += V * L;
+        }
+        for (int z = 0; z < 2; ++z) {
+            aj.in[aj.n] = (const double2*)q.inspec + (size_t)z * K;
+            aj.filt[aj.n] = (const double2*)s->fspec + (size_t)oc * K;
+            aj.out[aj.n] = (double2*)spec + (size_t)oc * K;
+            aj.first[aj.n++] = oc;
+            oc += L;
+        }
+        aj.first[aj.n] = oc;
+        hipLaunchKernelGGL(apply_f64_jobs_kernel, dim3((K + 255) / 256, oc), dim3(256), 0, st, K, aj);
     }
     BCHK(h, apv_launch_synthesis(1, N, H, s->n_out, spec, K, 1, s->outov, s->out, st, &why));
     BCHK(h, hipMemcpyAsync(h_out, s->out, sizeof(double) * (size_t)s->n_out * H, hipMemcpyDeviceToHost, st));
