@@ -131,31 +131,51 @@ __global__ void __launch_bounds__(256) chol_panel_kernel(int ld, int k, int nbk,
         Wp[r * LS + c] = (r == c) ? 1.0 : 0.0;
     }
     __syncthreads();
-    for (int j = 0; j < BT; ++j) {
-        const double d = Dm[j * LS + j];
-        if (!(d > 0.0) || !(d < 1e300)) {          // the same value in every workgroup of the panel: all leave
-            if (tid == 0 && blockIdx.x == 0) flag[z] = 1;
-            return;
-        }
-        const double inv = 1.0 / d;
-        for (int i = 0; i < 4; ++i) {
-            const int r = ty + ((i >> 1) << 4), c = tx + ((i & 1) << 4);
-            if (r > j) {
-                const double lik = Dm[r * LS + j] * inv;
-                if (c > j) {
-                    if (c <= r) Dm[r * LS + c] -= lik * Dm[c * LS + j];
-                } else {
-                    Wp[r * LS + c] -= lik * Wp[j * LS + c];
-                }
+    // [D | I] -> [ . | L_D^-1 ] by elimination with the rows in REGISTERS (round 4): thread (r, cq) holds columns 8 cq .. 8 cq + 7 of
+    // row r of the augmented matrix; a step publishes the pivot row and the pivot column through LDS (two alternating buffers:
+    // one barrier per step), everything else is eight multiply-adds per thread.  Before, every element of both halves went
+    // through LDS in every step (three reads and a write each, 0.45 us a step; 25-36 us of a panel launch were this loop).
+    {
+        const int er = tid >> 3, cq = tid & 7;
+        double a[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = cq < 4 ? Dm[er * LS + 8 * cq + i] : ((8 * (cq - 4) + i == er) ? 1.0 : 0.0);
+        double* const prow = La;                   // [2][64]   (La holds T only for I != k: parked in registers below)
+        double* const pcol = Lb;                   // [2][32]
+        double tsave[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tsave[i] = La[((wq >> 1) * 16 + (lq >> 4) + 4 * i) * LS + (wq & 1) * 16 + (lq & 15)];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < BT; ++j) {
+            const int par = j & 1;
+            if (er == j) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) prow[par * 64 + 8 * cq + i] = a[i];
+            }
+            if (cq == (j >> 3)) pcol[par * 32 + er] = a[j & 7];
+            __syncthreads();
+            const double d = pcol[par * 32 + j];
+            if (!(d > 0.0) || !(d < 1e300)) {          // the same value in every workgroup of the panel: all leave
+                if (tid == 0 && blockIdx.x == 0) flag[z] = 1;
+                return;
+            }
+            if (tid == 0) rs[j] = 1.0 / sqrt(d);
+            if (er > j) {
+                const double f = pcol[par * 32 + er] * (1.0 / d);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) a[i] = __builtin_fma(-f, prow[par * 64 + 8 * cq + i], a[i]);
             }
         }
         __syncthreads();
-    }
-    if (tid < BT) rs[tid] = 1.0 / sqrt(Dm[tid * LS + tid]);
-    __syncthreads();
-    for (int i = 0; i < 4; ++i) {
-        const int r = ty + ((i >> 1) << 4), c = tx + ((i & 1) << 4);
-        Wp[r * LS + c] *= rs[r];                                   // L_D^-1 (lower)
+        if (cq >= 4) {
+            const double sc = rs[er];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) Wp[er * LS + 8 * (cq - 4) + i] = a[i] * sc;                 // L_D^-1 (lower)
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) La[((wq >> 1) * 16 + (lq >> 4) + 4 * i) * LS + (wq & 1) * 16 + (lq & 15)] = tsave[i];
+        __syncthreads();
     }
     if (I == k) {
         // only the inverse of the diagonal block is ever used again; B[K,K] itself must stay as it is, the other
