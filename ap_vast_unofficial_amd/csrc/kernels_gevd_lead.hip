@@ -44,6 +44,8 @@ constexpr int kMaxPass = 12;             // Rayleigh-Ritz passes before the call
 struct LeadCoef {                        // Ynew = a C Ycur + b Ycur + g Yprev, per matrix
     double a[LEAD_MAXB], b[LEAD_MAXB], g[LEAD_MAXB];
     unsigned active;                     // bit z: matrix z takes part in this launch
+    const double* dev;                   // non-null: the coefficients are dev[(2 z + dev_step) * 3 + {0, 1, 2}] (lead_bounds_kernel's)
+    int dev_step;
 };
 
 __device__ __forceinline__ double lead_rnd(unsigned i) {
@@ -72,7 +74,8 @@ __global__ void __launch_bounds__(256) lead_mult_kernel(int ne, int lda, size_t 
     __shared__ double red[4][NB][256];
     const int z = blockIdx.z;
     if (!((cf.active >> z) & 1u)) return;
-    const double ca = cf.a[z], cb = cf.b[z], cg = cf.g[z];
+    const double ca = cf.dev ? cf.dev[(2 * z + cf.dev_step) * 3] : cf.a[z], cb = cf.dev ? cf.dev[(2 * z + cf.dev_step) * 3 + 1] : cf.b[z],
+                 cg = cf.dev ? cf.dev[(2 * z + cf.dev_step) * 3 + 2] : cf.g[z];
     A += z * a_stride;
     Yc += z * y_stride;
     Yo += z * o_stride;
@@ -149,6 +152,68 @@ __global__ void __launch_bounds__(256) lead_mult_kernel(int ne, int lda, size_t 
         if (cb != 0.0) v = __builtin_fma(cb, Yc[(size_t)row * b + col], v);
         if (cg != 0.0) v = __builtin_fma(cg, Yp[z * y_stride + (size_t)row * b + col], v);
         if (row < rows_out) Yo[(size_t)row * ldo + col] = v;
+    }
+}
+
+// Bounds for the FIRST filter, before any Ritz value exists: c = trace(C) / n -- on the oracle's pairs 0.29-0.61 of lambda_{b+1}
+// (tools/probes/lead_model.py): below the block, so nothing wanted is damped -- and s1 = max_j sum_i |C_ij| >= lambda_1 (3-6 x it).
+// The filter [0, c] of degree 1 or 2 (amplification T_m(2 s1 / c - 1) <= 1e6) takes the place of a Rayleigh-Ritz pass on the
+// random start block, which gave no better bounds (its smallest Ritz value is about the mean too) and cost a projected
+// eigenproblem and a host synchronisation.  coef[z][2][3]: the two steps' (a, b, g); fixed-order sums: the same bits every run.
+// part[z][chunk][j] = sum over the chunk's rows i of |C_ij| (column j = row j); 8 row chunks
+constexpr int LEAD_BCH = 8;
+__global__ void __launch_bounds__(256) lead_colsum_kernel(int n, int ld, const double* __restrict__ C, size_t mat_stride,
+                                                          double* __restrict__ part) {
+    const int z = blockIdx.z, ch = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    C += z * mat_stride;
+    const int rows = (n + LEAD_BCH - 1) / LEAD_BCH, i0 = ch * rows, i1 = min(n, i0 + rows);
+    double cs = 0.0;
+#pragma unroll 8
+    for (int i = i0; i < i1; ++i) cs += fabs(C[(size_t)i * ld + j]);
+    part[((size_t)z * LEAD_BCH + ch) * n + j] = cs;
+}
+
+__global__ void __launch_bounds__(1024) lead_bounds_kernel(int n, int ld, const double* __restrict__ C, size_t mat_stride,
+                                                           const double* __restrict__ part, double* __restrict__ coef) {
+    __shared__ double red[1024], redm[1024];
+    const int z = blockIdx.x, tid = threadIdx.x;
+    C += z * mat_stride;
+    part += (size_t)z * LEAD_BCH * n;
+    double tr = 0.0, mx = 0.0;
+    for (int j = tid; j < n; j += 1024) {
+        tr += C[(size_t)j * ld + j];
+        double cs = 0.0;
+#pragma unroll
+        for (int ch = 0; ch < LEAD_BCH; ++ch) cs += part[(size_t)ch * n + j];
+        mx = cs > mx ? cs : mx;
+    }
+    red[tid] = tr;
+    redm[tid] = mx;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if (tid < w) {
+            red[tid] += red[tid + w];
+            redm[tid] = redm[tid] > redm[tid + w] ? redm[tid] : redm[tid + w];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        double s1 = redm[0], c = red[0] / (double)n;
+        if (!(s1 > 0.0)) s1 = 1.0;
+        if (!(c > 1e-12 * s1)) c = 1e-12 * s1;
+        if (c > 0.5 * s1) c = 0.5 * s1;
+        const double x1 = 2.0 * s1 / c - 1.0;
+        const int m = acosh(1e6) / acosh(x1) >= 2.0 ? 2 : 1;
+        const double e = 0.5 * c, sigma1 = e / (s1 - e);
+        double* o = coef + (size_t)z * 6;
+        o[0] = sigma1 / e; o[1] = -sigma1; o[2] = 0.0;                                  // Y1 = (sigma_1 / e) (C - e) X
+        if (m == 2) {
+            const double sn = 1.0 / (2.0 / sigma1 - sigma1);
+            o[3] = 2.0 * sn / e; o[4] = -2.0 * sn; o[5] = -sigma1 * sn;                 // Y2 = (2 sigma_2 / e) (C - e) Y1 - sigma_1 sigma_2 X
+        } else {
+            o[3] = 0.0; o[4] = 1.0; o[5] = 0.0;                                         // degree 1: the second step copies
+        }
     }
 }
 
@@ -508,10 +573,11 @@ struct LeadWs {
     int ne = 0, b = 0, cap = 0;
     double* P[3] = {nullptr, nullptr, nullptr};
     double *Zb = nullptr, *Gp = nullptr, *Hp = nullptr, *T = nullptr, *theta = nullptr;
+    double* coefdev = nullptr;        // [batch][2][3] the first filter's coefficients (lead_bounds_kernel)
     double* out = nullptr;            // what the host reads after a pass: [batch][row tiles][b] residual partials, then [batch][b + 4] hinfo
     double* h_out = nullptr;          // pinned
     void release() {
-        void* bufs[] = {P[0], P[1], P[2], Zb, Gp, Hp, T, theta, out};
+        void* bufs[] = {P[0], P[1], P[2], Zb, Gp, Hp, T, theta, out, coefdev};
         for (void* p : bufs)
             if (p) (void)hipFree(p);
         if (h_out) (void)hipHostFree(h_out);
@@ -588,6 +654,7 @@ int apv_gevd_lead(apv_handle* h, int n, int ne, int batch, int b, int rank, cons
         LCHK(hipMalloc((void**)&ws.Hp, sizeof(double) * (size_t)batch * nslab * npair * 256));
         LCHK(hipMalloc((void**)&ws.T, sizeof(double) * (size_t)batch * b * b));
         LCHK(hipMalloc((void**)&ws.theta, sizeof(double) * (size_t)batch * b));
+        LCHK(hipMalloc((void**)&ws.coefdev, sizeof(double) * 6 * batch));
         LCHK(hipMalloc((void**)&ws.out, sizeof(double) * ow));
         LCHK(hipHostMalloc((void**)&ws.h_out, sizeof(double) * ow));
     }
@@ -609,13 +676,30 @@ int apv_gevd_lead(apv_handle* h, int n, int ne, int batch, int b, int rank, cons
     int final_buf[LEAD_MAXB];
     for (int z = 0; z < batch; ++z) final_buf[z] = -1;
     hipLaunchKernelGGL(lead_init_kernel, dim3((unsigned)((ys + 255) / 256), 1, batch), dim3(256), 0, st, n, ne, b, ws.P[ic], ys);
-    static const double kLimits[3] = {1e6, 1e10, 1e12};
+    // the first filter from trace and column-sum bounds (lead_bounds_kernel); APV_LEAD_PREFILTER=0: a Rayleigh-Ritz pass on the
+    // random block instead, as until the middle of round 4 (A/B switch)
+    static const bool prefilter = !(getenv("APV_LEAD_PREFILTER") && atoi(getenv("APV_LEAD_PREFILTER")) == 0);
+    int total_mv = 0;
+    if (prefilter) {
+        hipLaunchKernelGGL(lead_colsum_kernel, dim3((n + 255) / 256, LEAD_BCH, batch), dim3(256), 0, st, n, ne, C, ms, ws.Zb);   // Zb is free here
+        hipLaunchKernelGGL(lead_bounds_kernel, dim3(batch), dim3(1024), 0, st, n, ne, C, ms, (const double*)ws.Zb, ws.coefdev);
+        LeadCoef d0 = one, d1 = one;
+        d0.dev = d1.dev = ws.coefdev;
+        d0.dev_step = 0;
+        d1.dev_step = 1;
+        mult(C, ws.P[0], nullptr, ws.P[1], ne, b, ys, d0);
+        mult(C, ws.P[1], ws.P[0], ws.P[2], ne, b, ys, d1);
+        total_mv += 2;
+        ic = 2; ix = 0; iy = 1;
+    }
+    static const double kLimitsRR[3] = {1e6, 1e10, 1e12}, kLimitsPF[3] = {1e10, 1e12, 1e12};
+    const double* const kLimits = prefilter ? kLimitsPF : kLimitsRR;
     // measured (tools/probes/lead_sweeps_probe.sh, profiles/r04/lead_sweeps_probe.txt): one sweep per non-final pass at b = 64
     // (n = 800: 1.61 ms for seven passes; two sweeps 1.77 for six, three 2.09, four 2.39), two at b = 32 (n = 256: 0.51 ms, the same
     // with one or three)
     static const int kSweepsEnv = getenv("APV_LEAD_SWEEPS") ? atoi(getenv("APV_LEAD_SWEEPS")) : 0;     // tuning aid
     const int kPartialSweeps = kSweepsEnv > 0 ? kSweepsEnv : (b >= 48 ? 1 : 2);
-    int total_mv = 0, pass = 0;
+    int pass = 0;
     bool fallback = false;
     for (;; ++pass) {
         // Rayleigh-Ritz on span P[ic]
@@ -695,7 +779,7 @@ int apv_gevd_lead(apv_handle* h, int n, int ne, int batch, int b, int rank, cons
         }
         if (fallback || active == 0) break;
         // coefficients of the scaled three-term recurrence (Zhou & Saad 2007): damped interval [0, c], sigma_1 = e / (theta_1 - e)
-        for (int i = 0; i < mdeg; ++i) step[i].active = active;
+        for (int i = 0; i < mdeg; ++i) { step[i].active = active; step[i].dev = nullptr; step[i].dev_step = 0; }
         for (int z = 0; z < batch; ++z) {
             if (!((active >> z) & 1u)) continue;
             const double* th = ws.h_out + n_part + (size_t)z * (b + 4);
