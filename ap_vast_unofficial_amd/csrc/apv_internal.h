@@ -23,6 +23,9 @@ struct GevdParams {
     int out_c128;
     // fused input: c64, or c128 when x_c128 is set (the float64 streaming front-end)
     int x_c128;
+    // fused input in the grouped layout [K / x_group][M n][x_group] (0 or 1: bin-major [K][M][n]); only the order-16 float64 kernel
+    // on c128 slabs reads it (kernels_gevd16m.hip), every other kernel refuses a launch with x_group > 1
+    int x_group;
     const void* XB;
     const void* XD;
     const void* d;
@@ -98,6 +101,7 @@ GevdParams apv_base_params(const apv_handle* h);
 
 // kernels_gevd.hip
 hipError_t apv_launch_gevd(const GevdParams& p, int compute_dtype, bool fused, hipStream_t s, std::string* why);
+int apv_gevd_reads_groups(const GevdParams& p, int compute_dtype, bool x_c128);      // bins per group of the spectra layout that launch reads (1: bin-major)
 // HBM scratch the kernel that WILL run needs for K bins of order n (0 for most configurations): the order-64 kernel's slots when
 // it is eligible, the float64 LDS kernel's parked Cholesky factor at orders 33..64 otherwise.  zones: 1 or 2 zone programs.
 size_t apv_gevd_spill_bytes(int n, int K, int compute_dtype, int reg_mode, double reg_bright, double sweep_tol2, int zones);
@@ -218,6 +222,7 @@ int apv_fir_pad_f64();
 hipError_t apv_launch_perceptual_weights(int f64, int K, int M, int nch, const void* spec, const double* G2, const double* G2T,
                                          double Cs, double Ca, double Leff, int N, int norm_mode, void* W, hipStream_t s);
 hipError_t apv_launch_scale_spectra(int f64, int K, int C, int L, void* spec, const void* W, hipStream_t s);
+hipError_t apv_launch_ungroup_spectra(int f64, int K, int C, int g, const void* in, void* out, hipStream_t s);
 hipError_t apv_launch_perceptual_weights_f64(int K, int M, int nch, const double2* spec, const double* G2,
                                              const double* G2T, double Cs, double Ca, double Leff, int N, int norm_mode,
                                              double* W, hipStream_t s);

@@ -94,7 +94,9 @@ struct NoStamp { __device__ __forceinline__ void operator()(int) const {} };
 // `stamp(i)`: diagnostic hook (stage stamps of the diagnostic kernel instantiation; NoStamp in the product)
 // WITH_D: also r = X^H d (a compile-time flag: tested at run time, `dvec != nullptr` put every d load into a basic block of its own
 // that ended in `s_waitcnt vmcnt(0)`, i.e. waited for the x loads before it as well)
-template <typename T, typename XT, bool WITH_D, typename ST = NoStamp>
+// GS: element stride of the slab (1: bin-major [K][M][L]; 4: the grouped layout [K/4][M L][4] of the float64 streaming front-end,
+// where X points at the bin's first element inside its group and consecutive slab elements are four apart)
+template <typename T, typename XT, bool WITH_D, typename ST = NoStamp, int GS = 1>
 __device__ __forceinline__ void correlate16(const XT* __restrict__ X, const XT* __restrict__ dvec, int M,
                                             Cx<T>* dst, Cx<T>* sr, int lane, ST stamp = ST(), int stamp_base = 0) {
     using MM = Mfma16<T>;
@@ -109,7 +111,7 @@ __device__ __forceinline__ void correlate16(const XT* __restrict__ X, const XT* 
     auto chunk = [&](int mc, auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
         XT xv[8], dv[8];
-        const XT* const xrow0 = X + (size_t)(mc + msub) * N + (lane & 15);
+        const XT* const xrow0 = X + ((size_t)(mc + msub) * N + (lane & 15)) * GS;
         const XT* const drow0 = WITH_D ? dvec + mc + msub : nullptr;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -123,11 +125,11 @@ __device__ __forceinline__ void correlate16(const XT* __restrict__ X, const XT* 
             if constexpr (FULL) {
                 // one base address per chunk, the eight rows at constant offsets (512 q bytes: immediate offsets of the loads;
                 // indexed per load the compiler spent three 64-bit address instructions on each)
-                xl = xrow0[(size_t)(4 * q) * N];
+                xl = xrow0[(size_t)(4 * q) * N * GS];
                 if constexpr (WITH_D) dl = drow0[4 * q];
             } else {
                 const int mcl = ok ? m : M - 1;
-                xl = X[(size_t)mcl * N + (lane & 15)];
+                xl = X[((size_t)mcl * N + (lane & 15)) * GS];
                 if constexpr (WITH_D) dl = dvec[mcl];
             }
             xv[q].x = ok ? xl.x : zero.x;

@@ -652,6 +652,17 @@ size_t apv_gevd_spill_bytes(int n, int K, int compute_dtype, int reg_mode, doubl
     return 0;
 }
 
+// will a fused launch of these parameters go to the kernel that reads grouped spectra?  (the conditions of apv_launch_gevd16m's
+// grouped branch and of the dispatch below)
+int apv_gevd_reads_groups(const GevdParams& p, int compute_dtype, bool x_c128) {
+    static const bool force_generic = (getenv("APV_FORCE_GENERIC") != nullptr);
+    static const int env = getenv("APV_SPECTRA_GROUP") ? atoi(getenv("APV_SPECTRA_GROUP")) : 4;      // A/B switch: 1 = bin-major spectra, 4 | 8 bins a group
+    const int g = (env == 4 || env == 8) ? env : 1;
+    const bool ok = g > 1 && !force_generic && p.n == 16 && p.reg_mode == APV_REG_ABS && p.reg_bright == 0.0 && compute_dtype == APV_F64 && x_c128 &&
+           p.debug_stop == 0 && p.stamps == nullptr;
+    return ok ? g : 1;
+}
+
 hipError_t apv_launch_gevd(const GevdParams& p, int compute_dtype, bool fused, hipStream_t s, std::string* why) {
     const int n = p.n;
     static const bool force_generic = (getenv("APV_FORCE_GENERIC") != nullptr);
@@ -663,6 +674,10 @@ hipError_t apv_launch_gevd(const GevdParams& p, int compute_dtype, bool fused, h
     }
     if (n < 1 || n > APV_MAX_N) {
         if (why) *why = "GEVD order n out of range (1..64)";
+        return hipErrorInvalidValue;
+    }
+    if (p.x_group > 1) {
+        if (why) *why = "grouped spectra (x_group > 1) are read by the order-16 float64 kernel only";
         return hipErrorInvalidValue;
     }
     if (compute_dtype == APV_F64) {

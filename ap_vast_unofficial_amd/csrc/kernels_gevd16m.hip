@@ -29,7 +29,7 @@ namespace {
 // DBG: the diagnostic instantiation.  It alone carries the run-time `debug_stop` tests (stage cuts and A/B switches of the
 // probes under tools/probes/) and the in-kernel stage stamps (p.stamps); in the product instantiation `dstop` is the constant 0
 // and all of it folds away, the round-2a two-sided pre-solve included.
-template <typename T, bool FUSED, typename XT, bool DBG>
+template <typename T, bool FUSED, typename XT, bool DBG, int GS = 1>
 __device__ __forceinline__ void gevd16m_body(const GevdParams& p, const int k, const bool z1) {
     const int dstop = DBG ? p.debug_stop : 0;
     // stage stamps (diagnostic build only): s_memtime of lane 0 at the stage boundaries, 8 per bin, into a buffer of their own
@@ -76,6 +76,11 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p, const int k, c
             correlate16<T, XT, true>(pXB + slab, pd + (size_t)k * p.M, p.M, sA, sr, lane, stamp, 8);
             stamp(10);
             correlate16<T, XT, false>(pXD + slab, (const XT*)nullptr, p.M, sB, sr, lane, stamp, 11);
+        } else if constexpr (GS > 1) {
+            // grouped spectra [K / GS][M L][GS]: the bin's elements are GS apart, starting at its place inside the group
+            const size_t gslab = (size_t)(k / GS) * p.M * N * GS + (k % GS);
+            correlate16<T, XT, true, NoStamp, GS>(pXB + gslab, pd + (size_t)k * p.M, p.M, sA, sr, lane);
+            correlate16<T, XT, false, NoStamp, GS>(pXD + gslab, (const XT*)nullptr, p.M, sB, sr, lane);
         } else {
             correlate16<T, XT, true>(pXB + slab, pd + (size_t)k * p.M, p.M, sA, sr, lane);
             correlate16<T, XT, false>(pXD + slab, (const XT*)nullptr, p.M, sB, sr, lane);
@@ -600,6 +605,16 @@ template <bool FUSED, typename XT, bool DBG = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) gevd16m_kernel_f64(const GevdParams p) {
     gevd16m_body<double, FUSED, XT, DBG>(p, blockIdx.x, blockIdx.y == 1);
 }
+// The float64 streaming front-end's grouped spectra (p.x_group = GS).  Workgroups go to the eight XCDs round robin by their linear
+// index and the GS bins of a group read the same lines: index 8 GS q + 8 r + x (x = XCD, r < GS) takes bin 8 GS q + GS x + r, so
+// that a group's bins share one L2 (the last, partial block of 8 GS keeps its order).
+template <int GS>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) gevd16m_kernel_f64_grouped(const GevdParams p) {
+    constexpr int BLK = 8 * GS;
+    const int id = blockIdx.x;
+    const int k = ((id | (BLK - 1)) < p.K) ? ((id & ~(BLK - 1)) | ((id & 7) * GS) | ((id >> 3) & (GS - 1))) : id;
+    gevd16m_body<double, true, double2, false, GS>(p, k, blockIdx.y == 1);
+}
 
 }  // namespace
 
@@ -608,6 +623,14 @@ hipError_t apv_launch_gevd16m(const GevdParams& p, int compute_dtype, bool fused
     if (p.K <= 0) return hipSuccess;
     const dim3 grid(p.K, p.n_zones > 1 ? 2 : 1);
     const bool xd = fused && p.x_c128;
+    if (p.x_group > 1) {
+        // only the float64 product kernel on c128 slabs reads the grouped layout (apv_gevd16m_reads_groups says when)
+        if (!xd || compute_dtype != APV_F64 || p.debug_stop != 0 || p.stamps != nullptr) return hipErrorInvalidValue;
+        if (p.x_group == 4) hipLaunchKernelGGL(gevd16m_kernel_f64_grouped<4>, grid, dim3(64), 0, s, p);
+        else if (p.x_group == 8) hipLaunchKernelGGL(gevd16m_kernel_f64_grouped<8>, grid, dim3(64), 0, s, p);
+        else return hipErrorInvalidValue;
+        return hipGetLastError();
+    }
     if (p.debug_stop != 0 || p.stamps != nullptr) {
         // diagnostic instantiations (probes only): stage cuts, A/B switches, stage stamps
         if (compute_dtype == APV_F64) {

@@ -246,12 +246,12 @@ __device__ __forceinline__ C2<T>* fft_forward(const FftPlan& plan, C2<T>* a, C2<
 
 template <typename T, int MI = INPLACE_MAX_IT>
 __device__ __forceinline__ void rfft_from_lds(const FftPlan& plan, C2<T>* za, C2<T>* zb, C2<T>* __restrict__ out, long stride_k,
-                                              const C2<T>* __restrict__ tw);
+                                              const C2<T>* __restrict__ tw, int kgroup = 1);
 
 template <typename T, int MI = INPLACE_MAX_IT>
 __device__ __forceinline__ void stft_analysis_body(const FftPlan& plan, const T* __restrict__ xin, int in_len, int ring_off,
                                                    int use_win, C2<T>* __restrict__ out, long stride_k,
-                                                   const C2<T>* __restrict__ tw, const T* __restrict__ win) {
+                                                   const C2<T>* __restrict__ tw, const T* __restrict__ win, int kgroup = 1) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     C2<T>* za = reinterpret_cast<C2<T>*>(smem_raw);
     const int N = plan.N, Nh = plan.Nh;
@@ -276,13 +276,16 @@ __device__ __forceinline__ void stft_analysis_body(const FftPlan& plan, const T*
         za[n] = c2<T>(v0, v1);
     }
     __syncthreads();
-    rfft_from_lds<T, MI>(plan, za, zb, out, stride_k, tw);
+    rfft_from_lds<T, MI>(plan, za, zb, out, stride_k, tw, kgroup);
 }
 
 // the real series x[2n], x[2n+1] sits in za[n] (and the workgroup has met): spectrum to out[k * stride_k], k <= N/2
+// kgroup > 1: GROUPED bin-major layout [K / g][C][g] (round 4): bins k .. k + g - 1 of a channel are contiguous (g = 4: one 64-byte
+// line of c128), the groups stride_k * g elements apart; the caller has offset `out` by c * g.  A transform then fills whole
+// lines -- 34.7 million 16-byte pieces per chunk of cfg3, each in another DRAM page, were what its stores cost.
 template <typename T, int MI>
 __device__ __forceinline__ void rfft_from_lds(const FftPlan& plan, C2<T>* za, C2<T>* zb, C2<T>* __restrict__ out, long stride_k,
-                                              const C2<T>* __restrict__ tw) {
+                                              const C2<T>* __restrict__ tw, int kgroup) {
     const int Nh = plan.Nh, tid = threadIdx.x;
     const C2<T>* z = (plan.debug & 4) ? za : fft_forward<T, MI>(plan, za, zb, tw);
     // even/odd split: X[k] = E[k] + e^{-2 pi i k/N} O[k]
@@ -297,7 +300,8 @@ __device__ __forceinline__ void rfft_from_lds(const FftPlan& plan, C2<T>* za, C2
         const C2<T> dm = c2<T>((T)0.5 * (a.x - b.x), (T)0.5 * (a.y - b.y));
         const C2<T> o = c2<T>(dm.y, -dm.x);                              // -i * dm
         const C2<T> ow = cmul(o, tw[k]);                                 // tw[Nh] = -1
-        if (!(plan.debug & 1) || e.x == (T)12345.678) out[(size_t)k * stride_k] = c2<T>(e.x + ow.x, e.y + ow.y);
+        const size_t oi = kgroup > 1 ? (size_t)(k / kgroup) * kgroup * stride_k + (k % kgroup) : (size_t)k * stride_k;
+        if (!(plan.debug & 1) || e.x == (T)12345.678) out[oi] = c2<T>(e.x + ow.x, e.y + ow.y);
     }
 }
 
@@ -345,9 +349,12 @@ __global__ void __launch_bounds__(STFT_TPB) stft_analysis_jobs_kernel(FftPlan pl
     // timing aid (APV_STFT_DEBUG & 64; the spectra come out in the wrong places): every channel writes its bins as ONE contiguous run
     // inside the set's region -- what a channel-major spectra layout would cost this kernel
     const bool cm = (plan.debug & 64) && jobs.stride_c[j] == 1;
+    // a set whose channel stride AND bin stride exceed one is in the grouped layout, the channel stride being the group (see
+    // rfft_from_lds): bin-major sets have stride_c = 1, channel-major ones stride_k = 1
+    const int kgroup = (jobs.stride_c[j] > 1 && jobs.stride_k[j] > 1) ? (int)jobs.stride_c[j] : 1;
     stft_analysis_body<T, MI>(plan, jobs.x[j] + (size_t)c * jobs.x_stride + hop * jobs.x_hop, plan.N, ring_off, 1,
                           jobs.spec[j] + hop * jobs.spec_hop[j] + (cm ? (size_t)c * (plan.Nh + 1) : (size_t)c * jobs.stride_c[j]),
-                          cm ? 1 : jobs.stride_k[j], tw, win);
+                          cm ? 1 : jobs.stride_k[j], tw, win, kgroup);
 }
 
 // (Four neighbouring channels per 1024-thread workgroup, so that every bin's four values go out as one 64-byte line instead of four

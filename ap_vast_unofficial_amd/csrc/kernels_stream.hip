@@ -407,6 +407,21 @@ hipError_t apv_launch_scale_spectra_cm_f64(int K, int C, int L, double2* spec, c
     return hipGetLastError();
 }
 
+// out[k][c] = in[(k / g) g C + c g + k % g]: grouped spectra [K / g][C][g] back to bin-major [K][C] (attribute reads only)
+template <typename E>
+__global__ void __launch_bounds__(256) ungroup_spectra_kernel(int K, int C, int g, const E* __restrict__ in, E* __restrict__ out) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)K * C) return;
+    const int k = (int)(idx / C), c = (int)(idx % C);
+    out[idx] = in[(size_t)(k / g) * g * C + (size_t)c * g + (k % g)];
+}
+hipError_t apv_launch_ungroup_spectra(int f64, int K, int C, int g, const void* in, void* out, hipStream_t s) {
+    const unsigned blocks = (unsigned)(((size_t)K * C + 255) / 256);
+    if (f64) hipLaunchKernelGGL(ungroup_spectra_kernel<double2>, dim3(blocks), dim3(256), 0, s, K, C, g, (const double2*)in, (double2*)out);
+    else hipLaunchKernelGGL(ungroup_spectra_kernel<float2>, dim3(blocks), dim3(256), 0, s, K, C, g, (const float2*)in, (float2*)out);
+    return hipGetLastError();
+}
+
 hipError_t apv_launch_scale_spectra(int f64, int K, int C, int L, void* spec, const void* W, hipStream_t s) {
     const size_t total = (size_t)K * C;
     const dim3 grid((unsigned)((total + 255) / 256));

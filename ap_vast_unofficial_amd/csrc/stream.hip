@@ -37,7 +37,11 @@ struct apv_stream {
     void* resp[4];                // [C][N] rings: A->A, A->B, B->A, B->B
     void* tresp[2];               // [M][N] rings: target A, target B
     void* inblk;                  // [2][N] rings: input blocks
-    void* X[4];                   // [K][C] bin-major control-point spectra
+    void* X[4];                   // control-point spectra: bin-major [K][C], or grouped [Kp / xg][C][xg] (see xg); Kp C elements each
+    int xg, xg_default;           // bins per group of the spectra layout (1 = bin-major).  4 where the joint diagonalisation that will
+                                  // run reads groups (float64 front-end, order 16, apv_gevd_reads_groups) and no perceptual weighting
+                                  // is on (its kernels scale bin-major spectra): a transform then fills 64-byte lines
+    int Kp;                       // K rounded up to a multiple of 8: bins a spectra set is allocated for
     void* tspec[2];               // [K][M]
     void* inspec;                 // [2][K]
     void* w[2];                   // [K][nV][L] per zone
@@ -109,7 +113,7 @@ struct apv_stream {
     hipEvent_t ck_backdone[2][CK_NB]; // [chunk parity][back stream]: that stream has read the parity's spectra sets for the last time
     hipEvent_t ck_k3[CK_NB];      // [back stream]: output spectra written (the tail stream starts the synthesis there)
     // work space of apv_stream_get_statistics (R_B, R_D, r, U, w, lam, spill, status), allocated at its first call and kept
-    void* stat_ws[8];
+    void* stat_ws[10];
     size_t stat_spill_bytes;
     std::vector<hipGraphExec_t> execs;
     std::vector<int32_t> h_status;
@@ -333,7 +337,7 @@ static int enqueue_front(apv_handle* h, hipStream_t st, int set, const void* pin
         for (int p = 0; p < 4; ++p) {
             const bool need = (p < 2) ? runA : runB;       // A->A, A->B feed zone program A; B->A, B->B feed B
             if (!need) continue;
-            jx[nj] = s->resp[p]; jspec[nj] = q.X[p]; jch[nj] = C; jsc[nj] = 1; jsk[nj] = C; ++nj;
+            jx[nj] = s->resp[p]; jspec[nj] = q.X[p]; jch[nj] = C; jsc[nj] = s->xg; jsk[nj] = C; ++nj;      // (xg, C): grouped when xg > 1
         }
         for (int z = 0; z < 2; ++z) { jx[nj] = s->tresp[z]; jspec[nj] = q.tspec[z]; jch[nj] = M; jsc[nj] = 1; jsk[nj] = M; ++nj; }
         jx[nj] = s->inblk; jspec[nj] = q.inspec; jch[nj] = 2; jsc[nj] = K; jsk[nj] = 1; ++nj;
@@ -392,6 +396,7 @@ static int enqueue_back(apv_handle* h, hipStream_t st, const HopSpectra& q, void
         GevdParams p = apv_base_params(h);
         const int first = runA ? 0 : 1;
         p.x_c128 = f64;
+        p.x_group = s->xg;
         p.XB = first ? q.X[3] : q.X[0];
         p.XD = first ? q.X[2] : q.X[1];
         p.d = q.tspec[first];
@@ -563,7 +568,7 @@ static int signal_prepare(apv_handle* h) {
     const int chunk = (chunk_env >= 4 && chunk_env <= 64) ? chunk_env : 16;
     int rc;
     for (int p = 0; p < 4; ++p)
-        if (!s->X1[p] && (rc = dalloc(h, &s->X1[p], K * C, e2))) return rc;
+        if (!s->X1[p] && (rc = dalloc(h, &s->X1[p], (size_t)s->Kp * C, e2))) return rc;
     for (int z = 0; z < 2; ++z)
         if (!s->tspec1[z] && (rc = dalloc(h, &s->tspec1[z], K * M, e2))) return rc;
     if (!s->inspec1 && (rc = dalloc(h, &s->inspec1, 2 * K, e2))) return rc;
@@ -743,7 +748,7 @@ static int process_signal_t(apv_handle* h, int n_hops, const TI* h_in_A, const T
         // the state arrays and apv_process_block live in set 0: bring the last hop's spectra there
         const size_t C = s->C, M = s->M, e2 = 2 * e1;
         hipError_t e = hipSuccess;
-        for (int p = 0; p < 4 && e == hipSuccess; ++p) e = hipMemcpyAsync(s->X[p], s->X1[p], (size_t)K * C * e2, hipMemcpyDeviceToDevice, back);
+        for (int p = 0; p < 4 && e == hipSuccess; ++p) e = hipMemcpyAsync(s->X[p], s->X1[p], (size_t)s->Kp * C * e2, hipMemcpyDeviceToDevice, back);
         for (int z = 0; z < 2 && e == hipSuccess; ++z) e = hipMemcpyAsync(s->tspec[z], s->tspec1[z], (size_t)K * M * e2, hipMemcpyDeviceToDevice, back);
         if (e == hipSuccess) e = hipMemcpyAsync(s->inspec, s->inspec1, (size_t)2 * K * e2, hipMemcpyDeviceToDevice, back);
         if (e != hipSuccess) return hipbail(e);
@@ -795,7 +800,7 @@ static int chunk_prepare(apv_handle* h) {
     SCHK(h, hipHostMalloc(&s->ck_pin_out, (size_t)CK_NS * chunk * hop_result_bytes(s), hipHostMallocDefault));
     std::memset(s->ck_pin_out, 0, (size_t)CK_NS * chunk * hop_result_bytes(s));
     for (int p = 0; p < 4; ++p)
-        if ((rc = dalloc(h, &s->ck_X[p], (size_t)2 * chunk * K * C, e2))) return rc;
+        if ((rc = dalloc(h, &s->ck_X[p], (size_t)2 * chunk * s->Kp * C, e2))) return rc;
     if ((rc = dalloc(h, &s->ck_inspec, (size_t)2 * chunk * 2 * K, e2))) return rc;
     if ((rc = dalloc(h, &s->ck_out, (size_t)2 * chunk * hop_result_bytes(s), 1))) return rc;
     if ((rc = dalloc(h, &s->ck_ospec, (size_t)2 * chunk * s->n_out * K, e2))) return rc;
@@ -910,7 +915,7 @@ static int process_signal_chunked_t(apv_handle* h, int n_hops, const TI* h_in_A,
     auto set_of = [&](int par, int i) {
         HopSpectra q;
         const size_t idx = (size_t)par * chunk + i;
-        for (int p = 0; p < 4; ++p) q.X[p] = (char*)s->ck_X[p] + idx * K * C * e2;
+        for (int p = 0; p < 4; ++p) q.X[p] = (char*)s->ck_X[p] + idx * (size_t)s->Kp * C * e2;
         for (int z = 0; z < 2; ++z) q.tspec[z] = (char*)s->ck_tspec[z] + idx * K * M * e2;
         q.inspec = (char*)s->ck_inspec + idx * 2 * K * e2;
         return q;
@@ -973,7 +978,7 @@ static int process_signal_chunked_t(apv_handle* h, int n_hops, const TI* h_in_A,
             for (int p = 0; p < 4; ++p) {
                 const bool need = (p < 2) ? runA : runB;
                 if (!need) continue;
-                jx[nj] = s->ck_resp[par][p]; jspec[nj] = q0.X[p]; jch[nj] = C; jsc[nj] = 1; jsk[nj] = C; jhop[nj] = (long)K * C; ++nj;
+                jx[nj] = s->ck_resp[par][p]; jspec[nj] = q0.X[p]; jch[nj] = C; jsc[nj] = s->xg; jsk[nj] = C; jhop[nj] = (long)s->Kp * C; ++nj;
             }
             for (int z = 0; z < 2; ++z) {
                 jx[nj] = s->ck_tresp[par][z]; jspec[nj] = q0.tspec[z]; jch[nj] = M; jsc[nj] = 1; jsk[nj] = M; jhop[nj] = (long)K * M; ++nj;
@@ -1071,7 +1076,7 @@ static int process_signal_chunked_t(apv_handle* h, int n_hops, const TI* h_in_A,
         }
         // the last hop's spectra, filters and eigenvalues where the state arrays and the per-hop path keep them
         const HopSpectra q = set_of(last_par, last_nc - 1);
-        for (int p = 0; p < 4; ++p) CK(hipMemcpyAsync(s->X[p], q.X[p], (size_t)K * C * e2, hipMemcpyDeviceToDevice, st));
+        for (int p = 0; p < 4; ++p) CK(hipMemcpyAsync(s->X[p], q.X[p], (size_t)s->Kp * C * e2, hipMemcpyDeviceToDevice, st));
         for (int z = 0; z < 2; ++z) CK(hipMemcpyAsync(s->tspec[z], q.tspec[z], (size_t)K * M * e2, hipMemcpyDeviceToDevice, st));
         CK(hipMemcpyAsync(s->inspec, q.inspec, (size_t)2 * K * e2, hipMemcpyDeviceToDevice, st));
         if (last_b != 0) {
@@ -1134,6 +1139,9 @@ int apv_stream_init(apv_handle* h, int32_t rir_len, const double* h_rir_A, const
     const int nz = ((s->zones & 1) ? 1 : 0) + ((s->zones & 2) ? 1 : 0);
     s->n_out = nz * s->nV * s->L + 2 * s->L;
     s->out_group = c.out_layout == 1 ? s->L : 0;
+    s->Kp = (s->K + 7) / 8 * 8;
+    s->xg_default = apv_gevd_reads_groups(apv_base_params(h), h->cfg.compute_dtype, f64 != 0);
+    s->xg = s->xg_default;
     const int L = s->L, M = s->M, C = s->C, P = s->P, K = s->K;
     const size_t e1 = s->esz, e2 = 2 * s->esz;
     int rc;
@@ -1215,7 +1223,7 @@ int apv_stream_init(apv_handle* h, int32_t rir_len, const double* h_rir_A, const
             if ((rc = dalloc(h, &s->xhist[b][g], hist, e1))) return rc;
     for (int p = 0; p < 4; ++p) {
         if ((rc = dalloc(h, &s->resp[p], (size_t)C * N, e1))) return rc;
-        if ((rc = dalloc(h, &s->X[p], (size_t)K * C, e2))) return rc;
+        if ((rc = dalloc(h, &s->X[p], (size_t)s->Kp * C, e2))) return rc;
     }
     for (int z = 0; z < 2; ++z) {
         if ((rc = dalloc(h, &s->tresp[z], (size_t)M * N, e1))) return rc;
@@ -1316,6 +1324,17 @@ int apv_stream_get_statistics(apv_handle* h, int32_t zone, double* h_RB, double*
     if (!dr) SCHK(h, hipMalloc(&dr, vec));
     const void* XB = zone ? s->X[3] : s->X[0];
     const void* XD = zone ? s->X[2] : s->X[1];
+    if (s->xg > 1) {
+        // grouped spectra: the correlation kernel reads bin-major slabs, so the two sets are regrouped into scratch first
+        void*& dgb = s->stat_ws[8]; void*& dgd = s->stat_ws[9];
+        const size_t sb = (size_t)K * s->C * 2 * s->esz;
+        if (!dgb) SCHK(h, hipMalloc(&dgb, sb));
+        if (!dgd) SCHK(h, hipMalloc(&dgd, sb));
+        SCHK(h, apv_launch_ungroup_spectra(s->f64, K, s->C, s->xg, XB, dgb, st));
+        SCHK(h, apv_launch_ungroup_spectra(s->f64, K, s->C, s->xg, XD, dgd, st));
+        XB = dgb;
+        XD = dgd;
+    }
     hipError_t e = s->f64 ? apv_launch_corr_c128(K, M, L, (const double2*)XB, (const double2*)XD, (const double2*)s->tspec[zone],
                                                  (double2*)dRB, (double2*)dRD, (double2*)dr, st)
                           : apv_launch_corr(APV_F64, K, M, L, (const float2*)XB, (const float2*)XD, (const float2*)s->tspec[zone], dRB, dRD,
@@ -1367,8 +1386,10 @@ int apv_stream_set_perceptual(apv_handle* h, int32_t n_channels, const double* h
     }
     if (n_channels <= 0) {
         s->nch = 0;
+        s->xg = s->xg_default;
         return APV_OK;
     }
+    s->xg = 1;                   // the weighting's kernels scale bin-major spectra
     if (!h_G2 || n_channels > 512 || (normalisation != 0 && normalisation != 1)) return apv_fail(h, APV_ERR_ARG, "bad perceptual tables");
     const int K = s->K;
     void* old[] = {s->G2, s->G2T, s->Wgt[0], s->Wgt[1]};
@@ -1411,7 +1432,7 @@ static int state_lookup(apv_handle* h, const char* name, void** dptr, size_t* by
         *dptr = s->xhist[s->cur][n.back() - '0']; *bytes = (size_t)(s->keep + s->H) * e1; return APV_OK; }
     if (n == "out_overlap") { *dptr = s->outov; *bytes = (size_t)s->n_out * N * e1; return APV_OK; }
     if (n.rfind("spectra", 0) == 0 && n.size() == 8 && n[7] >= '0' && n[7] <= '3') {
-        *dptr = s->X[n[7] - '0']; *bytes = K * C * e2; return APV_OK; }
+        *dptr = s->X[n[7] - '0']; *bytes = K * C * e2; *ring_rows = s->xg > 1 ? -1 : 0; return APV_OK; }      // -1: grouped on the device
     if (n == "target_spectra0" || n == "target_spectra1") { *dptr = s->tspec[n.back() - '0']; *bytes = K * M * e2; return APV_OK; }
     if (n == "input_spectrum") { *dptr = s->inspec; *bytes = 2 * K * e2; return APV_OK; }
     if ((n == "weights0" || n == "weights1") && s->nch > 0) { *dptr = s->Wgt[n.back() - '0']; *bytes = K * M * e1; return APV_OK; }
@@ -1438,6 +1459,19 @@ int apv_get_state(apv_handle* h, const char* name, void* h_dst, size_t bytes) {
         SCHK(h, hipStreamSynchronize(h->stream));
         return APV_OK;
     }
+    if (rr < 0) {
+        // control-point spectra in the grouped layout [Kp / g][C][g]: the caller gets them bin-major [K][C], as documented
+        const apv_stream* s = h->st;
+        const size_t K = s->K, C = s->C, g = s->xg, e2 = 2 * s->esz;
+        std::vector<char> tmp((size_t)s->Kp * C * e2);
+        SCHK(h, hipMemcpyAsync(tmp.data(), d, tmp.size(), hipMemcpyDeviceToHost, h->stream));
+        SCHK(h, hipStreamSynchronize(h->stream));
+        char* out = (char*)h_dst;
+        for (size_t k = 0; k < K; ++k)
+            for (size_t c = 0; c < C; ++c)
+                std::memcpy(out + (k * C + c) * e2, tmp.data() + ((k / g) * g * C + c * g + k % g) * e2, e2);
+        return APV_OK;
+    }
     // ring: rotate rows into logical order
     const size_t N = h->st->N, off = h->st->ring_off, e1 = h->st->esz;
     std::vector<char> tmp(need);
@@ -1459,6 +1493,7 @@ int apv_set_state(apv_handle* h, const char* name, const void* h_src, size_t byt
     if (rc != APV_OK) return rc;
     if (bytes != need) return apv_fail(h, APV_ERR_STATE, "state size mismatch");
     SCHK(h, hipSetDevice(h->device));
+    if (rr < 0) return apv_fail(h, APV_ERR_STATE, "the control-point spectra are recomputed by every hop and cannot be set");
     if (rr == 0) {
         SCHK(h, hipMemcpyAsync(d, h_src, need, hipMemcpyHostToDevice, h->stream));
         SCHK(h, hipStreamSynchronize(h->stream));
