@@ -1238,7 +1238,8 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
             hipLaunchKernelGGL(vast_prefix_kernel, dim3(gx, 1, batch), dim3(TPB), 0, st, n, V, d_ranks, d_U, ws.coef, d_w, (size_t)n * n, vs,
                                (size_t)V * n);
         }
-        LCHK(hipStreamSynchronize(st));
+        // no synchronisation here: whoever consumes d_U / d_lam / d_w does so on this stream (the hop's output stage, a copy back)
+        if (timing) LCHK(hipStreamSynchronize(st));
         LCHK(hipGetLastError());
         if (timing)
             fprintf(stderr, "[apv gevd_large] n=%d batch=%d: factor+whiten %.3f ms, leading %d of block %d %.3f ms\n", n, batch,

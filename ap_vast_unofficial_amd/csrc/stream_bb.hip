@@ -66,6 +66,11 @@ struct apv_bb {
     // them) -- so that the hop's windowed transforms, its synthesis and its append to the statistics rings are one launch each
     // instead of six (apvast.py:197-311 runs the same three steps per buffer).
     double *resp_all, *ov_all, *stats_all, *pspec_all;
+    // pinned staging of the per-hop call (round 4): the caller's arrays are pageable, and an asynchronous copy from / to pageable
+    // memory is staged by the runtime behind a synchronisation of its own -- 83 us between the last kernel of a hop and the start
+    // of its copy back in the trace.  The hop's inputs are copied here first and its outputs land here.
+    double* pin_in;        // [2][H]
+    double* pin_out;       // [n_out][H]
     int n_all;             // 4 C + 2 M
     double* Wgt[2];        // [M][K]
     // apv_bb_process_signal: G consecutive hops share ONE batched joint diagonalisation (allocated on first use)
@@ -495,6 +500,8 @@ void apv_bb_free(apv_handle* h) {
     for (double* b : bufs)
         if (b) (void)hipFree(b);
     if (s->d_ranks) (void)hipFree(s->d_ranks);
+    if (s->pin_in) (void)hipHostFree(s->pin_in);
+    if (s->pin_out) (void)hipHostFree(s->pin_out);
     if (s->front) (void)hipStreamDestroy(s->front);
     for (int i = 0; i < 2; ++i) {
         if (s->ev_front[i]) (void)hipEventDestroy(s->ev_front[i]);
@@ -619,6 +626,8 @@ int apv_bb_init(apv_handle* h, int32_t rir_len, const double* h_rir_A, const dou
     if ((rc = dalloc(h, &s->inspec, (size_t)2 * K * 2))) return rc;
     if ((rc = dalloc(h, &s->outov, (size_t)s->n_out * N))) return rc;
     if ((rc = dalloc(h, &s->out, (size_t)s->n_out * H))) return rc;
+    BCHK(h, hipHostMalloc((void**)&s->pin_in, sizeof(double) * 2 * H, hipHostMallocDefault));
+    BCHK(h, hipHostMalloc((void**)&s->pin_out, sizeof(double) * (size_t)s->n_out * H, hipHostMallocDefault));
     // target filter spectra: the Python class uses the zone-A reference for both A_t and B_t (apvast.py:389-390, 418,
     // 422), the MATLAB class one reference per zone (apVast.m:597-602)
     std::vector<double> tg((size_t)2 * L * K * 2, 0.0);
@@ -837,8 +846,9 @@ int apv_bb_process_block(apv_handle* h, const double* h_in_A, const double* h_in
     // rocprofv3 cannot trace this path)
     static const bool timing = getenv("APV_BB_TIMING") != nullptr;
     double t_stage[8] = {0};
-    BCHK(h, hipMemcpyAsync(s->xin, h_in_A, sizeof(double) * H, hipMemcpyHostToDevice, st));
-    BCHK(h, hipMemcpyAsync(s->xin + H, h_in_B, sizeof(double) * H, hipMemcpyHostToDevice, st));
+    std::memcpy(s->pin_in, h_in_A, sizeof(double) * H);
+    std::memcpy(s->pin_in + H, h_in_B, sizeof(double) * H);
+    BCHK(h, hipMemcpyAsync(s->xin, s->pin_in, sizeof(double) * 2 * H, hipMemcpyHostToDevice, st));
     const BbHop q = bb_own_hop(s);
     int rc = bb_front(h, s, q, timing ? t_stage : nullptr, st);
     if (rc != APV_OK) return rc;
@@ -863,10 +873,11 @@ int apv_bb_process_block(apv_handle* h, const double* h_in_A, const double* h_in
         t_stage[3] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_prev).count();
         t_prev = std::chrono::steady_clock::now();
     }
-    rc = bb_back(h, s, q, h_out, s->spec);
+    rc = bb_back(h, s, q, s->pin_out, s->spec);
     if (rc != APV_OK) return rc;
     BCHK(h, hipStreamSynchronize(st));
     BCHK(h, hipGetLastError());
+    std::memcpy(h_out, s->pin_out, sizeof(double) * (size_t)s->n_out * H);
     if (timing)
         fprintf(stderr, "[apv bb] fir %.3f  wola %.3f  stats %.3f  gevd %.3f  out %.3f ms\n", t_stage[0], t_stage[1],
                 t_stage[2], t_stage[3], std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_prev).count());
