@@ -256,6 +256,138 @@ __global__ void __launch_bounds__(256) syrk_hankel_kernel(int n, int J, int L, i
     }
 }
 
+// ---- the same statistics from the displacement structure of the data matrix (round 4) ---------------------------------------
+// Row (s, i) of Y_m is the window of g_{s,m} that starts at u = J - 1 - i, so R[(s, i), (s', i')] = E(u, u') =
+// sum_m sum_{n < ncols} g_{s,m}[u + n] g_{s',m}[u' + n] depends on the lag d = u' - u and, weakly, on where the window sits:
+// E(u + 1, u' + 1) = E(u, u') - sum_m g_s[u] g_s'[u'] + sum_m g_s[u + ncols] g_s'[u' + ncols].  One full sum per lag (2 J - 1 of
+// them per pair of loudspeakers) and a walk down each diagonal replace J^2 full sums: (2 J - 1)(ncols + 2 J) instead of J^2 ncols
+// multiply-adds per pair and microphone -- 16 x fewer at J = 32, 41 x at J = 100 (apvast.py:334-347 forms Y and Y Y^T outright;
+// numpy's own summation order differs from any of these by the same few ulp).  A workgroup owns a pair (s <= s') of one
+// matrix: the unwrapped sequences of all microphones of both loudspeakers sit in LDS (2 M (S + 8) doubles: 128 KB at the
+// reference's parameters); the full sums take four consecutive lags per thread (one new LDS read per lag block and sample)
+// and split the column range over the thread groups; the walks take one lag per thread.  R's mirror image is written too.
+constexpr int HC_TPB = 1024, HC_MAXPARTS = 10, HC_MAXSEG = 16;
+// doubles of the work array behind the sequences: the full sums' partials [parts][lag blocks][4], later the walks' segment sums
+__host__ __device__ inline int hc_red_len(int J) {
+    const int nbk = (J + 3) / 4 + (J - 1 + 3) / 4, nqmax = 2 * J - 1;
+    int nseg = HC_TPB / nqmax;
+    nseg = nseg < 1 ? 1 : (nseg > HC_MAXSEG ? HC_MAXSEG : nseg);
+    const int a = HC_MAXPARTS * nbk * 4, b = nqmax * nseg;
+    return a > b ? a : b;
+}
+__global__ void __launch_bounds__(HC_TPB) hankel_corr_kernel(int n, int J, int L, int M, int S, int off, int skip, int ncols, int Sg,
+                                                             SyrkJobs jobs) {
+    extern __shared__ double hc_lds[];           // g[2][M][Sg], then red[parts][NBK][4] (later: seg[nq][nseg]), then e0[2 J]
+    const double* __restrict__ stats = jobs.stats[blockIdx.z];
+    double* __restrict__ R = jobs.R[blockIdx.z];
+    const int tid = threadIdx.x;
+    int sa = 0, sb = blockIdx.x;                  // pair index -> s <= s'
+    while (sb >= L - sa) { sb -= L - sa; ++sa; }
+    sb += sa;
+    const bool same = sa == sb;
+    const int tmax = skip ? S - 2 : S - 1;
+    double* const gA = hc_lds;
+    double* const gB = hc_lds + (size_t)M * Sg;
+    for (int e = tid; e < 2 * M * Sg; e += HC_TPB) {
+        const int side = e / (M * Sg), r = e - side * M * Sg, m = r / Sg, t = r - m * Sg;
+        const int sp = side ? sb : sa;
+        hc_lds[e] = t <= tmax ? stat_at(stats + (size_t)(m * L + sp) * S, S, off, J, t, skip) : 0.0;
+    }
+    __syncthreads();
+    // lag jobs: q < J: d = q >= 0 (A = g_s, B = g_s', u = 0, u' = d); q >= J: d = -(q - J + 1) (A = g_s', B = g_s, u' = 0, u = -d)
+    const int nq = same ? J : 2 * J - 1;
+    const int nb_pos = (J + 3) / 4, nb_neg = same ? 0 : (J - 1 + 3) / 4, NBK = nb_pos + nb_neg;
+    int parts = HC_TPB / NBK;
+    parts = parts < 1 ? 1 : (parts > HC_MAXPARTS ? HC_MAXPARTS : parts);
+    double* const red = hc_lds + (size_t)2 * M * Sg;                 // [parts][NBK][4]; the walks reuse it as seg[nq][nseg]
+    const int red_len = hc_red_len(J);
+    double* const e0 = red + red_len;                                 // [2 J]
+    for (int item = tid; item < NBK * parts; item += HC_TPB) {
+        // neighbouring lanes take neighbouring column ranges of the same lag block, an ODD number of samples apart: their LDS reads
+        // fall into different banks (lanes on neighbouring lag blocks read 32 bytes apart: a four-way conflict on every access)
+        const int part = item % parts, blk = item / parts;
+        const bool neg = blk >= nb_pos;
+        const int dd0 = neg ? 1 + 4 * (blk - nb_pos) : 4 * blk;
+        const double* const A = neg ? gB : gA;
+        const double* const B = neg ? gA : gB;
+        const int per = ((ncols + parts - 1) / parts) | 1, n0 = min(ncols, part * per), n1 = min(ncols, n0 + per);
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        for (int m = 0; m < M; ++m) {
+            const double* const Am = A + (size_t)m * Sg;
+            const double* const Bm = B + (size_t)m * Sg + dd0;
+            if (n0 < n1) {
+                double b0 = Bm[n0], b1 = Bm[n0 + 1], b2 = Bm[n0 + 2];
+#pragma unroll 4
+                for (int nn = n0; nn < n1; ++nn) {
+                    const double b3 = Bm[nn + 3], a = Am[nn];
+                    a0 = __builtin_fma(a, b0, a0);
+                    a1 = __builtin_fma(a, b1, a1);
+                    a2 = __builtin_fma(a, b2, a2);
+                    a3 = __builtin_fma(a, b3, a3);
+                    b0 = b1; b1 = b2; b2 = b3;
+                }
+            }
+        }
+        double* o = red + ((size_t)part * NBK + blk) * 4;
+        o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3;
+    }
+    __syncthreads();
+    for (int q = tid; q < nq; q += HC_TPB) {
+        const bool neg = q >= J;
+        const int dd = neg ? q - J + 1 : q;
+        const int blk = neg ? nb_pos + (dd - 1) / 4 : dd / 4, sub = neg ? (dd - 1) % 4 : dd % 4;
+        double v = 0.0;
+        for (int part = 0; part < parts; ++part) v += red[((size_t)part * NBK + blk) * 4 + sub];
+        e0[q] = v;
+    }
+    __syncthreads();
+    // The walks, E(u + 1, u' + 1) = E(u, u') + delta(u), cut into nseg segments per diagonal so that every thread has one: first
+    // every segment's sum of deltas, then each segment starts from e0 plus the sums of the segments before it (fixed order) and
+    // walks, forming its deltas a second time (twice the multiply-adds, nseg times the threads).
+    int nseg = HC_TPB / nq;
+    nseg = nseg < 1 ? 1 : (nseg > HC_MAXSEG ? HC_MAXSEG : nseg);
+    const int seglen = ((J + nseg - 1) / nseg) | 1;            // odd: the segments of a diagonal start in different LDS banks
+    auto delta = [&](const double* A, const double* B, int dd, int u) {
+        double dl = 0.0;
+        for (int m = 0; m < M; ++m) {
+            const double* const Am = A + (size_t)m * Sg;
+            const double* const Bm = B + (size_t)m * Sg;
+            dl = __builtin_fma(Am[u + ncols], Bm[u + dd + ncols], dl);
+            dl = __builtin_fma(-Am[u], Bm[u + dd], dl);
+        }
+        return dl;
+    };
+    double* const seg = red;
+    for (int item = tid; item < nq * nseg; item += HC_TPB) {
+        const int q = item / nseg, g = item - q * nseg;
+        const bool neg = q >= J;
+        const int dd = neg ? q - J + 1 : q, len = J - dd;
+        const double* const A = neg ? gB : gA;
+        const double* const B = neg ? gA : gB;
+        double sum = 0.0;
+        for (int u = g * seglen; u < (g + 1) * seglen && u + 1 < len; ++u) sum += delta(A, B, dd, u);
+        seg[(size_t)q * nseg + g] = sum;
+    }
+    __syncthreads();
+    for (int item = tid; item < nq * nseg; item += HC_TPB) {
+        const int q = item / nseg, g = item - q * nseg;
+        const bool neg = q >= J;
+        const int dd = neg ? q - J + 1 : q, len = J - dd;
+        const double* const A = neg ? gB : gA;
+        const double* const B = neg ? gA : gB;
+        double E = e0[q];
+        for (int gp = 0; gp < g; ++gp) E += seg[(size_t)q * nseg + gp];
+        for (int u = g * seglen; u < (g + 1) * seglen && u < len; ++u) {
+            // A's window starts at u, B's at u + dd: rows i = J - 1 - start
+            const int iA = J - 1 - u, iB = J - 1 - (u + dd);
+            const int row = (neg ? sb : sa) * J + iA, col = (neg ? sa : sb) * J + iB;
+            R[(size_t)row * n + col] = E;
+            R[(size_t)col * n + row] = E;
+            if (u + 1 < len) E += delta(A, B, dd, u);
+        }
+    }
+}
+
 // window length and segment count that fit the staging buffer for this (J, S)
 static void syrk_plan(int J, int ncols, int* TC, int* nseg) {
     *nseg = 31 / J + 2;                                   // loudspeakers a run of 32 rows can touch
@@ -269,6 +401,22 @@ static void syrk_plan(int J, int ncols, int* TC, int* nseg) {
 
 static void launch_syrk(hipStream_t st, int n, int J, int L, int M, int S, int off, int skip, int ncols, int njobs,
                         const SyrkJobs& jobs) {
+    // the displacement form where its LDS fits (both loudspeakers' sequences of all microphones) and a thread has a lag block;
+    // APV_SYRK_MFMA=1: the dense products on the matrix cores, as until round 4 (A/B switch)
+    static const bool dense = getenv("APV_SYRK_MFMA") != nullptr;
+    {
+        const int Sg = S + 8;
+        const size_t lds = sizeof(double) * ((size_t)2 * M * Sg + (size_t)hc_red_len(J) + 2 * (size_t)J);
+        if (!dense && 2 * J - 1 <= HC_TPB && lds <= 158 * 1024 && ncols + J + 2 <= Sg) {
+            static bool once = false;
+            if (!once) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hankel_corr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+                once = true;
+            }
+            hipLaunchKernelGGL(hankel_corr_kernel, dim3(L * (L + 1) / 2, 1, njobs), dim3(HC_TPB), lds, st, n, J, L, M, S, off, skip, ncols, Sg, jobs);
+            return;
+        }
+    }
     int TC, nseg;
     syrk_plan(J, ncols, &TC, &nseg);
     hipLaunchKernelGGL(syrk_hankel_kernel, dim3((n + 31) / 32, (n + 31) / 32, njobs), dim3(256), sizeof(double) * 2 * SY_BUF, st, n, J,
