@@ -297,7 +297,8 @@ __device__ __forceinline__ d4 lead_tile(const double* A, const double* Bm, int l
 template <int B, int NT>
 __global__ void __launch_bounds__(NT) lead_small_kernel(int nslab, const double* __restrict__ Gp, const double* __restrict__ Hp,
                                                         int max_sweeps, double tol2, double* __restrict__ T,
-                                                        double* __restrict__ theta, double* __restrict__ hinfo, unsigned active) {
+                                                        double* __restrict__ theta, double* __restrict__ hinfo, unsigned active,
+                                                        unsigned long long* __restrict__ stamps) {
     constexpr int LD = B + 1, NTL = B / 16, NPAIR = NTL * (NTL + 1) / 2, NP = B / 2, NW = NT / 64;
     extern __shared__ double sm[];
     double* S0 = sm;                 // G -> W H -> Q
@@ -314,6 +315,9 @@ __global__ void __launch_bounds__(NT) lead_small_kernel(int nslab, const double*
     const int z = blockIdx.x;
     if (!((active >> z) & 1u)) return;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    // diagnostics (APV_LEAD_DEBUG=2): s_memtime of thread 0 at the phase boundaries, eight per matrix
+    auto stamp = [&](int i) { if (stamps != nullptr && tid == 0) stamps[8 * z + i] = __builtin_amdgcn_s_memtime(); };
+    stamp(0);
     Gp += (size_t)z * nslab * NPAIR * 256;
     Hp += (size_t)z * nslab * NPAIR * 256;
     if (tid == 0) fail = 0;
@@ -361,7 +365,10 @@ __global__ void __launch_bounds__(NT) lead_small_kernel(int nslab, const double*
         S2[i * LD + j] = i == j ? 1.0 : 0.0;
     }
     __syncthreads();
+    stamp(1);
     // c: eliminate [G | I]: G = Lt D Lt^T, the right half becomes Lt^-1; pivots stay on G's diagonal
+    // (a register-resident variant -- rows in registers, pivot row and column published through LDS, the 64 steps unrolled --
+    // was measured: 8 256 instructions, and SLOWER, 178 949 ticks against 66 928 at B = 64; this loop stays)
     for (int k = 0; k < B - 1; ++k) {
         const double piv = S0[k * LD + k];
         if (!(piv > 1e-13)) {                    // uniform: every thread reads the same word
@@ -392,6 +399,7 @@ __global__ void __launch_bounds__(NT) lead_small_kernel(int nslab, const double*
     __syncthreads();
     for (int e = tid; e < B * B; e += NT) S2[(e / B) * LD + e % B] *= th[e / B];        // W = D^-1/2 Lt^-1
     __syncthreads();
+    stamp(2);
     // d: M = W H W^T
     for (int tile = wv; tile < NTL * NTL; tile += NW) {
         const int r0 = (tile / NTL) * 16, c0 = (tile % NTL) * 16;
@@ -430,6 +438,7 @@ __global__ void __launch_bounds__(NT) lead_small_kernel(int nslab, const double*
         __syncthreads();
     }
     const double norm2 = redn[0];
+    stamp(3);
     // e: cyclic Jacobi, round-robin pairing (player 0 fixed, the others rotate): slot s holds player s == 0 ? 0 : 1 + (s - 1 - r) mod (B - 1)
     int sweeps = 0, conv = 0;
     for (int sw = 0; sw < max_sweeps && !conv; ++sw) {
@@ -484,6 +493,7 @@ __global__ void __launch_bounds__(NT) lead_small_kernel(int nslab, const double*
         __syncthreads();
     }
     // f: descending order, T = D W^T Q with its columns in that order
+    stamp(4);
     if (tid < B) th[tid] = S1[tid * LD + tid];
     __syncthreads();
     if (tid < B) {
@@ -510,6 +520,7 @@ __global__ void __launch_bounds__(NT) lead_small_kernel(int nslab, const double*
         hinfo[(size_t)z * (B + 4) + B + 1] = (double)sweeps;
         hinfo[(size_t)z * (B + 4) + B + 2] = (double)conv;
     }
+    stamp(5);
 }
 
 // X = Y T and, from CX = Z T, the residual partials respart[z][row tile][col] = sum over the tile's 16 rows of (CX - theta X)^2
@@ -573,11 +584,12 @@ struct LeadWs {
     int ne = 0, b = 0, cap = 0;
     double* P[3] = {nullptr, nullptr, nullptr};
     double *Zb = nullptr, *Gp = nullptr, *Hp = nullptr, *T = nullptr, *theta = nullptr;
+    unsigned long long* stamps = nullptr;   // APV_LEAD_DEBUG=2: phase stamps of lead_small_kernel, [batch][8]
     double* coefdev = nullptr;        // [batch][2][3] the first filter's coefficients (lead_bounds_kernel)
     double* out = nullptr;            // what the host reads after a pass: [batch][row tiles][b] residual partials, then [batch][b + 4] hinfo
     double* h_out = nullptr;          // pinned
     void release() {
-        void* bufs[] = {P[0], P[1], P[2], Zb, Gp, Hp, T, theta, out, coefdev};
+        void* bufs[] = {P[0], P[1], P[2], Zb, Gp, Hp, T, theta, out, coefdev, stamps};
         for (void* p : bufs)
             if (p) (void)hipFree(p);
         if (h_out) (void)hipHostFree(h_out);
@@ -587,7 +599,7 @@ struct LeadWs {
 
 template <int B, int NT>
 hipError_t launch_small(hipStream_t st, int batch, int nslab, const double* Gp, const double* Hp, int max_sweeps, double tol2,
-                        double* T, double* theta, double* hinfo, unsigned active) {
+                        double* T, double* theta, double* hinfo, unsigned active, unsigned long long* stamps) {
     constexpr int LD = B + 1, NP = B / 2;
     const size_t bytes = sizeof(double) * (3 * (size_t)B * LD + 2 * B + NP + (NP & 1)) + sizeof(double2) * NP + sizeof(int) * 2 * B;
     static bool once = false;
@@ -598,7 +610,7 @@ hipError_t launch_small(hipStream_t st, int batch, int nslab, const double* Gp, 
         once = true;
     }
     hipLaunchKernelGGL((lead_small_kernel<B, NT>), dim3(batch), dim3(NT), bytes, st, nslab, Gp, Hp, max_sweeps, tol2, T, theta, hinfo,
-                       active);
+                       active, stamps);
     return hipGetLastError();
 }
 
@@ -655,10 +667,12 @@ int apv_gevd_lead(apv_handle* h, int n, int ne, int batch, int b, int rank, cons
         LCHK(hipMalloc((void**)&ws.T, sizeof(double) * (size_t)batch * b * b));
         LCHK(hipMalloc((void**)&ws.theta, sizeof(double) * (size_t)batch * b));
         LCHK(hipMalloc((void**)&ws.coefdev, sizeof(double) * 6 * batch));
+        LCHK(hipMalloc((void**)&ws.stamps, sizeof(unsigned long long) * 8 * batch));
         LCHK(hipMalloc((void**)&ws.out, sizeof(double) * ow));
         LCHK(hipHostMalloc((void**)&ws.h_out, sizeof(double) * ow));
     }
     static const bool dbg = getenv("APV_LEAD_DEBUG") != nullptr;
+    static const bool dbg2 = dbg && atoi(getenv("APV_LEAD_DEBUG")) >= 2;
     const auto t0 = std::chrono::steady_clock::now();
     unsigned active = batch >= 32 ? 0xFFFFFFFFu : ((1u << batch) - 1u);
     LeadCoef one{};
@@ -716,9 +730,15 @@ int apv_gevd_lead(apv_handle* h, int n, int ne, int batch, int b, int rank, cons
         static const int kSweepEvery = getenv("APV_LEAD_SWEEP_EVERY") ? atoi(getenv("APV_LEAD_SWEEP_EVERY")) : 1;      // tuning aid
         const int msw = (kSweepEvery > 1 && pass > 1 && pass % kSweepEvery != 0) ? 0 : kPartialSweeps;
         double* const hinfo = ws.out + n_part;
-        if (b == 32) se = launch_small<32, 256>(st, batch, nslab, ws.Gp, ws.Hp, msw, 1e-18, ws.T, ws.theta, hinfo, active);
-        else if (b == 48) se = launch_small<48, 256>(st, batch, nslab, ws.Gp, ws.Hp, msw, 1e-18, ws.T, ws.theta, hinfo, active);
-        else se = launch_small<64, 512>(st, batch, nslab, ws.Gp, ws.Hp, msw, 1e-18, ws.T, ws.theta, hinfo, active);
+        // sixteen waves for the one workgroup of a matrix (the Jacobi round is a dependent chain: more waves hide more of its LDS
+        // latency; measured 58 -> 50 us at b = 32, 123 -> 109 at b = 64); APV_LEAD_WIDE=0 restores 256 / 512 threads
+        static const bool kWide = getenv("APV_LEAD_WIDE") == nullptr || atoi(getenv("APV_LEAD_WIDE")) != 0;
+        unsigned long long* const stp = dbg2 ? ws.stamps : nullptr;
+        if (b == 32) se = kWide ? launch_small<32, 512>(st, batch, nslab, ws.Gp, ws.Hp, msw, 1e-18, ws.T, ws.theta, hinfo, active, stp)
+                                : launch_small<32, 256>(st, batch, nslab, ws.Gp, ws.Hp, msw, 1e-18, ws.T, ws.theta, hinfo, active, stp);
+        else if (b == 48) se = launch_small<48, 256>(st, batch, nslab, ws.Gp, ws.Hp, msw, 1e-18, ws.T, ws.theta, hinfo, active, stp);
+        else se = kWide ? launch_small<64, 1024>(st, batch, nslab, ws.Gp, ws.Hp, msw, 1e-18, ws.T, ws.theta, hinfo, active, stp)
+                        : launch_small<64, 512>(st, batch, nslab, ws.Gp, ws.Hp, msw, 1e-18, ws.T, ws.theta, hinfo, active, stp);
         LCHK(se);
         // Ritz vectors into P[ix], the next filter's first step into P[iy]; the residual partials are summed by the host (row tiles in order)
         hipLaunchKernelGGL(lead_rot_kernel, dim3(nrt, b / 16, batch), dim3(256), 0, st, ne, b, ys, ws.P[ic], ws.Zb, ws.T, ws.theta, ws.P[ix],
@@ -726,6 +746,12 @@ int apv_gevd_lead(apv_handle* h, int n, int ne, int batch, int b, int rank, cons
         LCHK(hipMemcpyAsync(ws.h_out, ws.out, sizeof(double) * ow, hipMemcpyDeviceToHost, st));
         // (polling the stream instead of the blocking wait was measured: no difference, the runtime's wait spins already)
         LCHK(hipStreamSynchronize(st));
+        if (dbg2) {
+            unsigned long long hs[8];
+            (void)hipMemcpy(hs, ws.stamps, sizeof(hs), hipMemcpyDeviceToHost);
+            fprintf(stderr, "[apv lead]   lead_small_kernel matrix 0, s_memtime ticks: load+scale %llu, eliminate %llu, whiten+norm %llu, sweeps %llu, sort+T %llu\n",
+                    hs[1] - hs[0], hs[2] - hs[1], hs[3] - hs[2], hs[4] - hs[3], hs[5] - hs[4]);
+        }
         if (pass == 0 && h_pd_flags)
             for (int z = 0; z < batch; ++z)
                 if (h_pd_flags[z]) return APV_ERR_NOT_PD;
