@@ -29,10 +29,25 @@ EXPORTS = (
     "apv_stft_analysis_dev", "apv_istft_ola_dev",
     "apv_stream_init", "apv_stream_set_perceptual", "apv_process_block", "apv_process_block_f64", "apv_process_signal", "apv_process_signal_f64", "apv_stream_is_f64", "apv_stream_get_statistics", "apv_stream_not_converged", "apv_state_bytes", "apv_get_state", "apv_set_state",
     "apv_bb_set_rank_list", "apv_bb_init", "apv_bb_set_perceptual", "apv_bb_process_block", "apv_bb_process_signal", "apv_bb_get_state", "apv_bb_set_state",
+    "apv_host_alloc", "apv_host_free",
     "apv_predict_pressure", "apv_vast_static",
     "apv_comm_unique_id", "apv_comm_init", "apv_allgather_filters_dev", "apv_comm_count", "apv_comm_last_gather", "apv_comm_barrier",
     "apv_debug_set_stamps", "apv_device_sync", "apv_device_info",
 )
+
+
+class _PinnedBlock:
+    """Owner of one apv_host_alloc block; numpy arrays made from it (and their views) keep it alive through .base."""
+
+    def __init__(self, lib, ptr, nbytes):
+        self._lib, self._ptr = lib, ptr
+        self.__array_interface__ = {"data": (ptr, False), "shape": (nbytes,), "typestr": "|u1", "version": 3}
+
+    def __del__(self):
+        try:
+            self._lib.apv_host_free(self._ptr)
+        except Exception:           # interpreter shutdown: the library may be gone, and so is the process's memory
+            pass
 
 
 class Config(C.Structure):
@@ -121,6 +136,8 @@ def load():
     lib.apv_bb_process_block.argtypes = [vp, vp, vp, vp]
     lib.apv_bb_process_signal.argtypes = [vp, i32, vp, vp, vp]
     lib.apv_bb_get_state.argtypes = [vp, C.c_char_p, vp, sz]
+    lib.apv_host_alloc.argtypes = [C.POINTER(vp), sz]
+    lib.apv_host_free.argtypes = [vp]
     lib.apv_bb_set_state.argtypes = [vp, C.c_char_p, vp, sz]
     lib.apv_predict_pressure.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp]
     lib.apv_vast_static.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, i32, C.c_double, vp, vp, vp]
@@ -544,22 +561,44 @@ class Engine:
         self._chk(self.lib.apv_bb_set_perceptual(self.h, G2.shape[1], _ptr(G2), float(tables.Cs), float(tables.Ca),
                                                  float(tables.Leff), 1 if normalisation == "matlab" else 0))
 
+    def pinned_empty(self, shape, dtype=np.float64):
+        """An uninitialised array in page-locked host memory (apv_host_alloc): the library's copies into it are DMA transfers that
+        run while the device computes.  Freed when the array and every view of it are gone.  None when the runtime refuses."""
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+        p = C.c_void_p()
+        if self.lib.apv_host_alloc(C.byref(p), max(nbytes, 1)) != 0 or not p.value:
+            return None
+        return np.asarray(_PinnedBlock(self.lib, p.value, nbytes)).view(dtype).reshape(shape)
+
     def bb_process_block(self, in_A, in_B, n_out):
+        """One hop: (n_out, H) float64, or with out_layout = 1 (n_out / L, H, L)."""
         in_A = np.ascontiguousarray(in_A, dtype=np.float64).ravel()
         in_B = np.ascontiguousarray(in_B, dtype=np.float64).ravel()
-        out = np.empty((n_out, self.cfg.hop_size), dtype=np.float64)
+        H = self.cfg.hop_size
+        out = np.empty((n_out // self.L, H, self.L) if self.out_layout == 1 else (n_out, H), dtype=np.float64)
         self._chk_stream(self.lib.apv_bb_process_block(self.h, _ptr(in_A), _ptr(in_B), _ptr(out)))
         return out
 
-    def bb_process_signal(self, in_A, in_B, n_out):
-        """n_hops hops in one call: (n_hops, n_out, H) float64; the joint diagonalisations of up to 16 consecutive hops are one batch."""
+    def bb_signal_shape(self, n_hops, n_out):
+        H = self.cfg.hop_size
+        return (n_out // self.L, n_hops * H, self.L) if self.out_layout == 1 else (n_hops, n_out, H)
+
+    def bb_process_signal(self, in_A, in_B, n_out, out=None):
+        """n_hops hops in one call: (n_hops, n_out, H) float64 -- with out_layout = 1 (n_out / L, n_hops * H, L); the joint
+        diagonalisations of up to 16 consecutive hops are one batch.  `out`: a C-contiguous float64 array of that shape to write
+        into (one from pinned_empty is filled by DMA; any other through the library's staging buffers)."""
         in_A = np.ascontiguousarray(in_A, dtype=np.float64).ravel()
         in_B = np.ascontiguousarray(in_B, dtype=np.float64).ravel()
         H = self.cfg.hop_size
         if in_A.size != in_B.size or in_A.size % H:
             raise ValueError("inputs must hold a whole number of hops")
         n_hops = in_A.size // H
-        out = np.empty((n_hops, n_out, H), dtype=np.float64)
+        shape = self.bb_signal_shape(n_hops, n_out)
+        if out is None:
+            out = np.empty(shape, dtype=np.float64)
+        elif out.shape != shape or out.dtype != np.float64 or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous float64 array of shape %r" % (shape,))
         self._chk_stream(self.lib.apv_bb_process_signal(self.h, n_hops, _ptr(in_A), _ptr(in_B), _ptr(out)))
         return out
 

@@ -212,7 +212,9 @@ class apvast:
         self._K = N // 2 + 1
         zones = (1 if self.run_A else 0) | (2 if self.run_B else 0)
         self._eng = _capi.Engine(self._K, L, M, ranks=(1,), mu=self.mu, compute_dtype="f64", device=device, block_size=N,
-                                 hop_size=H, n_zones=zones, dialect=self.dialect, max_sweeps=self._max_sweeps, **reg)
+                                 hop_size=H, n_zones=zones, dialect=self.dialect, max_sweeps=self._max_sweeps,
+                                 out_layout=1,     # the device emits (hop, loudspeaker) arrays: nothing to transpose here
+                                 **reg)
         self._eng.bb_set_rank_list(self._ranks if matlab else [])
         self._eng.bb_init(self.rir_A, self.rir_B, self.reference_index_A, self.reference_index_B, self.modeling_delay,
                           J, S, max(self._ranks))
@@ -274,8 +276,8 @@ class apvast:
         if input_A.size != self.hop_size or input_B.size != self.hop_size:
             raise RuntimeError("invalid input size")                          # apvast.py:154-155
         if self.mode == "broadband":
-            out = self._eng.bb_process_block(input_A, input_B, self._n_out)
-            res = self._split_outputs(out)
+            out = self._eng.bb_process_block(input_A, input_B, self._n_out)      # (groups, H, L), fresh for every hop
+            res = self._split_groups(out)
             self._refresh_broadband()
             return res
         out = self._eng.process_block(input_A, input_B, self._n_out)         # (groups, H, L): one (H, L) array per zone and rank
@@ -288,7 +290,7 @@ class apvast:
     def process_signal(self, input_A, input_B, out=None):
         """Every hop of two whole signals in one call: the hop loop of main.m:52-62 / make_python_test.m:44-51 around
         process_input_buffers, with consecutive hops pipelined on the device (subband mode) or their joint
-        diagonalisations solved as one batch (broadband mode; `out` is not used there).  Returns
+        diagonalisations solved as one batch (broadband mode).  Returns
         (output_A, output_B, target_A, target_B): per zone a list over the ranks of (n_samples, L) arrays, None for a
         zone that does not run; sample for sample what the per-hop calls return, concatenated.  The attributes
         afterwards are those of the last hop.
@@ -302,14 +304,11 @@ class apvast:
         if input_A.size == 0:
             raise RuntimeError("invalid input size")
         if self.mode == "broadband":
-            # the joint diagonalisations of up to 16 consecutive hops are solved as one batch (apv_bb_process_signal)
-            blocks = self._eng.bb_process_signal(input_A, input_B, self._n_out)          # (hops, n_out, H)
-            L = self.number_of_srcs
-            hops, H = blocks.shape[0], blocks.shape[2]
-            # (hops, groups x L, H) -> (groups, samples, L) in one pass over the samples
-            grp = np.ascontiguousarray(blocks.reshape(hops, self._n_out // L, L, H).transpose(1, 0, 3, 2))
-            res = self._split_groups(grp.reshape(self._n_out // L, hops * H, L))
-            self._hops += blocks.shape[0] - 1
+            # the joint diagonalisations of up to 16 consecutive hops are solved as one batch (apv_bb_process_signal); the library
+            # writes (groups, n_samples, L) -- every zone program's and rank's whole signal as the array handed out below
+            out = self._eng.bb_process_signal(input_A, input_B, self._n_out, out=out)
+            res = self._split_groups(out)
+            self._hops += input_A.size // self.hop_size - 1
             self._refresh_broadband()
             return res
         given = out is not None
@@ -326,9 +325,17 @@ class apvast:
         """Shape of process_signal's `out`: (zones x ranks + 2 target paths, n_samples, L)."""
         return (self._n_out // self.number_of_srcs, int(n_samples), self.number_of_srcs)
 
+    def alloc_signal_output(self, n_samples):
+        """An array for process_signal's `out` in page-locked host memory: the device writes the samples into it by DMA while it
+        computes the next hops (broadband mode at the reference's test parameters returns 5.2 MB a hop: a pageable array costs a
+        second pass over all of it on the host).  Falls back to an ordinary array when the runtime refuses the allocation."""
+        shape, dt = self.signal_output_shape(n_samples), self.signal_output_dtype
+        arr = self._eng.pinned_empty(shape, dt)
+        return arr if arr is not None else np.empty(shape, dtype=dt)
+
     @property
     def signal_output_dtype(self):
-        return self._eng.s_dtype
+        return np.float64 if self.mode == "broadband" else self._eng.s_dtype
 
     def _split_groups(self, out):
         """out: (groups, samples, L) with the groups [zone A: rank 1..V][zone B: rank 1..V][A_t][B_t] (zones that run) ->
@@ -343,25 +350,12 @@ class apvast:
             else:
                 res.append(None)
         for _ in range(2):
-            res.append([out[g]] + [out[g].copy() for _ in range(V - 1)])         # the same target filter at every rank
+            # the same target filter at every rank (apvast.py:389-390, 418-422): the V entries are ONE read-only array (V copies
+            # were 5 MB a hop at the reference's test parameters; a caller that wants to write into one takes a copy)
+            t = out[g]
+            t.flags.writeable = False
+            res.append([t] * V)
             g += 1
-        return tuple(res)
-
-    def _split_outputs(self, out):
-        L, V, H = self.number_of_srcs, len(self._ranks), self.hop_size
-        pos = 0
-        res = []
-        for run in (self.run_A, self.run_B):
-            if run:
-                blk = out[pos:pos + V * L].reshape(V, L, H)
-                res.append([np.ascontiguousarray(blk[i].T) for i in range(V)])
-                pos += V * L
-            else:
-                res.append(None)                                              # apvast.py:433-443
-        for _ in range(2):
-            t = np.ascontiguousarray(out[pos:pos + L].T)
-            res.append([t.copy() for _ in range(V)])                          # same target filter at every rank
-            pos += L
         return tuple(res)
 
     def _refresh_attributes(self):

@@ -158,9 +158,9 @@ hipError_t apv_stft_prepare(int N, int f64);
 hipError_t apv_launch_analysis(int f64, int N, int n_ch, const void* x, long x_stride, int in_len, int ring_off,
                                int use_win, void* spec, long stride_c, long stride_k, hipStream_t s, std::string* why);
 // out_group > 0 (and dividing n_ch): the emitted hop is written sample-major in groups of out_group channels, [n_ch / out_group][H]
-// [out_group], instead of channel-major [n_ch][H]
+// [out_group], instead of channel-major [n_ch][H]; out_gstride > 0: elements between two groups (default H out_group)
 hipError_t apv_launch_synthesis(int f64, int N, int H, int n_ch, const void* spec, long stride_c, long stride_k,
-                                void* overlap, void* out, hipStream_t s, std::string* why, int out_group = 0);
+                                void* overlap, void* out, hipStream_t s, std::string* why, int out_group = 0, long out_gstride = 0);
 // K1 (RIR convolution of a hop) by fast convolution, float (f64 = 0) or double data: see fir_fft_kernel
 int apv_fir_fft_size(int f64, int P, int H);       // segment length F, 0 = use the direct form
 hipError_t apv_launch_fir_spectra(int f64, int F, int n_ch, const void* x, int P, void* Hf, hipStream_t s, std::string* why);

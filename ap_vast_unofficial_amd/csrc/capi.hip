@@ -679,6 +679,22 @@ int apv_allgather_filters_dev(apv_handle* h, const void* d_w_shard, void* d_w_al
     return APV_OK;
 }
 
+int apv_host_alloc(void** p, size_t bytes) {
+    if (!p) return APV_ERR_ARG;
+    *p = nullptr;
+    if (hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) {
+        (void)hipGetLastError();
+        *p = nullptr;
+        return APV_ERR_HIP;
+    }
+    return APV_OK;
+}
+
+int apv_host_free(void* p) {
+    if (!p) return APV_OK;
+    return hipHostFree(p) == hipSuccess ? APV_OK : APV_ERR_HIP;
+}
+
 int apv_comm_count(apv_handle* h, int32_t* n_ranks, int32_t* user_rank) {
     if (!h || !n_ranks) return fail(h, APV_ERR_ARG, "null argument");
     if (!h->comm) return fail(h, APV_ERR_RCCL, "communicator not initialised (apv_comm_init)");

@@ -37,22 +37,6 @@ constexpr int LS = 33;   // LDS row stride in doubles (bank-conflict padding)
 
 // 32 x 32 x 32 product from LDS tiles, 2 x 2 outputs per thread: o = {(ty,tx), (ty,tx+16), (ty+16,tx), (ty+16,tx+16)}
 // of sum_k A(t,k) B(k,u) with A(t,k) = TA ? A[k][t] : A[t][k], B(k,u) = TB ? B[u][k] : B[k][u]
-template <bool TA, bool TB>
-__device__ __forceinline__ void mm32(const double* A, const double* B, int ty, int tx, double (&o)[4]) {
-    o[0] = o[1] = o[2] = o[3] = 0.0;
-#pragma unroll 8
-    for (int k = 0; k < BT; ++k) {
-        const double a0 = TA ? A[k * LS + ty] : A[ty * LS + k];
-        const double a1 = TA ? A[k * LS + ty + 16] : A[(ty + 16) * LS + k];
-        const double b0 = TB ? B[tx * LS + k] : B[k * LS + tx];
-        const double b1 = TB ? B[(tx + 16) * LS + k] : B[k * LS + tx + 16];
-        o[0] += a0 * b0;
-        o[1] += a0 * b1;
-        o[2] += a1 * b0;
-        o[3] += a1 * b1;
-    }
-}
-
 using d4 = __attribute__((ext_vector_type(4))) double;
 
 // The same product on v_mfma_f64_16x16x4_f64: four waves, wave w owns the 16 x 16 tile (w >> 1, w & 1).
@@ -70,11 +54,75 @@ __device__ __forceinline__ d4 mm32_mfma(const double* A, const double* B, int w,
     return acc;
 }
 
+// 1/sqrt(x) and 1/x to full double precision without the division sequence: v_rsq_f64 / v_rcp_f64 (5e-8 on gfx950) and Newton steps
+__device__ __forceinline__ double pn_rsq(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = __builtin_fma(-(x * y), y, 1.0);
+    return __builtin_fma(y * e, __builtin_fma(0.375, e, 0.5), y);
+}
+__device__ __forceinline__ double pn_rcp(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    y = y * __builtin_fma(-x, y, 2.0);
+    return y * __builtin_fma(-x, y, 2.0);
+}
+
+// ONE wave: D (order 16, symmetric, in LDS with row stride LS) -> W = L^-1 with D = L L^T, written to Wout (lower triangle, zeros
+// above).  [D | I] is eliminated with the rows in registers: lane = row i + 16 x column group cq holds D[i][4 cq ..] and the right
+// half's [i][4 cq ..]; a step hands the pivot COLUMN of the left half (its pivot row, by symmetry of what is left) and the pivot row of
+// the right half round through 32 doubles of LDS -- no barrier: the LDS executes a wave's accesses in order (the scheme of the
+// order-64 kernel's factorisation, kernels_gevd64.hip stage 1).  Returns true when a pivot is not positive and finite.
+__device__ __forceinline__ bool wave_inv_chol16(const double* D, double* Wout, double* buf, int lane) {
+    const int i = lane & 15, cq = lane >> 4;
+    double b[4], w[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        b[u] = D[i * LS + 4 * cq + u];
+        w[u] = (4 * cq + u == i) ? 1.0 : 0.0;
+    }
+    double dsc = 1.0;
+    bool bad = false;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int qc = q >> 2, qu = q & 3;
+        if (cq == qc) buf[i] = b[qu];
+        if (i == q) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) buf[16 + 4 * cq + u] = w[u];
+        }
+        const double dq = buf[q];
+        bad = bad || !(dq > 0.0) || !(dq < 1e300);
+        const double inv = pn_rcp(dq);
+        if (i == q) dsc = pn_rsq(dq);
+        if (i > q) {
+            const double m = buf[i] * inv;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                b[u] = __builtin_fma(-m, buf[4 * cq + u], b[u]);
+                w[u] = __builtin_fma(-m, buf[16 + 4 * cq + u], w[u]);
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) Wout[i * LS + 4 * cq + u] = (4 * cq + u <= i) ? w[u] * dsc : 0.0;
+    return bad;
+}
+
+// one wave, 16 x 16 x 16 on v_mfma_f64_16x16x4_f64 with operands fetched by fa(i, k), fb(k, j): acc[t] = element (kq + 4 t, il)
+template <typename FA, typename FB>
+__device__ __forceinline__ d4 wave_mm16(FA fa, FB fb, int lane) {
+    const int il = lane & 15, kq = lane >> 4;
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k0 = 0; k0 < 16; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fa(il, k0 + kq), fb(k0 + kq, il), acc, 0, 0, 0);
+    return acc;
+}
+
 // ---- step 1 ---------------------------------------------------------------------------------------
 // Left-looking Cholesky, column panel k (32 wide); workgroup x handles the row tile I = k + x.  Every workgroup
 // forms the updated diagonal block D = B[K,K] - sum_J L[K,J] L[K,J]^T itself and eliminates [D | I] in LDS (unscaled
 // columns of L_D on the left, rows of L_D^-1 up to 1/sqrt(d) on the right), then writes L[I,K] = T L_D^-T.
 // The strictly lower tiles of B are replaced by L; LiBuf[k] receives L_D^-1 (L_D itself is not kept).
+template <bool WAVE_ELIM>
 __global__ void __launch_bounds__(256) chol_panel_kernel(int ld, int k, int nbk, double* __restrict__ B,
                                                          double* __restrict__ LiBuf, int* __restrict__ flag,
                                                          size_t mat_stride) {
@@ -131,6 +179,38 @@ __global__ void __launch_bounds__(256) chol_panel_kernel(int ld, int k, int nbk,
         Wp[r * LS + c] = (r == c) ? 1.0 : 0.0;
     }
     __syncthreads();
+    if (WAVE_ELIM) {
+        // L_D^-1 of the 32 x 32 block by halving, all of it in ONE wave (no barrier inside: the wave's own LDS accesses are ordered):
+        //   W11 = inv chol(D11);  L21 = D21 W11^T;  S = D22 - L21 L21^T;  W22 = inv chol(S);  W21 = -W22 (L21 W11)
+        // two 16-step eliminations (wave_inv_chol16) and five 16^3 products on the matrix cores, instead of 32 steps with a
+        // workgroup barrier each (measured per panel launch: see DESIGN 4.8).  The block's memory is overwritten as it goes.
+        if (wq == 0) {
+            double* const D21 = Dm + 16 * LS;            // rows 16.., columns 0..15: D21 -> L21 -> L21 W11
+            double* const D22 = Dm + 16 * LS + 16;
+            double* const W22 = Wp + 16 * LS + 16;
+            const int il = lq & 15, kq = lq >> 4;
+            bool bad = wave_inv_chol16(Dm, Wp, rs, lq);
+            d4 t = wave_mm16([&](int i, int kk) { return D21[i * LS + kk]; }, [&](int kk, int j) { return Wp[j * LS + kk]; }, lq);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) D21[(kq + 4 * u) * LS + il] = t[u];
+            t = wave_mm16([&](int i, int kk) { return D21[i * LS + kk]; }, [&](int kk, int j) { return D21[j * LS + kk]; }, lq);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) D22[(kq + 4 * u) * LS + il] -= t[u];
+            bad = wave_inv_chol16(D22, W22, rs, lq) || bad;
+            t = wave_mm16([&](int i, int kk) { return D21[i * LS + kk]; }, [&](int kk, int j) { return Wp[kk * LS + j]; }, lq);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) D21[(kq + 4 * u) * LS + il] = t[u];
+            t = wave_mm16([&](int i, int kk) { return W22[i * LS + kk]; }, [&](int kk, int j) { return D21[kk * LS + j]; }, lq);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) Wp[(16 + kq + 4 * u) * LS + il] = -t[u];
+            if (lq == 0) sflag = bad ? 1 : 0;
+        }
+        __syncthreads();
+        if (sflag) {                                   // the same block in every workgroup of the panel: all leave
+            if (tid == 0 && blockIdx.x == 0) flag[z] = 1;
+            return;
+        }
+    } else
     // [D | I] -> [ . | L_D^-1 ] by elimination with the rows in REGISTERS (round 4): thread (r, cq) holds columns 8 cq .. 8 cq + 7 of
     // row r of the augmented matrix; a step publishes the pivot row and the pivot column through LDS (two alternating buffers:
     // one barrier per step), everything else is eight multiply-adds per thread.  Before, every element of both halves went
@@ -187,10 +267,9 @@ __global__ void __launch_bounds__(256) chol_panel_kernel(int ld, int k, int nbk,
         return;
     }
     __syncthreads();
-    double o[4];
-    mm32<false, true>(La, Wp, ty, tx, o);                          // T L_D^-T
+    const d4 o = mm32_mfma<false, true>(La, Wp, wq, lq);           // T L_D^-T (on the matrix cores too: 3 us on the vector ALU)
     for (int i = 0; i < 4; ++i) {
-        const int r = ty + ((i >> 1) << 4), c = tx + ((i & 1) << 4);
+        const int r = (wq >> 1) * 16 + (lq >> 4) + 4 * i, c = (wq & 1) * 16 + (lq & 15);
         B[(size_t)(I * BT + r) * ld + k * BT + c] = o[i];
     }
 }
@@ -1160,8 +1239,10 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
     LCHK(hipMemsetAsync(ws.flag, 0, sizeof(int) * batch, st));
     LCHK(hipMemsetAsync(ws.acc, 0, sizeof(double) * 3 * batch, st));
     hipLaunchKernelGGL(load_pair_kernel, dim3(gx, ne, batch), dim3(TPB), 0, st, n, ne, ld, d_A, d_B, reg, d_reg_scale, ws.C0, ws.Bw, ms);   // C0 holds A for now
+    static const bool old_panel = getenv("APV_LARGE_OLDPANEL") != nullptr;       // A/B switch: the 32-step elimination with a barrier a step
     for (int k = 0; k < nbk; ++k)
-        hipLaunchKernelGGL(chol_panel_kernel, dim3(nbk - k, 1, batch), dim3(256), 0, st, ld, k, nbk, ws.Bw, ws.Li, ws.flag, ms);
+        hipLaunchKernelGGL((old_panel ? chol_panel_kernel<false> : chol_panel_kernel<true>), dim3(nbk - k, 1, batch), dim3(256), 0, st, ld, k,
+                           nbk, ws.Bw, ws.Li, ws.flag, ms);
     // APV_LARGE_OLDPRE=1: round 3's tile walk for W = L^-1 and its 32 x 32-tile products (A/B switch)
     static const bool old_pre = getenv("APV_LARGE_OLDPRE") != nullptr;
     if (old_pre) {

@@ -365,7 +365,7 @@ template <typename T, int MI>
 __global__ void __launch_bounds__(STFT_TPB) istft_ola_kernel(FftPlan plan, int H, const C2<T>* __restrict__ spec,
                                                              long stride_c, long stride_k, T* __restrict__ overlap,
                                                              T* __restrict__ out, const C2<T>* __restrict__ tw,
-                                                             const T* __restrict__ win, int out_group) {
+                                                             const T* __restrict__ win, int out_group, long out_gstride) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     C2<T>* za = reinterpret_cast<C2<T>*>(smem_raw);
     const int N = plan.N, Nh = plan.Nh;
@@ -407,9 +407,10 @@ __global__ void __launch_bounds__(STFT_TPB) istft_ola_kernel(FftPlan plan, int H
     if (out != nullptr) {
         if (out_group > 0) {
             // sample-major emit: channels come in groups of out_group loudspeakers (one zone program and rank each) and a group is
-            // written [H][out_group], the (hop, loudspeaker) array the reference's caller receives (apvast.py:498-504)
+            // written [H][out_group], the (hop, loudspeaker) array the reference's caller receives (apvast.py:498-504); groups lie
+            // out_gstride elements apart (H out_group for one hop on its own; more when the hop is a slice of a longer signal)
             const int g = c / out_group, l = c - g * out_group;
-            T* const o = out + ((size_t)g * H) * out_group + l;
+            T* const o = out + (size_t)g * out_gstride + l;
             for (int n = tid; n < H; n += STFT_TPB) o[(size_t)n * out_group] = zf[n];
         } else {
             for (int n = tid; n < H; n += STFT_TPB) out[(size_t)c * H + n] = zf[n];
@@ -640,7 +641,7 @@ hipError_t launch_analysis(int N, int n_ch, const void* x, long x_stride, int in
 
 template <typename T>
 hipError_t launch_synthesis(int N, int H, int n_ch, const void* spec, long stride_c, long stride_k, void* overlap,
-                            void* out, hipStream_t s, std::string* why, int out_group = 0) {
+                            void* out, hipStream_t s, std::string* why, int out_group = 0, long out_gstride = 0) {
     FftPlan plan;
     if (!make_plan(N, &plan, why)) return hipErrorInvalidValue;
     if (H <= 0 || H > N) {
@@ -653,7 +654,8 @@ hipError_t launch_synthesis(int N, int H, int n_ch, const void* spec, long strid
     if (e != hipSuccess) return e;
     const size_t lds = plan_lds<T>(plan);
     hipLaunchKernelGGL((plan.max_it == 1 ? istft_ola_kernel<T, 1> : istft_ola_kernel<T, INPLACE_MAX_IT>), dim3(n_ch), dim3(STFT_TPB), lds, s, plan, H, (const C2<T>*)spec, stride_c,
-                       stride_k, (T*)overlap, (T*)out, t.tw, t.win, (out_group > 0 && n_ch % out_group == 0) ? out_group : 0);
+                       stride_k, (T*)overlap, (T*)out, t.tw, t.win, (out_group > 0 && n_ch % out_group == 0) ? out_group : 0,
+                       out_gstride > 0 ? out_gstride : (long)H * out_group);
     return hipGetLastError();
 }
 
@@ -733,9 +735,9 @@ hipError_t apv_launch_analysis(int f64, int N, int n_ch, const void* x, long x_s
 }
 
 hipError_t apv_launch_synthesis(int f64, int N, int H, int n_ch, const void* spec, long stride_c, long stride_k,
-                                void* overlap, void* out, hipStream_t s, std::string* why, int out_group) {
-    return f64 ? launch_synthesis<double>(N, H, n_ch, spec, stride_c, stride_k, overlap, out, s, why, out_group)
-               : launch_synthesis<float>(N, H, n_ch, spec, stride_c, stride_k, overlap, out, s, why, out_group);
+                                void* overlap, void* out, hipStream_t s, std::string* why, int out_group, long out_gstride) {
+    return f64 ? launch_synthesis<double>(N, H, n_ch, spec, stride_c, stride_k, overlap, out, s, why, out_group, out_gstride)
+               : launch_synthesis<float>(N, H, n_ch, spec, stride_c, stride_k, overlap, out, s, why, out_group, out_gstride);
 }
 
 hipError_t apv_launch_stft_analysis_strided(int N, int n_ch, const float* x, int ring_off, float2* spec,

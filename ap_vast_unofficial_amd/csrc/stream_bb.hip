@@ -22,6 +22,7 @@
 
 #include <cmath>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 struct apv_bb {
@@ -84,10 +85,17 @@ struct apv_bb {
     double* g_w;           // [grp * nz][V][n]
     double* g_nrm;         // [grp][4] + [grp * nz] dark norms in batch order
     double* g_inspec;      // [grp][2][K] c128
+    double* g_out;         // [2 sets] a group's output hops as the caller's array holds them: [n_out / L][grp H][L] with
+                           // cfg.out_layout = 1, else [grp][n_out][H]: ONE copy per group to the host
+    double* g_pin;         // [2 sets] the same, page-locked: staging for a caller's pageable array (allocated when first needed)
+    size_t g_pin_cap;      // doubles per set g_pin holds
+    int out_group;         // cfg.out_layout = 1: L (sample-major emit, see bb_back); 0: channel-major
     // (each of the above twice: the front stages of group g + 1 fill one set while the batched solve of group g reads the other)
     double* spec_out;      // [n_out][K] c128: the output stage's own spectra (the front stages use `spec` at the same time)
     hipStream_t front;     // the front stages of apv_bb_process_signal
+    hipStream_t copy;      // a group's outputs on their way to the host while the next group is solved
     hipEvent_t ev_front[2], ev_back[2];      // group set filled / group set read for the last time
+    hipEvent_t ev_out[2];                    // a group's outputs have reached g_pin
 };
 
 namespace {
@@ -97,6 +105,43 @@ namespace {
         hipError_t _e = (call);                                                          \
         if (_e != hipSuccess) return apv_fail(h, APV_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_e)); \
     } while (0)
+
+// true when p lies in page-locked host memory the runtime knows (hipHostMalloc / apv_host_alloc): a device-to-host copy into it is
+// a DMA that runs asynchronously; any other host pointer is staged by the runtime and blocks the caller
+bool host_is_pinned(const void* p) {
+    hipPointerAttribute_t a{};
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+
+// dst[r][0 : width] = src[r][0 : width], r < rows (pitches in doubles), shared out over a few threads: the collection of a group
+// of hops from the staging buffer into the caller's pageable array runs at memory speed, not at one core's
+void copy_rows(double* dst, size_t dpitch, const double* src, size_t spitch, size_t width, size_t rows) {
+    const size_t total = width * rows * sizeof(double);
+    const unsigned hw = std::thread::hardware_concurrency();
+    size_t nt = total >> 21;                            // a thread per 2 MiB
+    nt = nt < 1 ? 1 : (nt > 8 ? 8 : nt);
+    if (hw && nt > hw) nt = hw;
+    // rows are split in pieces when there are fewer rows than threads
+    const size_t pieces = rows >= nt ? 1 : (nt + rows - 1) / rows;
+    const size_t units = rows * pieces, pw = (width + pieces - 1) / pieces;
+    auto work = [&](size_t t) {
+        for (size_t u = t; u < units; u += nt) {
+            const size_t r = u / pieces, c0 = (u % pieces) * pw;
+            if (c0 >= width) continue;
+            const size_t w = width - c0 < pw ? width - c0 : pw;
+            std::memcpy(dst + r * dpitch + c0, src + r * spitch + c0, w * sizeof(double));
+        }
+    };
+    if (nt == 1) return work(0);
+    std::vector<std::thread> th;
+    for (size_t t = 1; t < nt; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
+}
 
 int dalloc(apv_handle* h, double** p, size_t count) {
     BCHK(h, hipMalloc((void**)p, sizeof(double) * (count ? count : 1)));
@@ -644,16 +689,19 @@ void apv_bb_free(apv_handle* h) {
                       s->xhist[1][1], s->xin, s->resp_all, s->ov_all, s->stats_all, s->pspec_all,
                       s->inblk, s->spec, s->R, s->r, s->U, s->lam, s->w,
                       s->fspec, s->inspec, s->outov, s->out, s->G2, s->G2T, s->Wgt[0], s->Wgt[1], s->nrm,
-                      s->g_xin, s->g_RA, s->g_RB, s->g_U, s->g_lam, s->g_r, s->g_w, s->g_nrm, s->g_inspec, s->spec_out};
+                      s->g_xin, s->g_RA, s->g_RB, s->g_U, s->g_lam, s->g_r, s->g_w, s->g_nrm, s->g_inspec, s->spec_out, s->g_out};
     for (double* b : bufs)
         if (b) (void)hipFree(b);
+    if (s->g_pin) (void)hipHostFree(s->g_pin);
     if (s->d_ranks) (void)hipFree(s->d_ranks);
     if (s->pin_in) (void)hipHostFree(s->pin_in);
     if (s->pin_out) (void)hipHostFree(s->pin_out);
     if (s->front) (void)hipStreamDestroy(s->front);
+    if (s->copy) (void)hipStreamDestroy(s->copy);
     for (int i = 0; i < 2; ++i) {
         if (s->ev_front[i]) (void)hipEventDestroy(s->ev_front[i]);
         if (s->ev_back[i]) (void)hipEventDestroy(s->ev_back[i]);
+        if (s->ev_out[i]) (void)hipEventDestroy(s->ev_out[i]);
     }
     delete s;
     h->bb = nullptr;
@@ -716,6 +764,7 @@ int apv_bb_init(apv_handle* h, int32_t rir_len, const double* h_rir_A, const dou
     s->rel_dark_py = c.reg_mode == APV_REG_REL && dialect == APV_DIALECT_PYTHON;      // apvast.py:26-27, inside jdiag
     const int nz = ((s->zones & 1) ? 1 : 0) + ((s->zones & 2) ? 1 : 0);
     s->n_out = nz * nsol * L + 2 * L;
+    s->out_group = c.out_layout == 1 ? L : 0;
     s->max_rank = ranks.back();
     s->full_valid = 1;
     BCHK(h, hipMalloc((void**)&s->d_ranks, sizeof(int) * nsol));
@@ -937,8 +986,11 @@ static int bb_front(apv_handle* h, apv_bb* s, const BbHop& q, double* t_stage, h
     return APV_OK;
 }
 
-// stages 5-6 of a hop: filter spectra, outputs, overlap-add; h_out [n_out][H] (the copy is queued on the handle's stream)
-static int bb_back(apv_handle* h, apv_bb* s, const BbHop& q, double* h_out, double* spec) {
+// stages 5-6 of a hop: filter spectra, outputs, overlap-add.  The hop is emitted at d_out: channel-major [n_out][H], or with
+// cfg.out_layout = 1 sample-major [n_out / L][H][L] (a group = one zone program and rank, or a target path: the (hop, loudspeaker)
+// array the reference's caller receives, apvast.py:498-504) with `gstride` elements between groups (0: H L).  h_out (may be null):
+// one contiguous hop copied to the host, queued on the handle's stream.
+static int bb_back(apv_handle* h, apv_bb* s, const BbHop& q, double* d_out, long gstride, double* h_out, double* spec) {
     hipStream_t st = h->stream;
     const int N = s->N, H = s->H, K = s->K, L = s->L, J = s->J, V = s->V;
     std::string why;
@@ -978,8 +1030,8 @@ static int bb_back(apv_handle* h, apv_bb* s, const BbHop& q, double* h_out, doub
         aj.first[aj.n] = oc;
         hipLaunchKernelGGL(apply_f64_jobs_kernel, dim3((K + 255) / 256, oc), dim3(256), 0, st, K, aj);
     }
-    BCHK(h, apv_launch_synthesis(1, N, H, s->n_out, spec, K, 1, s->outov, s->out, st, &why));
-    BCHK(h, hipMemcpyAsync(h_out, s->out, sizeof(double) * (size_t)s->n_out * H, hipMemcpyDeviceToHost, st));
+    BCHK(h, apv_launch_synthesis(1, N, H, s->n_out, spec, K, 1, s->outov, d_out, st, &why, s->out_group, gstride));
+    if (h_out) BCHK(h, hipMemcpyAsync(h_out, d_out, sizeof(double) * (size_t)s->n_out * H, hipMemcpyDeviceToHost, st));
     return APV_OK;
 }
 
@@ -1021,7 +1073,8 @@ int apv_bb_process_block(apv_handle* h, const double* h_in_A, const double* h_in
         t_stage[3] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_prev).count();
         t_prev = std::chrono::steady_clock::now();
     }
-    rc = bb_back(h, s, q, s->pin_out, s->spec);
+    // (the caller's array is not asked whether it is page-locked here: the query costs more than the copy of one hop)
+    rc = bb_back(h, s, q, s->out, 0, s->pin_out, s->spec);
     if (rc != APV_OK) return rc;
     BCHK(h, hipStreamSynchronize(st));
     BCHK(h, hipGetLastError());
@@ -1079,9 +1132,9 @@ int apv_bb_process_signal(apv_handle* h, int32_t n_hops, const double* h_in_A, c
     const size_t gz = (size_t)G * nz;
     // sizes of one buffer set
     const size_t z_xin = (size_t)G * 2 * H, z_mat = gz * nn, z_vec = gz * n, z_w = gz * V * n, z_nrm = (size_t)G * 4 + gz,
-                 z_insp = (size_t)G * 2 * K * 2;
+                 z_insp = (size_t)G * 2 * K * 2, z_out = (size_t)G * s->n_out * H;
     if (s->grp < G) {
-        double** bufs[] = {&s->g_xin, &s->g_RA, &s->g_RB, &s->g_U, &s->g_lam, &s->g_r, &s->g_w, &s->g_nrm, &s->g_inspec};
+        double** bufs[] = {&s->g_xin, &s->g_RA, &s->g_RB, &s->g_U, &s->g_lam, &s->g_r, &s->g_w, &s->g_nrm, &s->g_inspec, &s->g_out};
         for (double** b : bufs) {
             if (*b) (void)hipFree(*b);
             *b = nullptr;
@@ -1097,21 +1150,41 @@ int apv_bb_process_signal(apv_handle* h, int32_t n_hops, const double* h_in_A, c
         if ((rc = dalloc(h, &s->g_w, z_w))) return rc;
         if ((rc = dalloc(h, &s->g_nrm, 2 * z_nrm))) return rc;
         if ((rc = dalloc(h, &s->g_inspec, 2 * z_insp))) return rc;
+        if ((rc = dalloc(h, &s->g_out, 2 * z_out))) return rc;
         if (!s->spec_out && (rc = dalloc(h, &s->spec_out, (size_t)s->n_out * K * 2))) return rc;
         if (!s->front) {
             BCHK(h, hipStreamCreateWithFlags(&s->front, hipStreamNonBlocking));
+            BCHK(h, hipStreamCreateWithFlags(&s->copy, hipStreamNonBlocking));
             for (int i = 0; i < 2; ++i) {
                 BCHK(h, hipEventCreateWithFlags(&s->ev_front[i], hipEventDisableTiming));
                 BCHK(h, hipEventCreateWithFlags(&s->ev_back[i], hipEventDisableTiming));
+                BCHK(h, hipEventCreateWithFlags(&s->ev_out[i], hipEventDisableTiming));
             }
         }
         BCHK(h, hipStreamSynchronize(st));            // the zero fills
         s->grp = G;
     }
     // (a handle whose group buffers were sized for a larger G keeps them: the set offsets below follow the CURRENT G)
+    // The caller's array: [n_out / L][n_hops H][L] with cfg.out_layout = 1 (every group's samples of the whole signal in a row: what
+    // the class hands out without touching it), else [n_hops][n_out][H].  A group of hops is written on the device as the slice of
+    // that array it is, and goes to the host in ONE copy: by DMA straight into the caller's array when that is page-locked
+    // (apv_host_alloc), else into the staging set, from where the host moves it while the device works on the next group.
+    // (Before: one copy per hop into the pageable array -- which the runtime stages and waits for -- and the class transposed the
+    // whole signal afterwards: at the reference's test parameters, 5.2 MB a hop, that was 2.9 of the 3.5 ms a hop took.)
+    const int og = s->out_group;
+    const size_t ngrp = og > 0 ? (size_t)s->n_out / og : 1, HL = (size_t)H * (og > 0 ? og : s->n_out);
+    const bool direct = host_is_pinned(h_out);
+    if (!direct && s->g_pin_cap < z_out) {
+        if (s->g_pin) (void)hipHostFree(s->g_pin);
+        s->g_pin = nullptr;
+        s->g_pin_cap = 0;
+        BCHK(h, hipHostMalloc((void**)&s->g_pin, sizeof(double) * 2 * z_out, hipHostMallocDefault));
+        s->g_pin_cap = z_out;
+    }
     hipStream_t fs = s->front;
     // every exit below drains both streams first: copies into the caller's h_out may be in flight
-    auto drained = [&](int rc) { (void)hipStreamSynchronize(fs); (void)hipStreamSynchronize(st); return rc; };
+    hipStream_t cs = s->copy;
+    auto drained = [&](int rc) { (void)hipStreamSynchronize(fs); (void)hipStreamSynchronize(st); (void)hipStreamSynchronize(cs); return rc; };
 #define BDCHK(h, call)                                                                                                     \
     do {                                                                                                                    \
         hipError_t _e = (call);                                                                                             \
@@ -1155,22 +1228,34 @@ int apv_bb_process_signal(apv_handle* h, int32_t n_hops, const double* h_in_A, c
     BDCHK(h, hipStreamWaitEvent(fs, s->ev_back[0], 0));
     int rc = enqueue_front(0);
     if (rc != APV_OK) return rc;
+    static const bool timing = getenv("APV_BB_TIMING") != nullptr;
+    auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     for (int g = 0; g < n_groups; ++g) {
         const int set = g & 1, h0 = g * G, g_n = n_hops - h0 < G ? n_hops - h0 : G;
+        const double t_a = now_ms();
         if (g + 1 < n_groups) {
             // group g + 1 fills the other set, which the back half of group g - 1 has read (its event is on the handle's stream)
             if (g >= 1) BDCHK(h, hipStreamWaitEvent(fs, s->ev_back[set ^ 1], 0));
             if ((rc = enqueue_front(g + 1)) != APV_OK) return rc;
         }
         BDCHK(h, hipStreamWaitEvent(st, s->ev_front[set], 0));
+        double t_b = now_ms(), t_b2 = t_b;
+        if (timing) {
+            (void)hipStreamSynchronize(st);         // the group's front stages alone
+            t_b2 = now_ms();
+        }
         h->gl_lead_rank = s->max_rank;
         rc = apv_gevd_large(h, n, g_n * nz, s->g_RA + set * z_mat, s->g_RB + set * z_mat, s->rel_loading ? 0.0 : h->cfg.reg_dark,
                             s->rel_dark_py ? s->g_nrm + set * z_nrm + (size_t)G * 4 : nullptr, s->g_U, s->g_lam, s->g_r + set * z_vec,
                             h->cfg.mu, V, s->d_ranks, s->g_w, status.data());
         if (rc != APV_OK) return drained(rc);
         if (g + 1 == n_groups) s->full_valid = !h->gl_lead_done;
+        const double t_c = now_ms();
+        double* const gout = s->g_out + set * z_out;
+        if (g >= 2) BDCHK(h, hipStreamWaitEvent(st, s->ev_out[set], 0));          // group g - 2 has left this output set
         for (int i = 0; i < g_n; ++i) {
-            rc = bb_back(h, s, hops[set][i], h_out + (size_t)(h0 + i) * s->n_out * H, s->spec_out);
+            rc = og > 0 ? bb_back(h, s, hops[set][i], gout + (size_t)i * HL, (long)((size_t)G * HL), nullptr, s->spec_out)
+                        : bb_back(h, s, hops[set][i], gout + (size_t)i * HL, 0, nullptr, s->spec_out);
             if (rc != APV_OK) return drained(rc);
             bool bad = false;
             for (int z = 0; z < nz; ++z) bad = bad || status[(size_t)i * nz + z] == 2;
@@ -1193,9 +1278,36 @@ int apv_bb_process_signal(apv_handle* h, int32_t n_hops, const double* h_in_A, c
             BDCHK(h, hipMemcpyAsync(s->inspec, q.inspec, sizeof(double) * 2 * K * 2, hipMemcpyDeviceToDevice, st));
         }
         BDCHK(h, hipEventRecord(s->ev_back[set], st));
+        // the group's outputs: rows = groups of channels (one row when channel-major), g_n hops wide; on the copy stream, so that
+        // the next group's solve does not wait for the transfer (84 MB = 1.7 ms of a group's 10 at the reference's test parameters)
+        const size_t width = (size_t)g_n * HL, spitch = (size_t)G * HL, dpitch = (size_t)n_hops * HL;
+        BDCHK(h, hipStreamWaitEvent(cs, s->ev_back[set], 0));
+        if (direct) {
+            BDCHK(h, hipMemcpy2DAsync(h_out + (size_t)h0 * HL, sizeof(double) * dpitch, gout, sizeof(double) * spitch,
+                                      sizeof(double) * width, ngrp, hipMemcpyDeviceToHost, cs));
+        } else {
+            BDCHK(h, hipMemcpyAsync(s->g_pin + set * s->g_pin_cap, gout, sizeof(double) * ((ngrp - 1) * spitch + width), hipMemcpyDeviceToHost, cs));
+        }
+        BDCHK(h, hipEventRecord(s->ev_out[set], cs));
+        // the previous group has long arrived in its staging set: move it while the device works on this one
+        auto collect = [&](int gg) {
+            const int cset = gg & 1, c0 = gg * G, c_n = n_hops - c0 < G ? n_hops - c0 : G;
+            (void)hipEventSynchronize(s->ev_out[cset]);
+            copy_rows(h_out + (size_t)c0 * HL, dpitch, s->g_pin + cset * s->g_pin_cap, spitch, (size_t)c_n * HL, ngrp);
+        };
+        const double t_d = now_ms();
+        if (!direct && g >= 1) collect(g - 1);
+        if (!direct && g + 1 == n_groups) collect(g);
+        if (timing) {
+            const double t_e = now_ms();
+            (void)hipStreamSynchronize(st);
+            fprintf(stderr, "[apv bb signal] group %d (%d hops): enqueue next front %.2f, wait for this front %.2f, solve %.2f, enqueue back %.2f, "
+                    "collect %.2f, drain %.2f ms\n", g, g_n, t_b - t_a, t_b2 - t_b, t_c - t_b2, t_d - t_c, t_e - t_d, now_ms() - t_e);
+        }
     }
     BDCHK(h, hipStreamSynchronize(fs));
     BDCHK(h, hipStreamSynchronize(st));
+    BDCHK(h, hipStreamSynchronize(cs));
     BDCHK(h, hipGetLastError());
     if (bad_hops) {
         s->not_converged += bad_hops;

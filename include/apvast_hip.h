@@ -259,15 +259,22 @@ int  apv_bb_init(apv_handle* h, int32_t rir_len, const double* h_rir_A, const do
                  int32_t reference_index_A, int32_t reference_index_B, int32_t modeling_delay,
                  int32_t filter_length, int32_t statistics_buffer_length, int32_t number_of_eigenvectors);
 /* One hop (H float64 samples per signal).  h_out: [n_out][H] float64, channels as for apv_process_block with
- * nV = the number of ranks kept.                          replaces process_input_buffers, apvast.py:153-165 */
+ * nV = the number of ranks kept; with cfg.out_layout = 1: [n_out / L][H][L], one (hop, loudspeaker) array per zone program
+ * and rank as process_input_buffers returns them (apvast.py:498-504).   replaces process_input_buffers, apvast.py:153-165 */
 int  apv_bb_process_block(apv_handle* h, const double* h_in_A, const double* h_in_B, double* h_out);
 /* n_hops consecutive hops in one call: h_in_A / h_in_B hold n_hops * H samples, h_out is [n_hops][n_out][H] with the channel
- * order of apv_bb_process_block.  A hop's statistics never depend on an earlier hop's filters, so the joint diagonalisations
+ * order of apv_bb_process_block -- with cfg.out_layout = 1: [n_out / L][n_hops * H][L], every group's whole signal as one
+ * (sample, loudspeaker) array.  Each group of hops reaches the host in one copy: by DMA into a page-locked h_out
+ * (apv_host_alloc), else through a staging set that the host empties while the device works on the next group.  A hop's statistics never depend on an earlier hop's filters, so the joint diagonalisations
  * of up to 16 consecutive hops (8 at large orders) are solved as ONE batch (the dependent launches of a single n = 256 pair leave most of the chip
  * idle); rings, overlap buffers and outputs advance hop by hop as in the per-hop call.  Outputs equal those of n_hops calls
  * of apv_bb_process_block up to the rounding of the eigen-iteration (a batch sweeps until its slowest member has converged).
  *                        replaces the hop loop of main.m:52-62 / make_python_test.m:44-51 around apvast.py:153-165 */
 int  apv_bb_process_signal(apv_handle* h, int32_t n_hops, const double* h_in_A, const double* h_in_B, double* h_out);
+/* Page-locked host memory for result arrays (hipHostMalloc, visible to every device): device-to-host copies into it are
+ * asynchronous DMA transfers.  No reference counterpart (numpy allocates the reference's results, apvast.py:433-443). */
+int  apv_host_alloc(void** p, size_t bytes);
+int  apv_host_free(void* p);
 /* perceptual weighting for the broadband stream; arguments as for apv_stream_set_perceptual */
 int  apv_bb_set_perceptual(apv_handle* h, int32_t n_channels, const double* h_G2, double Cs, double Ca, double Leff,
                            int32_t normalisation);

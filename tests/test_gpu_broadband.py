@@ -451,3 +451,49 @@ def test_sweep_cap_is_reported_in_both_modes(golden):
         res = ap.process_signal(x[0, :4 * H], x[1, :4 * H])
     assert res[0][0].shape == (4 * H, 8) and np.isfinite(res[0][0]).all() and ap.not_converged >= 1
     ap.close()
+
+
+def test_broadband_signal_into_pinned_and_pageable_arrays(golden):
+    """apv_bb_process_signal writes the caller's array in its final layout, (groups, samples, L): by DMA when the array is
+    page-locked (alloc_signal_output), through the staging sets otherwise.  Both, over 37 hops (three groups, the last ragged),
+    equal each other bit for bit; the channel-major layout of the C interface (cfg.out_layout = 0) holds the same samples."""
+    g, rirs = golden("g1_broadband_cfg1"), golden("rirs_cfg1")
+    H, hops = 128, 37
+    x = np.random.default_rng(23).standard_normal((2, hops * H))
+    a, b = make(g, rirs), make(g, rirs)
+    pinned = a.alloc_signal_output(hops * H)
+    assert pinned.shape == a.signal_output_shape(hops * H) and pinned.dtype == np.float64
+    pinned[...] = np.nan
+    ra = a.process_signal(x[0], x[1], out=pinned)
+    assert not np.isnan(pinned).any()
+    assert ra[0][0].base is not None and np.shares_memory(ra[0][0], pinned)
+    rb = b.process_signal(x[0], x[1])
+    for q in range(4):
+        for v in range(len(ra[q])):
+            assert np.array_equal(ra[q][v], rb[q][v]), (q, v)
+    with pytest.raises(ValueError):
+        a.process_signal(x[0], x[1], out=np.empty((3, 3)))
+    a.close()
+    b.close()
+    del ra, pinned                              # the page-locked block goes when its last view goes
+    # the C interface's channel-major form on a third object: (hops, n_out, H)
+    from ap_vast_unofficial_amd import _capi
+    p = CFG1
+    L = rirs["rirA"].shape[1]
+    eng = _capi.Engine(p["block_size"] // 2 + 1, L, rirs["rirA"].shape[2], ranks=(1,), mu=p["mu"], compute_dtype="f64",
+                       block_size=p["block_size"], hop_size=H, n_zones=3, dialect="python", reg_mode=_capi.REG_ABS, reg_dark=1e-7)       # apvast.py:7, 22-24
+    eng.bb_set_rank_list([])
+    eng.bb_init(rirs["rirA"], rirs["rirB"], p["reference_index_A"], p["reference_index_B"], p["modeling_delay"],
+                p["filter_length"], p["statistics_buffer_length"], p["number_of_eigenvectors"])
+    resp, tresp = g["init_response"], g["init_target_response"]
+    for i in range(4):                                                          # (len, L, M) -> [M][L][len]
+        eng.bb_set_state(f"response{i}", np.ascontiguousarray(resp[i].transpose(2, 1, 0)))
+    for i in range(2):
+        eng.bb_set_state(f"target_response{i}", np.ascontiguousarray(tresp[i].T))
+    n_out = 2 * p["number_of_eigenvectors"] * L + 2 * L
+    blocks = eng.bb_process_signal(x[0], x[1], n_out)
+    assert blocks.shape == (hops, n_out, H)
+    grp = blocks.reshape(hops, n_out // L, L, H).transpose(1, 0, 3, 2).reshape(n_out // L, hops * H, L)
+    ref = np.stack([rb[q][v] for q in range(2) for v in range(len(rb[q]))] + [rb[2][0], rb[3][0]])
+    assert np.abs(grp - ref).max() <= 1e-10 * np.abs(ref).max()
+    eng.close()
