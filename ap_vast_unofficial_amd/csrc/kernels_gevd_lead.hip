@@ -433,8 +433,10 @@ __global__ void __launch_bounds__(NT) lead_small_kernel(int nslab, const double*
     __shared__ double redn[NT];
     redn[tid] = nrm;
     __syncthreads();
-    for (int s = NT / 2; s > 0; s >>= 1) {
-        if (tid < s) redn[tid] += redn[tid + s];
+    for (int len = NT; len > 1;) {                     // (NT = 768 is not a power of two)
+        const int half = (len + 1) >> 1;
+        if (tid < len - half) redn[tid] += redn[tid + half];
+        len = half;
         __syncthreads();
     }
     const double norm2 = redn[0];
@@ -443,6 +445,10 @@ __global__ void __launch_bounds__(NT) lead_small_kernel(int nslab, const double*
     int sweeps = 0, conv = 0;
     for (int sw = 0; sw < max_sweeps && !conv; ++sw) {
         double pwk = 0.0;
+        // (Tried: every thread forms the two rotations its 2 x 2 block needs from the pivots it reads itself -- one barrier and no
+        // rotation table per round.  Slower: 1.00 -> 1.63 us a round at B = 64.  The round is bound by the instructions the one
+        // compute unit issues, not by its three LDS round trips, and sixteen waves forming rotations redundantly are ~60 more
+        // vector instructions per thread and round.  The table stays.)
         for (int r = 0; r < B - 1; ++r) {
             if (tid < NP) {
                 const int s1 = tid, s2 = B - 1 - tid;
@@ -731,12 +737,13 @@ int apv_gevd_lead(apv_handle* h, int n, int ne, int batch, int b, int rank, cons
         const int msw = (kSweepEvery > 1 && pass > 1 && pass % kSweepEvery != 0) ? 0 : kPartialSweeps;
         double* const hinfo = ws.out + n_part;
         // sixteen waves for the one workgroup of a matrix (the Jacobi round is a dependent chain: more waves hide more of its LDS
-        // latency; measured 58 -> 50 us at b = 32, 123 -> 109 at b = 64); APV_LEAD_WIDE=0 restores 256 / 512 threads
+        // latency; measured 58 -> 50 us at b = 32, 123 -> 109 at b = 64); APV_LEAD_WIDE=0 restores 256 / 256 / 512 threads
         static const bool kWide = getenv("APV_LEAD_WIDE") == nullptr || atoi(getenv("APV_LEAD_WIDE")) != 0;
         unsigned long long* const stp = dbg2 ? ws.stamps : nullptr;
         if (b == 32) se = kWide ? launch_small<32, 512>(st, batch, nslab, ws.Gp, ws.Hp, msw, 1e-18, ws.T, ws.theta, hinfo, active, stp)
                                 : launch_small<32, 256>(st, batch, nslab, ws.Gp, ws.Hp, msw, 1e-18, ws.T, ws.theta, hinfo, active, stp);
-        else if (b == 48) se = launch_small<48, 256>(st, batch, nslab, ws.Gp, ws.Hp, msw, 1e-18, ws.T, ws.theta, hinfo, active, stp);
+        else if (b == 48) se = kWide ? launch_small<48, 768>(st, batch, nslab, ws.Gp, ws.Hp, msw, 1e-18, ws.T, ws.theta, hinfo, active, stp)
+                                     : launch_small<48, 256>(st, batch, nslab, ws.Gp, ws.Hp, msw, 1e-18, ws.T, ws.theta, hinfo, active, stp);
         else se = kWide ? launch_small<64, 1024>(st, batch, nslab, ws.Gp, ws.Hp, msw, 1e-18, ws.T, ws.theta, hinfo, active, stp)
                         : launch_small<64, 512>(st, batch, nslab, ws.Gp, ws.Hp, msw, 1e-18, ws.T, ws.theta, hinfo, active, stp);
         LCHK(se);

@@ -308,6 +308,28 @@ def also_cfg3(device, hops=468):
     return rec
 
 
+def _time_bb_signal(obj, xs, signal_hops, H):
+    """ONE process_signal call over signal_hops hops, twice: returning a fresh result array, as the reference's caller would get
+    it (`process_signal`), and into the caller's own page-locked array (alloc_signal_output, allocated outside the timed region
+    and written by DMA: `process_signal_out`).  (tests/test_gpu_broadband.py holds the two forms to bit-equal samples.)"""
+    t0 = time.perf_counter()
+    res = obj.process_signal(xs[0], xs[1])
+    dt = time.perf_counter() - t0
+    assert res[0][0].shape == (signal_hops * H, 8)
+    rec = {"process_signal": {"ms_per_hop": dt / signal_hops * 1e3, "hops": signal_hops, "realtime_factor": (signal_hops * H / 48000.0) / dt,
+                              "output": "fresh array per call"}}
+    del res
+    out = obj.alloc_signal_output(signal_hops * H)
+    out[...] = 0.0
+    t0 = time.perf_counter()
+    res = obj.process_signal(xs[0], xs[1], out=out)
+    dt = time.perf_counter() - t0
+    assert np.shares_memory(res[0][0], out) and np.isfinite(out).all()
+    rec["process_signal_out"] = {"ms_per_hop": dt / signal_hops * 1e3, "hops": signal_hops, "realtime_factor": (signal_hops * H / 48000.0) / dt,
+                                 "output": "caller-provided page-locked array (alloc_signal_output), allocated before the call"}
+    return rec
+
+
 def also_cfg1(device, hops=40, signal_hops=128):
     """BASELINE config 1 in the reference's own (broadband, time-domain) formulation through class apvast: the bundled
     rirs.mat (8 loudspeakers x 8 microphones), N = 256, H = 128, J = 32 (n = J L = 256), S = 512, V = 8, both zone
@@ -331,12 +353,7 @@ def also_cfg1(device, hops=40, signal_hops=128):
         rec["process_input_buffers"] = {"ms_per_hop": dt / hops * 1e3, "hops": hops, "realtime_factor": (hops * H / 48000.0) / dt}
         xs = np.random.default_rng(8).standard_normal((2, signal_hops * H))
         obj.process_signal(xs[0, :16 * H], xs[1, :16 * H])       # allocates the group buffers, captures the batch's sweep graph
-        t0 = time.perf_counter()
-        res = obj.process_signal(xs[0], xs[1])
-        dt = time.perf_counter() - t0
-        assert res[0][0].shape == (signal_hops * H, 8)
-        rec["process_signal"] = {"ms_per_hop": dt / signal_hops * 1e3, "hops": signal_hops,
-                                 "realtime_factor": (signal_hops * H / 48000.0) / dt}
+        rec.update(_time_bb_signal(obj, xs, signal_hops, H))
         rec["not_converged_hops"] = obj.not_converged
     finally:
         obj.close()
@@ -365,12 +382,7 @@ def also_reftest(device, hops=6, signal_hops=16):
         rec["process_input_buffers"] = {"ms_per_hop": dt / hops * 1e3, "hops": hops, "realtime_factor": (hops * H / 48000.0) / dt}
         xs = np.random.default_rng(8).standard_normal((2, signal_hops * H))
         obj.process_signal(xs[0, :8 * H], xs[1, :8 * H])         # allocates the group buffers, captures the batch's sweep graphs
-        t0 = time.perf_counter()
-        res = obj.process_signal(xs[0], xs[1])
-        dt = time.perf_counter() - t0
-        assert res[0][0].shape == (signal_hops * H, 8)
-        rec["process_signal"] = {"ms_per_hop": dt / signal_hops * 1e3, "hops": signal_hops,
-                                 "realtime_factor": (signal_hops * H / 48000.0) / dt}
+        rec.update(_time_bb_signal(obj, xs, signal_hops, H))
         rec["not_converged_hops"] = obj.not_converged
     finally:
         obj.close()
