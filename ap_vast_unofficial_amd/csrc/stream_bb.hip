@@ -89,6 +89,7 @@ struct apv_bb {
                            // cfg.out_layout = 1, else [grp][n_out][H]: ONE copy per group to the host
     double* g_pin;         // [2 sets] the same, page-locked: staging for a caller's pageable array (allocated when first needed)
     size_t g_pin_cap;      // doubles per set g_pin holds
+    double* g_pin_in;      // [2 sets][grp][2][H] page-locked: a group's input hops, gathered here and sent in ONE copy
     int out_group;         // cfg.out_layout = 1: L (sample-major emit, see bb_back); 0: channel-major
     // (each of the above twice: the front stages of group g + 1 fill one set while the batched solve of group g reads the other)
     double* spec_out;      // [n_out][K] c128: the output stage's own spectra (the front stages use `spec` at the same time)
@@ -693,6 +694,7 @@ void apv_bb_free(apv_handle* h) {
     for (double* b : bufs)
         if (b) (void)hipFree(b);
     if (s->g_pin) (void)hipHostFree(s->g_pin);
+    if (s->g_pin_in) (void)hipHostFree(s->g_pin_in);
     if (s->d_ranks) (void)hipFree(s->d_ranks);
     if (s->pin_in) (void)hipHostFree(s->pin_in);
     if (s->pin_out) (void)hipHostFree(s->pin_out);
@@ -1151,6 +1153,9 @@ int apv_bb_process_signal(apv_handle* h, int32_t n_hops, const double* h_in_A, c
         if ((rc = dalloc(h, &s->g_nrm, 2 * z_nrm))) return rc;
         if ((rc = dalloc(h, &s->g_inspec, 2 * z_insp))) return rc;
         if ((rc = dalloc(h, &s->g_out, 2 * z_out))) return rc;
+        if (s->g_pin_in) (void)hipHostFree(s->g_pin_in);
+        s->g_pin_in = nullptr;
+        BCHK(h, hipHostMalloc((void**)&s->g_pin_in, sizeof(double) * 2 * z_xin, hipHostMallocDefault));
         if (!s->spec_out && (rc = dalloc(h, &s->spec_out, (size_t)s->n_out * K * 2))) return rc;
         if (!s->front) {
             BCHK(h, hipStreamCreateWithFlags(&s->front, hipStreamNonBlocking));
@@ -1184,6 +1189,9 @@ int apv_bb_process_signal(apv_handle* h, int32_t n_hops, const double* h_in_A, c
     hipStream_t fs = s->front;
     // every exit below drains both streams first: copies into the caller's h_out may be in flight
     hipStream_t cs = s->copy;
+    // (Enqueueing the next group's front stages from a helper thread while this one solves was tried once the input copies had
+    // become one per group: no gain, 0.096 against 0.094 ms per hop at cfg1 -- a group is now bound by its sixteen hops' front
+    // stages on the device, ~90 us of small dependent launches each.)
     auto drained = [&](int rc) { (void)hipStreamSynchronize(fs); (void)hipStreamSynchronize(st); (void)hipStreamSynchronize(cs); return rc; };
 #define BDCHK(h, call)                                                                                                     \
     do {                                                                                                                    \
@@ -1196,10 +1204,14 @@ int apv_bb_process_signal(apv_handle* h, int32_t n_hops, const double* h_in_A, c
     auto enqueue_front = [&](int g) -> int {
         const int set = g & 1, h0 = g * G, g_n = n_hops - h0 < G ? n_hops - h0 : G;
         double* xin = s->g_xin + set * z_xin;
+        // (one copy per group from page-locked staging: two copies per hop from the caller's pageable arrays were 32 blocking calls)
+        double* const pin = s->g_pin_in + set * z_xin;
+        if (g >= 2) (void)hipEventSynchronize(s->ev_front[set]);        // group g - 2's copy out of this staging set has run
         for (int i = 0; i < g_n; ++i) {
-            BDCHK(h, hipMemcpyAsync(xin + (size_t)i * 2 * H, h_in_A + (size_t)(h0 + i) * H, sizeof(double) * H, hipMemcpyHostToDevice, fs));
-            BDCHK(h, hipMemcpyAsync(xin + (size_t)i * 2 * H + H, h_in_B + (size_t)(h0 + i) * H, sizeof(double) * H, hipMemcpyHostToDevice, fs));
+            std::memcpy(pin + (size_t)i * 2 * H, h_in_A + (size_t)(h0 + i) * H, sizeof(double) * H);
+            std::memcpy(pin + (size_t)i * 2 * H + H, h_in_B + (size_t)(h0 + i) * H, sizeof(double) * H);
         }
+        BDCHK(h, hipMemcpyAsync(xin, pin, sizeof(double) * (size_t)g_n * 2 * H, hipMemcpyHostToDevice, fs));
         hops[set].assign(g_n, BbHop{});
         for (int i = 0; i < g_n; ++i) {
             BbHop& q = hops[set][i];

@@ -312,13 +312,17 @@ def _time_bb_signal(obj, xs, signal_hops, H):
     """ONE process_signal call over signal_hops hops, twice: returning a fresh result array, as the reference's caller would get
     it (`process_signal`), and into the caller's own page-locked array (alloc_signal_output, allocated outside the timed region
     and written by DMA: `process_signal_out`).  (tests/test_gpu_broadband.py holds the two forms to bit-equal samples.)"""
-    t0 = time.perf_counter()
-    res = obj.process_signal(xs[0], xs[1])
-    dt = time.perf_counter() - t0
-    assert res[0][0].shape == (signal_hops * H, 8)
+    first = None
+    for rep in range(2):                        # the first call of this length sizes the group buffers and the staging sets
+        t0 = time.perf_counter()
+        res = obj.process_signal(xs[0], xs[1])
+        dt = time.perf_counter() - t0
+        assert res[0][0].shape == (signal_hops * H, 8)
+        del res
+        if first is None:
+            first = dt
     rec = {"process_signal": {"ms_per_hop": dt / signal_hops * 1e3, "hops": signal_hops, "realtime_factor": (signal_hops * H / 48000.0) / dt,
-                              "output": "fresh array per call"}}
-    del res
+                              "output": "fresh array per call", "first_call_ms_per_hop": first / signal_hops * 1e3}}
     out = obj.alloc_signal_output(signal_hops * H)
     out[...] = 0.0
     t0 = time.perf_counter()
@@ -381,7 +385,7 @@ def also_reftest(device, hops=6, signal_hops=16):
         dt = time.perf_counter() - t0
         rec["process_input_buffers"] = {"ms_per_hop": dt / hops * 1e3, "hops": hops, "realtime_factor": (hops * H / 48000.0) / dt}
         xs = np.random.default_rng(8).standard_normal((2, signal_hops * H))
-        obj.process_signal(xs[0, :8 * H], xs[1, :8 * H])         # allocates the group buffers, captures the batch's sweep graphs
+        obj.process_signal(xs[0, :8 * H], xs[1, :8 * H])         # allocates the group buffers (for groups of eight: the timed length re-sizes them in its first call)
         rec.update(_time_bb_signal(obj, xs, signal_hops, H))
         rec["not_converged_hops"] = obj.not_converged
     finally:
