@@ -734,7 +734,19 @@ int apv_gevd_lead(apv_handle* h, int n, int ne, int batch, int b, int rank, cons
         // parallel) and sharpen the Ritz values that set the next filter's bounds; an off-diagonal element left in the leading
         // block shows in the residuals and costs another pass.
         static const int kSweepEvery = getenv("APV_LEAD_SWEEP_EVERY") ? atoi(getenv("APV_LEAD_SWEEP_EVERY")) : 1;      // tuning aid
-        const int msw = (kSweepEvery > 1 && pass > 1 && pass % kSweepEvery != 0) ? 0 : kPartialSweeps;
+        // APV_LEAD_SWEEP_SCHEDULE="a,b,c,...": sweeps of pass 0, 1, 2, ... (the last entry for all later passes); tuning aid
+        static const std::vector<int> kSchedule = [] {
+            std::vector<int> v;
+            if (const char* e = getenv("APV_LEAD_SWEEP_SCHEDULE"))
+                for (const char* q = e; *q;) {
+                    v.push_back(atoi(q));
+                    while (*q && *q != ',') ++q;
+                    if (*q == ',') ++q;
+                }
+            return v;
+        }();
+        int msw = (kSweepEvery > 1 && pass > 1 && pass % kSweepEvery != 0) ? 0 : kPartialSweeps;
+        if (!kSchedule.empty()) msw = kSchedule[pass < (int)kSchedule.size() ? pass : (int)kSchedule.size() - 1];
         double* const hinfo = ws.out + n_part;
         // sixteen waves for the one workgroup of a matrix (the Jacobi round is a dependent chain: more waves hide more of its LDS
         // latency; measured 58 -> 50 us at b = 32, 123 -> 109 at b = 64); APV_LEAD_WIDE=0 restores 256 / 256 / 512 threads
