@@ -4,6 +4,7 @@ No fallback: if the HIP library is missing or a call fails this module raises.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -233,6 +234,8 @@ class Engine:
         # streaming outputs: 0 = channel-major (n_out, H); 1 = sample-major groups (n_out / L, H, L), see include/apvast_hip.h
         cfg.out_layout = int(out_layout)
         self.out_layout = int(out_layout)
+        self.pooled_results = os.environ.get("APV_RESULT_POOL", "1") != "0"
+        self._pin_pool = {}
         self.cfg = cfg
         self.K, self.L, self.M, self.nV = cfg.n_bins, cfg.n_srcs, cfg.n_mics, cfg.n_ranks
         h = C.c_void_p()
@@ -268,6 +271,7 @@ class Engine:
         if self.h is not None:
             self.lib.apv_destroy(self.h)
             self.h = None
+        self._pin_pool = {}          # the page-locked blocks go when their last array goes
 
     def __del__(self):
         try:
@@ -576,9 +580,31 @@ class Engine:
         in_A = np.ascontiguousarray(in_A, dtype=np.float64).ravel()
         in_B = np.ascontiguousarray(in_B, dtype=np.float64).ravel()
         H = self.cfg.hop_size
-        out = np.empty((n_out // self.L, H, self.L) if self.out_layout == 1 else (n_out, H), dtype=np.float64)
+        out = self._result_array((n_out // self.L, H, self.L) if self.out_layout == 1 else (n_out, H))
         self._chk_stream(self.lib.apv_bb_process_block(self.h, _ptr(in_A), _ptr(in_B), _ptr(out)))
         return out
+
+    def _result_array(self, shape):
+        """A float64 array for one hop's outputs.  Large hops (the reference's test parameters return 5.2 MB) come from a small pool of
+        page-locked blocks, which the device fills by DMA: a block is handed out again once nothing refers to the array made
+        from it or to any slice of it; otherwise, and for small hops, an ordinary fresh array."""
+        nbytes = int(np.prod(shape)) * 8
+        if nbytes < (1 << 20) or not self.pooled_results:
+            return np.empty(shape, dtype=np.float64)
+        pool = self._pin_pool.setdefault(tuple(shape), [])
+        for ent in pool:
+            # [array, references to the array when idle, references to its owner block when idle]
+            if sys.getrefcount(ent[0]) == ent[1] and sys.getrefcount(ent[0].base) == ent[2]:
+                return ent[0]
+        if len(pool) < 4:
+            a = self.pinned_empty(shape)
+            if a is not None:
+                ent = [a, 0, 0]
+                pool.append(ent)
+                del a
+                ent[1], ent[2] = sys.getrefcount(ent[0]), sys.getrefcount(ent[0].base)
+                return ent[0]
+        return np.empty(shape, dtype=np.float64)
 
     def bb_signal_shape(self, n_hops, n_out):
         H = self.cfg.hop_size

@@ -122,6 +122,9 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
 
 // kernels_gevd_lead.hip: the leading b eigenpairs of whitened matrices by Chebyshev-filtered subspace iteration (see the file header)
 int apv_gevd_lead_block(int n, int rank);
+// blocks of page-locked host memory handed out by apv_host_alloc (capi.hip)
+void apv_host_blocks_note(const void* p, size_t bytes, bool add);
+bool apv_host_block_contains(const void* p, size_t bytes);
 int apv_gevd_lead(apv_handle* h, int n, int ne, int batch, int b, int rank, const double* C, const double* WT, double* d_U,
                   double* d_lam, const int* h_pd_flags, int* done);
 

@@ -7,7 +7,9 @@
 
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <new>
 
 namespace {
@@ -118,6 +120,28 @@ int ensure_staging(apv_handle* h) {
 }
 
 }  // namespace
+
+// The blocks apv_host_alloc has handed out (page-locked, visible to every device): a result pointer inside one of them takes a
+// device-to-host copy by DMA.  A table of our own, because asking the runtime about an arbitrary pointer
+// (hipPointerGetAttributes) costs a search and, for pageable memory, an error path on every call.
+namespace {
+std::mutex g_host_blocks_mu;
+std::map<uintptr_t, size_t> g_host_blocks;
+}  // namespace
+
+void apv_host_blocks_note(const void* p, size_t bytes, bool add) {
+    std::lock_guard<std::mutex> lk(g_host_blocks_mu);
+    if (add) g_host_blocks[(uintptr_t)p] = bytes;
+    else g_host_blocks.erase((uintptr_t)p);
+}
+
+bool apv_host_block_contains(const void* p, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_host_blocks_mu);
+    auto it = g_host_blocks.upper_bound((uintptr_t)p);
+    if (it == g_host_blocks.begin()) return false;
+    --it;
+    return (uintptr_t)p >= it->first && (uintptr_t)p + bytes <= it->first + it->second;
+}
 
 extern "C" {
 
@@ -687,11 +711,13 @@ int apv_host_alloc(void** p, size_t bytes) {
         *p = nullptr;
         return APV_ERR_HIP;
     }
+    apv_host_blocks_note(*p, bytes ? bytes : 1, true);
     return APV_OK;
 }
 
 int apv_host_free(void* p) {
     if (!p) return APV_OK;
+    apv_host_blocks_note(p, 0, false);
     return hipHostFree(p) == hipSuccess ? APV_OK : APV_ERR_HIP;
 }
 

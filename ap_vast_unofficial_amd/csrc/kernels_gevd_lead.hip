@@ -687,7 +687,8 @@ int apv_gevd_lead(apv_handle* h, int n, int ne, int batch, int b, int rank, cons
     auto mult = [&](const double* A, const double* Yc, const double* Yp, double* Yo, int rows_out, int ldo, size_t os, const LeadCoef& cf) {
         // 16 x 16 outputs per workgroup while that fills the chip, 16 x 32 beyond
         const long wgs = (long)nrt * (b / 16) * batch;
-        if (wgs > 2048 && b % 32 == 0)
+        static const int kForceNB = getenv("APV_LEAD_NB") ? atoi(getenv("APV_LEAD_NB")) : 0;      // tuning aid
+        if ((kForceNB == 2 || (kForceNB == 0 && wgs > 2048)) && b % 32 == 0)
             hipLaunchKernelGGL((lead_mult_kernel<2>), dim3(nrt * (b / 32), 1, batch), dim3(256), 0, st, ne, ne, ms, A, b, ys, Yc, Yp, Yo, rows_out, ldo, os, cf);
         else
             hipLaunchKernelGGL((lead_mult_kernel<1>), dim3(nrt * (b / 16), 1, batch), dim3(256), 0, st, ne, ne, ms, A, b, ys, Yc, Yp, Yo, rows_out, ldo, os, cf);

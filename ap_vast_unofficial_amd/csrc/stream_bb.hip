@@ -107,9 +107,13 @@ namespace {
         if (_e != hipSuccess) return apv_fail(h, APV_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_e)); \
     } while (0)
 
-// true when p lies in page-locked host memory the runtime knows (hipHostMalloc / apv_host_alloc): a device-to-host copy into it is
-// a DMA that runs asynchronously; any other host pointer is staged by the runtime and blocks the caller
-bool host_is_pinned(const void* p) {
+// true when [p, p + bytes) lies in page-locked host memory: a device-to-host copy into it is a DMA that runs asynchronously; any
+// other host pointer is staged by the runtime and blocks the caller.  Blocks of apv_host_alloc are known without asking the
+// runtime; with `ask` any other pointer is looked up there (a search and, for pageable memory, an error path: once per whole
+// signal, never per hop).
+bool host_is_pinned(const void* p, size_t bytes, bool ask) {
+    if (apv_host_block_contains(p, bytes)) return true;
+    if (!ask) return false;
     hipPointerAttribute_t a{};
     if (hipPointerGetAttributes(&a, p) != hipSuccess) {
         (void)hipGetLastError();
@@ -1075,12 +1079,14 @@ int apv_bb_process_block(apv_handle* h, const double* h_in_A, const double* h_in
         t_stage[3] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_prev).count();
         t_prev = std::chrono::steady_clock::now();
     }
-    // (the caller's array is not asked whether it is page-locked here: the query costs more than the copy of one hop)
-    rc = bb_back(h, s, q, s->out, 0, s->pin_out, s->spec);
+    // a result array from apv_host_alloc receives the hop by DMA; any other goes through the handle's page-locked buffer and a copy
+    const size_t out_bytes = sizeof(double) * (size_t)s->n_out * H;
+    const bool direct = host_is_pinned(h_out, out_bytes, false);
+    rc = bb_back(h, s, q, s->out, 0, direct ? h_out : s->pin_out, s->spec);
     if (rc != APV_OK) return rc;
     BCHK(h, hipStreamSynchronize(st));
     BCHK(h, hipGetLastError());
-    std::memcpy(h_out, s->pin_out, sizeof(double) * (size_t)s->n_out * H);
+    if (!direct) std::memcpy(h_out, s->pin_out, out_bytes);
     if (timing)
         fprintf(stderr, "[apv bb] fir %.3f  wola %.3f  stats %.3f  gevd %.3f  out %.3f ms\n", t_stage[0], t_stage[1],
                 t_stage[2], t_stage[3], std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_prev).count());
@@ -1178,7 +1184,7 @@ int apv_bb_process_signal(apv_handle* h, int32_t n_hops, const double* h_in_A, c
     // whole signal afterwards: at the reference's test parameters, 5.2 MB a hop, that was 2.9 of the 3.5 ms a hop took.)
     const int og = s->out_group;
     const size_t ngrp = og > 0 ? (size_t)s->n_out / og : 1, HL = (size_t)H * (og > 0 ? og : s->n_out);
-    const bool direct = host_is_pinned(h_out);
+    const bool direct = host_is_pinned(h_out, sizeof(double) * (size_t)n_hops * s->n_out * H, true);
     if (!direct && s->g_pin_cap < z_out) {
         if (s->g_pin) (void)hipHostFree(s->g_pin);
         s->g_pin = nullptr;

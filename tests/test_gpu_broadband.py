@@ -497,3 +497,37 @@ def test_broadband_signal_into_pinned_and_pageable_arrays(golden):
     ref = np.stack([rb[q][v] for q in range(2) for v in range(len(rb[q]))] + [rb[2][0], rb[3][0]])
     assert np.abs(grp - ref).max() <= 1e-10 * np.abs(ref).max()
     eng.close()
+
+
+def test_broadband_large_hops_come_from_a_page_locked_pool(golden):
+    """Hops of a megabyte or more (here 5.2 MB: the reference's test parameters) are written by DMA into page-locked arrays from a
+    small pool.  A result that is still referred to -- the array or any slice of it -- is never handed out again; one that was
+    dropped is; and the samples are those of an engine that uses fresh arrays."""
+    from ap_vast_unofficial_amd.apvast import apvast
+    rirs = golden("rirs_cfg1")
+    N, J, V, S, H = 1600, 100, 50, 1000, 800
+    mk = lambda: apvast(N, rirs["rirA"], rirs["rirB"], J, 20, 6, 6, V, 1.0, S, perceptual=False, mode="broadband", seed=0)
+    a, b = mk(), mk()
+    b._eng.pooled_results = False
+    x = np.random.default_rng(31).standard_normal((2, 4 * H))
+    kept = []
+    for h in range(4):
+        ra = a.process_input_buffers(x[0, h * H:(h + 1) * H], x[1, h * H:(h + 1) * H])
+        rb = b.process_input_buffers(x[0, h * H:(h + 1) * H], x[1, h * H:(h + 1) * H])
+        for q in range(4):
+            for v in (0, V - 1):
+                assert np.array_equal(ra[q][v], rb[q][v]), (h, q, v)
+        kept.append(ra[0][3])                                    # one slice of every hop stays alive
+        del ra, rb
+    pool = a._eng._pin_pool[(2 * V + 2, H, 8)]
+    assert len(pool) == 4                                        # four hops held: four blocks, none reused
+    for i in range(4):
+        for j in range(i):
+            assert not np.shares_memory(kept[i], kept[j])
+    snap = [k.copy() for k in kept]
+    del kept[1:]                                                 # three blocks are free again
+    r5 = a.process_input_buffers(x[0, :H], x[1, :H])
+    assert len(pool) == 4 and not np.shares_memory(r5[0][0], kept[0])
+    assert np.array_equal(kept[0], snap[0])                      # the slice still held was not written over
+    a.close()
+    b.close()
