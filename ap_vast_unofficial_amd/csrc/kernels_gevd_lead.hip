@@ -294,7 +294,7 @@ __device__ __forceinline__ d4 lead_tile(const double* A, const double* Bm, int l
 
 // The projected problem of one pass: (H, G) of order B -> T [B][B] (X = Y T has orthonormal columns that diagonalise C on
 // span Y), theta [B] descending; hinfo[z] = {theta[B], Gram breakdown, sweeps, Jacobi met its bound, -} is what the host reads.
-template <int B, int NT>
+template <int B, int NT, bool MOVE>
 __global__ void __launch_bounds__(NT) lead_small_kernel(int nslab, const double* __restrict__ Gp, const double* __restrict__ Hp,
                                                         int max_sweeps, double tol2, double* __restrict__ T,
                                                         double* __restrict__ theta, double* __restrict__ hinfo, unsigned active,
@@ -304,7 +304,8 @@ __global__ void __launch_bounds__(NT) lead_small_kernel(int nslab, const double*
     double* S0 = sm;                 // G -> W H -> Q
     double* S1 = S0 + B * LD;        // H -> M
     double* S2 = S1 + B * LD;        // W = L^-1
-    double* dsc = S2 + B * LD;       // [B] 1/sqrt(diag G)
+    double* S3 = S2 + B * LD;        // MOVE: the second buffer of M's ping-pong (S2 is Q's once W^T has moved into S0)
+    double* dsc = S3 + (MOVE ? B * LD : 0);       // [B] 1/sqrt(diag G)
     double* th = dsc + B;            // [B]
     double* pw = th + B;             // [NP] pivot weights of a sweep
     double2* cs = reinterpret_cast<double2*>(pw + NP + (NP & 1));    // [NP]
@@ -427,7 +428,8 @@ __global__ void __launch_bounds__(NT) lead_small_kernel(int nslab, const double*
             const double m = S1[i * LD + i];
             nrm += m * m;
         }
-        S0[i * LD + j] = i == j ? 1.0 : 0.0;        // Q = I (W H is spent)
+        // Q = I (W H is spent); MOVE: the accumulator starts as W^T, so that the sweeps leave W^T Q and W's buffer is free for them
+        S0[i * LD + j] = MOVE ? S2[j * LD + i] : (i == j ? 1.0 : 0.0);
     }
     // ||M||_F^2 (order of the sum fixed: lanes through DPP-free LDS tree)
     __shared__ double redn[NT];
@@ -441,8 +443,88 @@ __global__ void __launch_bounds__(NT) lead_small_kernel(int nslab, const double*
     }
     const double norm2 = redn[0];
     stamp(3);
-    // e: cyclic Jacobi, round-robin pairing (player 0 fixed, the others rotate): slot s holds player s == 0 ? 0 : 1 + (s - 1 - r) mod (B - 1)
+    // e: cyclic Jacobi, round-robin pairing (player 0 fixed, the others rotate)
     int sweeps = 0, conv = 0;
+    double *Mc = S1, *Qc = S0;                 // where M and the accumulator are when the sweeps are done
+    if constexpr (MOVE) {
+        // The same tournament with the ROWS AND COLUMNS MOVING instead of the pairing: pair k is always slots (k, B-1-k), and a
+        // round writes what it rotated one slot on (slot 0 stays, s -> s + 1, B-1 -> 1: the circle method), M and the accumulator
+        // each into a second buffer.  Which elements a thread reads and where it writes them is then the same in every round --
+        // no pairing table, no index arithmetic inside the round, the addresses are loop invariants -- and the rotations are
+        // those of the in-place form bit for bit (same pairs, same order of operands).  After B - 1 rounds everything is back in
+        // its own slot.  The round is bound by the instructions the one compute unit issues: the in-place form spent ~150 per
+        // thread and round at B = 64 (pair indices and rotations fetched from LDS, two multiply-adds per address).
+        auto nx = [](int sl) { return sl == 0 ? 0 : (sl == B - 1 ? 1 : sl + 1); };
+        double *Mn = S3, *Qn = S2;
+        constexpr int MI = (NP * NP + NT - 1) / NT, QI = (B * NP + NT - 1) / NT;
+        // loop-invariant element offsets of this thread's blocks
+        int m_rd[MI][4], m_wr[MI][4], m_k[MI], m_l[MI], q_rd[QI][2], q_wr[QI][2], q_l[QI];
+#pragma unroll
+        for (int it = 0; it < MI; ++it) {
+            const int e = tid + it * NT, k = e / NP, l = e - k * NP;
+            const int pk = k, qk = B - 1 - k, pl = l, ql = B - 1 - l;
+            m_k[it] = e < NP * NP ? k : -1;
+            m_l[it] = l;
+            m_rd[it][0] = pk * LD + pl; m_rd[it][1] = pk * LD + ql; m_rd[it][2] = qk * LD + pl; m_rd[it][3] = qk * LD + ql;
+            m_wr[it][0] = nx(pk) * LD + nx(pl); m_wr[it][1] = nx(pk) * LD + nx(ql);
+            m_wr[it][2] = nx(qk) * LD + nx(pl); m_wr[it][3] = nx(qk) * LD + nx(ql);
+        }
+#pragma unroll
+        for (int it = 0; it < QI; ++it) {
+            const int e = tid + it * NT, i = e / NP, l = e - i * NP;
+            q_l[it] = e < B * NP ? l : -1;
+            q_rd[it][0] = i * LD + l; q_rd[it][1] = i * LD + B - 1 - l;
+            q_wr[it][0] = i * LD + nx(l); q_wr[it][1] = i * LD + nx(B - 1 - l);
+        }
+        for (int sw = 0; sw < max_sweeps && !conv; ++sw) {
+            double pwk = 0.0;
+            for (int r = 0; r < B - 1; ++r) {
+                if (tid < NP) {
+                    const int p = tid, q = B - 1 - tid;
+                    const double al = Mc[p * LD + p], ga = Mc[q * LD + q], be = Mc[p * LD + q];
+                    double c, sn;
+                    lead_rotation(al, ga, be, c, sn);
+                    pwk = __builtin_fma(be, be, pwk);
+                    cs[tid] = double2{c, sn};
+                }
+                __syncthreads();
+#pragma unroll
+                for (int it = 0; it < MI; ++it) {
+                    if (m_k[it] < 0) continue;
+                    const double2 rk2 = cs[m_k[it]], rl = cs[m_l[it]];
+                    const double a = Mc[m_rd[it][0]], b_ = Mc[m_rd[it][1]], c_ = Mc[m_rd[it][2]], d_ = Mc[m_rd[it][3]];
+                    const double a1 = a * rl.x - b_ * rl.y, b1 = a * rl.y + b_ * rl.x;
+                    const double c1 = c_ * rl.x - d_ * rl.y, d1 = c_ * rl.y + d_ * rl.x;
+                    Mn[m_wr[it][0]] = rk2.x * a1 - rk2.y * c1;
+                    Mn[m_wr[it][1]] = rk2.x * b1 - rk2.y * d1;
+                    Mn[m_wr[it][2]] = rk2.y * a1 + rk2.x * c1;
+                    Mn[m_wr[it][3]] = rk2.y * b1 + rk2.x * d1;
+                }
+#pragma unroll
+                for (int it = 0; it < QI; ++it) {
+                    if (q_l[it] < 0) continue;
+                    const double2 rl = cs[q_l[it]];
+                    const double x = Qc[q_rd[it][0]], y = Qc[q_rd[it][1]];
+                    Qn[q_wr[it][0]] = x * rl.x - y * rl.y;
+                    Qn[q_wr[it][1]] = x * rl.y + y * rl.x;
+                }
+                __syncthreads();
+                double* t = Mc; Mc = Mn; Mn = t;
+                t = Qc; Qc = Qn; Qn = t;
+            }
+            if (tid < NP) pw[tid] = pwk;
+            __syncthreads();
+            if (tid == 0) {
+                double t = 0.0;
+                for (int k = 0; k < NP; ++k) t += pw[k];
+                scal[0] = t;
+            }
+            __syncthreads();
+            ++sweeps;
+            conv = scal[0] <= tol2 * norm2;
+            __syncthreads();
+        }
+    } else {
     for (int sw = 0; sw < max_sweeps && !conv; ++sw) {
         double pwk = 0.0;
         // (Tried: every thread forms the two rotations its 2 x 2 block needs from the pivots it reads itself -- one barrier and no
@@ -498,9 +580,10 @@ __global__ void __launch_bounds__(NT) lead_small_kernel(int nslab, const double*
         conv = scal[0] <= tol2 * norm2;         // a sweep whose pivots weigh <= tol2 ||M||^2 leaves ~tol2^2 behind
         __syncthreads();
     }
+    }
     // f: descending order, T = D W^T Q with its columns in that order
     stamp(4);
-    if (tid < B) th[tid] = S1[tid * LD + tid];
+    if (tid < B) th[tid] = Mc[tid * LD + tid];
     __syncthreads();
     if (tid < B) {
         const double li = th[tid];
@@ -512,13 +595,21 @@ __global__ void __launch_bounds__(NT) lead_small_kernel(int nslab, const double*
     }
     __syncthreads();
     T += (size_t)z * B * B;
-    for (int tile = wv; tile < NTL * NTL; tile += NW) {
-        const int r0 = (tile / NTL) * 16, c0 = (tile % NTL) * 16;
-        const d4 a = lead_tile<true, false, B>(S2, S0, LD, r0, c0, lane);
+    if constexpr (MOVE) {
+        // the accumulator started as W^T: it holds W^T Q
+        for (int e = tid; e < B * B; e += NT) {
+            const int i = e / B, j = e - i * B;
+            T[(size_t)i * B + rk[j]] = dsc[i] * Qc[i * LD + j];
+        }
+    } else {
+        for (int tile = wv; tile < NTL * NTL; tile += NW) {
+            const int r0 = (tile / NTL) * 16, c0 = (tile % NTL) * 16;
+            const d4 a = lead_tile<true, false, B>(S2, S0, LD, r0, c0, lane);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int i = r0 + (lane >> 4) + 4 * t, j = c0 + (lane & 15);
-            T[(size_t)i * B + rk[j]] = dsc[i] * a[t];
+            for (int t = 0; t < 4; ++t) {
+                const int i = r0 + (lane >> 4) + 4 * t, j = c0 + (lane & 15);
+                T[(size_t)i * B + rk[j]] = dsc[i] * a[t];
+            }
         }
     }
     if (tid == 0) {
@@ -603,19 +694,19 @@ struct LeadWs {
     }
 };
 
-template <int B, int NT>
+template <int B, int NT, bool MOVE>
 hipError_t launch_small(hipStream_t st, int batch, int nslab, const double* Gp, const double* Hp, int max_sweeps, double tol2,
                         double* T, double* theta, double* hinfo, unsigned active, unsigned long long* stamps) {
     constexpr int LD = B + 1, NP = B / 2;
-    const size_t bytes = sizeof(double) * (3 * (size_t)B * LD + 2 * B + NP + (NP & 1)) + sizeof(double2) * NP + sizeof(int) * 2 * B;
+    const size_t bytes = sizeof(double) * ((MOVE ? 4 : 3) * (size_t)B * LD + 2 * B + NP + (NP & 1)) + sizeof(double2) * NP + sizeof(int) * 2 * B;
     static bool once = false;
     if (!once) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lead_small_kernel<B, NT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lead_small_kernel<B, NT, MOVE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) return e;
         once = true;
     }
-    hipLaunchKernelGGL((lead_small_kernel<B, NT>), dim3(batch), dim3(NT), bytes, st, nslab, Gp, Hp, max_sweeps, tol2, T, theta, hinfo,
+    hipLaunchKernelGGL((lead_small_kernel<B, NT, MOVE>), dim3(batch), dim3(NT), bytes, st, nslab, Gp, Hp, max_sweeps, tol2, T, theta, hinfo,
                        active, stamps);
     return hipGetLastError();
 }
@@ -749,16 +840,16 @@ int apv_gevd_lead(apv_handle* h, int n, int ne, int batch, int b, int rank, cons
         int msw = (kSweepEvery > 1 && pass > 1 && pass % kSweepEvery != 0) ? 0 : kPartialSweeps;
         if (!kSchedule.empty()) msw = kSchedule[pass < (int)kSchedule.size() ? pass : (int)kSchedule.size() - 1];
         double* const hinfo = ws.out + n_part;
-        // sixteen waves for the one workgroup of a matrix (the Jacobi round is a dependent chain: more waves hide more of its LDS
-        // latency; measured 58 -> 50 us at b = 32, 123 -> 109 at b = 64); APV_LEAD_WIDE=0 restores 256 / 256 / 512 threads
+        // sixteen waves for the one workgroup of a matrix and the sweeps in their moving-slot form (lead_small_kernel, e);
+        // APV_LEAD_WIDE=0: 256 / 256 / 512 threads and the in-place sweeps with their pairing table, as in the middle of round 4
         static const bool kWide = getenv("APV_LEAD_WIDE") == nullptr || atoi(getenv("APV_LEAD_WIDE")) != 0;
         unsigned long long* const stp = dbg2 ? ws.stamps : nullptr;
-        if (b == 32) se = kWide ? launch_small<32, 512>(st, batch, nslab, ws.Gp, ws.Hp, msw, 1e-18, ws.T, ws.theta, hinfo, active, stp)
-                                : launch_small<32, 256>(st, batch, nslab, ws.Gp, ws.Hp, msw, 1e-18, ws.T, ws.theta, hinfo, active, stp);
-        else if (b == 48) se = kWide ? launch_small<48, 768>(st, batch, nslab, ws.Gp, ws.Hp, msw, 1e-18, ws.T, ws.theta, hinfo, active, stp)
-                                     : launch_small<48, 256>(st, batch, nslab, ws.Gp, ws.Hp, msw, 1e-18, ws.T, ws.theta, hinfo, active, stp);
-        else se = kWide ? launch_small<64, 1024>(st, batch, nslab, ws.Gp, ws.Hp, msw, 1e-18, ws.T, ws.theta, hinfo, active, stp)
-                        : launch_small<64, 512>(st, batch, nslab, ws.Gp, ws.Hp, msw, 1e-18, ws.T, ws.theta, hinfo, active, stp);
+        if (b == 32) se = kWide ? launch_small<32, 512, true>(st, batch, nslab, ws.Gp, ws.Hp, msw, 1e-18, ws.T, ws.theta, hinfo, active, stp)
+                                : launch_small<32, 256, false>(st, batch, nslab, ws.Gp, ws.Hp, msw, 1e-18, ws.T, ws.theta, hinfo, active, stp);
+        else if (b == 48) se = kWide ? launch_small<48, 768, true>(st, batch, nslab, ws.Gp, ws.Hp, msw, 1e-18, ws.T, ws.theta, hinfo, active, stp)
+                                     : launch_small<48, 256, false>(st, batch, nslab, ws.Gp, ws.Hp, msw, 1e-18, ws.T, ws.theta, hinfo, active, stp);
+        else se = kWide ? launch_small<64, 1024, true>(st, batch, nslab, ws.Gp, ws.Hp, msw, 1e-18, ws.T, ws.theta, hinfo, active, stp)
+                        : launch_small<64, 512, false>(st, batch, nslab, ws.Gp, ws.Hp, msw, 1e-18, ws.T, ws.theta, hinfo, active, stp);
         LCHK(se);
         // Ritz vectors into P[ix], the next filter's first step into P[iy]; the residual partials are summed by the host (row tiles in order)
         hipLaunchKernelGGL(lead_rot_kernel, dim3(nrt, b / 16, batch), dim3(256), 0, st, ne, b, ys, ws.P[ic], ws.Zb, ws.T, ws.theta, ws.P[ix],
