@@ -589,8 +589,8 @@ class Engine:
         page-locked blocks, which the device fills by DMA: a block is handed out again once nothing refers to the array made
         from it or to any slice of it; otherwise, and for small hops, an ordinary fresh array."""
         nbytes = int(np.prod(shape)) * 8
-        if nbytes < (1 << 20) or not self.pooled_results:
-            return np.empty(shape, dtype=np.float64)
+        if nbytes < (1 << 20) or not self.pooled_results or not hasattr(sys, "getrefcount"):
+            return np.empty(shape, dtype=np.float64)          # (the pool tells an idle block by its reference counts: CPython)
         pool = self._pin_pool.setdefault(tuple(shape), [])
         for ent in pool:
             # [array, references to the array when idle, references to its owner block when idle]
