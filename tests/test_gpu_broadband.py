@@ -531,3 +531,26 @@ def test_broadband_large_hops_come_from_a_page_locked_pool(golden):
     assert np.array_equal(kept[0], snap[0])                      # the slice still held was not written over
     a.close()
     b.close()
+
+
+def test_broadband_silence_is_finite(golden):
+    """All-zero response buffers and all-zero input: R_bright = 0, R_dark + reg I = reg I.  Every eigenvalue is zero -- nothing for a
+    subspace iteration to separate -- and the hop must still come back with finite (zero) outputs, per hop and for a whole signal."""
+    g, rirs = golden("g1_broadband_cfg1"), golden("rirs_cfg1")
+    ap = make(g, rirs)
+    ap.set_state({"response": np.zeros_like(g["init_response"]), "target_response": np.zeros_like(g["init_target_response"])})
+    H = 128
+    z = np.zeros(H)
+    for _ in range(2):
+        out = ap.process_input_buffers(z, z)
+        for q in range(4):
+            assert np.isfinite(np.stack(out[q])).all() and np.abs(np.stack(out[q])).max() == 0.0
+    res = ap.process_signal(np.zeros(5 * H), np.zeros(5 * H))
+    for q in range(4):
+        assert np.isfinite(np.stack(res[q])).all() and np.abs(np.stack(res[q])).max() == 0.0
+    assert np.isfinite(np.asarray(ap.lambda_A)).all()
+    # and a signal that starts after silence carries on
+    x = np.random.default_rng(3).standard_normal((2, 3 * H))
+    res = ap.process_signal(x[0], x[1])
+    assert all(np.isfinite(np.stack(res[q])).all() for q in range(4))
+    ap.close()
