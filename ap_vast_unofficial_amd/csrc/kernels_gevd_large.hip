@@ -122,6 +122,10 @@ __device__ __forceinline__ d4 wave_mm16(FA fa, FB fb, int lane) {
 // forms the updated diagonal block D = B[K,K] - sum_J L[K,J] L[K,J]^T itself and eliminates [D | I] in LDS (unscaled
 // columns of L_D on the left, rows of L_D^-1 up to 1/sqrt(d) on the right), then writes L[I,K] = T L_D^-T.
 // The strictly lower tiles of B are replaced by L; LiBuf[k] receives L_D^-1 (L_D itself is not kept).
+// diagnostics (APV_LARGE_DEBUG=2): s_memtime of thread 0 of the LAST row tile's workgroup of matrix 0 at the phase boundaries, [panel][4]
+__device__ unsigned long long g_panel_stamps[64 * 4];
+__device__ int g_panel_stamps_on;
+
 template <bool WAVE_ELIM>
 __global__ void __launch_bounds__(256) chol_panel_kernel(int ld, int k, int nbk, double* __restrict__ B,
                                                          double* __restrict__ LiBuf, int* __restrict__ flag,
@@ -137,6 +141,9 @@ __global__ void __launch_bounds__(256) chol_panel_kernel(int ld, int k, int nbk,
     LiBuf += (size_t)z * nbk * BT * BT;
     const int I = k + blockIdx.x;
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    const bool stamping = g_panel_stamps_on && z == 0 && I == nbk - 1 && tid == 0 && k < 64;
+    auto stamp = [&](int i) { if (stamping) g_panel_stamps[4 * k + i] = __builtin_amdgcn_s_memtime(); };
+    stamp(0);
     // the products of the left-looking update on the f64 matrix cores, one 16 x 16 quadrant per wave (round 3: they ran on the
     // vector ALU with four LDS reads per four multiply-adds, 3 us per product; the late panels of n = 800 took 100-200 us)
     const int wq = tid >> 6, lq = tid & 63;
@@ -172,6 +179,12 @@ __global__ void __launch_bounds__(256) chol_panel_kernel(int ld, int k, int nbk,
         }
         __syncthreads();
     }
+    // (Measured with the phase stamps below, APV_LARGE_DEBUG=2: a term of this loop costs ~2 050 cycles = 0.85 us, the diagonal block
+    // 9.6 us, the last product and the stores 0.45 us.  Three other forms of the loop were tried at the end of round 4 -- two and
+    // four terms per stage with the next stage's tiles in registers, the two accumulator chains of a wave interleaved and sharing
+    // their B operand, a term's 24 operands read before its 16 MFMAs -- and every one of them cost the same 2 050 cycles a term:
+    // it is neither the trip to the earlier panels' tiles nor the LDS round trips in front of the matrix instructions.)
+    stamp(1);
     for (int i = 0; i < 4; ++i) {                      // accumulator element i of wave wq: row (wq >> 1) 16 + (lane >> 4) + 4 i
         const int r = (wq >> 1) * 16 + (lq >> 4) + 4 * i, c = (wq & 1) * 16 + (lq & 15);
         Dm[r * LS + c] = B[(size_t)(k * BT + r) * ld + k * BT + c] + accD[i];
@@ -257,6 +270,7 @@ __global__ void __launch_bounds__(256) chol_panel_kernel(int ld, int k, int nbk,
         for (int i = 0; i < 4; ++i) La[((wq >> 1) * 16 + (lq >> 4) + 4 * i) * LS + (wq & 1) * 16 + (lq & 15)] = tsave[i];
         __syncthreads();
     }
+    stamp(2);
     if (I == k) {
         // only the inverse of the diagonal block is ever used again; B[K,K] itself must stay as it is, the other
         // workgroups of this launch are still reading it
@@ -272,6 +286,7 @@ __global__ void __launch_bounds__(256) chol_panel_kernel(int ld, int k, int nbk,
         const int r = (wq >> 1) * 16 + (lq >> 4) + 4 * i, c = (wq & 1) * 16 + (lq & 15);
         B[(size_t)(I * BT + r) * ld + k * BT + c] = o[i];
     }
+    stamp(3);
 }
 
 // W = L^-1 by forward substitution on tiles: workgroup (K, cq) owns 8 columns of block column K and walks down
@@ -1240,10 +1255,23 @@ int apv_gevd_large(apv_handle* h, int n, int batch, const double* d_A, const dou
     LCHK(hipMemsetAsync(ws.acc, 0, sizeof(double) * 3 * batch, st));
     hipLaunchKernelGGL(load_pair_kernel, dim3(gx, ne, batch), dim3(TPB), 0, st, n, ne, ld, d_A, d_B, reg, d_reg_scale, ws.C0, ws.Bw, ms);   // C0 holds A for now
     static const bool old_panel = getenv("APV_LARGE_OLDPANEL") != nullptr;       // A/B switch: the 32-step elimination with a barrier a step
+    static const bool panel_dbg = getenv("APV_LARGE_DEBUG") && atoi(getenv("APV_LARGE_DEBUG")) >= 2;
+    if (panel_dbg) {
+        const int on = 1;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_panel_stamps_on), &on, sizeof(int));
+    }
     for (int k = 0; k < nbk; ++k)
         hipLaunchKernelGGL((old_panel ? chol_panel_kernel<false> : chol_panel_kernel<true>), dim3(nbk - k, 1, batch), dim3(256), 0, st, ld, k,
                            nbk, ws.Bw, ws.Li, ws.flag, ms);
     // APV_LARGE_OLDPRE=1: round 3's tile walk for W = L^-1 and its 32 x 32-tile products (A/B switch)
+    if (panel_dbg) {
+        (void)hipStreamSynchronize(st);
+        unsigned long long hs[64 * 4];
+        (void)hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_panel_stamps), sizeof(hs));
+        for (int k = 0; k < nbk - 1 && k < 64; k += (nbk > 12 ? 4 : 1))
+            fprintf(stderr, "[apv gevd_large] panel %d, last row tile, s_memtime ticks: left-looking terms %llu, diagonal block %llu, product + store %llu\n", k,
+                    hs[4 * k + 1] - hs[4 * k], hs[4 * k + 2] - hs[4 * k + 1], hs[4 * k + 3] - hs[4 * k + 2]);
+    }
     static const bool old_pre = getenv("APV_LARGE_OLDPRE") != nullptr;
     if (old_pre) {
         hipLaunchKernelGGL(tri_inverse_kernel, dim3(nbk, BT / 8, batch), dim3(256), 0, st, ld, nbk, ws.Bw, ws.Li, ws.W, ws.flag, ms);
