@@ -66,12 +66,12 @@ __global__ void __launch_bounds__(256) lead_init_kernel(int n, int ne, int b, do
 // is dealt to its four waves in chunks of 16 (one 32-byte load per lane of A's rows: lane (r, kq) holds A[r][k0 + 4 kq .. + 3],
 // and MFMA j of the chunk contracts the indices k0 + 4 kq + j -- any order of the contraction index serves, as long as the B
 // operand follows it), the four partial tiles meet in LDS in a fixed order.
-template <int NB>
-__global__ void __launch_bounds__(256) lead_mult_kernel(int ne, int lda, size_t a_stride, const double* __restrict__ A, int b,
+template <int NB, int NWV = 4>
+__global__ void __launch_bounds__(64 * NWV) lead_mult_kernel(int ne, int lda, size_t a_stride, const double* __restrict__ A, int b,
                                                         size_t y_stride, const double* __restrict__ Yc,
                                                         const double* __restrict__ Yp, double* __restrict__ Yo, int rows_out,
                                                         int ldo, size_t o_stride, LeadCoef cf) {
-    __shared__ double red[4][NB][256];
+    __shared__ double red[NWV][NB][256];
     const int z = blockIdx.z;
     if (!((cf.active >> z) & 1u)) return;
     const double ca = cf.dev ? cf.dev[(2 * z + cf.dev_step) * 3] : cf.a[z], cb = cf.dev ? cf.dev[(2 * z + cf.dev_step) * 3 + 1] : cf.b[z],
@@ -113,8 +113,8 @@ __global__ void __launch_bounds__(256) lead_mult_kernel(int ne, int lda, size_t 
             }
         };
 #pragma unroll
-        for (int u = 0; u < PF; ++u) fetch(w * 16 + 64 * u, u);
-        for (int k0 = w * 16; k0 < ne; k0 += 64 * PF) {
+        for (int u = 0; u < PF; ++u) fetch(w * 16 + 16 * NWV * u, u);
+        for (int k0 = w * 16; k0 < ne; k0 += 16 * NWV * PF) {
             d4 cav[PF];
             double cbv[PF][4][NB];
 #pragma unroll
@@ -126,10 +126,10 @@ __global__ void __launch_bounds__(256) lead_mult_kernel(int ne, int lda, size_t 
                     for (int c = 0; c < NB; ++c) cbv[u][j][c] = bv[u][j][c];
             }
 #pragma unroll
-            for (int u = 0; u < PF; ++u) fetch(k0 + 64 * (PF + u), u);
+            for (int u = 0; u < PF; ++u) fetch(k0 + 16 * NWV * (PF + u), u);
 #pragma unroll
             for (int u = 0; u < PF; ++u)
-                if (k0 + 64 * u < ne) {
+                if (k0 + 16 * NWV * u < ne) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -142,12 +142,15 @@ __global__ void __launch_bounds__(256) lead_mult_kernel(int ne, int lda, size_t 
 #pragma unroll
         for (int t = 0; t < 4; ++t) red[w][c][t * 64 + lane] = acc[c][t];
     __syncthreads();
-    // wave w finishes accumulator row t = w: element (row0 + kq + 4 w, col0 + 16 c + il)
+    // wave w < 4 finishes accumulator row t = w: element (row0 + kq + 4 w, col0 + 16 c + il); the partials are added in wave order
+    if (w >= 4) return;
     const int row = row0 + kq + 4 * w;
 #pragma unroll
     for (int c = 0; c < NB; ++c) {
         const int col = col0 + 16 * c + il;
-        const double s = ((red[0][c][w * 64 + lane] + red[1][c][w * 64 + lane]) + red[2][c][w * 64 + lane]) + red[3][c][w * 64 + lane];
+        double s = ((red[0][c][w * 64 + lane] + red[1][c][w * 64 + lane]) + red[2][c][w * 64 + lane]) + red[3][c][w * 64 + lane];
+#pragma unroll
+        for (int x = 4; x < NWV; ++x) s += red[x][c][w * 64 + lane];
         double v = ca * s;
         if (cb != 0.0) v = __builtin_fma(cb, Yc[(size_t)row * b + col], v);
         if (cg != 0.0) v = __builtin_fma(cg, Yp[z * y_stride + (size_t)row * b + col], v);
@@ -779,8 +782,15 @@ int apv_gevd_lead(apv_handle* h, int n, int ne, int batch, int b, int rank, cons
         // 16 x 16 outputs per workgroup while that fills the chip, 16 x 32 beyond
         const long wgs = (long)nrt * (b / 16) * batch;
         static const int kForceNB = getenv("APV_LEAD_NB") ? atoi(getenv("APV_LEAD_NB")) : 0;      // tuning aid
+        // waves that split K in a 16 x 16 workgroup (tuning aid; measured at n = 800 / 256, whole solver: 4 -> 1.372 / 0.366 ms, 8 -> 1.339 /
+        // 0.358, 16 -> 1.421 / 0.396: the product is not bound by what one wave has in flight)
+        static const int kWaves = getenv("APV_LEAD_MULT_WAVES") ? atoi(getenv("APV_LEAD_MULT_WAVES")) : 8;
         if ((kForceNB == 2 || (kForceNB == 0 && wgs > 2048)) && b % 32 == 0)
             hipLaunchKernelGGL((lead_mult_kernel<2>), dim3(nrt * (b / 32), 1, batch), dim3(256), 0, st, ne, ne, ms, A, b, ys, Yc, Yp, Yo, rows_out, ldo, os, cf);
+        else if (kWaves == 8)
+            hipLaunchKernelGGL((lead_mult_kernel<1, 8>), dim3(nrt * (b / 16), 1, batch), dim3(512), 0, st, ne, ne, ms, A, b, ys, Yc, Yp, Yo, rows_out, ldo, os, cf);
+        else if (kWaves == 16)
+            hipLaunchKernelGGL((lead_mult_kernel<1, 16>), dim3(nrt * (b / 16), 1, batch), dim3(1024), 0, st, ne, ne, ms, A, b, ys, Yc, Yp, Yo, rows_out, ldo, os, cf);
         else
             hipLaunchKernelGGL((lead_mult_kernel<1>), dim3(nrt * (b / 16), 1, batch), dim3(256), 0, st, ne, ne, ms, A, b, ys, Yc, Yp, Yo, rows_out, ldo, os, cf);
     };
