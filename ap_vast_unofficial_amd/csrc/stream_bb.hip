@@ -95,6 +95,8 @@ struct apv_bb {
     double* spec_out;      // [n_out][K] c128: the output stage's own spectra (the front stages use `spec` at the same time)
     hipStream_t front;     // the front stages of apv_bb_process_signal
     hipStream_t copy;      // a group's outputs on their way to the host while the next group is solved
+    hipStream_t front2;    // the statistics of hop h beside the K1 / WOLA chain of hop h + 1 (apv_bb_process_signal)
+    hipEvent_t ev_ring, ev_stat;             // hop's statistics rings written / read
     hipEvent_t ev_front[2], ev_back[2];      // group set filled / group set read for the last time
     hipEvent_t ev_out[2];                    // a group's outputs have reached g_pin
 };
@@ -704,6 +706,9 @@ void apv_bb_free(apv_handle* h) {
     if (s->pin_out) (void)hipHostFree(s->pin_out);
     if (s->front) (void)hipStreamDestroy(s->front);
     if (s->copy) (void)hipStreamDestroy(s->copy);
+    if (s->front2) (void)hipStreamDestroy(s->front2);
+    if (s->ev_ring) (void)hipEventDestroy(s->ev_ring);
+    if (s->ev_stat) (void)hipEventDestroy(s->ev_stat);
     for (int i = 0; i < 2; ++i) {
         if (s->ev_front[i]) (void)hipEventDestroy(s->ev_front[i]);
         if (s->ev_back[i]) (void)hipEventDestroy(s->ev_back[i]);
@@ -879,7 +884,10 @@ static BbHop bb_own_hop(apv_bb* s) {
 
 // stages 1-3 of a hop (and the input spectra of stage 6, which depend on the input ring as it stands now): everything in front
 // of the joint diagonalisation.  t_stage: optional wall times of the stages (APV_BB_TIMING).
-static int bb_front(apv_handle* h, apv_bb* s, const BbHop& q, double* t_stage, hipStream_t st) {
+// st2 (optional, apv_bb_process_signal): the statistics of the hop run there, so that the next hop's K1 / WOLA chain on `st` does not
+// wait for them -- the two halves of a hop are about equal at cfg1, ~40 us of small dependent launches each.  The rings order them:
+// the statistics read the rings after this hop's append (ev_ring) and the next hop's append waits for them (ev_stat).
+static int bb_front(apv_handle* h, apv_bb* s, const BbHop& q, double* t_stage, hipStream_t st, hipStream_t st2 = nullptr) {
     const int N = s->N, H = s->H, K = s->K, L = s->L, M = s->M, C = s->C, P = s->P, J = s->J, S = s->S, n = s->n;
     std::string why;
     int n_stage = 0;
@@ -938,8 +946,15 @@ static int bb_front(apv_handle* h, apv_bb* s, const BbHop& q, double* t_stage, h
         }
     }
     BCHK(h, apv_launch_synthesis(1, N, H, s->n_all, s->pspec_all, K, 1, s->ov_all, nullptr, st, &why));
+    if (st2) BCHK(h, hipStreamWaitEvent(st, s->ev_stat, 0));          // the previous hop's statistics have read the rings
     hipLaunchKernelGGL(ring_append_f64_kernel, dim3((H + 255) / 256, s->n_all), dim3(256), 0, st, S, H, s->stat_off, s->ov_all, (long)N,
                        s->stats_all);
+    hipStream_t const chain = st;
+    if (st2) {
+        BCHK(h, hipEventRecord(s->ev_ring, st));
+        BCHK(h, hipStreamWaitEvent(st2, s->ev_ring, 0));
+        st = st2;                                                      // everything up to 6a below is the statistics stage
+    }
     stage_done();
     // 3: statistics.  R order: bright [0] A->A, [1] B->B; dark [2] A->B, [3] B->A
     const int stat_src[4] = {0, 3, 1, 2};
@@ -985,6 +1000,10 @@ static int bb_front(apv_handle* h, apv_bb* s, const BbHop& q, double* t_stage, h
             const double coef = i < 2 ? h->cfg.reg_bright : h->cfg.reg_dark;
             hipLaunchKernelGGL(add_rel_diag_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, q.Rq[i], coef, q.nrm + i);
         }
+    }
+    if (st2) {
+        BCHK(h, hipEventRecord(s->ev_stat, st2));
+        st = chain;
     }
     // 6a: the spectra of the two input blocks as the ring holds them now
     BCHK(h, apv_launch_analysis(1, N, 2, s->inblk, N, N, s->ring_off, 1, q.inspec, K, 1, st, &why));
@@ -1166,6 +1185,9 @@ int apv_bb_process_signal(apv_handle* h, int32_t n_hops, const double* h_in_A, c
         if (!s->front) {
             BCHK(h, hipStreamCreateWithFlags(&s->front, hipStreamNonBlocking));
             BCHK(h, hipStreamCreateWithFlags(&s->copy, hipStreamNonBlocking));
+            BCHK(h, hipStreamCreateWithFlags(&s->front2, hipStreamNonBlocking));
+            BCHK(h, hipEventCreateWithFlags(&s->ev_ring, hipEventDisableTiming));
+            BCHK(h, hipEventCreateWithFlags(&s->ev_stat, hipEventDisableTiming));
             for (int i = 0; i < 2; ++i) {
                 BCHK(h, hipEventCreateWithFlags(&s->ev_front[i], hipEventDisableTiming));
                 BCHK(h, hipEventCreateWithFlags(&s->ev_back[i], hipEventDisableTiming));
@@ -1195,10 +1217,21 @@ int apv_bb_process_signal(apv_handle* h, int32_t n_hops, const double* h_in_A, c
     hipStream_t fs = s->front;
     // every exit below drains both streams first: copies into the caller's h_out may be in flight
     hipStream_t cs = s->copy;
-    // (Enqueueing the next group's front stages from a helper thread while this one solves was tried once the input copies had
-    // become one per group: no gain, 0.096 against 0.094 ms per hop at cfg1 -- a group is now bound by its sixteen hops' front
-    // stages on the device, ~90 us of small dependent launches each.)
-    auto drained = [&](int rc) { (void)hipStreamSynchronize(fs); (void)hipStreamSynchronize(st); (void)hipStreamSynchronize(cs); return rc; };
+    // the statistics of a hop on a stream of their own beside the next hop's K1 / WOLA chain (bb_front); APV_BB_FRONT2=0: one stream
+    static const bool front2 = getenv("APV_BB_FRONT2") == nullptr || atoi(getenv("APV_BB_FRONT2")) != 0;
+    hipStream_t fs2 = front2 ? s->front2 : nullptr;
+    // The front stages of group g + 1 (~18 runtime calls a hop) are enqueued by a helper thread while this one solves group g: the
+    // solve's passes block the host, and with the statistics on a stream of their own a group is bound by the host's enqueueing,
+    // not by the device any more (0.6 ms of a group's 1.6 at cfg1).  (Tried earlier in the round, when a group was still bound
+    // by its front stages on the device: no gain then.)  APV_BB_FRONT_THREAD=0: enqueue them from this thread, before the solve.
+    static const bool front_threaded = getenv("APV_BB_FRONT_THREAD") == nullptr || atoi(getenv("APV_BB_FRONT_THREAD")) != 0;
+    std::thread front_thr;
+    int front_rc = APV_OK;
+    auto drained = [&](int rc) {
+        if (front_thr.joinable()) front_thr.join();
+        (void)hipStreamSynchronize(fs); (void)hipStreamSynchronize(s->front2); (void)hipStreamSynchronize(st); (void)hipStreamSynchronize(cs);
+        return rc;
+    };
 #define BDCHK(h, call)                                                                                                     \
     do {                                                                                                                    \
         hipError_t _e = (call);                                                                                             \
@@ -1208,6 +1241,7 @@ int apv_bb_process_signal(apv_handle* h, int32_t n_hops, const double* h_in_A, c
     std::vector<BbHop> hops[2];
     // the front stages of group g, all on the front stream (rings, histories and overlap buffers are sequential state)
     auto enqueue_front = [&](int g) -> int {
+        auto drained = [](int rc) { return rc; };          // (may run on the helper thread: the caller drains)
         const int set = g & 1, h0 = g * G, g_n = n_hops - h0 < G ? n_hops - h0 : G;
         double* xin = s->g_xin + set * z_xin;
         // (one copy per group from page-locked staging: two copies per hop from the caller's pageable arrays were 32 blocking calls)
@@ -1233,9 +1267,10 @@ int apv_bb_process_signal(apv_handle* h, int32_t n_hops, const double* h_in_A, c
             q.nrm = s->g_nrm + set * z_nrm + (size_t)i * 4;
             q.nrm_dark = s->g_nrm + set * z_nrm + (size_t)G * 4 + (size_t)i * nz;
             q.inspec = s->g_inspec + set * z_insp + (size_t)i * 2 * K * 2;
-            const int rc = bb_front(h, s, q, nullptr, fs);
+            const int rc = bb_front(h, s, q, nullptr, fs, fs2);
             if (rc != APV_OK) return drained(rc);
         }
+        if (fs2) BDCHK(h, hipStreamWaitEvent(fs, s->ev_stat, 0));          // the last hop's statistics belong to the group
         BDCHK(h, hipEventRecord(s->ev_front[set], fs));
         return APV_OK;
     };
@@ -1245,7 +1280,7 @@ int apv_bb_process_signal(apv_handle* h, int32_t n_hops, const double* h_in_A, c
     BDCHK(h, hipEventRecord(s->ev_back[0], st));
     BDCHK(h, hipStreamWaitEvent(fs, s->ev_back[0], 0));
     int rc = enqueue_front(0);
-    if (rc != APV_OK) return rc;
+    if (rc != APV_OK) return drained(rc);
     static const bool timing = getenv("APV_BB_TIMING") != nullptr;
     auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     for (int g = 0; g < n_groups; ++g) {
@@ -1254,7 +1289,13 @@ int apv_bb_process_signal(apv_handle* h, int32_t n_hops, const double* h_in_A, c
         if (g + 1 < n_groups) {
             // group g + 1 fills the other set, which the back half of group g - 1 has read (its event is on the handle's stream)
             if (g >= 1) BDCHK(h, hipStreamWaitEvent(fs, s->ev_back[set ^ 1], 0));
-            if ((rc = enqueue_front(g + 1)) != APV_OK) return rc;
+            if (front_threaded) {
+                front_rc = APV_OK;
+                front_thr = std::thread([&, g] {
+                    (void)hipSetDevice(h->device);
+                    front_rc = enqueue_front(g + 1);
+                });
+            } else if ((rc = enqueue_front(g + 1)) != APV_OK) return drained(rc);
         }
         BDCHK(h, hipStreamWaitEvent(st, s->ev_front[set], 0));
         double t_b = now_ms(), t_b2 = t_b;
@@ -1316,6 +1357,10 @@ int apv_bb_process_signal(apv_handle* h, int32_t n_hops, const double* h_in_A, c
         const double t_d = now_ms();
         if (!direct && g >= 1) collect(g - 1);
         if (!direct && g + 1 == n_groups) collect(g);
+        if (front_thr.joinable()) {
+            front_thr.join();
+            if (front_rc != APV_OK) return drained(front_rc);
+        }
         if (timing) {
             const double t_e = now_ms();
             (void)hipStreamSynchronize(st);
@@ -1324,6 +1369,7 @@ int apv_bb_process_signal(apv_handle* h, int32_t n_hops, const double* h_in_A, c
         }
     }
     BDCHK(h, hipStreamSynchronize(fs));
+    BDCHK(h, hipStreamSynchronize(s->front2));
     BDCHK(h, hipStreamSynchronize(st));
     BDCHK(h, hipStreamSynchronize(cs));
     BDCHK(h, hipGetLastError());
