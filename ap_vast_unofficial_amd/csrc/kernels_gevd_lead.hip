@@ -295,6 +295,58 @@ __device__ __forceinline__ d4 lead_tile(const double* A, const double* Bm, int l
     return acc;
 }
 
+// ONE wave: D (order 16, symmetric, in LDS with row stride ld) -> W = L^-1 with D = L L^T, written to Wout (lower triangle, zeros
+// above).  [D | I] is eliminated with the rows in registers: lane = row i + 16 x column group cq holds D[i][4 cq ..] and the right
+// half's [i][4 cq ..]; a step hands the pivot column of the left half (= its pivot row: what is left is symmetric) and the pivot
+// row of the right half round through 32 doubles of LDS -- no barrier, the LDS executes a wave's accesses in order (the scheme
+// of kernels_gevd64.hip stage 1 and of chol_panel_kernel).  Returns true when a pivot is <= floor or not finite.
+__device__ __forceinline__ bool lead_wave_inv16(const double* D, double* Wout, int ld, double* buf, int lane, double floor) {
+    const int i = lane & 15, cq = lane >> 4;
+    double b[4], w[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        b[u] = D[i * ld + 4 * cq + u];
+        w[u] = (4 * cq + u == i) ? 1.0 : 0.0;
+    }
+    double dsc = 1.0;
+    bool bad = false;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int qc = q >> 2, qu = q & 3;
+        if (cq == qc) buf[i] = b[qu];
+        if (i == q) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) buf[16 + 4 * cq + u] = w[u];
+        }
+        const double dq = buf[q];
+        bad = bad || !(dq > floor) || !(dq < 1e300);
+        double inv = __builtin_amdgcn_rcp(dq);
+        inv = inv * __builtin_fma(-dq, inv, 2.0);
+        inv = inv * __builtin_fma(-dq, inv, 2.0);
+        if (i == q) dsc = lead_rsq(dq);
+        if (i > q) {
+            const double m = buf[i] * inv;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                b[u] = __builtin_fma(-m, buf[4 * cq + u], b[u]);
+                w[u] = __builtin_fma(-m, buf[16 + 4 * cq + u], w[u]);
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) Wout[i * ld + 4 * cq + u] = (4 * cq + u <= i) ? w[u] * dsc : 0.0;
+    return bad;
+}
+
+// one wave, acc += fa(., k) fb(k, .) over 16 values of k on v_mfma_f64_16x16x4_f64: acc[t] = element (kq + 4 t, il)
+template <typename FA, typename FB>
+__device__ __forceinline__ d4 lead_mm16(FA fa, FB fb, int lane, d4 acc) {
+    const int il = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int k0 = 0; k0 < 16; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fa(il, k0 + kq), fb(k0 + kq, il), acc, 0, 0, 0);
+    return acc;
+}
+
 // The projected problem of one pass: (H, G) of order B -> T [B][B] (X = Y T has orthonormal columns that diagonalise C on
 // span Y), theta [B] descending; hinfo[z] = {theta[B], Gram breakdown, sweeps, Jacobi met its bound, -} is what the host reads.
 template <int B, int NT, bool MOVE>
@@ -370,6 +422,77 @@ __global__ void __launch_bounds__(NT) lead_small_kernel(int nslab, const double*
     }
     __syncthreads();
     stamp(1);
+    if constexpr (MOVE) {
+        // c: W = L^-1 with G = L L^T, blocked in 16 x 16 tiles as the order-64 kernel's factorisation: the diagonal tile is inverted by
+        // ONE wave (lead_wave_inv16, 16 steps without a barrier), the panel L_ik = G_ik W_kk^T and the trailing update
+        // G_ij -= L_ik L_jk^T are tile products on the matrix cores, and the off-diagonal tiles of W follow by block forward
+        // substitution, W_ba = -W_bb sum_k L_bk W_ka, one block diagonal after the other: 5 B / 16 - 2 barriers instead of B, and
+        // no pass over all of both halves per pivot (the loop below: 28 us of the kernel's 103 at B = 64).  The pivots are those of
+        // the unblocked elimination; one at or below 1e-13 (the Gram matrix has a unit diagonal) is a breakdown.
+        const int il = lane & 15, kq = lane >> 4;
+        for (int kb = 0; kb < NTL; ++kb) {
+            const int o = 16 * kb;
+            if (wv == 0) {
+                const bool bad = lead_wave_inv16(S0 + o * LD + o, S2 + o * LD + o, LD, th, lane, 1e-13);
+                if (bad && lane == 0) fail = 1;
+            }
+            __syncthreads();
+            if (fail || kb == NTL - 1) break;                          // (uniform: a shared word, read after the barrier)
+            for (int ib = kb + 1 + wv; ib < NTL; ib += NW) {
+                const double* const Gik = S0 + (16 * ib) * LD + o;
+                const double* const Wkk = S2 + o * LD + o;
+                const d4 t = lead_mm16([&](int i, int kk) { return Gik[i * LD + kk]; }, [&](int kk, int j) { return Wkk[j * LD + kk]; }, lane,
+                                       d4{0.0, 0.0, 0.0, 0.0});
+#pragma unroll
+                for (int u = 0; u < 4; ++u) S0[(16 * ib + kq + 4 * u) * LD + o + il] = t[u];      // only this wave reads this tile
+            }
+            __syncthreads();
+            const int rem = NTL - 1 - kb, ntile = rem * (rem + 1) / 2;
+            for (int tl = wv; tl < ntile; tl += NW) {
+                int ib = kb + 1, w2 = tl;
+                while (w2 > ib - kb - 1) {                                 // tiles (kb+1,kb+1), (kb+2,kb+1), (kb+2,kb+2), ...
+                    w2 -= ib - kb;
+                    ++ib;
+                }
+                const int jb = kb + 1 + w2;
+                const double* const Lik = S0 + (16 * ib) * LD + o;
+                const double* const Ljk = S0 + (16 * jb) * LD + o;
+                const d4 t = lead_mm16([&](int i, int kk) { return Lik[i * LD + kk]; }, [&](int kk, int j) { return Ljk[j * LD + kk]; }, lane,
+                                       d4{0.0, 0.0, 0.0, 0.0});
+#pragma unroll
+                for (int u = 0; u < 4; ++u) S0[(16 * ib + kq + 4 * u) * LD + 16 * jb + il] -= t[u];
+            }
+            __syncthreads();
+        }
+        if (fail) {
+            if (tid == 0) {
+                hinfo[(size_t)z * (B + 4) + B] = 1.0;
+                hinfo[(size_t)z * (B + 4) + B + 1] = 0.0;
+                hinfo[(size_t)z * (B + 4) + B + 2] = 0.0;
+            }
+            return;
+        }
+        for (int dg = 1; dg < NTL; ++dg) {
+            for (int a = wv; a + dg < NTL; a += NW) {
+                const int bb = a + dg;
+                d4 acc = {0.0, 0.0, 0.0, 0.0};
+                for (int k = a; k < bb; ++k) {
+                    const double* const Lbk = S0 + (16 * bb) * LD + 16 * k;
+                    const double* const Wka = S2 + (16 * k) * LD + 16 * a;
+                    acc = lead_mm16([&](int i, int kk) { return Lbk[i * LD + kk]; }, [&](int kk, int j) { return Wka[kk * LD + j]; }, lane, acc);
+                }
+                double* const Wba = S2 + (16 * bb) * LD + 16 * a;        // the sum first, as the second product's operand
+#pragma unroll
+                for (int u = 0; u < 4; ++u) Wba[(kq + 4 * u) * LD + il] = acc[u];
+                const double* const Wbb = S2 + (16 * bb) * LD + 16 * bb;
+                const d4 t = lead_mm16([&](int i, int kk) { return Wbb[i * LD + kk]; }, [&](int kk, int j) { return Wba[kk * LD + j]; }, lane,
+                                       d4{0.0, 0.0, 0.0, 0.0});
+#pragma unroll
+                for (int u = 0; u < 4; ++u) Wba[(kq + 4 * u) * LD + il] = -t[u];
+            }
+            __syncthreads();
+        }
+    } else {
     // c: eliminate [G | I]: G = Lt D Lt^T, the right half becomes Lt^-1; pivots stay on G's diagonal
     // (a register-resident variant -- rows in registers, pivot row and column published through LDS, the 64 steps unrolled --
     // was measured: 8 256 instructions, and SLOWER, 178 949 ticks against 66 928 at B = 64; this loop stays)
@@ -403,6 +526,7 @@ __global__ void __launch_bounds__(NT) lead_small_kernel(int nslab, const double*
     __syncthreads();
     for (int e = tid; e < B * B; e += NT) S2[(e / B) * LD + e % B] *= th[e / B];        // W = D^-1/2 Lt^-1
     __syncthreads();
+    }
     stamp(2);
     // d: M = W H W^T
     for (int tile = wv; tile < NTL * NTL; tile += NW) {
