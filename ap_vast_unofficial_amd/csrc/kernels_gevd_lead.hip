@@ -382,10 +382,22 @@ __global__ void __launch_bounds__(NT) lead_small_kernel(int nslab, const double*
         const int pair = e >> 8, rem = e & 255, t = rem >> 6, ln = rem & 63;
         int ti = 0, tj = pair;
         while (tj > ti) { tj -= ti + 1; ++ti; }
+        // (four slabs' loads go out together, the additions stay in slab order: one trip to memory per four slabs instead of one per slab)
         double g = 0.0, hh = 0.0;
-        for (int s = 0; s < nslab; ++s) {
-            g += Gp[((size_t)s * NPAIR + pair) * 256 + rem];
-            hh += Hp[((size_t)s * NPAIR + pair) * 256 + rem];
+        for (int s0 = 0; s0 < nslab; s0 += 4) {
+            double gv[4], hv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool in = s0 + u < nslab;
+                gv[u] = in ? Gp[((size_t)(s0 + u) * NPAIR + pair) * 256 + rem] : 0.0;
+                hv[u] = in ? Hp[((size_t)(s0 + u) * NPAIR + pair) * 256 + rem] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (s0 + u < nslab) {
+                    g += gv[u];
+                    hh += hv[u];
+                }
         }
         const int i = 16 * ti + (ln >> 4) + 4 * t, j = 16 * tj + (ln & 15);
         S0[i * LD + j] = g;
