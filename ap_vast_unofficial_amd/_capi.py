@@ -26,7 +26,7 @@ EXPORTS = (
     "apv_create", "apv_destroy", "apv_last_error", "apv_abi_version",
     "apv_dev_alloc", "apv_dev_free", "apv_memcpy_h2d", "apv_memcpy_d2h", "apv_sync",
     "apv_timer_start", "apv_timer_stop",
-    "apv_update_dev", "apv_update", "apv_corr_dev", "apv_corr_bf16_dev", "apv_to_bf16_dev", "apv_gevd_vast_dev", "apv_jdiag_batched", "apv_jdiag_large", "apv_jdiag_leading", "apv_jdiag_large_c128",
+    "apv_update_dev", "apv_set_update_streams", "apv_update", "apv_corr_dev", "apv_corr_bf16_dev", "apv_to_bf16_dev", "apv_gevd_vast_dev", "apv_jdiag_batched", "apv_jdiag_large", "apv_jdiag_leading", "apv_jdiag_large_c128",
     "apv_stft_analysis_dev", "apv_istft_ola_dev",
     "apv_stream_init", "apv_stream_set_perceptual", "apv_process_block", "apv_process_block_f64", "apv_process_signal", "apv_process_signal_f64", "apv_stream_is_f64", "apv_stream_get_statistics", "apv_stream_not_converged", "apv_state_bytes", "apv_get_state", "apv_set_state",
     "apv_bb_set_rank_list", "apv_bb_init", "apv_bb_set_perceptual", "apv_bb_process_block", "apv_bb_process_signal", "apv_bb_get_state", "apv_bb_set_state",
@@ -108,6 +108,7 @@ def load():
     lib.apv_timer_start.argtypes = [vp]
     lib.apv_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
     lib.apv_update_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    lib.apv_set_update_streams.argtypes = [vp, C.c_int32]
     lib.apv_update.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     lib.apv_corr_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     lib.apv_corr_bf16_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp]
@@ -330,6 +331,11 @@ class Engine:
             return w, lam, status
         self._chk(rc)
         return w, lam, status
+
+    def set_update_streams(self, n):
+        """n = 2: consecutive update_dev launches alternate between two streams of the handle's (the tail of one launch beside the head
+        of the next); the library orders them against each other, copies and the all-gather (include/apvast_hip.h)."""
+        self._chk(self.lib.apv_set_update_streams(self.h, int(n)))
 
     def update_dev(self, dXB, dXD, dd, dw, dlam=None, dstatus=None):
         self._chk(self.lib.apv_update_dev(self.h, dXB.ptr, dXD.ptr, dd.ptr, dw.ptr,

@@ -88,6 +88,23 @@ struct apv_handle {
     hipEvent_t ev_ag0, ev_ag1;    // timing events around the latest all-gather (comm stream)
     size_t ag_bytes;              // bytes this rank contributed to it
     int32_t* d_bar;               // one device word for apv_comm_barrier
+    // update lanes (apv_set_update_streams): consecutive apv_update_dev launches alternate between two streams of their own, so
+    // that the tail of one launch (waves of its last round finishing one by one) runs beside the head of the next.  `stream`
+    // stays the handle's control stream: copies, timers and the gather's hand-over are ordered against the lanes by events.
+    struct UpdateLane {
+        hipStream_t s;
+        hipEvent_t ev;            // recorded behind the lane's latest launch
+        bool used;                // ev has been recorded at least once
+        bool need_fork;           // the control stream has had work since this lane last looked: wait for ev_fork first
+        const void* rd[3];        // operand ranges of the latest launch: inputs ...
+        size_t rd_bytes[3];
+        const void* wr[3];        // ... and outputs
+        size_t wr_bytes[3];
+    } lane[2];
+    int n_lanes;                  // 1: every launch on `stream` (the default), 2: pipelined
+    int lane_next;
+    bool ctrl_dirty;              // work has been put on the control stream that the lanes have not been ordered behind yet
+    hipEvent_t ev_fork;
     std::string err;
 };
 

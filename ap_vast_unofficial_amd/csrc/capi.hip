@@ -119,6 +119,36 @@ int ensure_staging(apv_handle* h) {
     return APV_OK;
 }
 
+
+// ---- update lanes (apv_set_update_streams) -----------------------------------------------------------------------------------
+// With two lanes, launch i + 1 of apv_update_dev starts on the other lane while the waves of launch i's last round are still
+// finishing (a cfg2 launch is 8 rounds of 4 waves per SIMD; 3.6 of 4 alive on average: profiles/r03/stage_stamps_32768_b.md).
+// Ordering is by events, never by the host:
+//   lanes_join   the control stream waits for the latest launch of every lane (before anything it is asked to do with buffers)
+//   lanes_fork   a lane waits for what the control stream has been given since the lanes last looked (ctrl_dirty)
+//   operand ranges of the latest launch of the OTHER lane: a launch that writes what it reads or writes, or reads what it writes, waits
+bool lanes_on(const apv_handle* h) { return h->n_lanes > 1; }
+
+int lanes_join(apv_handle* h, bool dirties) {
+    if (!lanes_on(h)) return APV_OK;
+    for (auto& ln : h->lane)
+        if (ln.used) HIPCHK(h, hipStreamWaitEvent(h->stream, ln.ev, 0));
+    if (dirties) h->ctrl_dirty = true;
+    return APV_OK;
+}
+
+bool ranges_meet(const void* a, size_t na, const void* b, size_t nb) {
+    if (!a || !b || na == 0 || nb == 0) return false;
+    const uintptr_t a0 = (uintptr_t)a, b0 = (uintptr_t)b;
+    return a0 < b0 + nb && b0 < a0 + na;
+}
+
+int lanes_sync(apv_handle* h) {
+    for (auto& ln : h->lane)
+        if (ln.s) HIPCHK(h, hipStreamSynchronize(ln.s));
+    return APV_OK;
+}
+
 }  // namespace
 
 // The blocks apv_host_alloc has handed out (page-locked, visible to every device): a result pointer inside one of them takes a
@@ -198,6 +228,16 @@ int apv_create(const apv_config* cfg, apv_handle** out) {
     h->comm = nullptr;
     h->comm_rank = 0;
     h->comm_world = 1;
+    for (auto& ln : h->lane) {
+        ln.s = nullptr;
+        ln.ev = nullptr;
+        ln.used = ln.need_fork = false;
+        for (int i = 0; i < 3; ++i) { ln.rd[i] = ln.wr[i] = nullptr; ln.rd_bytes[i] = ln.wr_bytes[i] = 0; }
+    }
+    h->n_lanes = 1;
+    h->lane_next = 0;
+    h->ctrl_dirty = false;
+    h->ev_fork = nullptr;
 #define CR(call)                                                         \
     do {                                                                 \
         hipError_t _e = (call);                                          \
@@ -232,6 +272,12 @@ int apv_destroy(apv_handle* h) {
     apv_gevd_large_free(h);
     apv_gevd_lead_free(h);
     if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
+    for (auto& ln : h->lane) {
+        if (ln.s) (void)hipStreamSynchronize(ln.s);
+        if (ln.ev) (void)hipEventDestroy(ln.ev);
+        if (ln.s) (void)hipStreamDestroy(ln.s);
+    }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->comm) ncclCommDestroy((ncclComm_t)h->comm);
     for (auto& g : h->gather_done)
         if (g.ev) (void)hipEventDestroy(g.ev);
@@ -267,6 +313,7 @@ int apv_dev_free(apv_handle* h, void* d_ptr) {
 int apv_memcpy_h2d(apv_handle* h, void* d_dst, const void* h_src, size_t bytes) {
     if (!h) return APV_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->device));
+    if (int rc = lanes_join(h, true)) return rc;          // a launch in flight may still read what this copy overwrites
     HIPCHK(h, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, h->stream));
     return APV_OK;
 }
@@ -274,6 +321,7 @@ int apv_memcpy_h2d(apv_handle* h, void* d_dst, const void* h_src, size_t bytes) 
 int apv_memcpy_d2h(apv_handle* h, void* h_dst, const void* d_src, size_t bytes) {
     if (!h) return APV_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->device));
+    if (int rc = lanes_join(h, true)) return rc;          // (dirty: a later launch must not overwrite the source under the copy)
     HIPCHK(h, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, h->stream));
     return APV_OK;
 }
@@ -281,6 +329,7 @@ int apv_memcpy_d2h(apv_handle* h, void* h_dst, const void* d_src, size_t bytes) 
 int apv_sync(apv_handle* h) {
     if (!h) return APV_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->device));
+    if (int rc = lanes_sync(h)) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->comm_stream) HIPCHK(h, hipStreamSynchronize(h->comm_stream));
     return APV_OK;
@@ -288,12 +337,14 @@ int apv_sync(apv_handle* h) {
 
 int apv_timer_start(apv_handle* h) {
     if (!h) return APV_ERR_ARG;
+    if (int rc = lanes_join(h, false)) return rc;
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     return APV_OK;
 }
 
 int apv_timer_stop(apv_handle* h, float* elapsed_ms) {
     if (!h || !elapsed_ms) return APV_ERR_ARG;
+    if (int rc = lanes_join(h, false)) return rc;          // the interval ends behind the latest launch of every lane
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     HIPCHK(h, hipEventSynchronize(h->ev1));
     HIPCHK(h, hipEventElapsedTime(elapsed_ms, h->ev0, h->ev1));
@@ -306,9 +357,49 @@ int apv_update_dev(apv_handle* h, const void* d_XB, const void* d_XD, const void
     if (h->cfg.n_bins == 0) return APV_OK;
     if (!d_XB || !d_XD || !d_d || !d_w) return fail(h, APV_ERR_ARG, "null device pointer");
     HIPCHK(h, hipSetDevice(h->device));
+    const apv_config& c = h->cfg;
+    // the stream of this launch: the handle's own, or (apv_set_update_streams) the next lane.  Launches that park per-bin state in
+    // the handle's scratch (orders 33..64, the split float32 update) share that scratch: they all take lane 0, one after the other.
+    hipStream_t st = h->stream;
+    apv_handle::UpdateLane* ln = nullptr;
+    if (lanes_on(h)) {
+        const bool shares_scratch = h->d_Lspill != nullptr || split_f32_update(c);
+        const int li = shares_scratch ? 0 : h->lane_next;
+        if (!shares_scratch) h->lane_next ^= 1;
+        ln = &h->lane[li];
+        st = ln->s;
+        if (h->ctrl_dirty) {              // copies (or other work) went to the control stream since the lanes last looked
+            HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
+            for (auto& l2 : h->lane) l2.need_fork = true;
+            h->ctrl_dirty = false;
+        }
+        if (ln->need_fork) {
+            HIPCHK(h, hipStreamWaitEvent(st, h->ev_fork, 0));
+            ln->need_fork = false;
+        }
+        const size_t K = c.n_bins, M = c.n_mics, L = c.n_srcs;
+        const void* rd[3] = {d_XB, d_XD, d_d};
+        const size_t rd_bytes[3] = {K * M * L * 8, K * M * L * 8, K * M * 8};
+        const void* wr[3] = {d_w, d_lam, d_status};
+        const size_t wr_bytes[3] = {K * c.n_ranks * L * wsize(h), d_lam ? K * L * lsize(h) : 0, d_status ? K * sizeof(int32_t) : 0};
+        apv_handle::UpdateLane& other = h->lane[li ^ 1];
+        if (other.used) {
+            bool clash = false;
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j)
+                    clash = clash || ranges_meet(wr[i], wr_bytes[i], other.wr[j], other.wr_bytes[j]) ||
+                            ranges_meet(wr[i], wr_bytes[i], other.rd[j], other.rd_bytes[j]) ||
+                            ranges_meet(rd[i], rd_bytes[i], other.wr[j], other.wr_bytes[j]);
+            if (clash) HIPCHK(h, hipStreamWaitEvent(st, other.ev, 0));
+        }
+        for (int i = 0; i < 3; ++i) {
+            ln->rd[i] = rd[i]; ln->rd_bytes[i] = rd_bytes[i];
+            ln->wr[i] = wr[i]; ln->wr_bytes[i] = wr_bytes[i];
+        }
+    }
     for (auto& g : h->gather_done)
         if (g.ptr == d_w && g.ev) {       // an all-gather may still be reading this shard buffer
-            HIPCHK(h, hipStreamWaitEvent(h->stream, g.ev, 0));
+            HIPCHK(h, hipStreamWaitEvent(st, g.ev, 0));
             g.ptr = nullptr;
         }
     GevdParams p = base_params(h);
@@ -316,7 +407,6 @@ int apv_update_dev(apv_handle* h, const void* d_XB, const void* d_XD, const void
     p.lam = d_lam;
     p.status = d_status;
     std::string why;
-    const apv_config& c = h->cfg;
     hipError_t e;
     // order 64 takes the fused order-64 kernel in either arithmetic (kernels_gevd64.hip) unless that kernel is switched off
     if (split_f32_update(c)) {
@@ -329,20 +419,45 @@ int apv_update_dev(apv_handle* h, const void* d_XB, const void* d_XD, const void
         float2* RD = RB + K * L * L;
         float2* rr = RD + K * L * L;
         e = apv_launch_corr(APV_F32, c.n_bins, c.n_mics, c.n_srcs, (const float2*)d_XB, (const float2*)d_XD,
-                            (const float2*)d_d, RB, RD, rr, h->stream);
+                            (const float2*)d_d, RB, RD, rr, st);
         if (e != hipSuccess) return hipfail(h, e, "corr launch");
         p.RB = RB;
         p.RD = RD;
         p.r = rr;
-        e = apv_launch_gevd(p, APV_F32, false, h->stream, &why);
+        e = apv_launch_gevd(p, APV_F32, false, st, &why);
     } else {
         p.XB = (const float2*)d_XB;
         p.XD = (const float2*)d_XD;
         p.d = (const float2*)d_d;
-        e = apv_launch_gevd(p, h->cfg.compute_dtype, true, h->stream, &why);
+        e = apv_launch_gevd(p, h->cfg.compute_dtype, true, st, &why);
     }
     if (e != hipSuccess) return fail(h, e == hipErrorInvalidValue ? APV_ERR_ARG : APV_ERR_HIP,
                                      why.empty() ? hipGetErrorString(e) : why);
+    if (ln) {
+        HIPCHK(h, hipEventRecord(ln->ev, st));
+        ln->used = true;
+    }
+    return APV_OK;
+}
+
+int apv_set_update_streams(apv_handle* h, int32_t n) {
+    if (!h) return APV_ERR_ARG;
+    if (n != 1 && n != 2) return fail(h, APV_ERR_ARG, "update streams: 1 or 2");
+    HIPCHK(h, hipSetDevice(h->device));
+    // drain first: whatever is in flight was ordered under the old scheme
+    if (int rc = lanes_sync(h)) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (n == 2 && !h->lane[0].s) {
+        for (auto& ln : h->lane) {
+            HIPCHK(h, hipStreamCreateWithFlags(&ln.s, hipStreamNonBlocking));
+            HIPCHK(h, hipEventCreateWithFlags(&ln.ev, hipEventDisableTiming));
+        }
+        HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    }
+    for (auto& ln : h->lane) ln.used = ln.need_fork = false;
+    h->ctrl_dirty = false;
+    h->lane_next = 0;
+    h->n_lanes = n;
     return APV_OK;
 }
 
@@ -374,11 +489,13 @@ int apv_update(apv_handle* h, const float* h_XB, const float* h_XD, const float*
     if (rc != APV_OK) return rc;
     const apv_config& c = h->cfg;
     const size_t K = c.n_bins, M = c.n_mics, L = c.n_srcs;
+    if ((rc = lanes_join(h, true)) != APV_OK) return rc;          // the staging buffers may still be read by a launch in flight
     HIPCHK(h, hipMemcpyAsync(h->d_XB, h_XB, K * M * L * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->d_XD, h_XD, K * M * L * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->d_d, h_d, K * M * 8, hipMemcpyHostToDevice, h->stream));
     rc = apv_update_dev(h, h->d_XB, h->d_XD, h->d_d, h->d_w, h->d_lam, h->d_status);
     if (rc != APV_OK) return rc;
+    if ((rc = lanes_join(h, true)) != APV_OK) return rc;
     HIPCHK(h, hipMemcpyAsync(h_w, h->d_w, K * c.n_ranks * L * wsize(h), hipMemcpyDeviceToHost, h->stream));
     if (h_lam) HIPCHK(h, hipMemcpyAsync(h_lam, h->d_lam, K * L * lsize(h), hipMemcpyDeviceToHost, h->stream));
     std::string keep;
@@ -397,6 +514,7 @@ int apv_corr_dev(apv_handle* h, const void* d_XB, const void* d_XD, const void* 
                  void* d_r) {
     if (!h || !d_XB || !d_XD || !d_d || !d_RB || !d_RD || !d_r) return fail(h, APV_ERR_ARG, "null device pointer");
     HIPCHK(h, hipSetDevice(h->device));
+    if (int rc = lanes_join(h, true)) return rc;
     const apv_config& c = h->cfg;
     hipError_t e = apv_launch_corr(c.compute_dtype, c.n_bins, c.n_mics, c.n_srcs, (const float2*)d_XB,
                                    (const float2*)d_XD, (const float2*)d_d, d_RB, d_RD, d_r, h->stream);
@@ -407,6 +525,7 @@ int apv_corr_dev(apv_handle* h, const void* d_XB, const void* d_XD, const void* 
 int apv_to_bf16_dev(apv_handle* h, size_t count, const void* d_c64, void* d_bf16) {
     if (!h || !d_c64 || !d_bf16) return fail(h, APV_ERR_ARG, "null device pointer");
     HIPCHK(h, hipSetDevice(h->device));
+    if (int rc = lanes_join(h, true)) return rc;
     hipError_t e = apv_launch_to_bf16(count, (const float2*)d_c64, (uint32_t*)d_bf16, h->stream);
     if (e != hipSuccess) return hipfail(h, e, "to_bf16 launch");
     return APV_OK;
@@ -416,6 +535,7 @@ int apv_corr_bf16_dev(apv_handle* h, const void* d_XB, const void* d_XD, const v
                       void* d_r) {
     if (!h || !d_XB || !d_XD || !d_d || !d_RB || !d_RD || !d_r) return fail(h, APV_ERR_ARG, "null device pointer");
     HIPCHK(h, hipSetDevice(h->device));
+    if (int rc = lanes_join(h, true)) return rc;
     const apv_config& c = h->cfg;
     if ((c.n_srcs != 32 && c.n_srcs != 64) || (c.n_mics % 16) != 0)
         return fail(h, APV_ERR_ARG, "bf16 correlation: n_srcs must be 32 or 64 and n_mics a multiple of 16");
@@ -429,6 +549,7 @@ int apv_gevd_vast_dev(apv_handle* h, const void* d_RB, const void* d_RD, const v
                       int32_t* d_status) {
     if (!h || !d_RB || !d_RD || !d_r || !d_w) return fail(h, APV_ERR_ARG, "null device pointer");
     HIPCHK(h, hipSetDevice(h->device));
+    if (int rc = lanes_join(h, true)) return rc;
     GevdParams p = base_params(h);
     p.RB = d_RB;
     p.RD = d_RD;
@@ -679,6 +800,12 @@ int apv_allgather_filters_dev(apv_handle* h, const void* d_w_shard, void* d_w_al
     HIPCHK(h, hipSetDevice(h->device));
     // the gather starts once the kernels already queued on the compute stream have written the shard, and runs
     // on its own stream: the next block's update (into another shard buffer) overlaps it
+    if (lanes_on(h)) {
+        // the shard was written on a lane: the gather waits for the latest launch of every lane that wrote into it -- directly, so
+        // that no other stream carries a wait a later launch could queue up behind -- and for the control stream as below
+        for (auto& ln : h->lane)
+            if (ln.used && ranges_meet(d_w_shard, bytes, ln.wr[0], ln.wr_bytes[0])) HIPCHK(h, hipStreamWaitEvent(h->comm_stream, ln.ev, 0));
+    }
     HIPCHK(h, hipEventRecord(h->ev_ready, h->stream));
     HIPCHK(h, hipStreamWaitEvent(h->comm_stream, h->ev_ready, 0));
     HIPCHK(h, hipEventRecord(h->ev_ag0, h->comm_stream));
@@ -697,6 +824,8 @@ int apv_allgather_filters_dev(apv_handle* h, const void* d_w_shard, void* d_w_al
         slot = h->gather_next;
         h->gather_next = (h->gather_next + 1) & 3;
         HIPCHK(h, hipStreamWaitEvent(h->stream, h->gather_done[slot].ev, 0));
+        if (lanes_on(h))
+            for (auto& ln : h->lane) HIPCHK(h, hipStreamWaitEvent(ln.s, h->gather_done[slot].ev, 0));
     }
     h->gather_done[slot].ptr = d_w_shard;
     HIPCHK(h, hipEventRecord(h->gather_done[slot].ev, h->comm_stream));
@@ -747,6 +876,7 @@ int apv_comm_barrier(apv_handle* h) {
     if (!h) return APV_ERR_ARG;
     if (!h->comm) return fail(h, APV_ERR_RCCL, "communicator not initialised (apv_comm_init)");
     HIPCHK(h, hipSetDevice(h->device));
+    if (int rc = lanes_sync(h)) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     ncclResult_t r = ncclAllReduce(h->d_bar, h->d_bar, 1, ncclInt32, ncclSum, (ncclComm_t)h->comm, h->comm_stream);
     if (r != ncclSuccess) return fail(h, APV_ERR_RCCL, std::string("ncclAllReduce: ") + ncclGetErrorString(r));

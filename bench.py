@@ -545,6 +545,9 @@ def run_cfg4_rehearsal():
     rec["workload"] = line["config"]["workload"]
     rec["collective"] = line["config"]["collective"]
     rec["kernel_ms"] = line["roofline"]["kernel_ms"]
+    rec["update_streams"] = line["config"].get("update_streams")
+    if "pipelined" in line["roofline"]:
+        rec["pipelined_ms_per_launch"] = line["roofline"]["pipelined"]["ms_per_launch"]
     rec["child_wall_s"] = time.perf_counter() - t0
     return rec
 
@@ -647,6 +650,11 @@ def main():
                          "sharded over the ranks at N GPUs (default 8 N, the same 32768 bin-updates per GPU)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--prespin", type=float, default=0.3, help="seconds of untimed launches before the counted warm-up (clock ramp)")
+    ap.add_argument("--update-streams", type=int, default=0, choices=[0, 1, 2],
+                    help="2: consecutive steps alternate between two streams of the engine's (apv_set_update_streams), so that the "
+                         "last waves of one launch finish beside the first of the next; 1: every launch on one stream; 0 (default): "
+                         "2 on the single-GPU path, 1 on the sharded path (beside an RCCL gather per step the second stream gains "
+                         "nothing: profiles/r04/dist_rehearsal_ab.txt)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the cfg3 / cfg5 sub-records of the 1-GPU line")
     args = ap.parse_args()
@@ -702,12 +710,19 @@ def main():
         workload = ("cfg2: 16 loudspeakers x 32 control points x 1024 bins/block, fused correlate+GEVD+VAST filter, "
                     "1 zone program, V=8")
     eng = Engine(K, L, M, ranks=ranks, mu=mu, compute_dtype=args.dtype, out_c128=False, device=local_rank)
+    if args.update_streams == 0:
+        args.update_streams = 1 if multi else 2
+    eng.set_update_streams(args.update_streams)
     XB, XD, d = synth(K, 1234 + rank)
     dXB, dXD, dd = eng.to_device(XB), eng.to_device(XD), eng.to_device(d)
     w_bytes = K * len(ranks) * L * 8
-    dw = eng.alloc(w_bytes)
-    dw2 = eng.alloc(w_bytes)        # second shard buffer: the all-gather of step i overlaps the update of step i+1
+    # shard buffers in rotation: the all-gather of step i overlaps the update of step i+1, and with two update streams the launch
+    # of step i+2 (same stream as step i) must not wait for the gather of step i either: four buffers (the library tracks four)
+    n_ring = int(os.environ.get("APV_BENCH_RING", "4" if args.update_streams > 1 else "2"))
+    dws = [eng.alloc(w_bytes) for _ in range(n_ring)]
+    dw = dws[0]
     dstatus = eng.alloc(K * 4)
+    dstatus2 = eng.alloc(K * 4)     # consecutive steps write different buffers: the library serialises launches that share one
     collective = None
     dw_all = None
     rz = None
@@ -727,10 +742,10 @@ def main():
     last_out = [dw]
 
     def step():
-        out = dw if flip[0] == 0 else dw2
-        flip[0] ^= 1
+        out, st = dws[flip[0] % n_ring], (dstatus if flip[0] % 2 == 0 else dstatus2)
+        flip[0] += 1
         last_out[0] = out
-        eng.update_dev(dXB, dXD, dd, out, None, dstatus)
+        eng.update_dev(dXB, dXD, dd, out, None, st)
         if multi:
             eng.allgather_filters_dev(out, dw_all)
 
@@ -761,12 +776,28 @@ def main():
     eng.timer_start()
     for _ in range(args.steps):
         step()
-    kern_ms = eng.timer_stop() / args.steps       # waits for the last update kernel only
+    kern_ms = eng.timer_stop() / args.steps       # waits for the last update kernel(s) only
     fence()
     elapsed = time.perf_counter() - t0
-    status = dstatus.download((K,), np.int32)      # every launch rewrote it: this is the last step's
-    if status.any():
-        raise RuntimeError(f"GEVD status != 0 in {int((status != 0).sum())} bins")
+    # roofline leg of a pipelined run: the duration of a launch ALONE (what rocprofv3's kernel trace calls its duration) cannot be
+    # read off overlapping launches, so the same launches run once more on ONE stream between the same HIP events, straight
+    # behind the timed region (clocks as they are); with --update-streams 1 the timed region itself is that measurement.
+    pipelined_ms = None
+    if args.update_streams > 1:
+        pipelined_ms = kern_ms
+        eng.set_update_streams(1)
+        n_alone = min(args.steps, 100)
+        for _ in range(8):
+            eng.update_dev(dXB, dXD, dd, dw, None, dstatus)
+        eng.timer_start()
+        for _ in range(n_alone):
+            eng.update_dev(dXB, dXD, dd, dw, None, dstatus)
+        kern_ms = eng.timer_stop() / n_alone
+        eng.sync()
+    for buf in (dstatus, dstatus2):                # every launch rewrote one of them: the last steps'
+        status = buf.download((K,), np.int32)
+        if status.any():
+            raise RuntimeError(f"GEVD status != 0 in {int((status != 0).sum())} bins")
     gather_ms = gather_bytes = rccl_ranks = None
     gather_check = None
     if multi:
@@ -811,12 +842,25 @@ def main():
                          "traffic_source": "profiles/traffic.json (rocprofv3 --pmc passes of this command, committed; not re-measured "
                                            "in this run)" if traffic else None,
                          "kernel": "gevd16m_kernel_f64<fused>" if args.dtype == "f64" else "gevd16m_kernel<float, fused>", "kernel_ms": kern_ms,
+                         "kernel_ms_how": ("HIP events around launches on ONE stream, same process, straight behind the timed region "
+                                           "(a launch alone: the duration rocprofv3's kernel trace reports for --update-streams 1)")
+                                          if pipelined_ms is not None else "HIP events around the timed launches (one stream)",
                          "algorithmic_bytes_per_update": bpu, "updates_per_launch": K,
                          "alu": {"flop_per_update": FLOP_PER_UPDATE, "achieved_tflops": alu / 1e12,
                                  "peak_tflops": PEAK_FLOPS[args.dtype] / 1e12,
                                  "frac": alu / PEAK_FLOPS[args.dtype],
                                  "note": "the fused kernel is vector-ALU bound (SURVEY.md 8d); both fractions reported"}},
         }
+        if pipelined_ms is not None:
+            # the timed region itself: launches alternate between two streams, the tail of one beside the head of the next
+            out["config"]["update_streams"] = args.update_streams
+            out["roofline"]["pipelined"] = {
+                "ms_per_launch": pipelined_ms, "achieved": bpu * K / (pipelined_ms * 1e-3) / 1e9,
+                "frac": bpu * K / (pipelined_ms * 1e-3) / HBM_PEAK,
+                "alu_frac": (K / (pipelined_ms * 1e-3)) * FLOP_PER_UPDATE / PEAK_FLOPS[args.dtype],
+                "how": "HIP events around the timed region's launches / steps: two launches in flight, the rate `value` is made of"}
+        else:
+            out["config"]["update_streams"] = 1
         if multi:
             # the all-gather alone: device time of the last one (max over ranks), what each rank sent, and the per-link rate a
             # direct all-gather would need (each rank sends its shard to every one of the world-1 peers in parallel)
@@ -827,7 +871,7 @@ def main():
             out["collective_gbps_per_link"] = gather_bytes / (gather_ms * 1e-3) / 1e9 if gather_ms > 0 else None
 
     # the headline's buffers go before the sub-records allocate theirs
-    for b in (dXB, dXD, dd, dw, dw2, dstatus, dw_all):
+    for b in [dXB, dXD, dd, dstatus, dstatus2, dw_all] + dws:
         if b is not None:
             b.free()
     eng.close()

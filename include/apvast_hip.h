@@ -133,6 +133,15 @@ int  apv_timer_stop(apv_handle* h, float* elapsed_ms);         /* synchronises o
 int  apv_update_dev(apv_handle* h, const void* d_XB, const void* d_XD, const void* d_d,
                     void* d_w, void* d_lam, int32_t* d_status);
 
+/* Pipelining of consecutive apv_update_dev calls (the caller of apvast.py:153-165 runs one block after the other; blocks of
+ * different streams or hops are independent).  n = 2: launches alternate between two streams of the handle's, so that the last
+ * waves of one launch finish beside the first waves of the next (+6 % updates/s at BASELINE config 2).  Results are those of
+ * n = 1 bit for bit.  Ordering stays the library's business: a launch whose operands overlap the other lane's launch in flight
+ * (same output buffer, an input that the other writes) waits for it; copies, timers, apv_sync, apv_update and the all-gather see
+ * every launch queued before them; launches queued after a copy see the copy.  Configurations that park per-bin state in the
+ * handle's scratch (orders 33..64) keep to one lane.  n = 1 (the default): every launch on the handle's stream. */
+int  apv_set_update_streams(apv_handle* h, int32_t n);
+
 /* Same from caller-owned host buffers (copies in, runs, copies out, syncs). */
 int  apv_update(apv_handle* h, const float* h_XB, const float* h_XD, const float* h_d,
                 void* h_w, void* h_lam, int32_t* h_status);
