@@ -101,6 +101,7 @@ struct apv_handle {
         const void* wr[3];        // ... and outputs
         size_t wr_bytes[3];
     } lane[2];
+    void* d_Lspill_lane1;         // lane 1's own copy of the per-bin scratch slots (orders 33..64), allocated when pipelining is switched on
     int n_lanes;                  // 1: every launch on `stream` (the default), 2: pipelined
     int lane_next;
     bool ctrl_dirty;              // work has been put on the control stream that the lanes have not been ordered behind yet

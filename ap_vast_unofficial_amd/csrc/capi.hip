@@ -78,6 +78,10 @@ int ensure_spill(apv_handle* h, int n, int K) {
         if (h->d_Lspill) HIPCHK(h, hipFree(h->d_Lspill));
         h->d_Lspill = nullptr;
         h->lspill_bytes = 0;
+        if (h->d_Lspill_lane1) {          // (too small now: launches that need the scratch keep to one lane until pipelining is set again)
+            HIPCHK(h, hipFree(h->d_Lspill_lane1));
+            h->d_Lspill_lane1 = nullptr;
+        }
         HIPCHK(h, hipMalloc(&h->d_Lspill, need));
         h->lspill_bytes = need;
     }
@@ -234,6 +238,7 @@ int apv_create(const apv_config* cfg, apv_handle** out) {
         ln.used = ln.need_fork = false;
         for (int i = 0; i < 3; ++i) { ln.rd[i] = ln.wr[i] = nullptr; ln.rd_bytes[i] = ln.wr_bytes[i] = 0; }
     }
+    h->d_Lspill_lane1 = nullptr;
     h->n_lanes = 1;
     h->lane_next = 0;
     h->ctrl_dirty = false;
@@ -286,7 +291,7 @@ int apv_destroy(apv_handle* h) {
     if (h->ev_ag1) (void)hipEventDestroy(h->ev_ag1);
     if (h->d_bar) (void)hipFree(h->d_bar);
     if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
-    void* bufs[] = {h->d_XB, h->d_XD, h->d_d, h->d_w, h->d_lam, h->d_status, h->d_Lspill, h->d_Rscratch};
+    void* bufs[] = {h->d_XB, h->d_XD, h->d_d, h->d_w, h->d_lam, h->d_status, h->d_Lspill, h->d_Lspill_lane1, h->d_Rscratch};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -358,12 +363,13 @@ int apv_update_dev(apv_handle* h, const void* d_XB, const void* d_XD, const void
     if (!d_XB || !d_XD || !d_d || !d_w) return fail(h, APV_ERR_ARG, "null device pointer");
     HIPCHK(h, hipSetDevice(h->device));
     const apv_config& c = h->cfg;
-    // the stream of this launch: the handle's own, or (apv_set_update_streams) the next lane.  Launches that park per-bin state in
-    // the handle's scratch (orders 33..64, the split float32 update) share that scratch: they all take lane 0, one after the other.
+    // the stream of this launch: the handle's own, or (apv_set_update_streams) the next lane.  Orders 33..64 park per-bin state in
+    // scratch slots: lane 1 has slots of its own (d_Lspill_lane1).  The split float32 update shares ONE scratch R: its launches
+    // all take lane 0, one after the other.
     hipStream_t st = h->stream;
     apv_handle::UpdateLane* ln = nullptr;
     if (lanes_on(h)) {
-        const bool shares_scratch = h->d_Lspill != nullptr || split_f32_update(c);
+        const bool shares_scratch = (h->d_Lspill != nullptr && h->d_Lspill_lane1 == nullptr) || split_f32_update(c);
         const int li = shares_scratch ? 0 : h->lane_next;
         if (!shares_scratch) h->lane_next ^= 1;
         ln = &h->lane[li];
@@ -403,6 +409,7 @@ int apv_update_dev(apv_handle* h, const void* d_XB, const void* d_XD, const void
             g.ptr = nullptr;
         }
     GevdParams p = base_params(h);
+    if (ln == &h->lane[1] && h->d_Lspill_lane1) p.Lspill = h->d_Lspill_lane1;
     p.w = d_w;
     p.lam = d_lam;
     p.status = d_status;
@@ -454,6 +461,7 @@ int apv_set_update_streams(apv_handle* h, int32_t n) {
         }
         HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     }
+    if (n == 2 && h->lspill_bytes > 0 && !h->d_Lspill_lane1) HIPCHK(h, hipMalloc(&h->d_Lspill_lane1, h->lspill_bytes));
     for (auto& ln : h->lane) ln.used = ln.need_fork = false;
     h->ctrl_dirty = false;
     h->lane_next = 0;

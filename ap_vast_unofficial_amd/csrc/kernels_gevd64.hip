@@ -20,7 +20,11 @@
 //   stage 6  w_V = sum_{i<V} (x_i^H r)/(lam_i+mu) x_i                                            apvast.py:406-414
 //
 // LDS: two regions of 66 KB (R_B -> W R_B -> [C, V in float32] -> refinement work space; R_D -> L -> W -> V in float64).
-// C and W wait in a slot of HBM scratch per bin (L2 resident) while the LDS is used for the sweeps.
+// C and W wait in a slot of HBM scratch per bin (L2 resident) while the LDS is used for the sweeps: W as its ten 16 x 16 tiles on and
+// below the diagonal, C in full.  (C as its lower tiles was built and measured in round 4: the refinement then reads a tile above
+// the diagonal as the conjugate transpose of its mirror, and whichever way the summation index is dealt, the matrix cores want the
+// row index of an operand on lane & 15 -- sixteen lanes striding over rows 1 KB apart: 24 KB less written per bin, 6 us more per
+// refinement, 2.527 -> 2.588 ms per launch.  Both orientations of a tile are what the two waves that read it want: the full matrix.)
 //
 // Two kernels share the stages.  gevd64_kernel: one bin per workgroup.  gevd64x2_kernel: TWO bins per workgroup; the
 // float64 stages run for one bin after the other, but the float32 sweeps of the two bins (66 KB each: both fit) are
@@ -138,7 +142,7 @@ constexpr size_t SLOT_BYTES = (size_t)2 * N64 * N64 * 16 + (size_t)N64 * N64 * 8
 // scratch) and, if vf_dst is given, V = I beside it.  Returns the status (1: not positive definite), or -1 on a debug stop.
 template <bool FUSED, typename XT>
 __device__ __forceinline__ int front64(const GevdParams& p, const Sh& sh, bool z1, int k, C128* gC, C128* gW, C64* cf_dst, int cf_ld,
-                                       C64* vf_dst, double& normF2, double& scl) {
+                                       C64* vf_dst, double& normF2, double& scl, bool cf_lower_only = false) {
     const XT* const pXB = reinterpret_cast<const XT*>(z1 ? p.XB1 : p.XB);
     const XT* const pXD = reinterpret_cast<const XT*>(z1 ? p.XD1 : p.XD);
     const XT* const pd = reinterpret_cast<const XT*>(z1 ? p.d1 : p.d);
@@ -455,12 +459,13 @@ __device__ __forceinline__ int front64(const GevdParams& p, const Sh& sh, bool z
         stamp64(p, z1, k, 10);
         if (p.debug_stop == 3) return -1;
         // ---------------- stage 2: C = W A W^H ----------------
-        // W to the scratch slot first (zeros above the diagonal): the stores drain while the products below run
+        // W to the scratch slot first: the stores drain while the products below run.  Only the ten tiles on and below the
+        // diagonal (zeros above the diagonal INSIDE the diagonal tiles): stage 5 reads nothing else
 #pragma unroll
         for (int idx4 = 0; idx4 < 4; ++idx4) {
             const int idx = tid + 1024 * idx4;
             const int i = idx >> 6, j = idx & 63;
-            gW[idx] = j <= i ? Wel(i, j) : mk<double>(0, 0);
+            if ((j >> 4) <= (i >> 4)) gW[idx] = j <= i ? Wel(i, j) : mk<double>(0, 0);
         }
         C128 acc[4];
         // W is lower triangular: W[i][k] = 0 for k > i (the upper triangle of the region still holds R_D)
@@ -489,11 +494,12 @@ __device__ __forceinline__ int front64(const GevdParams& p, const Sh& sh, bool z
         normF2 = block_sum(nrm, sRed, tid);          // (its barriers also end every read of T in region A)
         const int sexp = (normF2 > 0.0) ? -(ilogb(normF2) / 2) : 0;
         scl = ldexp(1.0, sexp);
-        // float32 working copy: C scaled to ||C||_F ~ 1 (and V = I beside it)
+        // float32 working copy: C scaled to ||C||_F ~ 1 (and V = I beside it); cf_lower_only: a copy that waits in the scratch slot
+        // holds the tiles on and below the diagonal only (load_cf_lower mirrors them)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int row = 16 * ti2 + kq + 4 * t, col = 16 * tj2 + il;
-            cf_dst[row * cf_ld + col] = mk<float>((float)(acc[t].x * scl), (float)(acc[t].y * scl));
+            if (!cf_lower_only || ti2 >= tj2) cf_dst[row * cf_ld + col] = mk<float>((float)(acc[t].x * scl), (float)(acc[t].y * scl));
             if (vf_dst != nullptr) vf_dst[row * cf_ld + col] = mk<float>(row == col ? 1.f : 0.f, 0.f);
         }
     }
@@ -935,28 +941,34 @@ __global__ void __launch_bounds__(1024) gevd64x2_kernel(const GevdParams p) {
     int status0 = 0, status1 = 1;
     double normF2_0 = 0, normF2_1 = 0, scl0 = 1, scl1 = 1;
     stamp64(p, z1, k0, 0);
-    // float64 front stages, one bin after the other; the scaled float32 copy of C goes to the scratch slot
-    status0 = front64<FUSED, XT>(p, sh, z1, k0, gCb(0), gWb(0), gFb(0), N64, nullptr, normF2_0, scl0);
+    // float64 front stages, one bin after the other.  The scaled float32 copy of the FIRST bin's C waits in the scratch slot while the
+    // second bin's front stages use all of the LDS (its tiles on and below the diagonal only); the second bin's copy goes straight
+    // to where its sweeps want it (region B is free once front64's last product has been summed)
+    status0 = front64<FUSED, XT>(p, sh, z1, k0, gCb(0), gWb(0), nb == 2 ? gFb(0) : Cfb(0), nb == 2 ? N64 : LDF, nb == 2 ? nullptr : Vfb(0),
+                                 normF2_0, scl0, nb == 2);
     if (status0 < 0) return;
     if (tid < N64) gRb(0)[tid] = sr[tid];
     __syncthreads();
     stamp64(p, z1, k0, 1);
     if (nb == 2) {
-        status1 = front64<FUSED, XT>(p, sh, z1, k0 + 1, gCb(1), gWb(1), gFb(1), N64, nullptr, normF2_1, scl1);
+        status1 = front64<FUSED, XT>(p, sh, z1, k0 + 1, gCb(1), gWb(1), Cfb(1), LDF, Vfb(1), normF2_1, scl1);
         if (tid < N64) gRb(1)[tid] = sr[tid];
         __syncthreads();
-    }
-    for (int b = 0; b < nb; ++b) {
-        if ((b ? status1 : status0) != 0) continue;
-        C64* const Cf = Cfb(b);
-        C64* const Vf = Vfb(b);
-        const C64* const src = gFb(b);
-        #pragma unroll
-        for (int idx4 = 0; idx4 < 4; ++idx4) {
-            const int idx = tid + 1024 * idx4;
-            const int i = idx >> 6, j = idx & 63;
-            Cf[i * LDF + j] = src[idx];
-            Vf[i * LDF + j] = mk<float>(i == j ? 1.f : 0.f, 0.f);
+        if (status0 == 0) {
+            C64* const Cf = Cfb(0);
+            C64* const Vf = Vfb(0);
+            const C64* const src = gFb(0);
+            #pragma unroll
+            for (int idx4 = 0; idx4 < 4; ++idx4) {
+                const int idx = tid + 1024 * idx4;
+                const int i = idx >> 6, j = idx & 63;
+                Vf[i * LDF + j] = mk<float>(i == j ? 1.f : 0.f, 0.f);
+                if ((j >> 4) <= (i >> 4)) {                      // a stored tile; the tiles below the diagonal also fill their mirrors
+                    const C64 v = src[idx];
+                    Cf[i * LDF + j] = v;
+                    if ((j >> 4) < (i >> 4)) Cf[j * LDF + i] = mk<float>(v.x, -v.y);
+                }
+            }
         }
     }
     __syncthreads();
@@ -1048,11 +1060,11 @@ __global__ void __launch_bounds__(1024) gevd64x2_kernel(const GevdParams p) {
         if (wave == 0) row[15] = t_all;
     }
     stamp64(p, z1, k0, 3);
-    // the float32 eigenvector matrices wait in the scratch slots while the float64 back stages use all of the LDS
-    for (int b = 0; b < nb; ++b) {
-        if ((b ? status1 : status0) != 0) continue;
-        const C64* const Vf = Vfb(b);
-        C64* const dst = gFb(b);
+    // the SECOND bin's float32 eigenvector matrix waits in its scratch slot while the first bin's back stages use all of the LDS;
+    // the first bin's is consumed from region A where it lies (back64 reads it before it writes anything there)
+    if (nb == 2 && status1 == 0) {
+        const C64* const Vf = Vfb(1);
+        C64* const dst = gFb(1);
         #pragma unroll
         for (int idx4 = 0; idx4 < 4; ++idx4) {
             const int idx = tid + 1024 * idx4;
@@ -1068,7 +1080,7 @@ __global__ void __launch_bounds__(1024) gevd64x2_kernel(const GevdParams p) {
     if (tid < N64) sr[tid] = gRb(0)[tid];
     __syncthreads();
     stamp64(p, z1, k0, 4);
-    back64<XT>(p, sh, z1, k0, gCb(0), gWb(0), gFb(0), N64, status0, swp0);
+    back64<XT>(p, sh, z1, k0, gCb(0), gWb(0), Vfb(0), LDF, status0, swp0);
     stamp64(p, z1, k0, 5);
     if (nb == 2) {
         __syncthreads();

@@ -458,26 +458,40 @@ def cfg5_correlation(Engine, device, reps=20):
     return res
 
 
-def also_cfg5(Engine, device, steps=20, warmup=8):
-    """BASELINE config 5 at kernel level: 64 loudspeakers x 128 control points x 2048 bins, float64, V in {1, 32, 64}."""
+def also_cfg5(Engine, device, steps=20, warmup=8, update_streams=2):
+    """BASELINE config 5 at kernel level: 64 loudspeakers x 128 control points x 2048 bins, float64, V in {1, 32, 64}.  As in the
+    headline: the timed launches alternate between two streams of the engine's (each with scratch slots of its own) and into two
+    output sets; the roofline leg behind them runs the same launches on one stream."""
     L5, M5, K5 = 64, 128, 2048
     ranks = (1, 32, 64)
     eng = Engine(K5, L5, M5, ranks=ranks, mu=1.0, compute_dtype="f64", out_c128=False, device=device)
     try:
+        eng.set_update_streams(update_streams)
         XB, XD, d = synth(K5, 1234, L5, M5)
         dXB, dXD, dd = eng.to_device(XB), eng.to_device(XD), eng.to_device(d)
-        dw, ds = eng.alloc(K5 * len(ranks) * L5 * 8), eng.alloc(K5 * 4)
-        for _ in range(warmup):                    # a GPU that idled runs its first launches ~8 % slower (clock ramp, DESIGN.md 6)
-            eng.update_dev(dXB, dXD, dd, dw, None, ds)
+        outs = [(eng.alloc(K5 * len(ranks) * L5 * 8), eng.alloc(K5 * 4)) for _ in range(2)]
+        for i in range(warmup):                    # a GPU that idled runs its first launches ~8 % slower (clock ramp, DESIGN.md 6)
+            eng.update_dev(dXB, dXD, dd, outs[i & 1][0], None, outs[i & 1][1])
         eng.sync()
         t0 = time.perf_counter()
         eng.timer_start()
-        for _ in range(steps):
-            eng.update_dev(dXB, dXD, dd, dw, None, ds)
+        for i in range(steps):
+            eng.update_dev(dXB, dXD, dd, outs[i & 1][0], None, outs[i & 1][1])
         kern_ms = eng.timer_stop() / steps
         eng.sync()
         wall = time.perf_counter() - t0
-        st = ds.download((K5,), np.int32)
+        pipelined_ms = None
+        if update_streams > 1:
+            pipelined_ms = kern_ms
+            eng.set_update_streams(1)
+            for _ in range(2):
+                eng.update_dev(dXB, dXD, dd, outs[0][0], None, outs[0][1])
+            eng.timer_start()
+            for _ in range(steps):
+                eng.update_dev(dXB, dXD, dd, outs[0][0], None, outs[0][1])
+            kern_ms = eng.timer_stop() / steps
+            eng.sync()
+        st = np.concatenate([o[1].download((K5,), np.int32) for o in outs])
     finally:
         eng.close()
     bpu = bytes_per_update(len(ranks), L5, M5)
@@ -494,7 +508,11 @@ def also_cfg5(Engine, device, steps=20, warmup=8):
             "status_nonzero_bins": int((st != 0).sum()),
             "roofline": {"bound": "mfma", "kernel": "gevd64x2_kernel<fused>", "kernel_ms": kern_ms,
                          "achieved": alu / 1e12, "peak": PEAK_FLOPS["f64"] / 1e12, "unit": "TFLOP/s", "frac": alu / PEAK_FLOPS["f64"],
-                         "flop_per_update": fpu, "updates_per_launch": K5,
+                         "flop_per_update": fpu, "updates_per_launch": K5, "update_streams": update_streams,
+                         "kernel_ms_how": "a launch alone: HIP events around launches on one stream, behind the timed region",
+                         "pipelined": None if pipelined_ms is None else {
+                             "ms_per_launch": pipelined_ms, "frac": K5 / (pipelined_ms * 1e-3) * fpu / PEAK_FLOPS["f64"],
+                             "how": "HIP events around the timed launches / steps: two launches in flight"},
                          "note": "SURVEY.md 8(d) prices cfg5 against the float64 vector/matrix peak (78.6 TFLOP/s: the same number on "
                                  "MI355X) with its LAPACK-style flop count; the HBM fraction is reported beside it",
                          "hbm": {"algorithmic_bytes_per_update": bpu, "achieved_gbps": ach / 1e9, "peak_gbps": HBM_PEAK / 1e9,

@@ -138,8 +138,10 @@ int  apv_update_dev(apv_handle* h, const void* d_XB, const void* d_XD, const voi
  * waves of one launch finish beside the first waves of the next (+6 % updates/s at BASELINE config 2).  Results are those of
  * n = 1 bit for bit.  Ordering stays the library's business: a launch whose operands overlap the other lane's launch in flight
  * (same output buffer, an input that the other writes) waits for it; copies, timers, apv_sync, apv_update and the all-gather see
- * every launch queued before them; launches queued after a copy see the copy.  Configurations that park per-bin state in the
- * handle's scratch (orders 33..64) keep to one lane.  n = 1 (the default): every launch on the handle's stream. */
+ * every launch queued before them; launches queued after a copy see the copy.  Orders 33..64 park per-bin state in scratch slots:
+ * the second stream gets slots of its own (allocated by this call: the per-block path still allocates nothing); the split float32
+ * update (orders 32 / 64 in APV_F32) shares one scratch matrix and keeps to one stream.  n = 1 (the default): every launch on the
+ * handle's stream. */
 int  apv_set_update_streams(apv_handle* h, int32_t n);
 
 /* Same from caller-owned host buffers (copies in, runs, copies out, syncs). */

@@ -95,8 +95,8 @@ def test_host_entry_point_and_back_to_one_stream(Engine):
     eng.close()
 
 
-def test_order_64_keeps_to_one_lane(Engine):
-    """Order 64 parks per-bin state in the handle's scratch: its launches must not overlap (they take one lane)."""
+def test_order_64_lanes_have_scratch_of_their_own(Engine):
+    """Order 64 parks per-bin state in scratch slots: two launches in flight must not share them (lane 1 has its own)."""
     K, L, M, ranks = 600, 64, 128, (1, 32, 64)
     rng = np.random.default_rng(3)
     sets = [(cn(rng, K, M, L), cn(rng, K, M, L), cn(rng, K, M))]
@@ -105,7 +105,7 @@ def test_order_64_keeps_to_one_lane(Engine):
     eng.set_update_streams(2)
     dXB, dXD, dd = (eng.to_device(a) for a in sets[0])
     outs = [eng.alloc(K * len(ranks) * L * 8) for _ in range(2)]
-    for i in range(4):
+    for i in range(6):
         eng.update_dev(dXB, dXD, dd, outs[i & 1])
     for o in outs:
         assert np.array_equal(o.download((K, len(ranks), L), np.complex64), w_ref)
