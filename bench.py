@@ -275,13 +275,19 @@ def also_cfg3(device, hops=468):
         # the caller's output array, touched once: 10 s of drive signals are 184 MB and first-touch page faults of that much
         # fresh memory would otherwise be what is timed (apvast.process_signal(..., out=))
         buf = np.zeros(obj.signal_output_shape(hops * H), obj.signal_output_dtype)
-        t0 = time.perf_counter()
-        res = obj.process_signal(x[0], x[1], out=buf)
-        dt = time.perf_counter() - t0
-        assert res[0][0].shape == (hops * H, L3)
+        # the call is 35 ms of host and device work in step: one preemption of the calling thread is a third of it.  Two calls,
+        # the faster one counts, both are listed (the stream state simply moves on: the same 10 s of input twice)
+        runs = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            res = obj.process_signal(x[0], x[1], out=buf)
+            runs.append(time.perf_counter() - t0)
+            assert res[0][0].shape == (hops * H, L3)
+        dt = min(runs)
         rec["process_signal"] = {"ms_per_hop": dt / hops * 1e3, "blocks_per_s": hops / dt,
                                  "realtime_factor": (hops * H / 48000.0) / dt,
                                  "subband_updates_per_s": hops * (N // 2 + 1) * 2 / dt,
+                                 "runs_ms_per_hop": [r / hops * 1e3 for r in runs], "counted": "the faster of two calls",
                                  "output": "caller-provided array (out=), touched before the call"}
         rec["not_converged_hops"] = obj.not_converged
     finally:
@@ -312,24 +318,30 @@ def _time_bb_signal(obj, xs, signal_hops, H):
     """ONE process_signal call over signal_hops hops, twice: returning a fresh result array, as the reference's caller would get
     it (`process_signal`), and into the caller's own page-locked array (alloc_signal_output, allocated outside the timed region
     and written by DMA: `process_signal_out`).  (tests/test_gpu_broadband.py holds the two forms to bit-equal samples.)"""
-    first = None
-    for rep in range(2):                        # the first call of this length sizes the group buffers and the staging sets
+    # The first call of this length sizes the group buffers and the staging sets.  The calls after it are 10-15 ms of host and
+    # device work in step (a helper thread enqueues the next group): the faster of two counts, both are listed.
+    runs = []
+    for rep in range(3):
         t0 = time.perf_counter()
         res = obj.process_signal(xs[0], xs[1])
-        dt = time.perf_counter() - t0
+        runs.append(time.perf_counter() - t0)
         assert res[0][0].shape == (signal_hops * H, 8)
         del res
-        if first is None:
-            first = dt
+    first, dt = runs[0], min(runs[1:])
     rec = {"process_signal": {"ms_per_hop": dt / signal_hops * 1e3, "hops": signal_hops, "realtime_factor": (signal_hops * H / 48000.0) / dt,
-                              "output": "fresh array per call", "first_call_ms_per_hop": first / signal_hops * 1e3}}
+                              "output": "fresh array per call", "first_call_ms_per_hop": first / signal_hops * 1e3,
+                              "runs_ms_per_hop": [r / signal_hops * 1e3 for r in runs[1:]], "counted": "the faster of two calls behind the first"}}
     out = obj.alloc_signal_output(signal_hops * H)
     out[...] = 0.0
-    t0 = time.perf_counter()
-    res = obj.process_signal(xs[0], xs[1], out=out)
-    dt = time.perf_counter() - t0
-    assert np.shares_memory(res[0][0], out) and np.isfinite(out).all()
+    runs = []
+    for rep in range(2):
+        t0 = time.perf_counter()
+        res = obj.process_signal(xs[0], xs[1], out=out)
+        runs.append(time.perf_counter() - t0)
+        assert np.shares_memory(res[0][0], out) and np.isfinite(out).all()
+    dt = min(runs)
     rec["process_signal_out"] = {"ms_per_hop": dt / signal_hops * 1e3, "hops": signal_hops, "realtime_factor": (signal_hops * H / 48000.0) / dt,
+                                 "runs_ms_per_hop": [r / signal_hops * 1e3 for r in runs], "counted": "the faster of two calls",
                                  "output": "caller-provided page-locked array (alloc_signal_output), allocated before the call"}
     return rec
 
