@@ -94,7 +94,9 @@ struct apv_handle {
     struct UpdateLane {
         hipStream_t s;
         hipEvent_t ev;            // recorded behind the lane's latest launch
+        hipEvent_t ev_prev;       // ... and behind the one before it (the two handles swap at every launch)
         bool used;                // ev has been recorded at least once
+        bool used_prev;           // ev_prev too
         bool need_fork;           // the control stream has had work since this lane last looked: wait for ev_fork first
         const void* rd[3];        // operand ranges of the latest launch: inputs ...
         size_t rd_bytes[3];

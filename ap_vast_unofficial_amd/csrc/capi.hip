@@ -1,5 +1,6 @@
 // C ABI of libapvast_hip.so (see include/apvast_hip.h for the contract).
 #include "apv_internal.h"
+#include <utility>
 
 #include <cstdlib>
 
@@ -131,6 +132,9 @@ int ensure_staging(apv_handle* h) {
 //   lanes_join   the control stream waits for the latest launch of every lane (before anything it is asked to do with buffers)
 //   lanes_fork   a lane waits for what the control stream has been given since the lanes last looked (ctrl_dirty)
 //   operand ranges of the latest launch of the OTHER lane: a launch that writes what it reads or writes, or reads what it writes, waits
+//   for it; and every launch waits for the other lane's launch BEFORE its latest, so that the latest is the only launch of the other
+//   lane it can ever run beside (the ranges of one launch per lane are then all there is to compare; in the steady state that
+//   event completed a launch ago)
 bool lanes_on(const apv_handle* h) { return h->n_lanes > 1; }
 
 int lanes_join(apv_handle* h, bool dirties) {
@@ -234,8 +238,8 @@ int apv_create(const apv_config* cfg, apv_handle** out) {
     h->comm_world = 1;
     for (auto& ln : h->lane) {
         ln.s = nullptr;
-        ln.ev = nullptr;
-        ln.used = ln.need_fork = false;
+        ln.ev = ln.ev_prev = nullptr;
+        ln.used = ln.used_prev = ln.need_fork = false;
         for (int i = 0; i < 3; ++i) { ln.rd[i] = ln.wr[i] = nullptr; ln.rd_bytes[i] = ln.wr_bytes[i] = 0; }
     }
     h->d_Lspill_lane1 = nullptr;
@@ -280,6 +284,7 @@ int apv_destroy(apv_handle* h) {
     for (auto& ln : h->lane) {
         if (ln.s) (void)hipStreamSynchronize(ln.s);
         if (ln.ev) (void)hipEventDestroy(ln.ev);
+        if (ln.ev_prev) (void)hipEventDestroy(ln.ev_prev);
         if (ln.s) (void)hipStreamDestroy(ln.s);
     }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -389,6 +394,7 @@ int apv_update_dev(apv_handle* h, const void* d_XB, const void* d_XD, const void
         const void* wr[3] = {d_w, d_lam, d_status};
         const size_t wr_bytes[3] = {K * c.n_ranks * L * wsize(h), d_lam ? K * L * lsize(h) : 0, d_status ? K * sizeof(int32_t) : 0};
         apv_handle::UpdateLane& other = h->lane[li ^ 1];
+        if (other.used_prev) HIPCHK(h, hipStreamWaitEvent(st, other.ev_prev, 0));
         if (other.used) {
             bool clash = false;
             for (int i = 0; i < 3; ++i)
@@ -441,6 +447,8 @@ int apv_update_dev(apv_handle* h, const void* d_XB, const void* d_XD, const void
     if (e != hipSuccess) return fail(h, e == hipErrorInvalidValue ? APV_ERR_ARG : APV_ERR_HIP,
                                      why.empty() ? hipGetErrorString(e) : why);
     if (ln) {
+        std::swap(ln->ev, ln->ev_prev);              // the latest becomes the one before; its handle is recorded anew
+        ln->used_prev = ln->used;
         HIPCHK(h, hipEventRecord(ln->ev, st));
         ln->used = true;
     }
@@ -458,11 +466,12 @@ int apv_set_update_streams(apv_handle* h, int32_t n) {
         for (auto& ln : h->lane) {
             HIPCHK(h, hipStreamCreateWithFlags(&ln.s, hipStreamNonBlocking));
             HIPCHK(h, hipEventCreateWithFlags(&ln.ev, hipEventDisableTiming));
+            HIPCHK(h, hipEventCreateWithFlags(&ln.ev_prev, hipEventDisableTiming));
         }
         HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     }
     if (n == 2 && h->lspill_bytes > 0 && !h->d_Lspill_lane1) HIPCHK(h, hipMalloc(&h->d_Lspill_lane1, h->lspill_bytes));
-    for (auto& ln : h->lane) ln.used = ln.need_fork = false;
+    for (auto& ln : h->lane) ln.used = ln.used_prev = ln.need_fork = false;
     h->ctrl_dirty = false;
     h->lane_next = 0;
     h->n_lanes = n;
@@ -809,10 +818,11 @@ int apv_allgather_filters_dev(apv_handle* h, const void* d_w_shard, void* d_w_al
     // the gather starts once the kernels already queued on the compute stream have written the shard, and runs
     // on its own stream: the next block's update (into another shard buffer) overlaps it
     if (lanes_on(h)) {
-        // the shard was written on a lane: the gather waits for the latest launch of every lane that wrote into it -- directly, so
-        // that no other stream carries a wait a later launch could queue up behind -- and for the control stream as below
+        // the shard was written on a lane: the gather waits for the latest launch of BOTH lanes (whichever wrote it, now or
+        // earlier; the other one's finished a step ago in the usual order of calls) -- on its own stream, so that no stream a
+        // later launch could queue up behind carries the wait -- and for the control stream as below
         for (auto& ln : h->lane)
-            if (ln.used && ranges_meet(d_w_shard, bytes, ln.wr[0], ln.wr_bytes[0])) HIPCHK(h, hipStreamWaitEvent(h->comm_stream, ln.ev, 0));
+            if (ln.used) HIPCHK(h, hipStreamWaitEvent(h->comm_stream, ln.ev, 0));
     }
     HIPCHK(h, hipEventRecord(h->ev_ready, h->stream));
     HIPCHK(h, hipStreamWaitEvent(h->comm_stream, h->ev_ready, 0));
