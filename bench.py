@@ -13,8 +13,10 @@ Inputs are resident in HBM before the timed region; PCIe is not in `value`.
            --master-port P bench.py --gpus N         # the same under an external launcher
 
 At N GPUs the workload is BASELINE config 4: blocks of 4096 bins, rank g owns bins [g 4096/N, (g+1) 4096/N) of every
-block, 8 N blocks resident -- the same 32 768 bin-updates per GPU per step as the 1-GPU run (weak scaling) -- and the
-per-bin filters are reassembled on every rank by one RCCL all-gather per step, overlapped with the next step's update.
+block, 32 N blocks resident -- 131 072 bin-updates per GPU per step whatever N is (weak scaling) -- and the per-bin filters
+are reassembled on every rank by one RCCL all-gather per step (16 MiB per rank), overlapped with the next step's update.  (A
+step four times the 1-GPU run's because this path launches on ONE stream -- beside a collective a second update stream gains
+nothing -- and the head and tail of a launch cost the same once per step: 7.3 -> 7.7e7 updates/s at world size 1.)
 
 Launching.  A launcher (torchrun) provides RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*.  Without one, `--gpus N` makes
 THIS process the launcher: before anything touches a GPU it starts N children of itself (one per GPU, the same
@@ -677,7 +679,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--blocks", type=int, default=0,
                     help="audio blocks resident per step: per rank x 1024 bins at 1 GPU (default 32), GLOBAL x 4096 bins "
-                         "sharded over the ranks at N GPUs (default 8 N, the same 32768 bin-updates per GPU)")
+                         "sharded over the ranks at N GPUs (default 32 N: 131072 bin-updates per GPU and step)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--prespin", type=float, default=0.3, help="seconds of untimed launches before the counted warm-up (clock ramp)")
     ap.add_argument("--update-streams", type=int, default=0, choices=[0, 1, 2],
@@ -728,7 +730,7 @@ def main():
         lo, hi = shard_bins(bins_per_block, world, rank)
         if (hi - lo) * world != bins_per_block:
             raise SystemExit(f"[bench] {bins_per_block} bins do not split evenly over {world} ranks")
-        blocks = args.blocks if args.blocks > 0 else 8 * world
+        blocks = args.blocks if args.blocks > 0 else 32 * world
         K = blocks * (hi - lo)
         workload = (f"cfg4: 16 loudspeakers x 32 control points x 4096 bins/block, bins sharded over {world} GPUs "
                     f"({hi - lo} bins per rank per block, {blocks} blocks resident), fused correlate+GEVD+VAST filter, "

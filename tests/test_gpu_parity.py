@@ -564,4 +564,4 @@ def test_bench_distributed_rehearsal_without_torch():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["config"]["workload"].startswith("cfg4") and line["collective_us"] > 0
-    assert line["collective_bytes_per_rank"] == 32768 * 16 * 8 and line["value"] > 1e6
+    assert line["collective_bytes_per_rank"] == 32 * 4096 * 16 * 8 and line["value"] > 1e6          # 32 blocks of 4096 bins per rank and step
