@@ -20,7 +20,7 @@
 #include <cstring>
 #include <vector>
 
-constexpr int CK_NB = 3;      // back streams of the chunked whole-signal path
+constexpr int CK_NB = 4;      // back streams of the chunked whole-signal path
 constexpr int CK_NS = 3;      // pinned staging slots (chunks) of that path
 
 struct apv_stream {
@@ -793,7 +793,14 @@ static int chunk_prepare(apv_handle* h) {
             const size_t spill = apv_gevd_spill_bytes((int)L, (int)K, c.compute_dtype, c.reg_mode, c.reg_bright, c.sweep_tol2, c.n_zones == 3 ? 2 : 1);
             if (spill > 0 && (rc = dalloc(h, &s->ck_spill[b], spill, 1))) return rc;
         }
-        SCHK(h, hipStreamCreateWithFlags(&s->ck_back[b], hipStreamNonBlocking));
+        {
+            // experiment (APV_CK_BACK_PRIO): -1 lowest stream priority, 1 highest, else the default
+            static const int want = getenv("APV_CK_BACK_PRIO") ? atoi(getenv("APV_CK_BACK_PRIO")) : 0;
+            int lo = 0, hi = 0;
+            SCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
+            if (want == 0) SCHK(h, hipStreamCreateWithFlags(&s->ck_back[b], hipStreamNonBlocking));
+            else SCHK(h, hipStreamCreateWithPriority(&s->ck_back[b], hipStreamNonBlocking, want < 0 ? lo : hi));
+        }
     }
     for (int q = 0; q < CK_NS; ++q) SCHK(h, hipEventCreateWithFlags(&s->ck_done[q], hipEventDisableTiming));
     SCHK(h, hipHostMalloc(&s->ck_pin_in, e1 * CK_NS * chunk * 2 * s->H, hipHostMallocDefault));

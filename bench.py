@@ -584,6 +584,39 @@ def run_cfg4_rehearsal():
     return rec
 
 
+ALSO_RECORDS = ("cfg3", "cfg5", "cfg1", "reference_test_parameters")
+
+
+def also_record(name, device):
+    """One sub-record of the 1-GPU line, computed in THIS process."""
+    if name == "cfg3":
+        return also_cfg3(device)
+    if name == "cfg5":
+        from ap_vast_unofficial_amd import Engine
+        return also_cfg5(Engine, device)
+    if name == "cfg1":
+        return also_cfg1(device)
+    if name == "reference_test_parameters":
+        return also_reftest(device)
+    raise ValueError(name)
+
+
+def run_also_child(name, device):
+    """A sub-record in a child of this process, started -- and finished -- before this process has made any GPU call.  Each
+    sub-record gets a process of its own because the whole-signal paths are sensitive to the process's history: they run six to
+    eight streams side by side, HIP deals streams over a few hardware queues in the order of their creation, and three streams
+    created (even destroyed) before the path is set up cost its rate 40 % (profiles/r04/cfg3_queue_phase.txt, cfg3_history.txt:
+    0.069 -> 0.097 ms per hop at cfg3).  In a fresh process every record meets the same conditions, whatever ran before it."""
+    t0 = time.perf_counter()
+    p = subprocess.run([sys.executable, os.path.abspath(__file__), "--also-only", name, "--also-device", str(device)],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    if p.returncode != 0:
+        return {"error": f"child exited with code {p.returncode}: {p.stderr.decode(errors='replace')[-400:]}"}
+    rec = json.loads(p.stdout.decode().strip().splitlines()[-1])
+    rec["child_wall_s"] = time.perf_counter() - t0
+    return rec
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # self-launch
 # ---------------------------------------------------------------------------------------------------------------------
@@ -689,6 +722,8 @@ def main():
                          "nothing: profiles/r04/dist_rehearsal_ab.txt)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the cfg3 / cfg5 sub-records of the 1-GPU line")
+    ap.add_argument("--also-only", default=None, choices=ALSO_RECORDS, help="(internal) compute one sub-record and print it")
+    ap.add_argument("--also-device", type=int, default=0)
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not os.environ.get("APV_BENCH_FORCE_DIST"):
@@ -698,13 +733,26 @@ def main():
         return dryrun_rank()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL needs it); before HIP starts
+    if args.also_only:
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)                                             # (libraries write to stdout too)
+        rec = also_record(args.also_only, args.also_device)
+        os.write(json_fd, (json.dumps(rec) + "\n").encode())
+        return
     rehearsal = None
+    also_pre = {}
     if (args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not os.environ.get("APV_BENCH_FORCE_DIST")
             and not args.no_also):
         try:
             rehearsal = run_cfg4_rehearsal()          # before anything below loads HIP in this process
         except Exception as ex:
             rehearsal = {"error": f"{type(ex).__name__}: {ex}"}
+        for name in ALSO_RECORDS:                     # likewise: each in a fresh process, before this one touches the GPU
+            try:
+                also_pre[name] = run_also_child(name, int(os.environ.get("LOCAL_RANK", "0")))
+            except Exception as ex:                   # the headline stands on its own: a failing sub-record is reported, not fatal
+                also_pre[name] = {"error": f"{type(ex).__name__}: {ex}"}
     # ONE JSON line on stdout: libraries write there too (librccl prints a version banner when a communicator is made), so file
     # descriptor 1 is pointed at stderr for the life of the rank and the line goes out through a private copy of the original.
     sys.stdout.flush()
@@ -912,14 +960,8 @@ def main():
 
     if rank == 0:
         if world == 1 and not multi and not args.no_also:
-            also = {}
-            for name, fn in (("cfg3", lambda: also_cfg3(local_rank)), ("cfg5", lambda: also_cfg5(Engine, local_rank)),
-                             ("cfg1", lambda: also_cfg1(local_rank)),
-                             ("reference_test_parameters", lambda: also_reftest(local_rank))):
-                try:
-                    also[name] = fn()
-                except Exception as ex:  # the headline stands on its own: a failing sub-record is reported, not fatal
-                    also[name] = {"error": f"{type(ex).__name__}: {ex}"}
+            also = dict(also_pre)
+            also["how"] = "every sub-record in a child process of its own, run before this process touched the GPU (run_also_child)"
             if rehearsal is not None:
                 also["cfg4_rehearsal"] = rehearsal
             out["also"] = also
