@@ -52,6 +52,11 @@ struct GevdParams {
     int yield_issue;
     // diagnostic builds only (tools/probes/stage_stamps.py): s_memtime at the stage boundaries, [zones][K][16]; null in normal use
     unsigned long long* stamps;
+    // several hops of a chunk in ONE launch (chunked whole-signal path; blockIdx.z = hop): the same K bins for n_hops consecutive spectra
+    // sets, byte strides from hop to hop of the slabs (XB, XD and their second-zone twins), the targets, and the three outputs.  Only
+    // the order-16 float64 kernel on c128 slabs takes it (apv_gevd16m_takes_hops); 0 or 1: a single hop, strides unused
+    int n_hops;
+    size_t hop_X, hop_d, hop_w, hop_lam, hop_status;
 };
 
 struct apv_handle {
@@ -130,6 +135,7 @@ bool apv_gevd64_eligible(int n, int reg_mode, double reg_bright, double sweep_to
 // kernels_gevd16m.hip: order-16 fast path (MFMA correlation / whitening / back-transform + register-resident
 // Jacobi); hipErrorNotSupported when the problem does not qualify
 hipError_t apv_launch_gevd16m(const GevdParams& p, int compute_dtype, bool fused, hipStream_t s);
+bool apv_gevd16m_takes_hops(const GevdParams& p, int compute_dtype, bool fused);      // would that launch accept p.n_hops > 1?
 
 // kernels_gevd64.hip: order-64 float64 path (float32 block Jacobi on the f32 MFMA + float64 refinement on the f64 MFMA);
 // hipErrorNotSupported when the problem does not qualify.  Needs p.Lspill with apv_gevd_spill_bytes() bytes.

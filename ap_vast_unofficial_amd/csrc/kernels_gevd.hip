@@ -666,6 +666,10 @@ int apv_gevd_reads_groups(const GevdParams& p, int compute_dtype, bool x_c128) {
 hipError_t apv_launch_gevd(const GevdParams& p, int compute_dtype, bool fused, hipStream_t s, std::string* why) {
     const int n = p.n;
     static const bool force_generic = (getenv("APV_FORCE_GENERIC") != nullptr);
+    if (p.n_hops > 1 && (force_generic || !apv_gevd16m_takes_hops(p, compute_dtype, fused))) {
+        if (why) *why = "several hops per launch (n_hops > 1) are taken by the order-16 float64 kernel on c128 slabs only";
+        return hipErrorInvalidValue;
+    }
     if (!force_generic) {
         const hipError_t e16 = apv_launch_gevd16m(p, compute_dtype, fused, s);
         if (e16 != hipErrorNotSupported) return e16;
@@ -680,6 +684,7 @@ hipError_t apv_launch_gevd(const GevdParams& p, int compute_dtype, bool fused, h
         if (why) *why = "grouped spectra (x_group > 1) are read by the order-16 float64 kernel only";
         return hipErrorInvalidValue;
     }
+
     if (compute_dtype == APV_F64) {
         if (n <= 8) return launch_t<double, 8, 64, false>(p, fused, s);
         if (n <= 16) return launch_t<double, 16, 64, false>(p, fused, s);

@@ -29,8 +29,10 @@ namespace {
 // DBG: the diagnostic instantiation.  It alone carries the run-time `debug_stop` tests (stage cuts and A/B switches of the
 // probes under tools/probes/) and the in-kernel stage stamps (p.stamps); in the product instantiation `dstop` is the constant 0
 // and all of it folds away, the round-2a two-sided pre-solve included.
-template <typename T, bool FUSED, typename XT, bool DBG, int GS = 1>
-__device__ __forceinline__ void gevd16m_body(const GevdParams& p, const int k, const bool z1) {
+// HOPS: the launch covers several hops of a chunk (blockIdx.z = hop): every operand moves on by its byte stride per hop (scalar
+// arithmetic on the argument block; the instantiations without it are untouched)
+template <typename T, bool FUSED, typename XT, bool DBG, int GS = 1, bool HOPS = false>
+__device__ __forceinline__ void gevd16m_body(const GevdParams& p, const int k, const bool z1, const int hop = 0) {
     const int dstop = DBG ? p.debug_stop : 0;
     // stage stamps (diagnostic build only): s_memtime of lane 0 at the stage boundaries, 8 per bin, into a buffer of their own
     auto stamp = [&](int i) {
@@ -42,12 +44,17 @@ __device__ __forceinline__ void gevd16m_body(const GevdParams& p, const int k, c
     stamp(0);
     if constexpr (DBG) { if (p.stamps != nullptr && threadIdx.x == 0) p.stamps[((size_t)(z1 ? 1 : 0) * p.K + k) * 16 + 15] = __builtin_amdgcn_s_memrealtime(); }
     // zone program of a two-zone launch (z1); the argument block itself stays in scalar registers
-    const XT* const pXB = reinterpret_cast<const XT*>(z1 ? p.XB1 : p.XB);
-    const XT* const pXD = reinterpret_cast<const XT*>(z1 ? p.XD1 : p.XD);
-    const XT* const pd = reinterpret_cast<const XT*>(z1 ? p.d1 : p.d);
-    void* const pw = z1 ? p.w1 : p.w;
-    void* const plam = z1 ? p.lam1 : p.lam;
-    int32_t* const pstatus = z1 ? p.status1 : p.status;
+    auto at_hop = [&](const void* base, size_t stride) -> const char* {
+        const char* b = static_cast<const char*>(base);
+        if constexpr (HOPS) return b ? b + (size_t)hop * stride : b;
+        else return b;
+    };
+    const XT* const pXB = reinterpret_cast<const XT*>(at_hop(z1 ? p.XB1 : p.XB, p.hop_X));
+    const XT* const pXD = reinterpret_cast<const XT*>(at_hop(z1 ? p.XD1 : p.XD, p.hop_X));
+    const XT* const pd = reinterpret_cast<const XT*>(at_hop(z1 ? p.d1 : p.d, p.hop_d));
+    void* const pw = const_cast<char*>(at_hop(z1 ? p.w1 : p.w, p.hop_w));
+    void* const plam = const_cast<char*>(at_hop(z1 ? p.lam1 : p.lam, p.hop_lam));
+    int32_t* const pstatus = reinterpret_cast<int32_t*>(const_cast<char*>(at_hop(z1 ? p.status1 : p.status, p.hop_status)));
     using C = Cx<T>;
     __shared__ C sA[N * LD];       // R_B -> W R_B -> C -> Q (eigenvectors of C) -> X
     __shared__ C sB[N * LD];       // R_D -> W = L^-1
@@ -615,14 +622,36 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     const int k = ((id | (BLK - 1)) < p.K) ? ((id & ~(BLK - 1)) | ((id & 7) * GS) | ((id >> 3) & (GS - 1))) : id;
     gevd16m_body<double, true, double2, false, GS>(p, k, blockIdx.y == 1);
 }
+// The hops of a chunk in one launch (chunked whole-signal path: blockIdx.z = hop), bin-major (GS = 1) or grouped spectra.  A hop's 2050
+// waves are two per SIMD -- all head and tail; sixteen hops are a launch of the headline's size.
+template <int GS>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) gevd16m_kernel_f64_hops(const GevdParams p) {
+    constexpr int BLK = 8 * GS;
+    const int id = blockIdx.x;
+    const int k = (GS > 1 && (id | (BLK - 1)) < p.K) ? ((id & ~(BLK - 1)) | ((id & 7) * GS) | ((id >> 3) & (GS - 1))) : id;
+    gevd16m_body<double, true, double2, false, GS, true>(p, k, blockIdx.y == 1, blockIdx.z);
+}
 
 }  // namespace
+
+bool apv_gevd16m_takes_hops(const GevdParams& p, int compute_dtype, bool fused) {
+    return p.n == 16 && p.reg_mode == APV_REG_ABS && p.reg_bright == 0.0 && fused && p.x_c128 && compute_dtype == APV_F64 &&
+           p.debug_stop == 0 && p.stamps == nullptr && (p.x_group <= 1 || p.x_group == 4 || p.x_group == 8) && p.n_hops <= 65535;
+}
 
 hipError_t apv_launch_gevd16m(const GevdParams& p, int compute_dtype, bool fused, hipStream_t s) {
     if (p.n != 16 || p.reg_mode != APV_REG_ABS || p.reg_bright != 0.0) return hipErrorNotSupported;
     if (p.K <= 0) return hipSuccess;
     const dim3 grid(p.K, p.n_zones > 1 ? 2 : 1);
     const bool xd = fused && p.x_c128;
+    if (p.n_hops > 1) {
+        if (!apv_gevd16m_takes_hops(p, compute_dtype, fused)) return hipErrorInvalidValue;
+        const dim3 grid3(p.K, p.n_zones > 1 ? 2 : 1, p.n_hops);
+        if (p.x_group == 4) hipLaunchKernelGGL(gevd16m_kernel_f64_hops<4>, grid3, dim3(64), 0, s, p);
+        else if (p.x_group == 8) hipLaunchKernelGGL(gevd16m_kernel_f64_hops<8>, grid3, dim3(64), 0, s, p);
+        else hipLaunchKernelGGL(gevd16m_kernel_f64_hops<1>, grid3, dim3(64), 0, s, p);
+        return hipGetLastError();
+    }
     if (p.x_group > 1) {
         // only the float64 product kernel on c128 slabs reads the grouped layout (apv_gevd16m_reads_groups says when)
         if (!xd || compute_dtype != APV_F64 || p.debug_stop != 0 || p.stamps != nullptr) return hipErrorInvalidValue;

@@ -102,6 +102,8 @@ struct apv_stream {
     void* ck_inspec;              // [2 sig_chunk][2][K]
     void* ck_w[CK_NB - 1][2];     // [K][nV][L] per zone: filters of back streams 1 ... (back stream 0 uses w, lam)
     void* ck_lam[CK_NB - 1][2];
+    void* ck_wall[2];             // [sig_chunk][K][nV][L] per zone: the filters of every hop of a chunk whose joint diagonalisations are ONE launch
+    void* ck_lamall[2];           // [sig_chunk][K][L]
     void* ck_spill[CK_NB - 1];    // per-bin scratch of the joint diagonalisation (orders 33..64) for back streams 1 ...: two hops' workgroups for
                                   // the same bin run at once, each parks its state in its own stream's slot (back stream 0 uses d_Lspill)
     hipStream_t ck_back[CK_NB - 1];
@@ -214,6 +216,10 @@ void apv_stream_free(apv_handle* h) {
     }
     for (int b = 0; b < CK_NB; ++b)
         if (s->ck_k3[b]) (void)hipEventDestroy(s->ck_k3[b]);
+    for (int z = 0; z < 2; ++z) {
+        if (s->ck_wall[z]) (void)hipFree(s->ck_wall[z]);
+        if (s->ck_lamall[z]) (void)hipFree(s->ck_lamall[z]);
+    }
     for (int b = 0; b + 1 < CK_NB; ++b) {
         for (int z = 0; z < 2; ++z) {
             if (s->ck_w[b][z]) (void)hipFree(s->ck_w[b][z]);
@@ -374,6 +380,7 @@ struct BackSchedule {
     void* ospec = nullptr;
     bool no_copy = false;
     void* lspill = nullptr;   // GevdParams::Lspill of this launch (nullptr: the handle's d_Lspill)
+    bool skip_gevd = false;   // the filters are there already: the chunk's joint diagonalisations were one launch (enqueue_gevd_hops)
 };
 
 // Back half of a hop on stream `st`: spectra of set `set` -> per-bin filters (K5'-K10), output spectra (K3), synthesis
@@ -391,7 +398,7 @@ static int enqueue_back(apv_handle* h, hipStream_t st, const HopSpectra& q, void
     std::string why;
     // per-bin update per zone program: A: bright A->A, dark A->B, target A;  B: bright B->B, dark B->A, target B
     int oc = 0;     // output channel cursor
-    {
+    if (!sch.skip_gevd) {
         // both zone programs go out in ONE launch (blockIdx.y = zone): K = N/2+1 bins alone cannot fill the chip
         GevdParams p = apv_base_params(h);
         const int first = runA ? 0 : 1;
@@ -783,6 +790,10 @@ static int chunk_prepare(apv_handle* h) {
         for (int b = 0; b < CK_NB; ++b) SCHK(h, hipEventCreateWithFlags(&s->ck_backdone[q][b], hipEventDisableTiming));
     }
     for (int b = 0; b < CK_NB; ++b) SCHK(h, hipEventCreateWithFlags(&s->ck_k3[b], hipEventDisableTiming));
+    for (int z = 0; z < 2; ++z) {
+        if ((rc = dalloc(h, &s->ck_wall[z], (size_t)chunk * K * s->nV * L, wsz(h)))) return rc;
+        if ((rc = dalloc(h, &s->ck_lamall[z], (size_t)chunk * K * L, lsz(h)))) return rc;
+    }
     for (int b = 0; b + 1 < CK_NB; ++b) {
         for (int z = 0; z < 2; ++z) {
             if ((rc = dalloc(h, &s->ck_w[b][z], K * s->nV * L, wsz(h)))) return rc;
@@ -929,6 +940,18 @@ static int process_signal_chunked_t(apv_handle* h, int n_hops, const TI* h_in_A,
     };
     const size_t spec_bytes = ((size_t)s->fir_F / 2 + 1) * e2;       // one input spectrum of K1
     int last_par = 0, last_nc = 0, last_b = 0;
+    // the chunk's joint diagonalisations as one launch where the kernel that will run takes several hops (order 16, float64 on c128
+    // slabs, absolute loading, no diagnostics); APV_SIGNAL_BATCHED=0: hop by hop on the back streams, as before (A/B switch)
+    bool batched = false;
+    {
+        static const bool want = getenv("APV_SIGNAL_BATCHED") == nullptr || atoi(getenv("APV_SIGNAL_BATCHED")) != 0;
+        GevdParams probe = apv_base_params(h);
+        probe.x_c128 = f64;
+        probe.x_group = s->xg;
+        probe.n_hops = 2;
+        static const bool force_generic = getenv("APV_FORCE_GENERIC") != nullptr;
+        batched = want && !force_generic && apv_gevd16m_takes_hops(probe, h->cfg.compute_dtype, true);
+    }
     std::string why;
     for (int c = 0; c < n_chunks && worst != APV_ERR_NOT_PD; ++c) {
         const int base = c * chunk, nc = std::min(chunk, n_hops - base), par = c & 1;
@@ -1009,8 +1032,68 @@ static int process_signal_chunked_t(apv_handle* h, int n_hops, const TI* h_in_A,
         }
         CK(hipEventRecord(s->ev_front[par], s->front));
         tmark(s->front);
-        // ---------------- back halves, hop by hop, alternating between the two back streams ----------------
-        for (int i = 0; i < nc; ++i) {
+        // ---------------- back halves ----------------
+        // (a) the joint diagonalisations of the whole chunk as ONE launch (blockIdx.z = hop), then output spectra and synthesis hop
+        //     by hop.  A hop's 2050 waves are two per SIMD, all head and tail; every input of the sixteen exists once
+        //     the chunk's transforms have ended, and sixteen hops are a launch of the headline's size.  Same values per bin.
+        if (batched) {
+            hipStream_t b0 = bs[0];
+            CK(hipStreamWaitEvent(b0, s->ev_front[par], 0));
+            if (c >= 2) CK(hipStreamWaitEvent(b0, s->ck_done[(c - 2) % CK_NS], 0));        // the result slots of this parity are free
+            tmark(b0);
+            static const bool no_yield = getenv("APV_SIGNAL_NO_YIELD") != nullptr;       // A/B switch
+            const size_t hop_w = (size_t)K * s->nV * L * wsz(h), hop_lam = (size_t)K * L * lsz(h);
+            {
+                GevdParams p = apv_base_params(h);
+                const HopSpectra q0 = set_of(par, 0);
+                const int first = runA ? 0 : 1;
+                char* const obuf0 = (char*)s->ck_out + (size_t)par * chunk * hop_result_bytes(s);
+                int32_t* const st0 = reinterpret_cast<int32_t*>(obuf0 + hop_out_bytes(s));
+                p.x_c128 = f64;
+                p.x_group = s->xg;
+                p.XB = first ? q0.X[3] : q0.X[0];
+                p.XD = first ? q0.X[2] : q0.X[1];
+                p.d = q0.tspec[first];
+                p.w = s->ck_wall[first];
+                p.lam = s->ck_lamall[first];
+                p.status = st0 + (size_t)first * K;
+                p.n_zones = (runA && runB) ? 2 : 1;
+                p.yield_issue = no_yield ? 0 : 1;
+                if (p.n_zones == 2) {
+                    p.XB1 = q0.X[3]; p.XD1 = q0.X[2]; p.d1 = q0.tspec[1];
+                    p.w1 = s->ck_wall[1]; p.lam1 = s->ck_lamall[1]; p.status1 = st0 + K;
+                }
+                p.n_hops = nc;
+                p.hop_X = (size_t)s->Kp * C * e2;
+                p.hop_d = (size_t)K * M * e2;
+                p.hop_w = hop_w;
+                p.hop_lam = hop_lam;
+                p.hop_status = hop_result_bytes(s);
+                hipError_t e = apv_launch_gevd(p, h->cfg.compute_dtype, true, b0, &why);
+                if (e != hipSuccess) return bail(APV_ERR_HIP, why.empty() ? hipGetErrorString(e) : why);
+            }
+            for (int i = 0; i < nc; ++i) {
+                const size_t slot = (size_t)par * chunk + i;
+                BackSchedule sch;
+                sch.skip_gevd = true;
+                sch.spectra_free = s->ck_k3[0];
+                sch.tail_stream = s->tail;
+                sch.result = (char*)s->ck_out + slot * hop_result_bytes(s);
+                sch.ospec = (char*)s->ck_ospec + slot * (size_t)s->n_out * K * e2;
+                sch.no_copy = true;
+                void* wz[2] = {(char*)s->ck_wall[0] + i * hop_w, (char*)s->ck_wall[1] + i * hop_w};
+                void* lz[2] = {(char*)s->ck_lamall[0] + i * hop_lam, (char*)s->ck_lamall[1] + i * hop_lam};
+                rc = enqueue_back(h, b0, set_of(par, i), wz, lz, nullptr, sch);
+                if (rc != APV_OK) return bail(rc, h->err);
+                if (i + 1 == nc) CK(hipEventRecord(s->ck_backdone[par][0], b0));
+                if (i + 2 >= nc && nc >= 2) tmark(b0);
+                last_par = par; last_nc = nc; last_b = 0;
+                s->hop++;
+            }
+            if (nc < 2) { tmark(b0); tmark(b0); }          // (the schedule print expects six marks per chunk)
+        }
+        // (b) hop by hop, alternating between the back streams (configurations the batched launch does not take)
+        for (int i = 0; i < nc && !batched; ++i) {
             const int b = (int)((s->hop - hop_first) % CK_NB);
             if (i < CK_NB) {
                 CK(hipStreamWaitEvent(bs[b], s->ev_front[par], 0));
@@ -1086,7 +1169,13 @@ static int process_signal_chunked_t(apv_handle* h, int n_hops, const TI* h_in_A,
         for (int p = 0; p < 4; ++p) CK(hipMemcpyAsync(s->X[p], q.X[p], (size_t)s->Kp * C * e2, hipMemcpyDeviceToDevice, st));
         for (int z = 0; z < 2; ++z) CK(hipMemcpyAsync(s->tspec[z], q.tspec[z], (size_t)K * M * e2, hipMemcpyDeviceToDevice, st));
         CK(hipMemcpyAsync(s->inspec, q.inspec, (size_t)2 * K * e2, hipMemcpyDeviceToDevice, st));
-        if (last_b != 0) {
+        if (batched) {
+            const size_t hop_w = (size_t)K * s->nV * L * wsz(h), hop_lam = (size_t)K * L * lsz(h);
+            for (int z = 0; z < 2; ++z) {
+                CK(hipMemcpyAsync(s->w[z], (char*)s->ck_wall[z] + (size_t)(last_nc - 1) * hop_w, hop_w, hipMemcpyDeviceToDevice, st));
+                CK(hipMemcpyAsync(s->lam[z], (char*)s->ck_lamall[z] + (size_t)(last_nc - 1) * hop_lam, hop_lam, hipMemcpyDeviceToDevice, st));
+            }
+        } else if (last_b != 0) {
             for (int z = 0; z < 2; ++z) {
                 CK(hipMemcpyAsync(s->w[z], wset[last_b][z], (size_t)K * s->nV * L * wsz(h), hipMemcpyDeviceToDevice, st));
                 CK(hipMemcpyAsync(s->lam[z], lset[last_b][z], (size_t)K * L * lsz(h), hipMemcpyDeviceToDevice, st));
