@@ -1,0 +1,15 @@
+#!/usr/bin/env python3
+"""The broadband whole-signal path (cfg1) after n streams were created in the process (see cfg3_queue_phase.py).
+usage: cfg1_queue_phase.py <streams created and destroyed first>     (APV_BB_FRONT2 / APV_BB_FRONT_THREAD from the environment)"""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import bench
+from ap_vast_unofficial_amd import Engine
+n_pre = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+engs = [Engine(64, 16, 32, ranks=(8,), mu=1.0, compute_dtype="f64", out_c128=False, device=0) for _ in range(n_pre)]
+for e in engs:
+    e.close()
+a = bench.also_cfg1(0)
+print(json.dumps({"streams_before": n_pre, "front2": os.environ.get("APV_BB_FRONT2", "1"), "thread": os.environ.get("APV_BB_FRONT_THREAD", "1"),
+                  "pib": round(a["process_input_buffers"]["ms_per_hop"], 4), "sig": round(a["process_signal"]["ms_per_hop"], 4),
+                  "sig_out": round(a["process_signal_out"]["ms_per_hop"], 4)}), flush=True)
