@@ -110,3 +110,40 @@ def test_order_64_lanes_have_scratch_of_their_own(Engine):
     for o in outs:
         assert np.array_equal(o.download((K, len(ranks), L), np.complex64), w_ref)
     eng.close()
+
+
+def test_random_sequences_of_launches_copies_and_downloads(Engine):
+    """Sixty random sequences: launches into three output buffers (often the one just written), unsynchronised uploads of new inputs,
+    downloads in the middle -- every download is the one-stream result of the inputs that were in place when its buffer was last
+    launched into.  (tools/probes/update_lanes_soak.py is the long form.)"""
+    rng = np.random.default_rng(2026)
+    K, L, M, ranks = 8192, 16, 32, (8,)
+    sets = [(cn(rng, K, M, L), cn(rng, K, M, L), cn(rng, K, M)) for _ in range(4)]
+    refs = [r[0] for r in _reference(Engine, K, L, M, ranks, sets)]
+    eng = Engine(K, L, M, ranks=ranks, mu=0.7, compute_dtype="f64", reg_dark=1e-7, out_c128=False)
+    eng.set_update_streams(2)
+    dev = [eng.to_device(a) for a in sets[0]]
+    outs = [eng.alloc(K * L * 8) for _ in range(3)]
+    holds, cur, checks = [None] * 3, 0, 0
+    for r in range(60):
+        for step in range(int(rng.integers(4, 12))):
+            act = rng.random()
+            if act < 0.2:
+                cur = int(rng.integers(0, len(sets)))
+                for buf, a in zip(dev, sets[cur]):
+                    eng._chk(eng.lib.apv_memcpy_h2d(eng.h, buf.ptr, a.ctypes.data_as(C.c_void_p), a.nbytes))
+            elif act < 0.85:
+                o = int(rng.integers(0, 3))
+                eng.update_dev(dev[0], dev[1], dev[2], outs[o])
+                holds[o] = cur
+            else:
+                o = int(rng.integers(0, 3))
+                if holds[o] is not None:
+                    assert np.array_equal(outs[o].download((K, 1, L), np.complex64), refs[holds[o]]), (r, step, o)
+                    checks += 1
+        for o in range(3):
+            if holds[o] is not None:
+                assert np.array_equal(outs[o].download((K, 1, L), np.complex64), refs[holds[o]]), (r, "end", o)
+                checks += 1
+    eng.close()
+    assert checks > 150
