@@ -582,11 +582,16 @@ static int signal_prepare(apv_handle* h) {
     if (!s->out1 && (rc = dalloc(h, &s->out1, hop_result_bytes(s), 1))) return rc;
     if (!s->outspec1 && (rc = dalloc(h, &s->outspec1, (size_t)s->n_out * K, e2))) return rc;
     if (s->fir_F > 0 && !s->xspec_chunk && (rc = dalloc(h, &s->xspec_chunk, (size_t)chunk * 2 * (s->fir_F / 2 + 1), e2))) return rc;
-    // Front and tail run at the highest stream priority: their kernels are short or bandwidth-shaped and everything downstream
-    // waits for them, while the joint diagonalisations they run beside (handle's stream, back1: default priority) fill every SIMD
-    // with 60-90 us waves and would otherwise keep the front half of the NEXT chunk out until the current one has drained.
+    // Front and tail at the DEFAULT stream priority.  (Rounds 2-4 ran them at the highest: their kernels are short or bandwidth-shaped
+    // and everything downstream waits for them, and beside per-hop joint diagonalisations that is worth 3-6 % in a fresh process
+    // -- but with priority streams the rate of the hop-by-hop schedule depends on how many streams the process created before:
+    // 0.069 / 0.102 / 0.092 ms per hop at cfg3 after 0 / 3 / 5 earlier streams, against 0.074 / 0.071 / 0.074 at the default
+    // priority (profiles/r04/cfg3_front_prio.txt).  The schedule with one joint-diagonalisation launch per chunk measures the same
+    // either way.  APV_CK_FRONT_PRIO=1 asks for the highest priority again: A/B switch.)
     int prio_least = 0, prio_greatest = 0;
     SCHK(h, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    static const bool front_high = getenv("APV_CK_FRONT_PRIO") != nullptr && atoi(getenv("APV_CK_FRONT_PRIO")) == 1;
+    if (!front_high) prio_greatest = 0;
     if (!s->front) SCHK(h, hipStreamCreateWithPriority(&s->front, hipStreamNonBlocking, prio_greatest));
     if (!s->tail) SCHK(h, hipStreamCreateWithPriority(&s->tail, hipStreamNonBlocking, prio_greatest));
     for (int p = 0; p < 2; ++p) {
