@@ -5,7 +5,10 @@ Workload (BASELINE.json configs[1], SURVEY.md section 8d "cfg2"): 16 loudspeaker
 points x 1024 frequency bins per audio block, one zone program, V = L/2.  One *step* = one pass
 of the hot path (correlate R_B/R_D/r -> joint diagonalisation -> variable-span filter) over a
 resident batch of `--blocks` blocks, i.e. blocks*1024 independent bin-updates in one launch.
-Inputs are resident in HBM before the timed region; PCIe is not in `value`.
+Inputs are resident in HBM before the timed region; PCIe is not in `value`.  On the single-GPU path consecutive steps alternate
+between two streams of the engine's (`--update-streams`, apv_set_update_streams: the last waves of one launch finish beside the
+first of the next; same results) and between two filter / status buffers; `roofline` is the kernel ALONE (one-stream leg behind
+the timed region), `roofline.pipelined` the rate of the timed region.
 
     python bench.py                      # 1 GPU: cfg2, 32 blocks x 1024 bins resident; also.cfg3, also.cfg5, cpu_baseline
     python bench.py --gpus N             # N GPUs of this node: the program starts its own N ranks (below)
@@ -24,7 +27,8 @@ environment variables set, rendezvous on 127.0.0.1 and a free port), relays rank
 rank fails.  The parent never initialises HIP and nothing is ever re-exec'd.  Nothing here imports torch: the RCCL id
 is exchanged over a TCP hub (ap_vast_unofficial_amd/rendezvous.py) and barriers are one-word RCCL all-reduces.
 
-Rank 0 prints ONE JSON line.  At N = 1 it also carries:
+Rank 0 prints ONE JSON line.  At N = 1 it also carries (every sub-record computed in a child process of its own
+that has ended before this process touches the GPU: the whole-signal paths are sensitive to the streams a process created before):
   also.cfg3   BASELINE config 3 through the drop-in class: 468 hops of 10 s pink noise, 16 x 32, N = 2048, float64, once
               through apvast.process_input_buffers (one call per hop) and once through apvast.process_signal
   also.cfg5   BASELINE config 5 at kernel level: 64 x 128 x 2048 bins in float64, with its own roofline, and
