@@ -750,6 +750,7 @@ int apv_stft_analysis_dev(apv_handle* h, int32_t n_ch, const float* d_x, void* d
     if (!h || !d_x || !d_spec) return fail(h, APV_ERR_ARG, "null device pointer");
     if (h->cfg.block_size <= 0) return fail(h, APV_ERR_ARG, "handle was created without an STFT geometry");
     HIPCHK(h, hipSetDevice(h->device));
+    if (int rc = lanes_join(h, true)) return rc;
     std::string why;
     hipError_t e = apv_launch_stft_analysis(h->cfg.block_size, n_ch, d_x, (float2*)d_spec, h->stream, &why);
     if (e != hipSuccess) return fail(h, e == hipErrorInvalidValue ? APV_ERR_ARG : APV_ERR_HIP,
@@ -761,6 +762,7 @@ int apv_istft_ola_dev(apv_handle* h, int32_t n_ch, const void* d_spec, float* d_
     if (!h || !d_spec || !d_overlap) return fail(h, APV_ERR_ARG, "null device pointer");
     if (h->cfg.block_size <= 0) return fail(h, APV_ERR_ARG, "handle was created without an STFT geometry");
     HIPCHK(h, hipSetDevice(h->device));
+    if (int rc = lanes_join(h, true)) return rc;
     std::string why;
     hipError_t e = apv_launch_istft_ola(h->cfg.block_size, h->cfg.hop_size, n_ch, (const float2*)d_spec, d_overlap,
                                         d_out, h->stream, &why);
