@@ -1184,7 +1184,14 @@ int apv_bb_process_signal(apv_handle* h, int32_t n_hops, const double* h_in_A, c
         if (!s->spec_out && (rc = dalloc(h, &s->spec_out, (size_t)s->n_out * K * 2))) return rc;
         if (!s->front) {
             BCHK(h, hipStreamCreateWithFlags(&s->front, hipStreamNonBlocking));
-            BCHK(h, hipStreamCreateWithFlags(&s->copy, hipStreamNonBlocking));
+            // a copy stream of its own only where a group's outputs are large enough for the next group's solve to notice the
+            // transfer (84 MB at the reference's test parameters; 131 KB at cfg1: there the copy rides on the handle's stream --
+            // every stream fewer is one fewer to share the runtime's few hardware queues with)
+            {
+                static const int own = getenv("APV_BB_COPY_STREAM") ? atoi(getenv("APV_BB_COPY_STREAM")) : -1;      // A/B: 1 always, 0 never
+                const size_t group_bytes = sizeof(double) * (size_t)G * s->n_out * s->H;
+                if (own == 1 || (own != 0 && group_bytes >= ((size_t)4 << 20))) BCHK(h, hipStreamCreateWithFlags(&s->copy, hipStreamNonBlocking));
+            }
             BCHK(h, hipStreamCreateWithFlags(&s->front2, hipStreamNonBlocking));
             BCHK(h, hipEventCreateWithFlags(&s->ev_ring, hipEventDisableTiming));
             BCHK(h, hipEventCreateWithFlags(&s->ev_stat, hipEventDisableTiming));
@@ -1216,7 +1223,7 @@ int apv_bb_process_signal(apv_handle* h, int32_t n_hops, const double* h_in_A, c
     }
     hipStream_t fs = s->front;
     // every exit below drains both streams first: copies into the caller's h_out may be in flight
-    hipStream_t cs = s->copy;
+    hipStream_t cs = s->copy ? s->copy : st;
     // the statistics of a hop on a stream of their own beside the next hop's K1 / WOLA chain (bb_front); APV_BB_FRONT2=0: one stream
     static const bool front2 = getenv("APV_BB_FRONT2") == nullptr || atoi(getenv("APV_BB_FRONT2")) != 0;
     hipStream_t fs2 = front2 ? s->front2 : nullptr;
