@@ -54,7 +54,7 @@ struct GevdParams {
     unsigned long long* stamps;
     // several hops of a chunk in ONE launch (chunked whole-signal path; blockIdx.z = hop): the same K bins for n_hops consecutive spectra
     // sets, byte strides from hop to hop of the slabs (XB, XD and their second-zone twins), the targets, and the three outputs.  Only
-    // the order-16 float64 kernel on c128 slabs takes it (apv_gevd16m_takes_hops); 0 or 1: a single hop, strides unused
+    // the order-16 kernels on fused slabs take it (apv_gevd16m_takes_hops); 0 or 1: a single hop, strides unused
     int n_hops;
     size_t hop_X, hop_d, hop_w, hop_lam, hop_status;
 };

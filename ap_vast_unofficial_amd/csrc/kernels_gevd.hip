@@ -667,7 +667,7 @@ hipError_t apv_launch_gevd(const GevdParams& p, int compute_dtype, bool fused, h
     const int n = p.n;
     static const bool force_generic = (getenv("APV_FORCE_GENERIC") != nullptr);
     if (p.n_hops > 1 && (force_generic || !apv_gevd16m_takes_hops(p, compute_dtype, fused))) {
-        if (why) *why = "several hops per launch (n_hops > 1) are taken by the order-16 float64 kernel on c128 slabs only";
+        if (why) *why = "several hops per launch (n_hops > 1) are taken by the order-16 kernels on fused slabs only";
         return hipErrorInvalidValue;
     }
     if (!force_generic) {

@@ -632,11 +632,21 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     gevd16m_body<double, true, double2, false, GS, true>(p, k, blockIdx.y == 1, blockIdx.z);
 }
 
+// the same for c64 slabs (float32 front end): float64 arithmetic ("mixed") and float32 arithmetic
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) gevd16m_kernel_f64_hops_c64(const GevdParams p) {
+    gevd16m_body<double, true, float2, false, 1, true>(p, blockIdx.x, blockIdx.y == 1, blockIdx.z);
+}
+__global__ void __launch_bounds__(64) gevd16m_kernel_f32_hops_c64(const GevdParams p) {
+    gevd16m_body<float, true, float2, false, 1, true>(p, blockIdx.x, blockIdx.y == 1, blockIdx.z);
+}
+
 }  // namespace
 
 bool apv_gevd16m_takes_hops(const GevdParams& p, int compute_dtype, bool fused) {
-    return p.n == 16 && p.reg_mode == APV_REG_ABS && p.reg_bright == 0.0 && fused && p.x_c128 && compute_dtype == APV_F64 &&
-           p.debug_stop == 0 && p.stamps == nullptr && (p.x_group <= 1 || p.x_group == 4 || p.x_group == 8) && p.n_hops <= 65535;
+    if (!(p.n == 16 && p.reg_mode == APV_REG_ABS && p.reg_bright == 0.0 && fused && p.debug_stop == 0 && p.stamps == nullptr && p.n_hops <= 65535))
+        return false;
+    if (p.x_c128) return compute_dtype == APV_F64 && (p.x_group <= 1 || p.x_group == 4 || p.x_group == 8);
+    return p.x_group <= 1;          // c64 slabs: either arithmetic, bin-major
 }
 
 hipError_t apv_launch_gevd16m(const GevdParams& p, int compute_dtype, bool fused, hipStream_t s) {
@@ -647,6 +657,11 @@ hipError_t apv_launch_gevd16m(const GevdParams& p, int compute_dtype, bool fused
     if (p.n_hops > 1) {
         if (!apv_gevd16m_takes_hops(p, compute_dtype, fused)) return hipErrorInvalidValue;
         const dim3 grid3(p.K, p.n_zones > 1 ? 2 : 1, p.n_hops);
+        if (!p.x_c128) {
+            if (compute_dtype == APV_F64) hipLaunchKernelGGL(gevd16m_kernel_f64_hops_c64, grid3, dim3(64), 0, s, p);
+            else hipLaunchKernelGGL(gevd16m_kernel_f32_hops_c64, grid3, dim3(64), 0, s, p);
+            return hipGetLastError();
+        }
         if (p.x_group == 4) hipLaunchKernelGGL(gevd16m_kernel_f64_hops<4>, grid3, dim3(64), 0, s, p);
         else if (p.x_group == 8) hipLaunchKernelGGL(gevd16m_kernel_f64_hops<8>, grid3, dim3(64), 0, s, p);
         else hipLaunchKernelGGL(gevd16m_kernel_f64_hops<1>, grid3, dim3(64), 0, s, p);
