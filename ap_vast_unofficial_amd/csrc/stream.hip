@@ -809,14 +809,8 @@ static int chunk_prepare(apv_handle* h) {
             const size_t spill = apv_gevd_spill_bytes((int)L, (int)K, c.compute_dtype, c.reg_mode, c.reg_bright, c.sweep_tol2, c.n_zones == 3 ? 2 : 1);
             if (spill > 0 && (rc = dalloc(h, &s->ck_spill[b], spill, 1))) return rc;
         }
-        {
-            // experiment (APV_CK_BACK_PRIO): -1 lowest stream priority, 1 highest, else the default
-            static const int want = getenv("APV_CK_BACK_PRIO") ? atoi(getenv("APV_CK_BACK_PRIO")) : 0;
-            int lo = 0, hi = 0;
-            SCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
-            if (want == 0) SCHK(h, hipStreamCreateWithFlags(&s->ck_back[b], hipStreamNonBlocking));
-            else SCHK(h, hipStreamCreateWithPriority(&s->ck_back[b], hipStreamNonBlocking, want < 0 ? lo : hi));
-        }
+        // (the back streams themselves are made by process_signal_chunked_t, and only where the hop-by-hop schedule runs: the
+        // runtime deals a process's streams over four hardware queues, and a stream that exists takes part whether it is used or not)
     }
     for (int q = 0; q < CK_NS; ++q) SCHK(h, hipEventCreateWithFlags(&s->ck_done[q], hipEventDisableTiming));
     SCHK(h, hipHostMalloc(&s->ck_pin_in, e1 * CK_NS * chunk * 2 * s->H, hipHostMallocDefault));
@@ -854,11 +848,34 @@ static int process_signal_chunked_t(apv_handle* h, int n_hops, const TI* h_in_A,
     const int N = s->N, H = s->H, K = s->K, L = s->L, M = s->M, C = s->C, P = s->P, f64 = s->f64, chunk = s->sig_chunk, RL = s->ck_RL;
     const size_t e1 = s->esz, e2 = 2 * s->esz, nout = (size_t)s->n_out * H;
     const bool runA = s->zones & 1, runB = s->zones & 2;
+    // the chunk's joint diagonalisations as one launch where the kernel that will run takes several hops (order 16, absolute loading,
+    // no diagnostics); APV_SIGNAL_BATCHED=0: hop by hop on the back streams, as before (A/B switch)
+    bool batched = false;
+    {
+        static const bool want = getenv("APV_SIGNAL_BATCHED") == nullptr || atoi(getenv("APV_SIGNAL_BATCHED")) != 0;
+        GevdParams probe = apv_base_params(h);
+        probe.x_c128 = f64;
+        probe.x_group = s->xg;
+        probe.n_hops = 2;
+        static const bool force_generic = getenv("APV_FORCE_GENERIC") != nullptr;
+        batched = want && !force_generic && apv_gevd16m_takes_hops(probe, h->cfg.compute_dtype, true);
+    }
+    if (!batched) {
+        // experiment (APV_CK_BACK_PRIO): -1 lowest stream priority, 1 highest, else the default
+        static const int want = getenv("APV_CK_BACK_PRIO") ? atoi(getenv("APV_CK_BACK_PRIO")) : 0;
+        int lo = 0, hi = 0;
+        SCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
+        for (int b = 0; b + 1 < CK_NB; ++b) {
+            if (s->ck_back[b]) continue;
+            if (want == 0) SCHK(h, hipStreamCreateWithFlags(&s->ck_back[b], hipStreamNonBlocking));
+            else SCHK(h, hipStreamCreateWithPriority(&s->ck_back[b], hipStreamNonBlocking, want < 0 ? lo : hi));
+        }
+    }
     hipStream_t bs[CK_NB];
     void* wset[CK_NB][2];
     void* lset[CK_NB][2];
     for (int b = 0; b < CK_NB; ++b) {
-        bs[b] = b ? s->ck_back[b - 1] : h->stream;
+        bs[b] = (b && s->ck_back[b - 1]) ? s->ck_back[b - 1] : h->stream;
         for (int z = 0; z < 2; ++z) {
             wset[b][z] = b ? s->ck_w[b - 1][z] : s->w[z];
             lset[b][z] = b ? s->ck_lam[b - 1][z] : s->lam[z];
@@ -945,18 +962,6 @@ static int process_signal_chunked_t(apv_handle* h, int n_hops, const TI* h_in_A,
     };
     const size_t spec_bytes = ((size_t)s->fir_F / 2 + 1) * e2;       // one input spectrum of K1
     int last_par = 0, last_nc = 0, last_b = 0;
-    // the chunk's joint diagonalisations as one launch where the kernel that will run takes several hops (order 16, float64 on c128
-    // slabs, absolute loading, no diagnostics); APV_SIGNAL_BATCHED=0: hop by hop on the back streams, as before (A/B switch)
-    bool batched = false;
-    {
-        static const bool want = getenv("APV_SIGNAL_BATCHED") == nullptr || atoi(getenv("APV_SIGNAL_BATCHED")) != 0;
-        GevdParams probe = apv_base_params(h);
-        probe.x_c128 = f64;
-        probe.x_group = s->xg;
-        probe.n_hops = 2;
-        static const bool force_generic = getenv("APV_FORCE_GENERIC") != nullptr;
-        batched = want && !force_generic && apv_gevd16m_takes_hops(probe, h->cfg.compute_dtype, true);
-    }
     std::string why;
     for (int c = 0; c < n_chunks && worst != APV_ERR_NOT_PD; ++c) {
         const int base = c * chunk, nc = std::min(chunk, n_hops - base), par = c & 1;
