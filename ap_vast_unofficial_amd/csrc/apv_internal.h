@@ -93,9 +93,9 @@ struct apv_handle {
     hipEvent_t ev_ag0, ev_ag1;    // timing events around the latest all-gather (comm stream)
     size_t ag_bytes;              // bytes this rank contributed to it
     int32_t* d_bar;               // one device word for apv_comm_barrier
-    // update lanes (apv_set_update_streams): consecutive apv_update_dev launches alternate between two streams of their own, so
-    // that the tail of one launch (waves of its last round finishing one by one) runs beside the head of the next.  `stream`
-    // stays the handle's control stream: copies, timers and the gather's hand-over are ordered against the lanes by events.
+    // update lanes (apv_set_update_streams): consecutive apv_update_dev launches alternate between two streams -- `stream` itself
+    // (lane 0) and one more -- so that the tail of one launch (waves of its last round finishing one by one) runs beside the head
+    // of the next.  `stream` is also the control stream: copies, timers and the gather's hand-over are ordered against the lanes by events.
     struct UpdateLane {
         hipStream_t s;
         hipEvent_t ev;            // recorded behind the lane's latest launch

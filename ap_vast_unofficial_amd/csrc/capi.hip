@@ -126,7 +126,7 @@ int ensure_staging(apv_handle* h) {
 
 
 // ---- update lanes (apv_set_update_streams) -----------------------------------------------------------------------------------
-// With two lanes, launch i + 1 of apv_update_dev starts on the other lane while the waves of launch i's last round are still
+// With two lanes (the handle's stream and one more), launch i + 1 of apv_update_dev starts on the other lane while the waves of launch i's last round are still
 // finishing (a cfg2 launch is 8 rounds of 4 waves per SIMD; 3.6 of 4 alive on average: profiles/r03/stage_stamps_32768_b.md).
 // Ordering is by events, never by the host:
 //   lanes_join   the control stream waits for the latest launch of every lane (before anything it is asked to do with buffers)
@@ -285,7 +285,7 @@ int apv_destroy(apv_handle* h) {
         if (ln.s) (void)hipStreamSynchronize(ln.s);
         if (ln.ev) (void)hipEventDestroy(ln.ev);
         if (ln.ev_prev) (void)hipEventDestroy(ln.ev_prev);
-        if (ln.s) (void)hipStreamDestroy(ln.s);
+        if (ln.s && ln.s != h->stream) (void)hipStreamDestroy(ln.s);
     }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->comm) ncclCommDestroy((ncclComm_t)h->comm);
@@ -463,7 +463,15 @@ int apv_set_update_streams(apv_handle* h, int32_t n) {
     if (int rc = lanes_sync(h)) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (n == 2 && !h->lane[0].s) {
+        // Lane 0 IS the handle's control stream, lane 1 a stream of its own: the runtime deals a process's streams over four hardware
+        // queues and every stream fewer is one fewer to share them with (with the gather's stream the sharded path then has three
+        // streams and the lanes work beside the collective; with a control stream of its own they did not: DESIGN.md 4.9).  Waiting for
+        // its own events costs the control stream nothing; a join (copies, timers) holds back lane 0's NEXT launch until lane 1's
+        // latest has ended -- once per copy, not per launch.  APV_LANE0_CONTROL=0: a control stream apart from both lanes (A/B switch).
+        static const bool lane0_ctrl = getenv("APV_LANE0_CONTROL") == nullptr || atoi(getenv("APV_LANE0_CONTROL")) != 0;
         for (auto& ln : h->lane) {
+            if (lane0_ctrl && &ln == &h->lane[0]) ln.s = h->stream;
+            else
             HIPCHK(h, hipStreamCreateWithFlags(&ln.s, hipStreamNonBlocking));
             HIPCHK(h, hipEventCreateWithFlags(&ln.ev, hipEventDisableTiming));
             HIPCHK(h, hipEventCreateWithFlags(&ln.ev_prev, hipEventDisableTiming));
